@@ -1,0 +1,104 @@
+"""ctypes binding of libp3d_hip.so (C ABI declared in include/p3d_hip.h).
+
+The library is mandatory for CUDA/HIP tensors: ``lib()`` raises if it cannot be loaded, and no op
+in this package has a GPU fallback.  torch is imported first so the HIP runtime the library binds
+to (SONAME libamdhip64.so.7) is the one torch already mapped — streams and device pointers are
+then shared between torch and the kernels.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL: see module docstring)
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, 'libp3d_hip.so')
+
+P3D_OK = 0
+P3D_ERR_UNSUPPORTED = -1
+DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.float64: 2}
+FAMILY = {'bias_act': 0, 'upfirdn2d': 1, 'filtered_lrelu': 2, 'render': 3, 'conv': 4, 'aux': 5}
+
+_c_void_p, _c_int, _c_i32, _c_i64, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+_i32x4, _i64x4 = ctypes.c_int32 * 4, ctypes.c_int64 * 4
+_i32x2, _i64x2 = ctypes.c_int32 * 2, ctypes.c_int64 * 2
+
+_SIGNATURES = {
+    'p3d_last_error': (ctypes.c_char_p, []),
+    'p3d_abi_version': (_c_int, []),
+    'p3d_launch_count': (ctypes.c_uint64, []),
+    'p3d_launch_count_of': (ctypes.c_uint64, [_c_int]),
+    'p3d_bias_act': (_c_int, [_c_void_p] * 6 + [_c_int, _c_int, _c_int, _c_float, _c_float, _c_float,
+                              _c_i64, _c_i32, _c_i64, _c_void_p]),
+    'p3d_upfirdn2d': (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int,
+                               ctypes.POINTER(_c_i32), ctypes.POINTER(_c_i64),
+                               ctypes.POINTER(_c_i32), ctypes.POINTER(_c_i64),
+                               ctypes.POINTER(_c_i32), ctypes.POINTER(_c_i64),
+                               _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_float, _c_void_p]),
+}
+
+_lib = None
+_load_error = None
+
+
+def _load():
+    global _lib, _load_error
+    if _lib is not None or _load_error is not None:
+        return
+    try:
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the .so is stale
+            fn.restype, fn.argtypes = restype, argtypes
+        _lib = handle
+    except (OSError, AttributeError) as e:      # missing file, unresolved HIP runtime, stale build
+        _load_error = e
+
+
+def available():
+    _load()
+    return _lib is not None
+
+
+def lib():
+    """Return the loaded library or raise: there is no fallback for device tensors."""
+    _load()
+    if _lib is None:
+        raise RuntimeError(
+            f'pix2pix3d_amd: the gfx950 kernel library {LIB_PATH} could not be loaded ({_load_error}). '
+            'Build it with `python -m pix2pix3d_amd.build` (or __graft_entry__.build()); '
+            'CUDA/HIP tensors have no fallback path in this package.')
+    return _lib
+
+
+def register(name, restype, argtypes):
+    """Declare the signature of one more exported symbol (used by the op modules)."""
+    _SIGNATURES[name] = (restype, argtypes)
+    if _lib is not None:
+        fn = getattr(_lib, name)
+        fn.restype, fn.argtypes = restype, argtypes
+
+
+def check(code, what):
+    if code != P3D_OK:
+        msg = lib().p3d_last_error().decode('utf-8', 'replace')
+        raise RuntimeError(f'{what}: libp3d_hip error {code}: {msg}')
+
+
+def stream_of(t):
+    return _c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def ptr(t):
+    return None if t is None else _c_void_p(t.data_ptr())
+
+
+def launch_count(family=None):
+    if not available():
+        return 0
+    return int(_lib.p3d_launch_count() if family is None else _lib.p3d_launch_count_of(FAMILY[family]))
+
+
+def i32x4(*v): return _i32x4(*v)
+def i64x4(*v): return _i64x4(*v)
+def i32x2(*v): return _i32x2(*v)
+def i64x2(*v): return _i64x2(*v)

@@ -1,0 +1,34 @@
+// Shared host/device helpers for libp3d_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <atomic>
+#include "../../include/p3d_hip.h"
+
+namespace p3d {
+
+constexpr int kWave = 64;                       // gfx950 wavefront
+constexpr int kNumCU = 256;                     // MI355X
+enum Family { FAM_BIAS_ACT = 0, FAM_UPFIRDN = 1, FAM_FLRELU = 2, FAM_RENDER = 3, FAM_CONV = 4, FAM_AUX = 5, FAM_COUNT = 6 };
+
+void  set_error(const char* fmt, ...);
+int   fail(int code, const char* fmt, ...);
+void  count_launch(int family);
+int   check_launch(const char* what);         // hipGetLastError -> status
+
+template <class T> struct Acc            { typedef float  type; };
+template <>        struct Acc<double>    { typedef double type; };
+
+template <class T> __device__ __forceinline__ typename Acc<T>::type ld(const T* p)            { return (typename Acc<T>::type)(*p); }
+template <>        __device__ __forceinline__ float ld<__half>(const __half* p)                 { return __half2float(*p); }
+template <class T> __device__ __forceinline__ void st(T* p, typename Acc<T>::type v)          { *p = (T)v; }
+template <>        __device__ __forceinline__ void st<__half>(__half* p, float v)               { *p = __float2half(v); }
+
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+} // namespace p3d
+
+#define P3D_REQUIRE(cond, ...) do { if (!(cond)) return p3d::fail(P3D_ERR_ARGUMENT, __VA_ARGS__); } while (0)
