@@ -71,6 +71,63 @@ int p3d_upfirdn2d(const void* x, const float* f, void* y, int dtype,
                   int32_t up_x, int32_t up_y, int32_t down_x, int32_t down_y,
                   int32_t pad_x0, int32_t pad_y0, int32_t flip, float gain, p3d_stream_t stream);
 
+/* ---- fused tri-plane ray-marcher -----------------------------------------------------------
+ * Stands in for the tensor-op pipeline of training/volumetric_rendering:
+ *   ImportanceRenderer.forward   renderer.py:88-140   (p3d_render_forward)
+ *   ImportanceRenderer.run_model renderer.py:142-148  (p3d_sample_points)
+ *   sample_importance/sample_pdf renderer.py:194-253  (p3d_importance_sample, also fused above)
+ *   MipRayMarcher2.run_forward   ray_marcher.py:25-57 (fused)
+ * with the OSG decoders (training/triplane.py:112-135 one net; training/triplane_cond.py:926-970
+ * two nets, density from the second) evaluated on the f32 MFMA path.  Random numbers are inputs
+ * (the host draws them exactly where the reference would: renderer.py:190, :237).            */
+typedef struct p3d_render_desc {
+    int32_t n_img;                        /* N                                                  */
+    int32_t rays_per_img;                 /* M (ignored by p3d_sample_points)                   */
+    int32_t plane_h, plane_w;             /* tri-plane resolution; 32 channels per plane        */
+    int32_t n_nets;                       /* 1: OSGDecoder, 2: OSGDecoder_semantic_lateSeparate */
+    int32_t semantic_sigmoid;             /* 2-net decoder: squash the label channels too       */
+    int32_t depth_resolution;             /* S_c  rendering_options['depth_resolution']         */
+    int32_t depth_resolution_importance;  /* S_f                                                */
+    int32_t disparity_space_sampling;
+    int32_t white_back;
+    float   ray_start, ray_end;           /* used when t_start/t_end are null                   */
+    float   box_warp;
+} p3d_render_desc;
+
+int p3d_render_decoder_floats(void);     /* size of the packed decoder stream, in floats        */
+
+/* planes [N][96][H][W] (backbone output, NCHW) -> [N][3][H][W][32]: one 128-byte line per texel */
+int p3d_planes_to_channels_last(const float* planes_nchw, float* planes_cl, int32_t n_img, int32_t h, int32_t w,
+                                p3d_stream_t stream);
+
+/* FullyConnectedLayer weights (networks_stylegan2.py:96-130; w1 [64,32], b1 [64], w2 [33,64],
+ * b2 [33], raw parameters: the lr_mul / sqrt(fan_in) gains are applied here) -> MFMA operand
+ * stream.  Net a = colour net, net b = label+density net (null for the single-net decoder).   */
+int p3d_pack_decoder(const float* w1_a, const float* b1_a, const float* w2_a, const float* b2_a,
+                     const float* w1_b, const float* b1_b, const float* w2_b, const float* b2_b,
+                     int32_t n_nets, float lr_mul, float* packed, p3d_stream_t stream);
+
+/* ray_o, ray_d [N*M][3]; u_coarse [N*M][S_c] and u_fine [N*M][S_f] uniforms in [0,1);
+ * t_start/t_end optional per-ray limits [N*M] ('auto' ray range), null otherwise.
+ * Outputs: feat [N*M][32*n_nets] (already *2-1), depth [N*M] (clamped to the global sample-depth
+ * range, ray_marcher.py:49-50), wsum [N*M].  minmax_ws: 2 x uint32 device scratch.
+ * dbg_fine [N*M][S_f] (sorted importance depths) and dbg_wcoarse [N*M][S_c-1] are optional.
+ * Returns P3D_ERR_UNSUPPORTED when S_c or S_f exceed 64 (or S_f == 0).                        */
+int p3d_render_forward(const float* planes_cl, const float* decoder, const float* ray_o, const float* ray_d,
+                       const float* u_coarse, const float* u_fine, const float* t_start, const float* t_end,
+                       const p3d_render_desc* desc, float* feat, float* depth, float* wsum, uint32_t* minmax_ws,
+                       float* dbg_fine, float* dbg_wcoarse, p3d_stream_t stream);
+
+/* coords [N*P][3] -> rgb [N*P][32*n_nets], sigma [N*P]  (G.sample / G.sample_mixed, extract_mesh) */
+int p3d_sample_points(const float* planes_cl, const float* decoder, const float* coords, const p3d_render_desc* desc,
+                      int32_t pts_per_img, float* rgb, float* sigma, p3d_stream_t stream);
+
+/* z_coarse [R][S_c], w_coarse [R][S_c-1], u_fine [R][S_f] -> z_fine [R][S_f] (sorted ascending
+ * when `sorted`, else in draw order as sample_pdf returns them).                               */
+int p3d_importance_sample(const float* z_coarse, const float* w_coarse, const float* u_fine, float* z_fine,
+                          int32_t n_rays, int32_t depth_resolution, int32_t n_importance, int32_t sorted,
+                          p3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

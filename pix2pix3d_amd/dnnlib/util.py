@@ -21,6 +21,13 @@ class EasyDict(dict):
 
 def get_module_from_obj_name(obj_name: str):
     """Split 'pkg.mod.Obj.attr' into (imported module, 'Obj.attr'), trying the longest module prefix first."""
+    # the reference's dotted names ('training.superresolution.X') resolve to this package's mirrors first, so
+    # configs written for the reference work whether or not pix2pix3d_amd.dropin.install() has aliased sys.modules
+    if obj_name.split('.')[0] in ('training', 'torch_utils', 'dnnlib') and not obj_name.startswith('pix2pix3d_amd.'):
+        try:
+            return get_module_from_obj_name('pix2pix3d_amd.' + obj_name)
+        except ImportError:
+            pass
     parts = obj_name.split('.')
     last_err = None
     for cut in range(len(parts) - 1, 0, -1):

@@ -1,0 +1,48 @@
+"""Make this package answer to the reference's import paths.
+
+The reference (and every released checkpoint, whose pickles re-import module source by name — SURVEY §5 N3) uses
+absolute imports such as ``from torch_utils.ops import bias_act`` and ``training.triplane_cond.TriPlane...``.
+``install()`` registers this package's mirrors under those names in ``sys.modules`` so that
+``training_loop.py`` / ``applications/*.py`` of the reference run unchanged on top of the HIP kernels.
+Modules this package does not mirror (loss, dataset, legacy, camera_utils, metrics, ...) keep resolving to the
+reference checkout if it is on ``sys.path``: for that, ``training`` / ``torch_utils`` get the reference's
+directories appended to their ``__path__``.
+"""
+import importlib
+import os
+import sys
+
+_MIRRORED = [
+    'dnnlib', 'dnnlib.util',
+    'torch_utils', 'torch_utils.misc', 'torch_utils.persistence', 'torch_utils.custom_ops',
+    'torch_utils.ops', 'torch_utils.ops.bias_act', 'torch_utils.ops.upfirdn2d', 'torch_utils.ops.fma',
+    'torch_utils.ops.conv2d_gradfix', 'torch_utils.ops.conv2d_resample', 'torch_utils.ops.grid_sample_gradfix',
+    'torch_utils.ops.filtered_lrelu',
+    'training', 'training.networks_stylegan2', 'training.superresolution', 'training.triplane', 'training.triplane_cond',
+    'training.dual_discriminator',
+    'training.volumetric_rendering', 'training.volumetric_rendering.renderer', 'training.volumetric_rendering.ray_marcher',
+    'training.volumetric_rendering.ray_sampler', 'training.volumetric_rendering.math_utils',
+]
+
+
+def install(reference_root=None, strict=False):
+    """Alias the mirrors; returns the list of names installed.  ``reference_root`` (optional) is appended to the
+    package search paths so un-mirrored reference modules (e.g. ``training.loss``) remain importable."""
+    done = []
+    for name in _MIRRORED:
+        try:
+            mod = importlib.import_module('pix2pix3d_amd.' + name)
+        except ImportError:
+            if strict:
+                raise
+            continue
+        sys.modules[name] = mod
+        done.append(name)
+    if reference_root:
+        for pkg in ('training', 'torch_utils', 'dnnlib'):
+            extra = os.path.join(reference_root, pkg)
+            if pkg in sys.modules and os.path.isdir(extra) and extra not in sys.modules[pkg].__path__:
+                sys.modules[pkg].__path__.append(extra)
+        if reference_root not in sys.path:
+            sys.path.append(reference_root)
+    return done

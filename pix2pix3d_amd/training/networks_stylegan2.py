@@ -1,0 +1,547 @@
+"""StyleGAN2 building blocks of the tri-plane backbone, super-resolution heads and discriminator.
+
+Mirror of training/networks_stylegan2.py (line references below are to that file): identical class
+names, constructor arguments, parameter/buffer names (so ``copy_params_and_buffers`` and released
+checkpoints map 1:1) and forward semantics; the arithmetic runs on this package's operators.
+"""
+import numpy as np
+import torch
+
+from ..torch_utils import misc
+from ..torch_utils import persistence
+from ..torch_utils.ops import conv2d_resample, upfirdn2d, bias_act, fma
+
+
+@misc.profiled_function
+def normalize_2nd_moment(x, dim=1, eps=1e-8):
+    """x / rms(x) along ``dim`` (:28-29)."""
+    return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
+
+
+@misc.profiled_function
+def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None,
+                     demodulate=True, flip_weight=True, fused_modconv=True):
+    """Style-modulated convolution (:34-91).  x [N,I,H,W], weight [O,I,k,k], styles [N,I].
+
+    fused: per-sample weights w*s (optionally demodulated) run as one grouped conv.
+    unfused: activations are pre-scaled by s, a shared-weight conv runs, and the demodulation
+    coefficient (and noise) is applied afterwards — algebraically the same result."""
+    n = x.shape[0]
+    o, i, kh, kw = weight.shape
+    misc.assert_shape(weight, [o, i, kh, kw])
+    misc.assert_shape(x, [n, i, None, None])
+    misc.assert_shape(styles, [n, i])
+
+    if x.dtype == torch.float16 and demodulate:                      # keep fp16 products in range (:54-56)
+        weight = weight * (1 / np.sqrt(i * kh * kw) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
+        styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
+
+    w_mod = dcoefs = None
+    if demodulate or fused_modconv:
+        w_mod = weight.unsqueeze(0) * styles.reshape(n, 1, -1, 1, 1)              # [N,O,I,k,k]
+    if demodulate:
+        dcoefs = (w_mod.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt()               # [N,O]
+    if demodulate and fused_modconv:
+        w_mod = w_mod * dcoefs.reshape(n, -1, 1, 1, 1)
+
+    if not fused_modconv:
+        x = x * styles.to(x.dtype).reshape(n, -1, 1, 1)
+        x = conv2d_resample.conv2d_resample(x=x, w=weight.to(x.dtype), f=resample_filter, up=up, down=down, padding=padding, flip_weight=flip_weight)
+        if demodulate and noise is not None:
+            x = fma.fma(x, dcoefs.to(x.dtype).reshape(n, -1, 1, 1), noise.to(x.dtype))
+        elif demodulate:
+            x = x * dcoefs.to(x.dtype).reshape(n, -1, 1, 1)
+        elif noise is not None:
+            x = x.add_(noise.to(x.dtype))
+        return x
+
+    with misc.suppress_tracer_warnings():
+        n = int(n)
+    misc.assert_shape(x, [n, i, None, None])
+    x = x.reshape(1, -1, *x.shape[2:])
+    x = conv2d_resample.conv2d_resample(x=x, w=w_mod.reshape(-1, i, kh, kw).to(x.dtype), f=resample_filter, up=up, down=down,
+                                        padding=padding, groups=n, flip_weight=flip_weight)
+    x = x.reshape(n, -1, *x.shape[2:])
+    if noise is not None:
+        x = x.add_(noise)
+    return x
+
+
+@persistence.persistent_class
+class FullyConnectedLayer(torch.nn.Module):
+    """y = act(x @ (W * lr/sqrt(in)).T + b * lr)   (:96-130)."""
+
+    def __init__(self, in_features, out_features, bias=True, activation='linear', lr_multiplier=1, bias_init=0):
+        super().__init__()
+        self.in_features, self.out_features, self.activation = in_features, out_features, activation
+        self.weight = torch.nn.Parameter(torch.randn([out_features, in_features]) / lr_multiplier)
+        self.bias = torch.nn.Parameter(torch.full([out_features], np.float32(bias_init))) if bias else None
+        self.weight_gain = lr_multiplier / np.sqrt(in_features)
+        self.bias_gain = lr_multiplier
+
+    def forward(self, x):
+        w = self.weight.to(x.dtype) * self.weight_gain
+        b = self.bias
+        if b is not None:
+            b = b.to(x.dtype)
+            if self.bias_gain != 1:
+                b = b * self.bias_gain
+        if self.activation == 'linear' and b is not None:
+            return torch.addmm(b.unsqueeze(0), x, w.t())
+        return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
+
+    def extra_repr(self):
+        return f'in_features={self.in_features:d}, out_features={self.out_features:d}, activation={self.activation:s}'
+
+
+@persistence.persistent_class
+class Conv2dLayer(torch.nn.Module):
+    """Plain (unmodulated) conv + bias_act with optional resampling (:135-188)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, bias=True, activation='linear', up=1, down=1,
+                 resample_filter=[1, 3, 3, 1], conv_clamp=None, channels_last=False, trainable=True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.activation = in_channels, out_channels, activation
+        self.up, self.down, self.conv_clamp = up, down, conv_clamp
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.padding = kernel_size // 2
+        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+        self.act_gain = bias_act.activation_funcs[activation].def_gain
+        fmt = torch.channels_last if channels_last else torch.contiguous_format
+        weight = torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=fmt)
+        bias = torch.zeros([out_channels]) if bias else None
+        if trainable:
+            self.weight = torch.nn.Parameter(weight)
+            self.bias = torch.nn.Parameter(bias) if bias is not None else None
+        else:
+            self.register_buffer('weight', weight)
+            if bias is not None:
+                self.register_buffer('bias', bias)
+            else:
+                self.bias = None
+
+    def forward(self, x, gain=1):
+        w = self.weight * self.weight_gain
+        b = self.bias.to(x.dtype) if self.bias is not None else None
+        x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
+                                            padding=self.padding, flip_weight=(self.up == 1))
+        clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        return bias_act.bias_act(x, b, act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+
+    def extra_repr(self):
+        return f'in_channels={self.in_channels:d}, out_channels={self.out_channels:d}, activation={self.activation:s}, up={self.up}, down={self.down}'
+
+
+@persistence.persistent_class
+class MappingNetwork(torch.nn.Module):
+    """z (and optional label c) -> ws [N, num_ws, w_dim], with w_avg tracking and truncation (:193-272)."""
+
+    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=8, embed_features=None, layer_features=None,
+                 activation='lrelu', lr_multiplier=0.01, w_avg_beta=0.998):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim, self.num_ws, self.num_layers, self.w_avg_beta = z_dim, c_dim, w_dim, num_ws, num_layers, w_avg_beta
+        if embed_features is None:
+            embed_features = w_dim
+        if c_dim == 0:
+            embed_features = 0
+        if layer_features is None:
+            layer_features = w_dim
+        sizes = [z_dim + embed_features] + [layer_features] * (num_layers - 1) + [w_dim]
+        if c_dim > 0:
+            self.embed = FullyConnectedLayer(c_dim, embed_features)
+        for idx in range(num_layers):
+            setattr(self, f'fc{idx}', FullyConnectedLayer(sizes[idx], sizes[idx + 1], activation=activation, lr_multiplier=lr_multiplier))
+        if num_ws is not None and w_avg_beta is not None:
+            self.register_buffer('w_avg', torch.zeros([w_dim]))
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False):
+        x = None
+        with torch.autograd.profiler.record_function('input'):
+            if self.z_dim > 0:
+                misc.assert_shape(z, [None, self.z_dim])
+                x = normalize_2nd_moment(z.to(torch.float32))
+            if self.c_dim > 0:
+                misc.assert_shape(c, [None, self.c_dim])
+                y = normalize_2nd_moment(self.embed(c.to(torch.float32)))
+                x = torch.cat([x, y], dim=1) if x is not None else y
+        for idx in range(self.num_layers):
+            x = getattr(self, f'fc{idx}')(x)
+        if update_emas and self.w_avg_beta is not None:
+            with torch.autograd.profiler.record_function('update_w_avg'):
+                self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+        if self.num_ws is not None:
+            with torch.autograd.profiler.record_function('broadcast'):
+                x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if truncation_psi != 1:
+            with torch.autograd.profiler.record_function('truncate'):
+                assert self.w_avg_beta is not None
+                if self.num_ws is None or truncation_cutoff is None:
+                    x = self.w_avg.lerp(x, truncation_psi)
+                else:
+                    x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
+        return x
+
+    def extra_repr(self):
+        return f'z_dim={self.z_dim:d}, c_dim={self.c_dim:d}, w_dim={self.w_dim:d}, num_ws={self.num_ws:d}'
+
+
+@persistence.persistent_class
+class SynthesisLayer(torch.nn.Module):
+    """affine(w) -> modulated 3x3 conv (optionally x2 up) -> noise -> bias + lrelu (:277-337)."""
+
+    def __init__(self, in_channels, out_channels, w_dim, resolution, kernel_size=3, up=1, use_noise=True, activation='lrelu',
+                 resample_filter=[1, 3, 3, 1], conv_clamp=None, channels_last=False, **unused_kwargs):
+        super().__init__()
+        self.in_channels, self.out_channels, self.w_dim, self.resolution = in_channels, out_channels, w_dim, resolution
+        self.up, self.use_noise, self.activation, self.conv_clamp = up, use_noise, activation, conv_clamp
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.padding = kernel_size // 2
+        self.act_gain = bias_act.activation_funcs[activation].def_gain
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        fmt = torch.channels_last if channels_last else torch.contiguous_format
+        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=fmt))
+        if use_noise:
+            self.register_buffer('noise_const', torch.randn([resolution, resolution]))
+            self.noise_strength = torch.nn.Parameter(torch.zeros([]))
+        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1):
+        assert noise_mode in ['random', 'const', 'none']
+        in_res = self.resolution // self.up
+        misc.assert_shape(x, [None, self.in_channels, in_res, in_res])
+        styles = self.affine(w)
+        noise = None
+        if self.use_noise and noise_mode == 'random':
+            noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
+        if self.use_noise and noise_mode == 'const':
+            noise = self.noise_const * self.noise_strength
+        x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
+                             resample_filter=self.resample_filter, flip_weight=(self.up == 1), fused_modconv=fused_modconv)
+        clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+
+    def extra_repr(self):
+        return (f'in_channels={self.in_channels:d}, out_channels={self.out_channels:d}, w_dim={self.w_dim:d}, '
+                f'resolution={self.resolution:d}, up={self.up}, activation={self.activation:s}')
+
+
+@persistence.persistent_class
+class ToRGBLayer(torch.nn.Module):
+    """1x1 modulated conv without demodulation; the weight gain rides on the styles (:342-362)."""
+
+    def __init__(self, in_channels, out_channels, w_dim, kernel_size=1, conv_clamp=None, channels_last=False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.w_dim, self.conv_clamp = in_channels, out_channels, w_dim, conv_clamp
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        fmt = torch.channels_last if channels_last else torch.contiguous_format
+        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=fmt))
+        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+
+    def forward(self, x, w, fused_modconv=True):
+        styles = self.affine(w) * self.weight_gain
+        x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
+        return bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
+
+    def extra_repr(self):
+        return f'in_channels={self.in_channels:d}, out_channels={self.out_channels:d}, w_dim={self.w_dim:d}'
+
+
+def _block_mode(block, ws, force_fp32, fused_modconv):
+    """Shared dtype / layout / modconv-mode decision of the synthesis blocks (:421-430)."""
+    if ws.device.type != 'cuda':
+        force_fp32 = True
+    dtype = torch.float16 if block.use_fp16 and not force_fp32 else torch.float32
+    fmt = torch.channels_last if block.channels_last and not force_fp32 else torch.contiguous_format
+    if fused_modconv is None:
+        fused_modconv = block.fused_modconv_default
+    if fused_modconv == 'inference_only':
+        fused_modconv = (not block.training)
+    return dtype, fmt, fused_modconv
+
+
+@persistence.persistent_class
+class SynthesisBlock(torch.nn.Module):
+    """One resolution level: (up-)conv0, conv1, ToRGB with skip-image accumulation (:367-466)."""
+
+    def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, is_last, architecture='skip',
+                 resample_filter=[1, 3, 3, 1], conv_clamp=256, use_fp16=False, fp16_channels_last=False,
+                 fused_modconv_default=True, **layer_kwargs):
+        assert architecture in ['orig', 'skip', 'resnet']
+        super().__init__()
+        self.in_channels, self.w_dim, self.resolution, self.img_channels = in_channels, w_dim, resolution, img_channels
+        self.is_last, self.architecture, self.use_fp16 = is_last, architecture, use_fp16
+        self.channels_last = (use_fp16 and fp16_channels_last)
+        self.fused_modconv_default = fused_modconv_default
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.num_conv = self.num_torgb = 0
+        if in_channels == 0:
+            self.const = torch.nn.Parameter(torch.randn([out_channels, resolution, resolution]))
+        else:
+            self.conv0 = SynthesisLayer(in_channels, out_channels, w_dim=w_dim, resolution=resolution, up=2, resample_filter=resample_filter,
+                                        conv_clamp=conv_clamp, channels_last=self.channels_last, **layer_kwargs)
+            self.num_conv += 1
+        self.conv1 = SynthesisLayer(out_channels, out_channels, w_dim=w_dim, resolution=resolution, conv_clamp=conv_clamp,
+                                    channels_last=self.channels_last, **layer_kwargs)
+        self.num_conv += 1
+        if is_last or architecture == 'skip':
+            self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp, channels_last=self.channels_last)
+            self.num_torgb += 1
+        if in_channels != 0 and architecture == 'resnet':
+            self.skip = Conv2dLayer(in_channels, out_channels, kernel_size=1, bias=False, up=2, resample_filter=resample_filter,
+                                    channels_last=self.channels_last)
+
+    _in_div = 2          # input resolution = resolution // _in_div (the NoUp variant in superresolution.py uses 1)
+
+    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, **layer_kwargs):
+        _ = update_emas
+        misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
+        w_iter = iter(ws.unbind(dim=1))
+        dtype, fmt, fused_modconv = _block_mode(self, ws, force_fp32, fused_modconv)
+
+        if self.in_channels == 0:
+            x = self.const.to(dtype=dtype, memory_format=fmt).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
+        else:
+            misc.assert_shape(x, [None, self.in_channels, self.resolution // self._in_div, self.resolution // self._in_div])
+            x = x.to(dtype=dtype, memory_format=fmt)
+
+        if self.in_channels == 0:
+            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+        elif self.architecture == 'resnet':
+            y = self.skip(x, gain=np.sqrt(0.5))
+            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, gain=np.sqrt(0.5), **layer_kwargs)
+            x = y.add_(x)
+        else:
+            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+
+        if img is not None and self._in_div == 2:
+            misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
+            img = upfirdn2d.upsample2d(img, self.resample_filter)
+        if self.is_last or self.architecture == 'skip':
+            y = self.torgb(x, next(w_iter), fused_modconv=fused_modconv)
+            y = y.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+            img = img.add_(y) if img is not None else y
+
+        assert x.dtype == dtype
+        assert img is None or img.dtype == torch.float32
+        return x, img
+
+    def extra_repr(self):
+        return f'resolution={self.resolution:d}, architecture={self.architecture:s}'
+
+
+@persistence.persistent_class
+class SynthesisNetwork(torch.nn.Module):
+    """Stack of SynthesisBlocks b4..b{img_resolution}; ws are dealt out block by block (:471-526)."""
+
+    def __init__(self, w_dim, img_resolution, img_channels, channel_base=32768, channel_max=512, num_fp16_res=4, **block_kwargs):
+        assert img_resolution >= 4 and img_resolution & (img_resolution - 1) == 0
+        super().__init__()
+        self.w_dim, self.img_resolution, self.img_channels, self.num_fp16_res = w_dim, img_resolution, img_channels, num_fp16_res
+        self.img_resolution_log2 = int(np.log2(img_resolution))
+        self.block_resolutions = [2 ** i for i in range(2, self.img_resolution_log2 + 1)]
+        channels = {res: min(channel_base // res, channel_max) for res in self.block_resolutions}
+        fp16_resolution = max(2 ** (self.img_resolution_log2 + 1 - num_fp16_res), 8)
+        self.num_ws = 0
+        for res in self.block_resolutions:
+            block = SynthesisBlock(channels[res // 2] if res > 4 else 0, channels[res], w_dim=w_dim, resolution=res, img_channels=img_channels,
+                                   is_last=(res == img_resolution), use_fp16=(res >= fp16_resolution), **block_kwargs)
+            self.num_ws += block.num_conv
+            if res == img_resolution:
+                self.num_ws += block.num_torgb
+            setattr(self, f'b{res}', block)
+
+    def forward(self, ws, **block_kwargs):
+        with torch.autograd.profiler.record_function('split_ws'):
+            misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
+            ws = ws.to(torch.float32)
+            block_ws, idx = [], 0
+            for res in self.block_resolutions:
+                block = getattr(self, f'b{res}')
+                block_ws.append(ws.narrow(1, idx, block.num_conv + block.num_torgb))     # ToRGB shares the next block's first w
+                idx += block.num_conv
+        x = img = None
+        for res, cur in zip(self.block_resolutions, block_ws):
+            x, img = getattr(self, f'b{res}')(x, img, cur, **block_kwargs)
+        return img
+
+    def extra_repr(self):
+        return (f'w_dim={self.w_dim:d}, num_ws={self.num_ws:d}, img_resolution={self.img_resolution:d}, '
+                f'img_channels={self.img_channels:d}, num_fp16_res={self.num_fp16_res:d}')
+
+
+@persistence.persistent_class
+class Generator(torch.nn.Module):
+    """mapping + synthesis (:531-554)."""
+
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs={}, **synthesis_kwargs):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim, self.img_resolution, self.img_channels = z_dim, c_dim, w_dim, img_resolution, img_channels
+        self.synthesis = SynthesisNetwork(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels, **synthesis_kwargs)
+        self.num_ws = self.synthesis.num_ws
+        self.mapping = MappingNetwork(z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws, **mapping_kwargs)
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        return self.synthesis(ws, update_emas=update_emas, **synthesis_kwargs)
+
+
+@persistence.persistent_class
+class DiscriminatorBlock(torch.nn.Module):
+    """fromrgb (+skip) -> conv0 -> down-2 conv1, 'resnet' adds a down-2 1x1 branch (:559-643)."""
+
+    def __init__(self, in_channels, tmp_channels, out_channels, resolution, img_channels, first_layer_idx, architecture='resnet',
+                 activation='lrelu', resample_filter=[1, 3, 3, 1], conv_clamp=None, use_fp16=False, fp16_channels_last=False, freeze_layers=0):
+        assert in_channels in [0, tmp_channels]
+        assert architecture in ['orig', 'skip', 'resnet']
+        super().__init__()
+        self.in_channels, self.resolution, self.img_channels, self.first_layer_idx = in_channels, resolution, img_channels, first_layer_idx
+        self.architecture, self.use_fp16 = architecture, use_fp16
+        self.channels_last = (use_fp16 and fp16_channels_last)
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.num_layers = 0
+
+        def trainable_gen():
+            while True:
+                flag = (self.first_layer_idx + self.num_layers) >= freeze_layers
+                self.num_layers += 1
+                yield flag
+        trainable = trainable_gen()
+        if in_channels == 0 or architecture == 'skip':
+            self.fromrgb = Conv2dLayer(img_channels, tmp_channels, kernel_size=1, activation=activation, trainable=next(trainable),
+                                       conv_clamp=conv_clamp, channels_last=self.channels_last)
+        self.conv0 = Conv2dLayer(tmp_channels, tmp_channels, kernel_size=3, activation=activation, trainable=next(trainable),
+                                 conv_clamp=conv_clamp, channels_last=self.channels_last)
+        self.conv1 = Conv2dLayer(tmp_channels, out_channels, kernel_size=3, activation=activation, down=2, trainable=next(trainable),
+                                 resample_filter=resample_filter, conv_clamp=conv_clamp, channels_last=self.channels_last)
+        if architecture == 'resnet':
+            self.skip = Conv2dLayer(tmp_channels, out_channels, kernel_size=1, bias=False, down=2, trainable=next(trainable),
+                                    resample_filter=resample_filter, channels_last=self.channels_last)
+
+    def forward(self, x, img, force_fp32=False):
+        if (x if x is not None else img).device.type != 'cuda':
+            force_fp32 = True
+        dtype = torch.float16 if self.use_fp16 and not force_fp32 else torch.float32
+        fmt = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
+        if x is not None:
+            misc.assert_shape(x, [None, self.in_channels, self.resolution, self.resolution])
+            x = x.to(dtype=dtype, memory_format=fmt)
+        if self.in_channels == 0 or self.architecture == 'skip':
+            misc.assert_shape(img, [None, self.img_channels, self.resolution, self.resolution])
+            img = img.to(dtype=dtype, memory_format=fmt)
+            y = self.fromrgb(img)
+            x = x + y if x is not None else y
+            img = upfirdn2d.downsample2d(img, self.resample_filter) if self.architecture == 'skip' else None
+        if self.architecture == 'resnet':
+            y = self.skip(x, gain=np.sqrt(0.5))
+            x = self.conv0(x)
+            x = self.conv1(x, gain=np.sqrt(0.5))
+            x = y.add_(x)
+        else:
+            x = self.conv0(x)
+            x = self.conv1(x)
+        assert x.dtype == dtype
+        return x, img
+
+    def extra_repr(self):
+        return f'resolution={self.resolution:d}, architecture={self.architecture:s}'
+
+
+@persistence.persistent_class
+class MinibatchStdLayer(torch.nn.Module):
+    """Appends the per-group feature std as extra channel(s) (:648-672)."""
+
+    def __init__(self, group_size, num_channels=1):
+        super().__init__()
+        self.group_size, self.num_channels = group_size, num_channels
+
+    def forward(self, x):
+        n, c, h, w = x.shape
+        with misc.suppress_tracer_warnings():
+            g = torch.min(torch.as_tensor(self.group_size), torch.as_tensor(n)) if self.group_size is not None else n
+        f = self.num_channels
+        y = x.reshape(g, -1, f, c // f, h, w)
+        y = y - y.mean(dim=0)
+        y = (y.square().mean(dim=0) + 1e-8).sqrt()
+        y = y.mean(dim=[2, 3, 4]).reshape(-1, f, 1, 1).repeat(g, 1, h, w)
+        return torch.cat([x, y], dim=1)
+
+    def extra_repr(self):
+        return f'group_size={self.group_size}, num_channels={self.num_channels:d}'
+
+
+@persistence.persistent_class
+class DiscriminatorEpilogue(torch.nn.Module):
+    """4x4 tail: mbstd -> conv -> fc -> out, projected on the label embedding when cmap_dim > 0 (:677-733)."""
+
+    def __init__(self, in_channels, cmap_dim, resolution, img_channels, architecture='resnet', mbstd_group_size=4,
+                 mbstd_num_channels=1, activation='lrelu', conv_clamp=None):
+        assert architecture in ['orig', 'skip', 'resnet']
+        super().__init__()
+        self.in_channels, self.cmap_dim, self.resolution, self.img_channels, self.architecture = in_channels, cmap_dim, resolution, img_channels, architecture
+        if architecture == 'skip':
+            self.fromrgb = Conv2dLayer(img_channels, in_channels, kernel_size=1, activation=activation)
+        self.mbstd = MinibatchStdLayer(group_size=mbstd_group_size, num_channels=mbstd_num_channels) if mbstd_num_channels > 0 else None
+        self.conv = Conv2dLayer(in_channels + mbstd_num_channels, in_channels, kernel_size=3, activation=activation, conv_clamp=conv_clamp)
+        self.fc = FullyConnectedLayer(in_channels * (resolution ** 2), in_channels, activation=activation)
+        self.out = FullyConnectedLayer(in_channels, 1 if cmap_dim == 0 else cmap_dim)
+
+    def forward(self, x, img, cmap, force_fp32=False):
+        misc.assert_shape(x, [None, self.in_channels, self.resolution, self.resolution])
+        _ = force_fp32
+        x = x.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+        if self.architecture == 'skip':
+            misc.assert_shape(img, [None, self.img_channels, self.resolution, self.resolution])
+            x = x + self.fromrgb(img.to(dtype=torch.float32, memory_format=torch.contiguous_format))
+        if self.mbstd is not None:
+            x = self.mbstd(x)
+        x = self.out(self.fc(self.conv(x).flatten(1)))
+        if self.cmap_dim > 0:
+            misc.assert_shape(cmap, [None, self.cmap_dim])
+            x = (x * cmap).sum(dim=1, keepdim=True) * (1 / np.sqrt(self.cmap_dim))
+        assert x.dtype == torch.float32
+        return x
+
+    def extra_repr(self):
+        return f'resolution={self.resolution:d}, architecture={self.architecture:s}'
+
+
+@persistence.persistent_class
+class Discriminator(torch.nn.Module):
+    """StyleGAN2 discriminator b{res}..b8 + b4 epilogue (:738-797)."""
+
+    def __init__(self, c_dim, img_resolution, img_channels, architecture='resnet', channel_base=32768, channel_max=512, num_fp16_res=4,
+                 conv_clamp=256, cmap_dim=None, block_kwargs={}, mapping_kwargs={}, epilogue_kwargs={}):
+        super().__init__()
+        self.c_dim, self.img_resolution, self.img_channels = c_dim, img_resolution, img_channels
+        self.img_resolution_log2 = int(np.log2(img_resolution))
+        self.block_resolutions = [2 ** i for i in range(self.img_resolution_log2, 2, -1)]
+        channels = {res: min(channel_base // res, channel_max) for res in self.block_resolutions + [4]}
+        fp16_resolution = max(2 ** (self.img_resolution_log2 + 1 - num_fp16_res), 8)
+        if cmap_dim is None:
+            cmap_dim = channels[4]
+        if c_dim == 0:
+            cmap_dim = 0
+        common = dict(img_channels=img_channels, architecture=architecture, conv_clamp=conv_clamp)
+        cur = 0
+        for res in self.block_resolutions:
+            block = DiscriminatorBlock(channels[res] if res < img_resolution else 0, channels[res], channels[res // 2], resolution=res,
+                                       first_layer_idx=cur, use_fp16=(res >= fp16_resolution), **block_kwargs, **common)
+            setattr(self, f'b{res}', block)
+            cur += block.num_layers
+        if c_dim > 0:
+            self.mapping = MappingNetwork(z_dim=0, c_dim=c_dim, w_dim=cmap_dim, num_ws=None, w_avg_beta=None, **mapping_kwargs)
+        self.b4 = DiscriminatorEpilogue(channels[4], cmap_dim=cmap_dim, resolution=4, **epilogue_kwargs, **common)
+
+    def forward(self, img, c, update_emas=False, **block_kwargs):
+        _ = update_emas
+        x = None
+        for res in self.block_resolutions:
+            x, img = getattr(self, f'b{res}')(x, img, **block_kwargs)
+        cmap = self.mapping(None, c) if self.c_dim > 0 else None
+        return self.b4(x, img, cmap)
+
+    def extra_repr(self):
+        return f'c_dim={self.c_dim:d}, img_resolution={self.img_resolution:d}, img_channels={self.img_channels:d}'

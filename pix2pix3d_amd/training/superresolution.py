@@ -1,0 +1,123 @@
+"""Super-resolution heads: two StyleGAN2 synthesis blocks that lift the 128^2 (or 64^2) neural rendering to the
+output resolution.  Mirror of training/superresolution.py (line refs are to that file); same class and
+parameter names."""
+import torch
+
+from ..torch_utils import persistence
+from .networks_stylegan2 import SynthesisBlock
+
+
+@persistence.persistent_class
+class SynthesisBlockNoUp(SynthesisBlock):
+    """SynthesisBlock whose conv0 keeps the resolution and whose skip image is not upsampled (:191-290)."""
+    _in_div = 1
+
+    def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, is_last, **kwargs):
+        super().__init__(in_channels, out_channels, w_dim, resolution, img_channels, is_last, **kwargs)
+        if in_channels != 0:
+            self.conv0.up = 1                      # same weights/shapes as the x2 layer, no resampling
+
+
+class _SuperresolutionBase(torch.nn.Module):
+    """ws[:, -1] feeds all three layers of both blocks; inputs are resized to ``input_resolution`` first (:312-323)."""
+    input_resolution = 128
+
+    def _prep(self, rgb, x):
+        if x.shape[-1] != self.input_resolution:
+            size = (self.input_resolution, self.input_resolution)
+            x = torch.nn.functional.interpolate(x, size=size, mode='bilinear', align_corners=False, antialias=self.sr_antialias)
+            rgb = torch.nn.functional.interpolate(rgb, size=size, mode='bilinear', align_corners=False, antialias=self.sr_antialias)
+        return rgb, x
+
+    def forward(self, rgb, x, ws, **block_kwargs):
+        ws = ws[:, -1:, :].repeat(1, 3, 1)
+        rgb, x = self._prep(rgb, x)
+        x, rgb = self.block0(x, rgb, ws, **block_kwargs)
+        x, rgb = self.block1(x, rgb, ws, **block_kwargs)
+        return rgb
+
+
+def _two_blocks(self, cls0, cls1, channels, mid, out, res0, res1, img_channels, use_fp16, block_kwargs):
+    clamp = 256 if use_fp16 else None
+    self.block0 = cls0(channels, mid, w_dim=512, resolution=res0, img_channels=img_channels, is_last=False, use_fp16=use_fp16, conv_clamp=clamp, **block_kwargs)
+    self.block1 = cls1(mid, out, w_dim=512, resolution=res1, img_channels=img_channels, is_last=True, use_fp16=use_fp16, conv_clamp=clamp, **block_kwargs)
+
+
+@persistence.persistent_class
+class SuperresolutionHybrid8XDC(_SuperresolutionBase):
+    """128^2 -> 512^2, channels 32 -> 256 -> 128 (:297-323)."""
+
+    def __init__(self, channels, img_resolution, sr_num_fp16_res, sr_antialias, num_fp16_res=4, conv_clamp=None, channel_base=None,
+                 channel_max=None, **block_kwargs):
+        super().__init__()
+        assert img_resolution == 512
+        self.input_resolution, self.sr_antialias = 128, sr_antialias
+        _two_blocks(self, SynthesisBlock, SynthesisBlock, channels, 256, 128, 256, 512, 3, sr_num_fp16_res > 0, block_kwargs)
+
+
+@persistence.persistent_class
+class SuperresolutionHybrid8XDC_semantic(_SuperresolutionBase):
+    """Label-map twin of 8XDC: ToRGB emits ``semantic_channels`` (:328-354)."""
+
+    def __init__(self, channels, img_resolution, sr_num_fp16_res, sr_antialias, semantic_channels, num_fp16_res=4, conv_clamp=None,
+                 channel_base=None, channel_max=None, **block_kwargs):
+        super().__init__()
+        assert img_resolution == 512
+        self.input_resolution, self.sr_antialias = 128, sr_antialias
+        _two_blocks(self, SynthesisBlock, SynthesisBlock, channels, 256, 128, 256, 512, semantic_channels, sr_num_fp16_res > 0, block_kwargs)
+
+
+@persistence.persistent_class
+class SuperresolutionHybrid8X(_SuperresolutionBase):
+    """128^2 -> 512^2, channels 32 -> 128 -> 64 (:28-56)."""
+
+    def __init__(self, channels, img_resolution, sr_num_fp16_res, sr_antialias, num_fp16_res=4, conv_clamp=None, channel_base=None,
+                 channel_max=None, **block_kwargs):
+        super().__init__()
+        assert img_resolution == 512
+        self.input_resolution, self.sr_antialias = 128, sr_antialias
+        _two_blocks(self, SynthesisBlock, SynthesisBlock, channels, 128, 64, 256, 512, 3, sr_num_fp16_res > 0, block_kwargs)
+        from ..torch_utils.ops import upfirdn2d
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter([1, 3, 3, 1]))
+
+
+@persistence.persistent_class
+class SuperresolutionHybrid4X(_SuperresolutionBase):
+    """128^2 -> 256^2: a no-upsampling block then a x2 block (:62-88)."""
+
+    def __init__(self, channels, img_resolution, sr_num_fp16_res, sr_antialias, num_fp16_res=4, conv_clamp=None, channel_base=None,
+                 channel_max=None, **block_kwargs):
+        super().__init__()
+        assert img_resolution == 256
+        self.input_resolution, self.sr_antialias = 128, sr_antialias
+        _two_blocks(self, SynthesisBlockNoUp, SynthesisBlock, channels, 128, 64, 128, 256, 3, sr_num_fp16_res > 0, block_kwargs)
+        from ..torch_utils.ops import upfirdn2d
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter([1, 3, 3, 1]))
+
+
+@persistence.persistent_class
+class SuperresolutionHybrid2X(_SuperresolutionBase):
+    """64^2 -> 128^2 (ShapeNet cars): a no-upsampling block then a x2 block (:94-121)."""
+
+    def __init__(self, channels, img_resolution, sr_num_fp16_res, sr_antialias, num_fp16_res=4, conv_clamp=None, channel_base=None,
+                 channel_max=None, **block_kwargs):
+        super().__init__()
+        assert img_resolution == 128
+        self.input_resolution, self.sr_antialias = 64, sr_antialias
+        _two_blocks(self, SynthesisBlockNoUp, SynthesisBlock, channels, 128, 64, 64, 128, 3, sr_num_fp16_res > 0, block_kwargs)
+        from ..torch_utils.ops import upfirdn2d
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter([1, 3, 3, 1]))
+
+
+@persistence.persistent_class
+class SuperresolutionHybrid2X_semantic(_SuperresolutionBase):
+    """Label-map twin of 2X (:127-154)."""
+
+    def __init__(self, channels, img_resolution, sr_num_fp16_res, sr_antialias, semantic_channels, num_fp16_res=4, conv_clamp=None,
+                 channel_base=None, channel_max=None, **block_kwargs):
+        super().__init__()
+        assert img_resolution == 128
+        self.input_resolution, self.sr_antialias = 64, sr_antialias
+        _two_blocks(self, SynthesisBlockNoUp, SynthesisBlock, channels, 128, 64, 64, 128, semantic_channels, sr_num_fp16_res > 0, block_kwargs)
+        from ..torch_utils.ops import upfirdn2d
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter([1, 3, 3, 1]))

@@ -1,0 +1,349 @@
+"""Conditional tri-plane generators of pix2pix3D: label-map / edge-map encoders, the conditional mapping
+networks and the generators whose ``mapping`` / ``synthesis`` / ``sample`` / ``sample_mixed`` / ``forward``
+the training loop and the applications call.
+
+Mirror of training/triplane_cond.py (line refs are to that file).  Same class names, constructor
+arguments, attribute and parameter names; ``synthesis()`` = ray sampler -> StyleGAN2 backbone ->
+fused tri-plane ray-marcher -> super-resolution head(s).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .. import dnnlib
+from ..torch_utils import misc
+from ..torch_utils import persistence
+from .networks_stylegan2 import SynthesisNetwork, FullyConnectedLayer, normalize_2nd_moment, DiscriminatorBlock
+from .triplane import OSGDecoder, _osg_mlp
+from .volumetric_rendering.renderer import ImportanceRenderer
+from .volumetric_rendering.ray_sampler import RaySampler
+
+
+@persistence.persistent_class
+class EqualConv2d(torch.nn.Module):
+    """conv2d with the 1/sqrt(fan_in) scale applied at run time (:29-62)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.randn(out_channel, in_channel, kernel_size, kernel_size))
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.stride, self.padding = stride, padding
+        self.bias = torch.nn.Parameter(torch.zeros(out_channel)) if bias else None
+
+    def forward(self, input):
+        return F.conv2d(input, self.weight * self.scale, bias=self.bias, stride=self.stride, padding=self.padding)
+
+    def __repr__(self):
+        return (f'{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]}, {self.weight.shape[2]}, '
+                f'stride={self.stride}, padding={self.padding})')
+
+
+@persistence.persistent_class
+class Encoder(torch.nn.Module):
+    """Discriminator-style pyramid down to 4x4 then a 4x4 projection to ``n_latents`` w vectors (:65-196).
+
+    Only the configuration pix2pix3D instantiates is implemented (non-progressive, no low-res head,
+    output_mode in W / W+ / None); the progressive-growing branches of the original raise."""
+
+    def __init__(self, img_resolution, img_channels, bottleneck_factor=2, architecture='resnet', channel_base=1, channel_max=512,
+                 num_fp16_res=0, conv_clamp=None, lowres_head=None, block_kwargs={}, model_kwargs={}, upsample_type='default',
+                 progressive=False, **unused):
+        super().__init__()
+        if progressive or lowres_head is not None or model_kwargs.get('predict_camera', False):
+            raise NotImplementedError('Encoder: progressive / lowres_head / predict_camera variants are not part of the pix2pix3D path')
+        self.img_resolution, self.img_channels = img_resolution, img_channels
+        self.img_resolution_log2 = int(np.log2(img_resolution))
+        self.block_resolutions = [2 ** i for i in range(self.img_resolution_log2, bottleneck_factor, -1)]
+        self.architecture, self.lowres_head, self.upsample_type, self.progressive = architecture, lowres_head, upsample_type, progressive
+        self.model_kwargs = model_kwargs
+        self.output_mode = model_kwargs.get('output_mode', 'styles')
+        self.predict_camera = False
+        channel_base = int(channel_base * 32768)
+        channels = {res: min(channel_base // res, channel_max) for res in self.block_resolutions + [4]}
+        fp16_resolution = max(2 ** (self.img_resolution_log2 + 1 - num_fp16_res), 8)
+        common = dict(img_channels=img_channels, architecture=architecture, conv_clamp=conv_clamp)
+        cur = 0
+        for res in self.block_resolutions:
+            block = DiscriminatorBlock(channels[res] if res < img_resolution else 0, channels[res], channels[res // 2], resolution=res,
+                                       first_layer_idx=cur, use_fp16=(res >= fp16_resolution), **block_kwargs, **common)
+            setattr(self, f'b{res}', block)
+            cur += block.num_layers
+        if self.output_mode not in ['W', 'W+', 'None']:
+            raise NotImplementedError
+        self.num_ws = model_kwargs.get('num_ws', 0)
+        self.n_latents = self.num_ws if self.output_mode == 'W+' else (0 if self.output_mode == 'None' else 1)
+        self.w_dim = model_kwargs.get('w_dim', 512)
+        self.add_dim = model_kwargs.get('add_dim', 0)
+        self.out_dim = self.w_dim * self.n_latents + self.add_dim
+        assert self.out_dim > 0, 'output dimenstion has to be larger than 0'
+        assert self.block_resolutions[-1] // 2 == 4, 'make sure the last resolution is 4x4'
+        self.projector = EqualConv2d(channels[4], self.out_dim, 4, padding=0, bias=False)
+        self.register_buffer('alpha', torch.scalar_tensor(-1))
+
+    def set_alpha(self, alpha):
+        if alpha is not None:
+            self.alpha.fill_(alpha)
+
+    def set_resolution(self, res):
+        self.curr_status = res
+
+    def forward(self, inputs, **block_kwargs):
+        img = inputs['img'] if isinstance(inputs, dict) else inputs
+        assert img.size(-1) == self.block_resolutions[0], 'Encoder: input must already be at img_resolution'
+        x = None
+        for res in self.block_resolutions:
+            x, img = getattr(self, f'b{res}')(x, img, **block_kwargs)
+        out = self.projector(x)[:, :, 0, 0]
+        if self.output_mode == 'W+':
+            out = out.reshape(out.shape[0], self.num_ws, self.w_dim)
+        elif self.output_mode == 'W':
+            out = out.unsqueeze(1).expand(-1, self.num_ws, -1)
+        else:
+            out = None
+        return {'ws': out}
+
+
+class _DisentangledMapping(torch.nn.Module):
+    """Shared body of the two conditional mapping networks (:301-399, :499-592): the first ``geometry_layer``
+    (= 7) ws come from the conditioning image through the Encoder, the remaining ones from z (and the
+    embedded camera label) through the usual 8-layer MLP."""
+
+    def _setup(self, z_dim, c_dim, in_resolution, in_channels, w_dim, num_ws, num_layers, embed_features, layer_features,
+               activation, lr_multiplier, w_avg_beta):
+        self.z_dim, self.c_dim, self.in_resolution, self.in_channels = z_dim, c_dim, in_resolution, in_channels
+        self.w_dim, self.num_ws, self.num_layers, self.w_avg_beta = w_dim, num_ws, num_layers, w_avg_beta
+        self.geometry_layer = 7
+        embed_features = w_dim if embed_features is None else embed_features
+        layer_features = w_dim if layer_features is None else layer_features
+        sizes = [z_dim + (embed_features if c_dim > 0 else 0)] + [layer_features] * (num_layers - 1) + [w_dim]
+        if c_dim > 0:
+            self.embed = FullyConnectedLayer(c_dim, embed_features)
+        self.embed_mask = Encoder(img_resolution=in_resolution, img_channels=in_channels,
+                                  model_kwargs={'num_ws': self.geometry_layer, 'w_dim': w_dim, 'output_mode': 'W+'})
+        for idx in range(num_layers):
+            setattr(self, f'fc{idx}', FullyConnectedLayer(sizes[idx], sizes[idx + 1], activation=activation, lr_multiplier=lr_multiplier))
+        if num_ws is not None and w_avg_beta is not None:
+            self.register_buffer('w_avg', torch.zeros([num_ws, w_dim]))
+
+    def _condition_image(self, batch, n):
+        raise NotImplementedError
+
+    def forward(self, z=None, c=None, batch=None, truncation_psi=1, truncation_cutoff=None, update_emas=False, **unused_kwargs):
+        x = None
+        with torch.autograd.profiler.record_function('input'):
+            if self.z_dim > 0:
+                misc.assert_shape(z, [None, self.z_dim])
+                x = normalize_2nd_moment(z.to(torch.float32))
+            if self.c_dim > 0:
+                misc.assert_shape(c, [None, self.c_dim])
+                e = normalize_2nd_moment(self.embed(c.to(torch.float32)))
+                x = torch.cat([x, e], dim=1) if x is not None else e
+        for idx in range(self.num_layers):
+            x = getattr(self, f'fc{idx}')(x)
+
+        cond = self._condition_image(batch, z.shape[0])
+        misc.assert_shape(cond, [z.shape[0], self.in_channels, self.in_resolution, self.in_resolution])
+        y = self.embed_mask(cond.to(torch.float32))['ws']                       # [N, 7, w_dim]
+        misc.assert_shape(y, [None, self.geometry_layer, self.w_dim])
+
+        if self.num_ws is not None:
+            with torch.autograd.profiler.record_function('broadcast'):
+                x = torch.cat([y, x.unsqueeze(1).repeat([1, self.num_ws - self.geometry_layer, 1])], dim=1)
+        if self.w_avg_beta is not None and update_emas:
+            with torch.autograd.profiler.record_function('update_w_avg'):
+                self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+        if truncation_psi != 1:
+            with torch.autograd.profiler.record_function('truncate'):
+                assert self.w_avg_beta is not None
+                if self.num_ws is None or truncation_cutoff is None:
+                    x = self.w_avg.lerp(x, truncation_psi)
+                else:
+                    x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
+        return x
+
+
+@persistence.persistent_class
+class MaskMappingNetwork_disentangle(_DisentangledMapping):
+    """Label-map conditioning: integer mask -> one-hot -> Encoder (:301-399)."""
+
+    def __init__(self, z_dim, c_dim, in_resolution, in_channels, w_dim, num_ws, num_layers=8, embed_features=None, layer_features=None,
+                 activation='lrelu', lr_multiplier=0.01, w_avg_beta=0.995, one_hot=True, **unused):
+        super().__init__()
+        self.one_hot = one_hot
+        self._setup(z_dim, c_dim, in_resolution, in_channels, w_dim, num_ws, num_layers, embed_features, layer_features, activation, lr_multiplier, w_avg_beta)
+
+    def _condition_image(self, batch, n):
+        misc.assert_shape(batch['mask'], [n, 1, None, None])
+        if self.one_hot:
+            return torch.nn.functional.one_hot(batch['mask'].squeeze(1).long(), self.in_channels).permute(0, 3, 1, 2)
+        return batch['mask']
+
+
+@persistence.persistent_class
+class EdgeMappingNetwork_disentangle(_DisentangledMapping):
+    """Edge-map conditioning: the float edge image goes to the Encoder as is (:499-592)."""
+
+    def __init__(self, z_dim, c_dim, in_resolution, in_channels, w_dim, num_ws, num_layers=8, embed_features=None, layer_features=None,
+                 activation='lrelu', lr_multiplier=0.01, w_avg_beta=0.995, **unused):
+        super().__init__()
+        self._setup(z_dim, c_dim, in_resolution, in_channels, w_dim, num_ws, num_layers, embed_features, layer_features, activation, lr_multiplier, w_avg_beta)
+
+    def _condition_image(self, batch, n):
+        return batch['mask'].to(torch.float32)
+
+
+@persistence.persistent_class
+class Generator_cond(torch.nn.Module):
+    """StyleGAN2 backbone whose mapping network is chosen by name through ``mapping_kwargs['class_name']`` (:596-621)."""
+
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs={}, **synthesis_kwargs):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim, self.img_resolution, self.img_channels = z_dim, c_dim, w_dim, img_resolution, img_channels
+        self.synthesis = SynthesisNetwork(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels, **synthesis_kwargs)
+        self.num_ws = self.synthesis.num_ws
+        self.mapping = dnnlib.util.construct_class_by_name(**mapping_kwargs, z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws)
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        return self.synthesis(ws, update_emas=update_emas, **synthesis_kwargs)
+
+
+class OSGDecoder_semantic_lateSeparate(torch.nn.Module):
+    """Two independent 32-64-33 MLPs on the plane-averaged feature: a colour net and a label net; the density is
+    channel 0 of the LABEL net (:926-970).  Output 'rgb' = cat(32 colour channels, 32 label channels)."""
+
+    def __init__(self, n_features, options):
+        super().__init__()
+        self.hidden_dim = 64
+        self.net = _osg_mlp(n_features, self.hidden_dim, 1 + options['decoder_output_dim'], options['decoder_lr_mul'])
+        self.net_semantic = _osg_mlp(n_features, self.hidden_dim, 1 + options['decoder_output_dim'], options['decoder_lr_mul'])
+        self.semantic_sigmoid = options['sigmoid']
+
+    def forward(self, sampled_features, ray_directions):
+        x = sampled_features.mean(1)
+        n, m, c = x.shape
+        flat = x.reshape(n * m, c)
+        colour = self.net(flat).reshape(n, m, -1)
+        label = self.net_semantic(flat).reshape(n, m, -1)
+        squash = lambda t: torch.sigmoid(t) * (1 + 2 * 0.001) - 0.001
+        rgb = squash(colour[..., 1:])
+        sem = squash(label[..., 1:]) if self.semantic_sigmoid else label[..., 1:]
+        return {'rgb': torch.cat((rgb, sem), dim=-1), 'sigma': label[..., 0:1]}
+
+
+class _TriPlaneBase(torch.nn.Module):
+    """What the conditional tri-plane generators share: camera split, backbone (with the one-slot plane cache),
+    rendering, point queries."""
+
+    def _init_common(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs, rendering_kwargs, synthesis_kwargs):
+        self.z_dim, self.c_dim, self.w_dim, self.img_resolution, self.img_channels = z_dim, c_dim, w_dim, img_resolution, img_channels
+        self.renderer = ImportanceRenderer()
+        self.ray_sampler = RaySampler()
+        self.backbone = Generator_cond(z_dim, c_dim, w_dim, img_resolution=256, img_channels=32 * 3, mapping_kwargs=mapping_kwargs, **synthesis_kwargs)
+
+    def _finish_init(self, rendering_kwargs):
+        self.neural_rendering_resolution = 64
+        self.rendering_kwargs = rendering_kwargs
+        self._last_planes = None
+
+    def mapping(self, z, c, batch, truncation_psi=1, truncation_cutoff=None, update_emas=False):
+        if self.rendering_kwargs['c_gen_conditioning_zero']:
+            c = torch.zeros_like(c)
+        return self.backbone.mapping(z, c * self.rendering_kwargs.get('c_scale', 0), batch, truncation_psi=truncation_psi,
+                                     truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+
+    def _planes(self, ws, update_emas, synthesis_kwargs, cache_backbone=False, use_cached_backbone=False):
+        if use_cached_backbone and self._last_planes is not None:
+            planes = self._last_planes
+        else:
+            planes = self.backbone.synthesis(ws, update_emas=update_emas, **synthesis_kwargs)
+        if cache_backbone:
+            self._last_planes = planes
+        return planes.view(len(planes), 3, 32, planes.shape[-2], planes.shape[-1])
+
+    def _render(self, ws, c, neural_rendering_resolution, update_emas, cache_backbone, use_cached_backbone, synthesis_kwargs):
+        cam2world = c[:, :16].view(-1, 4, 4)
+        intrinsics = c[:, 16:25].view(-1, 3, 3)
+        if neural_rendering_resolution is None:
+            neural_rendering_resolution = self.neural_rendering_resolution
+        else:
+            self.neural_rendering_resolution = neural_rendering_resolution
+        ray_o, ray_d = self.ray_sampler(cam2world, intrinsics, neural_rendering_resolution)
+        n = ray_o.shape[0]
+        planes = self._planes(ws, update_emas, synthesis_kwargs, cache_backbone, use_cached_backbone)
+        feat, depth, _ = self.renderer(planes, self.decoder, ray_o, ray_d, self.rendering_kwargs)
+        r = self.neural_rendering_resolution
+        feature_image = feat.permute(0, 2, 1).reshape(n, feat.shape[-1], r, r).contiguous()
+        depth_image = depth.permute(0, 2, 1).reshape(n, 1, r, r)
+        return feature_image, depth_image
+
+    def _sr_kwargs(self, synthesis_kwargs):
+        kw = {k: v for k, v in synthesis_kwargs.items() if k != 'noise_mode'}
+        return dict(noise_mode=self.rendering_kwargs['superresolution_noise_mode'], **kw)
+
+    def sample(self, coordinates, directions, z, c, batch, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
+        """Colour features + density at arbitrary 3-D points (shape extraction)."""
+        ws = self.mapping(z, batch['pose'], batch, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        return self.sample_mixed(coordinates, directions, ws, update_emas=update_emas, **synthesis_kwargs)
+
+    def sample_mixed(self, coordinates, directions, ws, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
+        planes = self._planes(ws, update_emas, synthesis_kwargs)
+        return self.renderer.run_model(planes, self.decoder, coordinates, directions, self.rendering_kwargs)
+
+    def forward(self, z, c, batch, truncation_psi=1, truncation_cutoff=None, neural_rendering_resolution=None, update_emas=False,
+                cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
+        ws = self.mapping(z, batch['pose'], batch, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        return self.synthesis(ws, c, update_emas=update_emas, neural_rendering_resolution=neural_rendering_resolution,
+                              cache_backbone=cache_backbone, use_cached_backbone=use_cached_backbone, **synthesis_kwargs)
+
+
+@persistence.persistent_class
+class TriPlaneGenerator(_TriPlaneBase):
+    """Image-only conditional generator: one OSG decoder, one SR head (:626-715)."""
+
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, sr_num_fp16_res=0, mapping_kwargs={}, rendering_kwargs={},
+                 sr_kwargs={}, **synthesis_kwargs):
+        super().__init__()
+        self._init_common(z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs, rendering_kwargs, synthesis_kwargs)
+        self.superresolution = dnnlib.util.construct_class_by_name(class_name=rendering_kwargs['superresolution_module'], channels=32,
+                                                                   img_resolution=img_resolution, sr_num_fp16_res=sr_num_fp16_res,
+                                                                   sr_antialias=rendering_kwargs['sr_antialias'], **sr_kwargs)
+        self.decoder = OSGDecoder(32, {'decoder_lr_mul': rendering_kwargs.get('decoder_lr_mul', 1), 'decoder_output_dim': 32})
+        self._finish_init(rendering_kwargs)
+
+    def synthesis(self, ws, c, neural_rendering_resolution=None, update_emas=False, cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
+        feature_image, depth_image = self._render(ws, c, neural_rendering_resolution, update_emas, cache_backbone, use_cached_backbone, synthesis_kwargs)
+        rgb_image = feature_image[:, :3]
+        sr_image = self.superresolution(rgb_image, feature_image, ws, **self._sr_kwargs(synthesis_kwargs))
+        return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image}
+
+
+@persistence.persistent_class
+class TriPlaneSemanticEntangleGenerator(_TriPlaneBase):
+    """The generator train.py selects (train.py:374-380): shared planes, two-net decoder, colour and label SR heads (:975-1079)."""
+
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, semantic_channels, sr_num_fp16_res=0, mapping_kwargs={},
+                 rendering_kwargs={}, sr_kwargs={}, data_type=None, **synthesis_kwargs):
+        super().__init__()
+        self._init_common(z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs, rendering_kwargs, synthesis_kwargs)
+        self.semantic_channels, self.data_type = semantic_channels, data_type
+        sr_common = dict(channels=32, img_resolution=img_resolution, sr_num_fp16_res=sr_num_fp16_res, sr_antialias=rendering_kwargs['sr_antialias'])
+        self.superresolution = dnnlib.util.construct_class_by_name(class_name=rendering_kwargs['superresolution_module'], **sr_common, **sr_kwargs)
+        self.superresolution_semantic = dnnlib.util.construct_class_by_name(class_name=rendering_kwargs['superresolution_module_semantic'],
+                                                                            semantic_channels=semantic_channels, **sr_common, **sr_kwargs)
+        self.decoder = OSGDecoder_semantic_lateSeparate(32, {'decoder_lr_mul': rendering_kwargs.get('decoder_lr_mul', 1), 'decoder_output_dim': 32,
+                                                             'sigmoid': semantic_channels == 1, 'semantic_channels': semantic_channels})
+        self._finish_init(rendering_kwargs)
+
+    def synthesis(self, ws, c, neural_rendering_resolution=None, update_emas=False, cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
+        feature_image, depth_image = self._render(ws, c, neural_rendering_resolution, update_emas, cache_backbone, use_cached_backbone, synthesis_kwargs)
+        half = feature_image.shape[1] // 2
+        rgb_feat, sem_feat = feature_image[:, :half], feature_image[:, half:]
+        sr_kw = self._sr_kwargs(synthesis_kwargs)
+        rgb_image = rgb_feat[:, :3]
+        sr_image = self.superresolution(rgb_image, rgb_feat, ws, **sr_kw)
+        semantic_image = sem_feat[:, :self.semantic_channels]
+        sr_semantic = self.superresolution_semantic(semantic_image, sem_feat, ws, **sr_kw)
+        return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image, 'semantic': sr_semantic, 'semantic_raw': semantic_image}

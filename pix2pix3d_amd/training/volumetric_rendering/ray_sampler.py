@@ -1,0 +1,29 @@
+"""Pixel-centre rays from OpenCV-convention cameras (reference: training/volumetric_rendering/ray_sampler.py:24-62)."""
+import torch
+
+
+class RaySampler(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.ray_origins_h, self.ray_directions, self.depths, self.image_coords, self.rendering_options = None, None, None, None, None
+
+    def forward(self, cam2world_matrix, intrinsics, resolution):
+        """cam2world [N,4,4], intrinsics [N,3,3] (normalised: fx, fy, cx, cy, skew) -> origins, directions [N, R*R, 3].
+
+        Pixel (row i, col j) has image coordinates ((j+.5)/R, (i+.5)/R); it is lifted to z = 1 in the camera
+        frame, moved to world space and the direction normalised.  Rays are ordered row-major."""
+        n, dev = cam2world_matrix.shape[0], cam2world_matrix.device
+        r = int(resolution)
+        fx, fy = intrinsics[:, 0, 0, None], intrinsics[:, 1, 1, None]
+        cx, cy, sk = intrinsics[:, 0, 2, None], intrinsics[:, 1, 2, None], intrinsics[:, 0, 1, None]
+        centres = torch.arange(r, dtype=torch.float32, device=dev) * (1. / r) + (0.5 / r)
+        x_img = centres.repeat(r)[None].expand(n, -1)                    # column coordinate varies fastest
+        y_img = centres.repeat_interleave(r)[None].expand(n, -1)
+        x_cam = (x_img - cx + cy * sk / fy - sk * y_img / fy) / fx
+        y_cam = (y_img - cy) / fy
+        ones = torch.ones_like(x_cam)
+        pts = torch.stack([x_cam, y_cam, ones, ones], dim=-1)            # [N, M, 4] homogeneous, z = 1
+        world = torch.bmm(cam2world_matrix, pts.transpose(1, 2)).transpose(1, 2)[:, :, :3]
+        origin = cam2world_matrix[:, :3, 3]
+        dirs = torch.nn.functional.normalize(world - origin[:, None, :], dim=2)
+        return origin[:, None, :].expand(-1, r * r, -1).contiguous(), dirs

@@ -1,0 +1,344 @@
+"""Tri-plane importance renderer.
+
+Host-side mirror of training/volumetric_rendering/renderer.py:88-253 (``ImportanceRenderer``): same
+constructor, ``forward(planes, decoder, ray_origins, ray_directions, rendering_options)`` and
+``run_model(...)`` signatures, same ``rendering_options`` keys, same RNG draws in the same order.
+
+Device tensors without autograd run ONE fused HIP kernel (csrc/render.hip through
+``p3d_render_forward`` / ``p3d_sample_points``).  CPU tensors — and graphs that need gradients,
+until the fused backward lands — run the tensor-op restatement below (``_forward_tensor_ops``),
+which is also what the reference does on every device.  ``fused_policy = 'require'`` turns any
+silent use of the tensor-op path on a device tensor into an error.
+"""
+import ctypes
+
+import torch
+
+from ... import _lib
+from . import math_utils
+from .ray_marcher import MipRayMarcher2
+
+fused_policy = 'auto'          # 'auto' | 'require' | 'never'
+
+
+class _RenderDesc(ctypes.Structure):          # p3d_render_desc (include/p3d_hip.h)
+    _fields_ = [('n_img', ctypes.c_int32), ('rays_per_img', ctypes.c_int32), ('plane_h', ctypes.c_int32), ('plane_w', ctypes.c_int32),
+                ('n_nets', ctypes.c_int32), ('semantic_sigmoid', ctypes.c_int32), ('depth_resolution', ctypes.c_int32),
+                ('depth_resolution_importance', ctypes.c_int32), ('disparity_space_sampling', ctypes.c_int32), ('white_back', ctypes.c_int32),
+                ('ray_start', ctypes.c_float), ('ray_end', ctypes.c_float), ('box_warp', ctypes.c_float)]
+
+
+_vp, _i32, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
+_lib.register('p3d_render_decoder_floats', ctypes.c_int, [])
+_lib.register('p3d_planes_to_channels_last', ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp])
+_lib.register('p3d_pack_decoder', ctypes.c_int, [_vp] * 8 + [_i32, _f32, _vp, _vp])
+_lib.register('p3d_render_forward', ctypes.c_int, [_vp] * 8 + [ctypes.POINTER(_RenderDesc)] + [_vp] * 6 + [_vp])
+_lib.register('p3d_sample_points', ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(_RenderDesc), _i32, _vp, _vp, _vp])
+_lib.register('p3d_importance_sample', ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp])
+
+
+def generate_planes():
+    """Axes of the three feature planes (renderer.py:23-37): rows of each 3x3 are the plane's basis vectors."""
+    return torch.tensor([[[1, 0, 0], [0, 1, 0], [0, 0, 1]],
+                         [[1, 0, 0], [0, 0, 1], [0, 1, 0]],
+                         [[0, 0, 1], [1, 0, 0], [0, 1, 0]]], dtype=torch.float32)
+
+
+def project_onto_planes(planes, coordinates):
+    """coordinates [N,M,3] -> in-plane (u, v) per plane, [N*n_planes, M, 2] (renderer.py:39-53)."""
+    n, m, _ = coordinates.shape
+    k = planes.shape[0]
+    inv = torch.linalg.inv(planes)                                     # [k,3,3]
+    uvw = torch.einsum('nmc,kcd->nkmd', coordinates, inv)              # row vector times inverse basis
+    return uvw.reshape(n * k, m, 3)[..., :2]
+
+
+def sample_from_planes(plane_axes, plane_features, coordinates, mode='bilinear', padding_mode='zeros', box_warp=None):
+    """Bilinear taps of every plane at the projected points: [N, n_planes, M, C] (renderer.py:55-65)."""
+    assert padding_mode == 'zeros'
+    n, k, c, h, w = plane_features.shape
+    m = coordinates.shape[1]
+    uv = project_onto_planes(plane_axes, (2 / box_warp) * coordinates).unsqueeze(1)
+    out = torch.nn.functional.grid_sample(plane_features.reshape(n * k, c, h, w), uv.float(), mode=mode,
+                                          padding_mode=padding_mode, align_corners=False)
+    return out.permute(0, 3, 2, 1).reshape(n, k, m, c)
+
+
+def _decoder_nets(decoder):
+    """Recognise the OSG decoders the fused kernel implements; returns (nets, lr_mul-free raw params, sigmoid flag) or None.
+
+    OSGDecoder (training/triplane.py:112-135): one 32->64->33 MLP.  OSGDecoder_semantic_lateSeparate
+    (training/triplane_cond.py:926-970): colour net + label net, density from the label net."""
+    nets = []
+    for name in ('net', 'net_semantic'):
+        seq = getattr(decoder, name, None)
+        if seq is None:
+            continue
+        if not (isinstance(seq, torch.nn.Sequential) and len(seq) == 3 and isinstance(seq[1], torch.nn.Softplus)):
+            return None
+        fc1, fc2 = seq[0], seq[2]
+        ok = all(hasattr(fc, 'weight_gain') and hasattr(fc, 'bias_gain') and getattr(fc, 'activation', None) == 'linear' and fc.bias is not None for fc in (fc1, fc2))
+        if not ok or tuple(fc1.weight.shape) != (64, 32) or tuple(fc2.weight.shape) != (33, 64):
+            return None
+        if seq[1].beta != 1 or seq[1].threshold != 20:
+            return None
+        nets.append((fc1, fc2))
+    if len(nets) not in (1, 2) or (len(nets) == 2 and not hasattr(decoder, 'semantic_sigmoid')):
+        return None
+    if len(nets) == 1 and type(decoder).__name__ != 'OSGDecoder':
+        return None                                  # e.g. OSGDecoder_semantic slices its outputs differently
+    lr = float(nets[0][0].bias_gain)
+    for fc1, fc2 in nets:
+        if abs(fc1.weight_gain - lr / 32 ** 0.5) > 1e-12 or abs(fc2.weight_gain - lr / 64 ** 0.5) > 1e-12 or fc1.bias_gain != lr or fc2.bias_gain != lr:
+            return None
+    return nets, lr, bool(getattr(decoder, 'semantic_sigmoid', False))
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+class _FusedContext:
+    """Device-side operands shared by the fused entry points: channels-last planes + packed decoder."""
+
+    def __init__(self, planes, decoder_info):
+        nets, lr_mul, sem_sigmoid = decoder_info
+        lib = _lib.lib()
+        n, k, c, h, w = planes.shape
+        assert k == 3 and c == 32
+        src = _f32c(planes)
+        self.planes_cl = torch.empty([n, 3, h, w, 32], dtype=torch.float32, device=planes.device)
+        _lib.check(lib.p3d_planes_to_channels_last(_lib.ptr(src), _lib.ptr(self.planes_cl), n, h, w, _lib.stream_of(src)), 'planes_to_channels_last')
+        self.packed = torch.empty([lib.p3d_render_decoder_floats()], dtype=torch.float32, device=planes.device)
+        ws = []
+        for fc1, fc2 in nets:
+            ws += [_f32c(fc1.weight), _f32c(fc1.bias), _f32c(fc2.weight), _f32c(fc2.bias)]
+        ptrs = [_lib.ptr(t) for t in ws] + [None] * (8 - len(ws))
+        _lib.check(lib.p3d_pack_decoder(*ptrs, len(nets), lr_mul, _lib.ptr(self.packed), _lib.stream_of(src)), 'pack_decoder')
+        self._keep = ws
+        self.n_nets, self.sem_sigmoid, self.n, self.h, self.w = len(nets), sem_sigmoid, n, h, w
+
+    def desc(self, options, rays_per_img=1, start=0.0, end=0.0):
+        return _RenderDesc(self.n, rays_per_img, self.h, self.w, self.n_nets, int(self.sem_sigmoid),
+                           int(options.get('depth_resolution', 0)), int(options.get('depth_resolution_importance', 0)),
+                           int(bool(options.get('disparity_space_sampling', False))), int(bool(options.get('white_back', False))),
+                           float(start), float(end), float(options['box_warp']))
+
+
+class ImportanceRenderer(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.ray_marcher = MipRayMarcher2()
+        self.plane_axes = generate_planes()
+
+    # ------------------------------------------------------------------------------------------------
+    def _fused_reason(self, planes, decoder, options, needs_grad):
+        """None when the fused kernel applies, else why not."""
+        if fused_policy == 'never':
+            return 'fused_policy == never'
+        if planes.device.type != 'cuda':
+            return 'CPU tensors'
+        if needs_grad:
+            return 'autograd graph requested (fused backward not available yet)'
+        if planes.ndim != 5 or planes.shape[1] != 3 or planes.shape[2] != 32:
+            return f'planes shape {tuple(planes.shape)} is not [N,3,32,H,W]'
+        if options.get('density_noise', 0) > 0:
+            return 'density_noise > 0'
+        if _decoder_nets(decoder) is None:
+            return f'decoder {type(decoder).__name__} is not an OSG 32-64-33 decoder'
+        return None
+
+    def _tensor_op_guard(self, planes, reason):
+        if planes.device.type == 'cuda' and fused_policy == 'require':
+            raise RuntimeError(f'ImportanceRenderer: fused HIP path required but unavailable: {reason}')
+
+    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options):
+        self.plane_axes = self.plane_axes.to(ray_origins.device)
+        needs_grad = torch.is_grad_enabled() and (planes.requires_grad or ray_origins.requires_grad or ray_directions.requires_grad
+                                                  or any(p.requires_grad for p in decoder.parameters()))
+        reason = self._fused_reason(planes, decoder, rendering_options, needs_grad)
+        if reason is None:
+            out = self._forward_fused(planes, decoder, ray_origins, ray_directions, rendering_options)
+            if out is not None:
+                return out
+            reason = 'sample counts outside the fused kernel envelope (<= 64 coarse, 1..64 fine)'
+        self._tensor_op_guard(planes, reason)
+        return self._forward_tensor_ops(planes, decoder, ray_origins, ray_directions, rendering_options)
+
+    # ------------------------------------------------------------------------------------------------
+    def _ray_limits(self, ray_origins, ray_directions, opt):
+        """('auto' branch, renderer.py:91-97) per-ray near/far from the box, invalid rays patched."""
+        t0, t1 = math_utils.get_ray_limits_box(ray_origins, ray_directions, box_side_length=opt['box_warp'])
+        ok = t1 > t0
+        if torch.any(ok).item():
+            t0[~ok] = t0[ok].min()
+            t1[~ok] = t0[ok].max()
+        return t0, t1
+
+    def _forward_fused(self, planes, decoder, ray_origins, ray_directions, opt):
+        n, m, _ = ray_origins.shape
+        sc, sf = int(opt['depth_resolution']), int(opt['depth_resolution_importance'])
+        if not (4 <= sc <= 64 and 1 <= sf <= 64):
+            return None
+        dev = planes.device
+        t0 = t1 = None
+        if opt['ray_start'] == opt['ray_end'] == 'auto':
+            t0, t1 = self._ray_limits(ray_origins, ray_directions, opt)
+        # the reference's draws, in its order: rand_like(depths_coarse) [N,M,Sc,1] (renderer.py:190) then rand(N*M, Sf) (:237)
+        u_c = torch.rand([n, m, sc, 1], device=dev, dtype=torch.float32)
+        u_f = torch.rand([n * m, sf], device=dev, dtype=torch.float32)
+        return fused_render(planes, decoder, ray_origins, ray_directions, opt, u_c, u_f, t0, t1)
+
+    # ------------------------------------------------------------------------------------------------
+    def _forward_tensor_ops(self, planes, decoder, ray_origins, ray_directions, opt):
+        if opt['ray_start'] == opt['ray_end'] == 'auto':
+            t0, t1 = self._ray_limits(ray_origins, ray_directions, opt)
+            z_c = self.sample_stratified(ray_origins, t0, t1, opt['depth_resolution'], opt['disparity_space_sampling'])
+        else:
+            z_c = self.sample_stratified(ray_origins, opt['ray_start'], opt['ray_end'], opt['depth_resolution'], opt['disparity_space_sampling'])
+        n, m, sc, _ = z_c.shape
+
+        def decode(z):
+            s = z.shape[2]
+            pts = (ray_origins.unsqueeze(-2) + z * ray_directions.unsqueeze(-2)).reshape(n, -1, 3)
+            dirs = ray_directions.unsqueeze(-2).expand(-1, -1, s, -1).reshape(n, -1, 3)
+            out = self.run_model(planes, decoder, pts, dirs, opt)
+            return out['rgb'].reshape(n, m, s, -1), out['sigma'].reshape(n, m, s, 1)
+
+        c_c, s_c = decode(z_c)
+        sf = opt['depth_resolution_importance']
+        if sf > 0:
+            _, _, w = self.ray_marcher(c_c, s_c, z_c, opt)
+            z_f = self.sample_importance(z_c, w, sf)
+            c_f, s_f = decode(z_f)
+            z_all, c_all, s_all = self.unify_samples(z_c, c_c, s_c, z_f, c_f, s_f)
+            rgb, depth, w = self.ray_marcher(c_all, s_all, z_all, opt)
+        else:
+            rgb, depth, w = self.ray_marcher(c_c, s_c, z_c, opt)
+        return rgb, depth, w.sum(2)
+
+    def run_model(self, planes, decoder, sample_coordinates, sample_directions, options):
+        """Sample the planes at 3-D points and decode: {'rgb': [N,P,C], 'sigma': [N,P,1]} (renderer.py:142-148)."""
+        self.plane_axes = self.plane_axes.to(sample_coordinates.device)
+        needs_grad = torch.is_grad_enabled() and (planes.requires_grad or sample_coordinates.requires_grad
+                                                  or any(p.requires_grad for p in decoder.parameters()))
+        reason = self._fused_reason(planes, decoder, options, needs_grad)
+        if reason is None:
+            n, p, _ = sample_coordinates.shape
+            ctx = _FusedContext(planes, _decoder_nets(decoder))
+            xyz = _f32c(sample_coordinates)
+            rgb = torch.empty([n, p, 32 * ctx.n_nets], device=planes.device, dtype=torch.float32)
+            sigma = torch.empty([n, p, 1], device=planes.device, dtype=torch.float32)
+            d = ctx.desc(options)
+            code = _lib.lib().p3d_sample_points(_lib.ptr(ctx.planes_cl), _lib.ptr(ctx.packed), _lib.ptr(xyz), ctypes.byref(d), p,
+                                                _lib.ptr(rgb), _lib.ptr(sigma), _lib.stream_of(rgb))
+            _lib.check(code, 'sample_points')
+            return {'rgb': rgb, 'sigma': sigma}
+        self._tensor_op_guard(planes, reason)
+        feats = sample_from_planes(self.plane_axes, planes, sample_coordinates, padding_mode='zeros', box_warp=options['box_warp'])
+        out = decoder(feats, sample_directions)
+        if options.get('density_noise', 0) > 0:
+            out['sigma'] += torch.randn_like(out['sigma']) * options['density_noise']
+        return out
+
+    # ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _sorted_gather(depths, colors, densities):
+        _, order = torch.sort(depths, dim=-2)
+        take = lambda t: torch.gather(t, -2, order.expand(-1, -1, -1, t.shape[-1]))
+        return take(depths), take(colors), take(densities)
+
+    def sort_samples(self, all_depths, all_colors, all_densities):
+        return self._sorted_gather(all_depths, all_colors, all_densities)
+
+    def unify_samples(self, depths1, colors1, densities1, depths2, colors2, densities2):
+        """Concatenate both sample sets along the ray and order them by depth (renderer.py:157-167)."""
+        return self._sorted_gather(torch.cat([depths1, depths2], dim=-2), torch.cat([colors1, colors2], dim=-2),
+                                   torch.cat([densities1, densities2], dim=-2))
+
+    def sample_stratified(self, ray_origins, ray_start, ray_end, depth_resolution, disparity_space_sampling=False):
+        """Jittered, evenly spaced depths [N,M,S,1]; one uniform per sample (renderer.py:169-192)."""
+        n, m, _ = ray_origins.shape
+        dev, s = ray_origins.device, depth_resolution
+        if disparity_space_sampling:
+            t = torch.linspace(0, 1, s, device=dev).reshape(1, 1, s, 1).repeat(n, m, 1, 1)
+            t += torch.rand_like(t) * (1 / (s - 1))
+            return 1. / (1. / ray_start * (1. - t) + 1. / ray_end * t)
+        if isinstance(ray_start, torch.Tensor):
+            z = math_utils.linspace(ray_start, ray_end, s).permute(1, 2, 0, 3)
+            z += torch.rand_like(z) * ((ray_end - ray_start) / (s - 1))[..., None]
+            return z
+        z = torch.linspace(ray_start, ray_end, s, device=dev).reshape(1, 1, s, 1).repeat(n, m, 1, 1)
+        z += torch.rand_like(z) * ((ray_end - ray_start) / (s - 1))
+        return z
+
+    def sample_importance(self, z_vals, weights, N_importance):
+        """Importance depths from the coarse weights [N,M,S_f,1], detached (renderer.py:194-212)."""
+        with torch.no_grad():
+            n, m, s, _ = z_vals.shape
+            z = z_vals.reshape(n * m, s)
+            w = weights.reshape(n * m, -1)
+            w = torch.nn.functional.max_pool1d(w.unsqueeze(1).float(), 2, 1, padding=1)
+            w = torch.nn.functional.avg_pool1d(w, 2, 1).squeeze(1) + 0.01
+            mids = 0.5 * (z[:, :-1] + z[:, 1:])
+            return self.sample_pdf(mids, w[:, 1:-1], N_importance).detach().reshape(n, m, N_importance, 1)
+
+    def sample_pdf(self, bins, weights, N_importance, det=False, eps=1e-5):
+        """Inverse-CDF sampling of ``N_importance`` depths per ray (renderer.py:214-253)."""
+        rays, nb = weights.shape
+        w = weights + eps
+        cdf = torch.cumsum(w / w.sum(-1, keepdim=True), -1)
+        cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1)
+        if det:
+            u = torch.linspace(0, 1, N_importance, device=bins.device).expand(rays, N_importance)
+        else:
+            u = torch.rand(rays, N_importance, device=bins.device)
+        u = u.contiguous()
+        idx = torch.searchsorted(cdf, u, right=True)
+        lo, hi = (idx - 1).clamp_min(0), idx.clamp_max(nb)
+        c0, c1 = cdf.gather(1, lo), cdf.gather(1, hi)
+        b0, b1 = bins.gather(1, lo), bins.gather(1, hi)
+        span = c1 - c0
+        span = torch.where(span < eps, torch.ones_like(span), span)
+        return b0 + (u - c0) / span * (b1 - b0)
+
+
+def importance_sample_native(z_coarse, w_coarse, u_fine, sort=False):
+    """p3d_importance_sample on device tensors: z [R,Sc], w [R,Sc-1], u [R,Sf] -> z_fine [R,Sf]."""
+    z, w, u = _f32c(z_coarse), _f32c(w_coarse), _f32c(u_fine)
+    out = torch.empty_like(u)
+    code = _lib.lib().p3d_importance_sample(_lib.ptr(z), _lib.ptr(w), _lib.ptr(u), _lib.ptr(out), z.shape[0], z.shape[1], u.shape[1], int(sort), _lib.stream_of(z))
+    _lib.check(code, 'importance_sample')
+    return out
+
+
+def fused_render(planes, decoder, ray_origins, ray_directions, opt, u_coarse, u_fine, t_start=None, t_end=None, debug=False):
+    """One launch of the fused ray-marcher with explicit uniforms (u_coarse [N,M,Sc(,1)], u_fine [N*M,Sf]).
+    Returns (feat [N,M,C], depth [N,M,1], wsum [N,M,1]) and, with debug, the sorted fine depths [N*M,Sf] and the
+    coarse weights [N*M,Sc-1] the kernel used."""
+    info = _decoder_nets(decoder)
+    if info is None:
+        raise RuntimeError(f'fused_render: unsupported decoder {type(decoder).__name__}')
+    n, m, _ = ray_origins.shape
+    sc, sf = int(opt['depth_resolution']), int(opt['depth_resolution_importance'])
+    dev = planes.device
+    ctx = _FusedContext(planes, info)
+    auto = t_start is not None
+    t0 = _f32c(t_start).reshape(-1) if auto else None
+    t1 = _f32c(t_end).reshape(-1) if auto else None
+    ro, rd, uc, uf = _f32c(ray_origins), _f32c(ray_directions), _f32c(u_coarse), _f32c(u_fine)
+    assert uc.numel() == n * m * sc and uf.numel() == n * m * sf
+    feat = torch.empty([n, m, 32 * ctx.n_nets], device=dev, dtype=torch.float32)
+    depth = torch.empty([n, m, 1], device=dev, dtype=torch.float32)
+    wsum = torch.empty([n, m, 1], device=dev, dtype=torch.float32)
+    mm = torch.empty([2], device=dev, dtype=torch.int32)
+    dbg_f = torch.empty([n * m, sf], device=dev, dtype=torch.float32) if debug else None
+    dbg_w = torch.empty([n * m, sc - 1], device=dev, dtype=torch.float32) if debug else None
+    d = ctx.desc(opt, rays_per_img=m, start=0.0 if auto else opt['ray_start'], end=0.0 if auto else opt['ray_end'])
+    code = _lib.lib().p3d_render_forward(_lib.ptr(ctx.planes_cl), _lib.ptr(ctx.packed), _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(uc), _lib.ptr(uf),
+                                         _lib.ptr(t0), _lib.ptr(t1), ctypes.byref(d), _lib.ptr(feat), _lib.ptr(depth), _lib.ptr(wsum),
+                                         _lib.ptr(mm), _lib.ptr(dbg_f), _lib.ptr(dbg_w), _lib.stream_of(feat))
+    if code == _lib.P3D_ERR_UNSUPPORTED:
+        return None
+    _lib.check(code, 'render_forward')
+    return (feat, depth, wsum, dbg_f, dbg_w) if debug else (feat, depth, wsum)

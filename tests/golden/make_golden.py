@@ -126,6 +126,115 @@ def group_ops():
 
 GROUPS = {'ops': group_ops}
 
+
+# ---------------------------------------------------------------------------------------------------------
+class _RandTape:
+    """Records every torch.rand_like / torch.rand draw the reference makes (renderer.py:190, :237)."""
+
+    def __enter__(self):
+        self.draws, self._rl, self._r = [], torch.rand_like, torch.rand
+
+        def rand_like(t, *a, **k):
+            v = self._rl(t, *a, **k); self.draws.append(v.clone()); return v
+
+        def rand(*a, **k):
+            v = self._r(*a, **k); self.draws.append(v.clone()); return v
+        torch.rand_like, torch.rand = rand_like, rand
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand_like, torch.rand = self._rl, self._r
+
+
+def _look_at(radius, yaw, pitch):
+    """cam2world of a camera on a sphere looking at the origin (OpenCV convention: +z forward, +y down)."""
+    pos = np.array([radius * np.sin(pitch) * np.sin(yaw), radius * np.cos(pitch), radius * np.sin(pitch) * np.cos(yaw)])
+    fwd = -pos / np.linalg.norm(pos)
+    right = np.cross(fwd, np.array([0., 1., 0.])); right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    m = np.eye(4)
+    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = right, down, fwd, pos
+    return m.astype(np.float32)
+
+
+def _decoder_arrays(dec):
+    out = {'w1': dec.net[0].weight, 'b1': dec.net[0].bias, 'w2': dec.net[2].weight, 'b2': dec.net[2].bias}
+    if hasattr(dec, 'net_semantic'):
+        out.update({'w1s': dec.net_semantic[0].weight, 'b1s': dec.net_semantic[0].bias, 'w2s': dec.net_semantic[2].weight, 'b2s': dec.net_semantic[2].bias})
+    return out
+
+
+def group_renderer():
+    from training.volumetric_rendering.renderer import ImportanceRenderer
+    from training.volumetric_rendering.ray_sampler import RaySampler
+    from training.triplane import OSGDecoder
+    from training.triplane_cond import OSGDecoder_semantic_lateSeparate
+
+    cases = [
+        dict(name='seg', nets=2, sem_sigmoid=False, n=2, hw=(20, 16), res=6, focal=4.2647, radius=2.7, lr_mul=1.0,
+             opts=dict(depth_resolution=12, depth_resolution_importance=10, ray_start=2.25, ray_end=3.3, box_warp=1, disparity_space_sampling=False, clamp_mode='softplus')),
+        dict(name='car', nets=2, sem_sigmoid=True, n=1, hw=(16, 16), res=7, focal=1.2, radius=1.7, lr_mul=1.0,
+             opts=dict(depth_resolution=16, depth_resolution_importance=16, ray_start=0.1, ray_end=2.6, box_warp=1.6, disparity_space_sampling=False, clamp_mode='softplus', white_back=True)),
+        dict(name='osg', nets=1, sem_sigmoid=False, n=2, hw=(12, 12), res=5, focal=2.0, radius=2.7, lr_mul=0.5,
+             opts=dict(depth_resolution=9, depth_resolution_importance=5, ray_start=2.25, ray_end=3.3, box_warp=1, disparity_space_sampling=True, clamp_mode='softplus')),
+        dict(name='auto', nets=2, sem_sigmoid=False, n=1, hw=(16, 16), res=6, focal=1.0, radius=2.0, lr_mul=1.0,
+             opts=dict(depth_resolution=10, depth_resolution_importance=8, ray_start='auto', ray_end='auto', box_warp=1.2, disparity_space_sampling=False, clamp_mode='softplus')),
+    ]
+    for ci, cs in enumerate(cases):
+        torch.manual_seed(100 + ci)
+        n, (h, w), res = cs['n'], cs['hw'], cs['res']
+        planes = torch.randn(n, 3, 32, h, w)
+        dopt = {'decoder_lr_mul': cs['lr_mul'], 'decoder_output_dim': 32}
+        if cs['nets'] == 2:
+            dec = OSGDecoder_semantic_lateSeparate(32, dict(dopt, sigmoid=cs['sem_sigmoid'], semantic_channels=6))
+        else:
+            dec = OSGDecoder(32, dopt)
+        with torch.no_grad():
+            for p_ in dec.parameters():
+                if p_.ndim == 1:
+                    p_.copy_(torch.randn_like(p_) * 0.3 / cs['lr_mul'])
+        c2w = torch.tensor(np.stack([_look_at(cs['radius'], 0.3 + 0.9 * i, 1.4 - 0.2 * i) for i in range(n)]))
+        K = torch.tensor([[cs['focal'], 0.01 * ci, 0.5], [0, cs['focal'] * 1.05, 0.48], [0, 0, 1]], dtype=torch.float32).repeat(n, 1, 1)
+        ray_o, ray_d = RaySampler()(c2w, K, res)
+        rend = ImportanceRenderer()
+        rec = {}
+        orig_imp, orig_uni = rend.sample_importance, rend.unify_samples
+
+        def imp(z, wts, k):
+            rec['z_coarse'], rec['w_coarse'] = z.clone(), wts.clone()
+            out = orig_imp(z, wts, k); rec['z_fine'] = out.clone(); return out
+
+        def uni(*a):
+            out = orig_uni(*a); rec['z_all'] = out[0].clone(); return out
+        rend.sample_importance, rend.unify_samples = imp, uni
+        with _RandTape() as tape, torch.no_grad():
+            feat, depth, wsum = rend(planes, dec, ray_o, ray_d, cs['opts'])
+        assert len(tape.draws) == 2
+        pts = (torch.rand(n, 40, 3) - 0.5) * 1.3 * cs['opts']['box_warp']
+        with torch.no_grad():
+            pm = rend.run_model(planes, dec, pts, None, cs['opts'])
+        arrays = dict(planes=planes, c2w=c2w, K=K, res=np.int64(res), ray_o=ray_o, ray_d=ray_d, u_coarse=tape.draws[0], u_fine=tape.draws[1],
+                      feat=feat, depth=depth, wsum=wsum, pts=pts, pts_rgb=pm['rgb'], pts_sigma=pm['sigma'],
+                      nets=np.int64(cs['nets']), sem_sigmoid=np.int64(cs['sem_sigmoid']), lr_mul=np.float64(cs['lr_mul']),
+                      opt_keys=np.array(list(cs['opts'].keys())), opt_vals=np.array([str(v) for v in cs['opts'].values()]), **rec)
+        arrays.update({'dec_' + k: v for k, v in _decoder_arrays(dec).items()})
+        save('renderer_' + cs['name'], **arrays)
+
+    # sample_pdf alone, with the indices it derives (the "bit-exact index work" fixture)
+    torch.manual_seed(7)
+    rend = ImportanceRenderer()
+    rays, sc, sf = 64, 48, 48
+    z = torch.sort(torch.rand(rays, sc) * 1.05 + 2.25, dim=1)[0]
+    wts = torch.rand(rays, sc - 1) ** 4
+    wts[:8] = 0                                  # empty rays: uniform pdf
+    wts[8:12, 5:] = 0                            # everything in the first bins
+    with _RandTape() as tape, torch.no_grad():
+        zf = rend.sample_importance(z.reshape(1, rays, sc, 1), wts.reshape(1, rays, sc - 1, 1), sf)
+    save('renderer_importance', z=z, w=wts, u=tape.draws[0], z_fine=zf.reshape(rays, sf))
+
+
+GROUPS['renderer'] = group_renderer
+
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GROUPS)
     for nm in names:

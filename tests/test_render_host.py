@@ -1,0 +1,54 @@
+"""Host-side renderer mirror on CPU tensors (tensor-op path) against records of the reference renderer, with the
+reference's random draws replayed through torch's generator functions."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from render_cases import CASES, load_case, make_decoder
+
+
+class _Replay:
+    """Feeds recorded uniforms to torch.rand_like / torch.rand in call order."""
+
+    def __init__(self, draws):
+        self.draws = [torch.as_tensor(d) for d in draws]
+
+    def __enter__(self):
+        self._rl, self._r = torch.rand_like, torch.rand
+        it = iter(self.draws)
+        torch.rand_like = lambda t, *a, **k: next(it).to(t.device).reshape(t.shape)
+        torch.rand = lambda *a, **k: next(it).to(k.get('device', 'cpu'))
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand_like, torch.rand = self._rl, self._r
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_tensor_op_renderer_matches_reference(name):
+    from pix2pix3d_amd.training.volumetric_rendering.renderer import ImportanceRenderer
+    from pix2pix3d_amd.training.volumetric_rendering.ray_sampler import RaySampler
+    g, opts, _ = load_case(name)
+    dec = make_decoder(g)
+    o, d = RaySampler()(torch.tensor(g['c2w']), torch.tensor(g['K']), int(g['res']))
+    assert np.abs(o.numpy() - g['ray_o']).max() < 1e-6 and np.abs(d.numpy() - g['ray_d']).max() < 1e-6
+    rend = ImportanceRenderer()
+    with _Replay([g['u_coarse'], g['u_fine']]), torch.no_grad():
+        feat, depth, wsum = rend(torch.tensor(g['planes']), dec, torch.tensor(g['ray_o']), torch.tensor(g['ray_d']), opts)
+    assert rel_err(feat.numpy(), g['feat']) < 1e-5
+    assert np.abs(depth.numpy() - g['depth']).max() < 1e-5 and rel_err(wsum.numpy(), g['wsum']) < 1e-5
+    with torch.no_grad():
+        pm = rend.run_model(torch.tensor(g['planes']), dec, torch.tensor(g['pts']), None, opts)
+    assert rel_err(pm['rgb'].numpy(), g['pts_rgb']) < 1e-6 and rel_err(pm['sigma'].numpy(), g['pts_sigma']) < 1e-6
+
+
+def test_decoder_recognition_for_fused_path():
+    from pix2pix3d_amd.training.volumetric_rendering import renderer
+    g, _, _ = load_case('seg')
+    info = renderer._decoder_nets(make_decoder(g))
+    assert info is not None and len(info[0]) == 2 and info[1] == 1.0 and info[2] is False
+    g, _, _ = load_case('osg')
+    info = renderer._decoder_nets(make_decoder(g))
+    assert info is not None and len(info[0]) == 1 and info[1] == 0.5
+    assert renderer._decoder_nets(torch.nn.Linear(3, 3)) is None

@@ -1,0 +1,50 @@
+"""Renderer oracle (oracle/render_oracle.py) against records of the reference renderer.  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+from oracle import render_oracle as R
+from render_cases import CASES, load_case
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_ray_sampler_oracle(name):
+    g, _, _ = load_case(name)
+    o, d = R.ray_sampler(g['c2w'], g['K'], int(g['res']))
+    assert np.abs(o - g['ray_o']).max() < 1e-6 and np.abs(d - g['ray_d']).max() < 2e-6
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_render_oracle_matches_reference(name):
+    g, opts, dec = load_case(name)
+    auto = opts['ray_start'] == 'auto'
+    kw = {}
+    if auto:                                  # per-ray limits are host-side torch code in both implementations
+        import torch
+        from pix2pix3d_amd.training.volumetric_rendering.renderer import ImportanceRenderer
+        t0, t1 = ImportanceRenderer()._ray_limits(torch.tensor(g['ray_o']), torch.tensor(g['ray_d']), opts)
+        kw = dict(t_start=t0.numpy(), t_end=t1.numpy())
+    feat, depth, wsum, det = R.render(g['planes'], dec, g['ray_o'], g['ray_d'], opts, g['u_coarse'], g['u_fine'], details=True, **kw)
+    n, m = g['ray_o'].shape[:2]
+    assert np.abs(det['z_coarse'] - g['z_coarse'].reshape(n * m, -1)).max() < 1e-6
+    assert rel_err(det['w_coarse'], g['w_coarse'].reshape(n * m, -1)) < 2e-5
+    assert np.abs(det['z_fine'] - g['z_fine'].reshape(n * m, -1)).max() < 2e-5
+    assert np.abs(det['z_all'] - g['z_all'].reshape(n * m, -1)).max() < 2e-5
+    assert rel_err(feat, g['feat']) < 1e-4
+    assert np.abs(depth - g['depth'][..., 0]).max() < 1e-4
+    assert rel_err(wsum, g['wsum'][..., 0]) < 1e-4
+    rgb, sigma = R.run_model(g['planes'], dec, g['pts'], opts['box_warp'])
+    assert rel_err(rgb, g['pts_rgb']) < 1e-5 and rel_err(sigma, g['pts_sigma'][..., 0]) < 1e-5
+
+
+def test_importance_sampling_oracle_indices_and_values():
+    g = load_golden('renderer_importance')
+    zf = R.sample_importance(g['z'], g['w'], g['u'])
+    # values agree with the reference to fp32 rounding; a flipped bin would show up as an O(bin width) error
+    assert np.abs(zf - g["z_fine"]).max() < 3e-5          # bin width is ~2e-2; peaked pdfs amplify cdf rounding by 1/denom
+    bins, w = R.importance_bins(g['z'], g['w'])
+    _, inds = R.sample_pdf(bins, w, g['u'], return_index=True)
+    assert inds.min() >= 1 and inds.max() <= w.shape[1] + 1
+    # empty rays (first 8): pdf is uniform over the S-3 bins, so the index is floor(u * (S-3)) + 1 up to cdf rounding
+    exp = np.floor(g['u'][:8] * w.shape[1]).astype(np.int64) + 1
+    assert (np.abs(inds[:8] - exp) <= 1).all() and (inds[:8] == exp).mean() > 0.98
