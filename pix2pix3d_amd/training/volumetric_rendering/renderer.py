@@ -185,7 +185,10 @@ class ImportanceRenderer(torch.nn.Module):
         if opt['ray_start'] == opt['ray_end'] == 'auto':
             t0, t1 = self._ray_limits(ray_origins, ray_directions, opt)
         # the reference's draws, in its order: rand_like(depths_coarse) [N,M,Sc,1] (renderer.py:190) then rand(N*M, Sf) (:237)
-        u_c = torch.rand([n, m, sc, 1], device=dev, dtype=torch.float32)
+        if t0 is None:
+            u_c = torch.rand([n, m, sc, 1], device=dev, dtype=torch.float32)
+        else:   # tensor-limits branch: rand_like of the permuted [S,N,M,1] linspace fills in ITS memory order (:184-186)
+            u_c = torch.rand([sc, n, m, 1], device=dev, dtype=torch.float32).permute(1, 2, 0, 3)
         u_f = torch.rand([n * m, sf], device=dev, dtype=torch.float32)
         return fused_render(planes, decoder, ray_origins, ray_directions, opt, u_c, u_f, t0, t1)
 

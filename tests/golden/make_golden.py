@@ -235,6 +235,70 @@ def group_renderer():
 
 GROUPS['renderer'] = group_renderer
 
+
+# ---------------------------------------------------------------------------------------------------------
+def _load_by_path(name, path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    return mod
+
+
+def _thumb(t, step):
+    """Strided thumbnail + an exact central crop: enough to pin a 512^2 image in a few KiB."""
+    h = t.shape[-1]
+    c0 = h // 2 - 16
+    return t[..., ::step, ::step].contiguous(), t[..., c0:c0 + 32, c0:c0 + 32].contiguous()
+
+
+def group_model():
+    import dnnlib
+    configs = _load_by_path('p3d_configs', os.path.join(os.path.dirname(os.path.dirname(HERE)), 'pix2pix3d_amd', 'configs.py'))
+    weights = _load_by_path('p3d_weights', os.path.join(HERE, 'weights.py'))
+    runs = [dict(name='seg2cat', nrr=32, n=1, frames=[7]), dict(name='edge2car', nrr=64, n=2, frames=[3, 40])]
+    for run in runs:
+        kw = configs.generator_kwargs(run['name'])
+        info = configs.dataset_info(run['name'])
+        torch.manual_seed(0)
+        G = dnnlib.util.construct_class_by_name(**kw).eval().requires_grad_(False)
+        weights.seed_module(G, seed=1)
+        n = run['n']
+        gz = torch.Generator().manual_seed(5)
+        ws = torch.randn(n, G.backbone.num_ws, 512, generator=gz)
+        rk = kw['rendering_kwargs']
+        c = torch.tensor(np.stack([configs.orbit_camera(k, radius=rk['avg_camera_radius'], focal=4.2647 if run['name'] != 'edge2car' else 1.7074,
+                                                        pivot=rk['avg_camera_pivot']) for k in run['frames']]))
+        # the renderer's two uniform draws are NOT stored (MBs of incompressible floats): they are the first draws of
+        # the CPU generator after manual_seed(RENDER_SEED), in shapes [N,M,Sc,1] then [N*M,Sf]; tests re-draw them
+        torch.manual_seed(4321)
+        with _RandTape() as tape, torch.no_grad():
+            out = G.synthesis(ws, c, neural_rendering_resolution=run['nrr'], noise_mode='const')
+        assert len(tape.draws) == 2
+        arrays = dict(ws=ws, c=c, nrr=np.int64(run['nrr']), render_seed=np.int64(4321), u_coarse_head=tape.draws[0].reshape(-1)[:16], u_fine_head=tape.draws[1].reshape(-1)[:16],
+                      image_raw=out['image_raw'], image_depth=out['image_depth'], semantic_raw=out['semantic_raw'])
+        step = max(out['image'].shape[-1] // 64, 1)
+        arrays['image_thumb'], arrays['image_crop'] = _thumb(out['image'], step)
+        arrays['semantic_thumb'], arrays['semantic_crop'] = _thumb(out['semantic'], step)
+        arrays['thumb_step'] = np.int64(step)
+        # mapping network (G.mapping) on a synthetic conditioning image
+        gm = torch.Generator().manual_seed(9)
+        z = torch.randn(n, 512, generator=gm)
+        if info['data_type'] == 'seg':
+            mask = torch.randint(0, info['sem'], [n, 1, info['res'], info['res']], generator=gm)
+        else:
+            mask = torch.rand([n, 1, info['res'], info['res']], generator=gm) * 2 - 1
+        with torch.no_grad():
+            wsm = G.mapping(z, c, {'mask': mask, 'pose': c})
+        arrays.update(map_z=z, map_mask=mask.to(torch.int16 if info['data_type'] == 'seg' else torch.float32), map_ws=wsm)
+        pts = (torch.rand(n, 64, 3, generator=gm) - 0.5) * rk['box_warp']
+        with torch.no_grad():
+            sm = G.sample_mixed(pts, None, ws, noise_mode='const')
+        arrays.update(pts=pts, pts_rgb=sm['rgb'], pts_sigma=sm['sigma'])
+        save('model_' + run['name'], **arrays)
+
+
+GROUPS['model'] = group_model
+
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GROUPS)
     for nm in names:

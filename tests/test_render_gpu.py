@@ -107,8 +107,9 @@ def test_edge_cases_empty_space_tail_tile_and_oob(hip_lib):
     n, m = 1, 37
     torch.manual_seed(0)
     planes = torch.randn(n, 3, 32, 8, 8, device='cuda')
-    o = torch.tensor(g['ray_o'][:1, :m], device='cuda')
-    d = torch.tensor(g['ray_d'][:1, :m], device='cuda')
+    o = torch.tensor(np.concatenate([g['ray_o'][:1], g['ray_o'][:1, :1]], 1), device='cuda')          # 36 + 1 rays
+    d = torch.tensor(np.concatenate([g['ray_d'][:1], g['ray_d'][1:2, :1]], 1), device='cuda')
+    assert o.shape[1] == m
     d[:, -5:] = torch.nn.functional.normalize(torch.tensor([[1.0, 0.2, 0.1]], device='cuda'), dim=1)      # leaves the box sideways
     uc = torch.rand(n, m, opts['depth_resolution'], device='cuda')
     uf = torch.rand(n * m, opts['depth_resolution_importance'], device='cuda')
