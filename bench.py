@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""Headline benchmark: rendered img/s of ``G.synthesis`` (seg2cat, 512^2 output, 128^2 rays x 128 depth samples).
+
+    python bench.py --gpus N --steps K --warmup W           (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path — StyleGAN2 tri-plane backbone -> fused tri-plane ray-marcher -> two
+super-resolution heads — over one batch of synthetic inputs already resident in HBM (random-init weights of the
+real architecture, N(0,1) latents, orbit cameras).  Inference shards by image: every rank renders its own batch,
+no data-path collective ("weak" scaling); the only collectives are the barriers bracketing the timed region and a
+MAX-reduce of the elapsed time.  Rank 0 prints ONE JSON line (contract in the task statement) with two extra
+objects: ``roofline`` for the dominant hand-written kernel (the fused ray-marcher; HIP-event timed inside the
+timed region, on the stream it is launched on) and ``cpu_baseline`` (the CPU oracle — a port of the reference's
+force_fp32 CPU path — timed on the host cores on a bounded sample: batch 1, same resolution and sample counts).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec (MI355X_MICROARCH.md)
+BYTES_PER_SAMPLE = 1543.0         # algorithmic bytes per ray-sample of the ray-marcher (SURVEY §8d / DESIGN.md)
+FLOP_PER_IMG = 485e9              # modulated-conv FLOPs per 512^2 image
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--warmup', type=int, default=5)
+    p.add_argument('--batch', type=int, default=4, help='images per GPU per step (BASELINE configs[1]: 4)')
+    p.add_argument('--depth', type=int, default=128, choices=[96, 128], help='depth samples per ray, coarse+fine (metric: 128)')
+    p.add_argument('--dataset', default='seg2cat')
+    p.add_argument('--force-fp32', action='store_true', help='run the super-resolution heads in fp32 too')
+    p.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a captured hipGraph')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-reps', type=int, default=2)
+    return p.parse_args()
+
+
+def build(args, device):
+    from pix2pix3d_amd import configs, dnnlib
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('p3d_weights', os.path.join(ROOT, 'tests', 'golden', 'weights.py'))
+    _w = importlib.util.module_from_spec(spec)                       # name-seeded synthetic weights (torch + zlib only)
+    spec.loader.exec_module(_w)
+    kw = configs.generator_kwargs(args.dataset, depth=(args.depth // 2, args.depth // 2))
+    torch.manual_seed(0)
+    G = dnnlib.util.construct_class_by_name(**kw).eval().requires_grad_(False)
+    _w.seed_module(G, seed=1)
+    info = configs.dataset_info(args.dataset)
+    rk = kw['rendering_kwargs']
+    n = args.batch
+    g = torch.Generator().manual_seed(1234 + int(os.environ.get('RANK', 0)))
+    ws = torch.randn(n, G.backbone.num_ws, 512, generator=g)
+    c = torch.tensor(np.stack([configs.orbit_camera(7 * k + 3, radius=rk['avg_camera_radius'], pivot=rk['avg_camera_pivot']) for k in range(n)]))
+    return G, kw, info, ws, c
+
+
+def cpu_baseline(args, G_cpu, kw, info, ws, c):
+    """The oracle's synthesis (port of the reference CPU path) on the host cores, batch 1."""
+    from oracle import model_oracle as M
+    from pix2pix3d_amd import configs
+    cfg = configs.oracle_cfg(args.dataset, depth=(args.depth // 2, args.depth // 2))
+    sd = {k: v.float() for k, v in G_cpu.state_dict().items()}
+    nrr, rk = info['nrr'], kw['rendering_kwargs']
+    torch.manual_seed(1)
+    u_c = torch.rand(1, nrr * nrr, rk['depth_resolution'], 1)
+    u_f = torch.rand(nrr * nrr, rk['depth_resolution_importance'])
+    times = []
+    with torch.no_grad():
+        for i in range(args.cpu_reps + 1):
+            t0 = time.perf_counter()
+            M.synthesis(sd, cfg, ws[:1], c[:1], u_c, u_f, nrr=nrr, noise_mode='const')
+            times.append(time.perf_counter() - t0)
+    t = float(np.median(times[1:])) if len(times) > 1 else times[0]
+    return {'value': round(1.0 / t, 4), 'unit': 'img/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'oracle.model_oracle.synthesis, batch 1, {nrr}^2 rays x {args.depth} samples -> {info["res"]}^2, fp32, '
+                      f'median of {max(len(times) - 1, 1)} after 1 warm-up ({t:.2f} s/img; host has {os.cpu_count()} logical cores)'}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=device)          # RCCL over xGMI
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    from pix2pix3d_amd import _lib
+    from pix2pix3d_amd.torch_utils.ops import conv2d_gradfix
+    from pix2pix3d_amd.training.volumetric_rendering import renderer as rmod
+    _lib.lib()
+    conv2d_gradfix.enabled = True                                   # training_loop.py:281
+    rmod.fused_policy = 'require'
+    torch.backends.cudnn.benchmark = True                           # training_loop.py:280
+
+    G_cpu, kw, info, ws_cpu, c_cpu = build(args, device)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, G_cpu, kw, info, ws_cpu, c_cpu)
+    G = G_cpu.to(device)
+    ws, c = ws_cpu.to(device), c_cpu.to(device)
+    nrr = info['nrr']
+    syn_kw = dict(noise_mode='const', neural_rendering_resolution=nrr, force_fp32=args.force_fp32)
+
+    def step():
+        with torch.no_grad():
+            return G.synthesis(ws, c, **syn_kw)
+
+    # stage timers (HIP events on torch's current stream == the stream every kernel of the step is launched on)
+    stage_events = {'backbone': [], 'render': [], 'sr': []}
+
+    def hook(mod, key):
+        def pre(m, a):
+            e = torch.cuda.Event(enable_timing=True); e.record(); m._p3d_e0 = e
+
+        def post(m, a, o):
+            e = torch.cuda.Event(enable_timing=True); e.record(); stage_events[key].append((m._p3d_e0, e))
+        return mod.register_forward_pre_hook(pre), mod.register_forward_hook(post)
+
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+    assert out['image'].shape == (args.batch, 3, info['res'], info['res'])
+
+    launch = 'eager'
+    graph = None
+    if not args.no_graph:
+        try:                                                         # replay the whole step as one hipGraph
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                step()
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = step()
+            graph.replay()
+            torch.cuda.synchronize()
+            launch = 'hipgraph'
+        except Exception as e:                                       # noqa: BLE001 - report and fall back to eager launches
+            graph = None
+            launch = f'eager (graph capture failed: {type(e).__name__})'
+            torch.cuda.synchronize()
+
+    run = graph.replay if graph is not None else step
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel / per-stage HIP-event timing: a second, eager pass over the same K steps (events cannot be read back
+    # from inside a captured graph); the ray-marcher is one launch per step, so its event pair IS its launch duration
+    handles = []
+    handles += hook(G.backbone.synthesis, 'backbone') + hook(G.renderer, 'render')
+    handles += hook(G.superresolution, 'sr') + hook(G.superresolution_semantic, 'sr')
+    n_prof = min(args.steps, 10)
+    _lib.kernel_events['render_forward'] = []
+    for _ in range(n_prof):
+        step()
+    torch.cuda.synchronize()
+    kern = _lib.kernel_events.pop('render_forward')
+    render_kernel_ms = sum(a.elapsed_time(b) for a, b in kern) / max(len(kern), 1)
+    for h in handles:
+        h.remove()
+    stage_ms = {k: (sum(a.elapsed_time(b) for a, b in v) / n_prof if v else 0.0) for k, v in stage_events.items()}
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        imgs = args.batch * world * args.steps
+        samples_per_launch = args.batch * nrr * nrr * args.depth
+        render_s = render_kernel_ms * 1e-3
+        achieved = samples_per_launch * BYTES_PER_SAMPLE / render_s / 1e9 if render_s > 0 else 0.0
+        line = {
+            'metric': 'rendered img/s (512^2, 128 depth)' if args.depth == 128 else f'rendered img/s (512^2, {args.depth} depth)',
+            'value': round(imgs / elapsed, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.force_fp32 else 'f32 (backbone, ray-marcher) + f16/f32-acc (super-resolution), as the reference GPU config',
+            'data': 'synthetic',
+            'config': {'workload': f'{args.dataset} G.synthesis: batch {args.batch}/GPU, 256^2x96 tri-planes, {nrr}^2 rays x {args.depth // 2}+{args.depth // 2} samples, '
+                                   f'two 8XDC SR heads -> {info["res"]}^2 image + label map', 'launch': launch, 'parallelism': f'replicas x{world} (images sharded, no collective)'},
+            'ray_samples_per_s': round(samples_per_launch / render_s, 1) if render_s > 0 else None,
+            'stage_ms': {k: round(v, 3) for k, v in stage_ms.items()},
+            'conv_tflops': round(FLOP_PER_IMG * args.batch / ((stage_ms['backbone'] + stage_ms['sr']) * 1e-3) / 1e12, 2) if stage_ms['backbone'] + stage_ms['sr'] > 0 else None,
+            'roofline': {'kernel': 'render_forward_kernel (fused tri-plane ray-marcher)', 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'ms_per_launch': round(render_kernel_ms, 4), 'launches_timed': len(kern), 'units_per_launch': samples_per_launch, 'bytes_per_unit': BYTES_PER_SAMPLE},
+            'cpu_baseline': cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

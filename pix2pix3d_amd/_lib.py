@@ -38,6 +38,7 @@ _SIGNATURES = {
 
 _lib = None
 _load_error = None
+kernel_events = {}      # name -> list of (start, end) torch.cuda.Event pairs; filled only while a key exists (bench.py)
 
 
 def _load():
@@ -102,3 +103,24 @@ def i32x4(*v): return _i32x4(*v)
 def i64x4(*v): return _i64x4(*v)
 def i32x2(*v): return _i32x2(*v)
 def i64x2(*v): return _i64x2(*v)
+
+
+class kernel_timer:
+    """``with kernel_timer('render_forward', tensor):`` brackets the enclosed launches with events on the tensor's
+    current stream, but only while ``kernel_events['render_forward']`` exists — otherwise it costs one dict lookup."""
+
+    def __init__(self, name, t):
+        self.log = kernel_events.get(name)
+        self.dev = t.device
+
+    def __enter__(self):
+        if self.log is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream(self.dev))
+        return self
+
+    def __exit__(self, *exc):
+        if self.log is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(torch.cuda.current_stream(self.dev))
+            self.log.append((self.e0, e1))

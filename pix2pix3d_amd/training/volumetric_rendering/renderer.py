@@ -338,9 +338,10 @@ def fused_render(planes, decoder, ray_origins, ray_directions, opt, u_coarse, u_
     dbg_f = torch.empty([n * m, sf], device=dev, dtype=torch.float32) if debug else None
     dbg_w = torch.empty([n * m, sc - 1], device=dev, dtype=torch.float32) if debug else None
     d = ctx.desc(opt, rays_per_img=m, start=0.0 if auto else opt['ray_start'], end=0.0 if auto else opt['ray_end'])
-    code = _lib.lib().p3d_render_forward(_lib.ptr(ctx.planes_cl), _lib.ptr(ctx.packed), _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(uc), _lib.ptr(uf),
-                                         _lib.ptr(t0), _lib.ptr(t1), ctypes.byref(d), _lib.ptr(feat), _lib.ptr(depth), _lib.ptr(wsum),
-                                         _lib.ptr(mm), _lib.ptr(dbg_f), _lib.ptr(dbg_w), _lib.stream_of(feat))
+    with _lib.kernel_timer('render_forward', feat):
+        code = _lib.lib().p3d_render_forward(_lib.ptr(ctx.planes_cl), _lib.ptr(ctx.packed), _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(uc), _lib.ptr(uf),
+                                             _lib.ptr(t0), _lib.ptr(t1), ctypes.byref(d), _lib.ptr(feat), _lib.ptr(depth), _lib.ptr(wsum),
+                                             _lib.ptr(mm), _lib.ptr(dbg_f), _lib.ptr(dbg_w), _lib.stream_of(feat))
     if code == _lib.P3D_ERR_UNSUPPORTED:
         return None
     _lib.check(code, 'render_forward')

@@ -36,7 +36,10 @@ def test_synthesis_on_gpu_matches_reference(hip_lib, name, force_fp32):
     for k, v in before.items():
         assert _lib.launch_count(k) > v, f'{k}: HIP kernel did not run'
     assert out['image'].dtype == torch.float32
-    errs = compare_outputs(out, g, tol_raw=1e-3, tol_sr=1e-3 if force_fp32 else 3e-2)
+    # edge2car + fp16 heads: the no-upsampling SR block adds its fp16 ToRGB output into 'image_raw' IN PLACE (reference
+    # quirk, superresolution.py:281), so the "raw" images inherit fp16 rounding there; everywhere else they are pure fp32
+    tol_raw = 3e-2 if (name == 'edge2car' and not force_fp32) else 1e-3
+    errs = compare_outputs(out, g, tol_raw=tol_raw, tol_sr=1e-3 if force_fp32 else 3e-2)
     print(name, 'fp32' if force_fp32 else 'fp16-sr', errs)
 
 
