@@ -41,6 +41,7 @@ def parse():
     p.add_argument('--force-fp32', action='store_true', help='run the super-resolution heads in fp32 too')
     p.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a captured hipGraph')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--miopen-find', action='store_true', help='let MIOpen benchmark its solvers for the vendor-library convs (slow warm-up)')
     p.add_argument('--cpu-reps', type=int, default=2)
     return p.parse_args()
 
@@ -106,7 +107,7 @@ def main():
     _lib.lib()
     conv2d_gradfix.enabled = True                                   # training_loop.py:281
     rmod.fused_policy = 'require'
-    torch.backends.cudnn.benchmark = True                           # training_loop.py:280
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)         # training_loop.py:280 sets True; find-mode costs ~100 s of warm-up per fresh box
 
     G_cpu, kw, info, ws_cpu, c_cpu = build(args, device)
     cpu = None

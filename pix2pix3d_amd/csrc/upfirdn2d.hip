@@ -28,6 +28,7 @@ struct UpfirArgs {
 };
 
 __device__ __forceinline__ int pos_mod(int a, int m) { int r = a % m; return r < 0 ? r + m : r; }
+template <class T> struct alignas(16) Pack16 { T v[16 / sizeof(T)]; };
 
 template <class T, int UPX, int UPY, int DNX, int DNY, int FW, int FH>
 __global__ void __launch_bounds__(256) upfirdn2d_kernel(UpfirArgs a)
@@ -71,6 +72,188 @@ __global__ void __launch_bounds__(256) upfirdn2d_kernel(UpfirArgs a)
     }
 }
 
+// ---- LDS-tiled fast path: contiguous NCHW, square F x F filter (F <= 4), up/down in {1, 2} -----------------
+// One 256-thread block produces a 64 x 32 output tile of one (n, c) image: the input footprint of the tile is
+// staged once in LDS as fp32 (coalesced rows, zero-filled outside the image), then lane x / wave-row y computes a
+// vertical strip of 8 outputs.  For up = 2 only every other tap hits a real sample; which ones depends on the
+// output parity, so the four polyphase filters are selected per lane with v_cndmask instead of branching.
+constexpr int kTileW = 64, kTileH = 32, kStrip = 8;
+
+template <class T, int UP, int DN, int F>
+__global__ void __launch_bounds__(256) upfirdn2d_tiled_kernel(UpfirArgs a)
+{
+    typedef typename Acc<T>::type S;
+    constexpr int IW = ((kTileW - 1) * DN + F - 1) / UP + 2;      // input columns a tile can touch (+1 for the phase)
+    constexpr int IH = ((kTileH - 1) * DN + F - 1) / UP + 2;
+    constexpr int PITCH = IW | 1;                                  // odd pitch: conflict-free column walks
+    __shared__ float tile[IH * PITCH];
+
+    const int tiles_x = (a.out_w + kTileW - 1) / kTileW;
+    const int tx0 = (blockIdx.x % tiles_x) * kTileW, ty0 = (blockIdx.x / tiles_x) * kTileH;
+    const int nc = blockIdx.y;
+    const T* img = (const T*)a.x + (int64_t)nc * a.in_h * a.in_w;
+    T* out = (T*)a.y + (int64_t)nc * a.out_h * a.out_w;
+
+    // first input column/row the tile can touch: floor((o0*DN - pad0) / UP)
+    const int bx0 = tx0 * DN - a.pad_x0, by0 = ty0 * DN - a.pad_y0;
+    const int ix0 = (bx0 >= 0 ? bx0 : bx0 - (UP - 1)) / UP, iy0 = (by0 >= 0 ? by0 : by0 - (UP - 1)) / UP;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    for (int r = ly; r < IH; r += 4) {
+        const int iy = iy0 + r;
+        const bool rowok = (iy >= 0) & (iy < a.in_h);
+        for (int c = lx; c < IW; c += 64) {
+            const int ix = ix0 + c;
+            float v = 0.f;
+            if (rowok & (ix >= 0) & (ix < a.in_w)) v = (float)ld(img + (int64_t)iy * a.in_w + ix);
+            tile[r * PITCH + c] = v;
+        }
+    }
+    // filter taps in registers, already mirrored for convolution unless flip
+    float fr[F][F];
+#pragma unroll
+    for (int ky = 0; ky < F; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < F; ++kx) {
+            const int fx = a.flip ? kx : F - 1 - kx, fy = a.flip ? ky : F - 1 - ky;
+            fr[ky][kx] = a.f[fx * a.fsx + fy * a.fsy] * a.gain;
+        }
+    __syncthreads();
+
+    const int ox = tx0 + lx;
+    if (ox >= a.out_w) return;
+    const int bx = ox * DN - a.pad_x0;
+    const int kx0 = pos_mod(-bx, UP);                              // first tap that lands on a sample
+    const int cx = (bx + kx0) / UP - ix0;                          // its column in the tile
+    constexpr int NJ = (F + UP - 1) / UP;
+#pragma unroll
+    for (int r = 0; r < kStrip; ++r) {
+        const int oy = ty0 + ly * kStrip + r;
+        if (oy >= a.out_h) break;
+        const int by = oy * DN - a.pad_y0;
+        const int ky0 = pos_mod(-by, UP);
+        const int cy = (by + ky0) / UP - iy0;
+        float acc = 0.f;
+#pragma unroll
+        for (int jy = 0; jy < NJ; ++jy)
+#pragma unroll
+            for (int jx = 0; jx < NJ; ++jx) {
+                float w;
+                if (UP == 1) w = fr[jy][jx];
+                else {                                             // polyphase select: tap (ky0 + 2jy, kx0 + 2jx)
+                    const int y0 = 2 * jy, x0 = 2 * jx;
+                    const float w00 = fr[y0][x0], w01 = (x0 + 1 < F) ? fr[y0][x0 + 1] : 0.f;
+                    const float w10 = (y0 + 1 < F) ? fr[y0 + 1][x0] : 0.f, w11 = (y0 + 1 < F && x0 + 1 < F) ? fr[y0 + 1][x0 + 1] : 0.f;
+                    const float wa = kx0 ? w01 : w00, wb = kx0 ? w11 : w10;
+                    w = ky0 ? wb : wa;
+                }
+                acc = fmaf(tile[(cy + jy) * PITCH + cx + jx], w, acc);
+            }
+        st(out + (int64_t)oy * a.out_w + ox, (S)acc);
+    }
+}
+
+template <class T, int UP, int DN, int F>
+static void launch_tiled(const UpfirArgs& a, hipStream_t s)
+{
+    const int tiles = ((a.out_w + kTileW - 1) / kTileW) * ((a.out_h + kTileH - 1) / kTileH);
+    hipLaunchKernelGGL((upfirdn2d_tiled_kernel<T, UP, DN, F>), dim3(tiles, a.C * a.N), dim3(256), 0, s, a);
+}
+
+// ---- channels-last fast path: lanes walk the channel axis in 16-byte vectors -------------------------------------
+// x is [N][H][W][C] in memory (torch channels_last).  One lane owns VEC = 16/sizeof(T) consecutive channels of one
+// output pixel; every tap is a single aligned 16-byte load shared by no one else, and consecutive lanes read
+// consecutive channels, so each wave instruction covers whole 128-byte lines.  No LDS: the tap overlap between
+// neighbouring pixels is served by L1/L2.
+template <class T, int UP, int DN, int F>
+__global__ void __launch_bounds__(256) upfirdn2d_cl_kernel(UpfirArgs a)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    typedef Pack16<T> P;
+    const int cvec = a.C / VEC;
+    const int64_t total = (int64_t)a.N * a.out_h * a.out_w * cvec;
+    float fr[F][F];
+#pragma unroll
+    for (int ky = 0; ky < F; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < F; ++kx) {
+            const int fx = a.flip ? kx : F - 1 - kx, fy = a.flip ? ky : F - 1 - ky;
+            fr[ky][kx] = a.f[fx * a.fsx + fy * a.fsy] * a.gain;
+        }
+    constexpr int NJ = (F + UP - 1) / UP;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = idx;
+        const int cv = (int)(t % cvec); t /= cvec;
+        const int ox = (int)(t % a.out_w); t /= a.out_w;
+        const int oy = (int)(t % a.out_h);
+        const int n = (int)(t / a.out_h);
+        const int bx = ox * DN - a.pad_x0, by = oy * DN - a.pad_y0;
+        const int kx0 = pos_mod(-bx, UP), ky0 = pos_mod(-by, UP);
+        const int ixb = (bx + kx0) / UP, iyb = (by + ky0) / UP;
+        const T* img = (const T*)a.x + (int64_t)n * a.isn + cv * VEC;
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int jy = 0; jy < NJ; ++jy) {
+            const int iy = iyb + jy;
+#pragma unroll
+            for (int jx = 0; jx < NJ; ++jx) {
+                const int ix = ixb + jx;
+                float w;
+                if (UP == 1) w = fr[jy][jx];
+                else {
+                    const int y0 = 2 * jy, x0 = 2 * jx;
+                    const float w00 = fr[y0][x0], w01 = (x0 + 1 < F) ? fr[y0][x0 + 1] : 0.f;
+                    const float w10 = (y0 + 1 < F) ? fr[y0 + 1][x0] : 0.f, w11 = (y0 + 1 < F && x0 + 1 < F) ? fr[y0 + 1][x0 + 1] : 0.f;
+                    const float wa = kx0 ? w01 : w00, wb = kx0 ? w11 : w10;
+                    w = ky0 ? wb : wa;
+                }
+                if ((iy >= 0) & (iy < a.in_h) & (ix >= 0) & (ix < a.in_w)) {
+                    const P v = *(const P*)(img + (int64_t)iy * a.isy + (int64_t)ix * a.isx);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[e] = fmaf((float)ld(&v.v[e]), w, acc[e]);
+                }
+            }
+        }
+        P o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) st(&o.v[e], (typename Acc<T>::type)acc[e]);
+        *(P*)((T*)a.y + (int64_t)n * a.osn + (int64_t)oy * a.osy + (int64_t)ox * a.osx + cv * VEC) = o;
+    }
+}
+
+template <class T>
+static bool try_channels_last(const UpfirArgs& a, hipStream_t s)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    const bool cl = a.isc == 1 && a.osc == 1 && a.isx == a.C && a.osx == a.C && a.isy == (int64_t)a.in_w * a.C && a.osy == (int64_t)a.out_w * a.C;
+    if (!cl || sizeof(T) == 8 || a.C % VEC != 0 || a.fw != a.fh || a.up_x != a.up_y || a.down_x != a.down_y) return false;
+    if ((((uintptr_t)a.x) | ((uintptr_t)a.y)) & 15u) return false;
+    const int64_t total = (int64_t)a.N * a.out_h * a.out_w * (a.C / VEC);
+    int64_t blocks64 = (total + 255) / 256;
+    const int blocks = (int)(blocks64 > (int64_t)kNumCU * 32 ? (int64_t)kNumCU * 32 : blocks64);
+    const int u = a.up_x, d = a.down_x, f = a.fw;
+#define P3D_CL(U, D, FF) if (u == U && d == D && f == FF) { hipLaunchKernelGGL((upfirdn2d_cl_kernel<T, U, D, FF>), dim3(blocks), dim3(256), 0, s, a); return true; }
+    P3D_CL(1, 1, 4) P3D_CL(2, 1, 4) P3D_CL(1, 2, 4) P3D_CL(2, 2, 4)
+#undef P3D_CL
+    return false;
+}
+
+template <class T>
+static bool try_tiled(const UpfirArgs& a, hipStream_t s)
+{
+    const bool nchw = a.isx == 1 && a.isy == a.in_w && a.isc == (int64_t)a.in_w * a.in_h && a.isn == a.isc * a.C &&
+                      a.osx == 1 && a.osy == a.out_w && a.osc == (int64_t)a.out_w * a.out_h && a.osn == a.osc * a.C;
+    if (!nchw || a.fw != a.fh || a.up_x != a.up_y || a.down_x != a.down_y || (int64_t)a.C * a.N > 65535) return false;
+    if (sizeof(T) == 8) return false;                              // fp64 keeps the exact generic kernel
+    const int u = a.up_x, d = a.down_x, f = a.fw;
+#define P3D_TILED(U, D, FF) if (u == U && d == D && f == FF) { launch_tiled<T, U, D, FF>(a, s); return true; }
+    P3D_TILED(1, 1, 4) P3D_TILED(2, 1, 4) P3D_TILED(1, 2, 4) P3D_TILED(2, 2, 4)
+    P3D_TILED(1, 1, 3) P3D_TILED(2, 1, 3) P3D_TILED(1, 2, 3) P3D_TILED(1, 1, 2) P3D_TILED(2, 1, 2) P3D_TILED(1, 2, 2)
+#undef P3D_TILED
+    return false;
+}
+
 template <class T>
 static int launch_upfirdn2d(const UpfirArgs& a, hipStream_t s)
 {
@@ -79,6 +262,8 @@ static int launch_upfirdn2d(const UpfirArgs& a, hipStream_t s)
     const int64_t cap = (int64_t)kNumCU * 32;
     int blocks = (int)(blocks64 > cap ? cap : blocks64);
     if (blocks < 1) blocks = 1;
+    if (try_tiled<T>(a, s)) { count_launch(FAM_UPFIRDN); return check_launch("upfirdn2d(tiled)"); }
+    if (try_channels_last<T>(a, s)) { count_launch(FAM_UPFIRDN); return check_launch("upfirdn2d(channels_last)"); }
 #define P3D_UPFIR_CASE(ux, uy, dx, dy, w, h) \
     if (a.up_x == ux && a.up_y == uy && a.down_x == dx && a.down_y == dy && a.fw == w && a.fh == h) { \
         hipLaunchKernelGGL((upfirdn2d_kernel<T, ux, uy, dx, dy, w, h>), dim3(blocks), dim3(threads), 0, s, a); } else

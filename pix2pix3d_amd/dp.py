@@ -1,0 +1,53 @@
+"""Data-parallel gradient exchange of the training loop.
+
+The reference does not use DistributedDataParallel: after all backward passes of a phase it concatenates every
+``param.grad`` of the phase's module into ONE flat fp32 vector, all-reduces it (SUM), divides by the world size,
+sanitises it and scatters it back (training/training_loop.py:531-542).  This module is that step, kept as one flat
+message on purpose — on MI355X `backend='nccl'` is RCCL over xGMI, point-to-point links where a ring all-reduce is
+per-link bound, so few large messages (336 MB for G, 125 MB for D) are the best shape; nothing is overlapped
+because the reference's loop is synchronous at this point and gradient accumulation rounds must all have finished.
+
+Also here: the start-up parameter broadcast (training_loop.py:349-353) and the rank-sharded batch split
+(misc.InfiniteSampler, torch_utils/misc.py:113-144) helpers used by the tests and the benchmark.
+"""
+import torch
+import torch.distributed as dist
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def allreduce_gradients(module_or_params, world_size=None, group=None):
+    """Average gradients across ranks in place; returns the flat vector that was exchanged (or None).
+
+    Parameters without a gradient are skipped, exactly like the reference's ``if param.grad is not None`` filter, so
+    every rank must have the same set of parameters with gradients (true when all ranks run the same phase)."""
+    params = module_or_params.parameters() if isinstance(module_or_params, torch.nn.Module) else module_or_params
+    params = [p for p in params if p.grad is not None]
+    if not params:
+        return None
+    flat = torch.cat([p.grad.flatten() for p in params])
+    if world_size is None:
+        world_size = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    if world_size > 1:
+        dist.all_reduce(flat, group=group)              # SUM over ranks (RCCL on GPUs, gloo in the CPU tests)
+        flat /= world_size
+    torch.nan_to_num(flat, nan=0, posinf=1e5, neginf=-1e5, out=flat)
+    for p, g in zip(params, flat.split([p.numel() for p in params])):
+        p.grad = g.reshape(p.shape)
+    return flat
+
+
+def broadcast_module(module, src=0, group=None):
+    """Make every rank hold rank ``src``'s parameters and buffers (training_loop.py:349-353)."""
+    if not is_distributed():
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data if t.is_leaf else t, src=src, group=group)
+
+
+def shard_indices(n_items, rank, world_size):
+    """Indices of a length-``n_items`` batch that belong to ``rank`` under the reference's round-robin sharding
+    (position % num_replicas == rank, misc.py:139)."""
+    return list(range(rank, n_items, world_size))

@@ -25,6 +25,8 @@ for name, ci, co, r, dt in cases:
     res['plain NCHW'] = timeit(lambda: torch.nn.functional.conv2d(x, w, padding=1))
     xc, wc = x.to(memory_format=torch.channels_last), w.to(memory_format=torch.channels_last)
     res['plain NHWC'] = timeit(lambda: torch.nn.functional.conv2d(xc, wc, padding=1))
+    xgc, wgc = xg.to(memory_format=torch.channels_last), wg.to(memory_format=torch.channels_last)
+    res['grouped NHWC'] = timeit(lambda: torch.nn.functional.conv2d(xgc, wgc, padding=1, groups=N))
     if dt == torch.float32:
         xh, wh = xc.half(), wc.half()
         res['plain NHWC fp16'] = timeit(lambda: torch.nn.functional.conv2d(xh, wh, padding=1))
