@@ -128,6 +128,32 @@ int p3d_importance_sample(const float* z_coarse, const float* w_coarse, const fl
                           int32_t n_rays, int32_t depth_resolution, int32_t n_importance, int32_t sorted,
                           p3d_stream_t stream);
 
+/* ---- modulated convolution on the matrix cores (fp16 channels-last) --------------------------
+ * Stand in for the per-layer inference chain of the StyleGAN2 synthesis layers:
+ *   modulated_conv2d, fused branch      training/networks_stylegan2.py:34-69, 81-91
+ *   conv2d / conv_transpose2d(stride 2) torch_utils/ops/conv2d_gradfix.py:37-45 via conv2d_resample.py:114-136
+ *   noise add + bias_act epilogue       training/networks_stylegan2.py:319-332
+ *   ToRGB 1x1 modulated conv            training/networks_stylegan2.py:355-359                    */
+
+/* weight [Co][Ci][taps] fp32 (taps = kh*kw, PyTorch OIHW order), styles [N][Ci] fp32 ->
+ * out [N][Co][taps][Ci] fp16 = weight * pre_scale * styles (* rsqrt(sum^2 + 1e-8) if demodulate). */
+int p3d_modulate_weights(const float* weight, const float* styles, void* out_f16, int32_t n_img, int32_t co, int32_t ci,
+                         int32_t taps, int32_t demodulate, float pre_scale, p3d_stream_t stream);
+
+/* x [N][H][W][Ci] fp16, w [N or 1][Co][9][Ci] fp16 (w_img_stride elements between images, 0 = shared).
+ * transposed_stride2 = 0: 3x3 correlation, padding 1 -> y [N][H][W][Co]; optional epilogue
+ *   v = acc + noise[H][W] * noise_strength[0] + bias[co]; act (0 linear, 1 lrelu 0.2); * gain; clamp (< 0 off).
+ * transposed_stride2 = 1: conv_transpose2d(stride 2, padding 0) -> y [N][2H+1][2W+1][Co], no epilogue.
+ * Ci must be a multiple of 64 (else P3D_ERR_UNSUPPORTED); fp32 accumulation.                        */
+int p3d_conv2d_nhwc_f16(const void* x, const void* w, void* y, const float* bias, const float* noise, const float* noise_strength,
+                        int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
+                        int32_t transposed_stride2, int32_t act, float gain, float clamp, p3d_stream_t stream);
+
+/* x [N][HW][Ci] fp16 channels-last, weight [Co][Ci] fp32, styles [N][Ci] fp32 (weight gain already applied),
+ * bias [Co] or null -> y [N][Co][HW] fp32 (NCHW); accumulate != 0 adds into y (the skip-image sum).   */
+int p3d_torgb_nhwc_f16(const void* x, const float* weight, const float* styles, const float* bias, float* y_nchw,
+                       int32_t n_img, int32_t hw, int32_t ci, int32_t co, float clamp, int32_t accumulate, p3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

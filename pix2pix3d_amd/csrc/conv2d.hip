@@ -1,0 +1,315 @@
+// Modulated 3x3 convolution of the StyleGAN2 synthesis layers as an implicit GEMM on the gfx950 matrix cores.
+//
+// Replaces, for fp16 channels-last activations, the chain the reference runs per layer in inference
+// (training/networks_stylegan2.py:34-91 fused branch + :313-332): per-sample weight modulation/demodulation
+// (elementwise torch ops) -> reshape to one grouped conv (cuDNN through conv2d_gradfix.py:127-129) -> + noise ->
+// bias_act.  Here:
+//   p3d_modulate_weights   w[O,I,k,k] fp32, styles[N,I] -> per-sample fp16 weights [N][O][k*k][I] (tap-major K),
+//                          demodulation folded in (fp32 math, one rounding to fp16) — one launch, one pass.
+//   p3d_conv2d_nhwc_f16    y[n, p, o] = epilogue( sum_{tap, i} x[n, p + d(tap), i] * wm[n][o][tap][i] ), fp32 accumulate
+//                          on v_mfma_f32_32x32x16_f16; epilogue = (+ noise[p] * strength) (+ bias[o]) lrelu * gain, clamp.
+// The same kernel runs the stride-2 transposed conv of the upsampling layers (conv2d_resample.py:114-127) as four
+// polyphase sub-problems: output parity class (py, px) only sees taps with ky == py, kx == px (mod 2), i.e. a dense
+// conv over the low-res grid with 4 / 2 / 2 / 1 taps written to strided output positions — no zero-stuffing, no
+// col2im.
+//
+// Tiling: 256 threads = 4 waves in a 2 x 2 grid, block tile 128 pixels x 128 output channels, K step 64 input
+// channels of one tap.  A (pixels x K) and B (channels x K) tiles are staged through LDS in 16-byte chunks with an
+// XOR swizzle (chunk ^= row & 7) so the column-slice ds_read_b128 of the MFMA fragments are conflict-free; the next
+// K step's global loads are issued before the current step's MFMAs and written to the other LDS buffer after them
+// (register-staged double buffering, one barrier per step).  A rows are gathered per pixel (zero-filled at the
+// image border), so a tile may straddle image rows.  blockIdx.x walks pixel tiles fastest with the image index in
+// blockIdx.z, so concurrently resident blocks share one image's weight panel (1.2 MB, L2-resident).
+#include "p3d_common.h"
+
+namespace p3d {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 64;
+
+struct ConvTap { int dy, dx, widx; };
+
+struct ConvArgs {
+    const __half* x;       // [N][H][W][Ci]
+    const __half* w;       // [N or 1][Co][KT][Ci]   (KT = taps in the weight tensor: 9 for 3x3)
+    __half* y;             // [N][OH][OW][Co]
+    const float* bias;     // [Co] or null
+    const float* noise;    // [OH][OW] or null
+    const float* noise_strength;   // device scalar (used when noise != null)
+    int N, H, W, Ci, Co, KT;
+    int64_t w_img_stride;  // elements between images' weight panels (0: shared weights)
+    int SH, SW;            // sub-problem grid (pixels enumerated by this launch)
+    int OH, OW;            // full output size
+    int osy, osx, ooy, oox;   // output pixel = (i * osy + ooy, j * osx + oox)
+    int ntaps; ConvTap taps[9];
+    int act;               // 0: none (linear), 1: lrelu(0.2)
+    float gain, clamp;     // clamp < 0: off
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * (BK / 8) + (chunk ^ (row & 7)); }   // index in 16-B units
+
+__global__ void __launch_bounds__(256, 2) conv2d_nhwc_f16_kernel(ConvArgs a)
+{
+    __shared__ __attribute__((aligned(16))) h8 lds[2][2][BM * BK / 8];        // [buffer][A|B][row*8 + chunk]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;                                   // wave's 64x64 quadrant
+    const int n = blockIdx.z;
+    const int m0 = blockIdx.x * BM, co0 = blockIdx.y * BN;
+    const int M = a.SH * a.SW;
+    const __half* xin = a.x + (int64_t)n * a.H * a.W * a.Ci;
+    const __half* wgt = a.w + (int64_t)n * a.w_img_stride;
+
+    // staging assignment: 8 threads cover one 128-byte row (64 halfs); 32 rows per pass, 4 passes for 128 rows
+    const int chunk = tid & 7, srow = tid >> 3;
+    int pi[4], pj[4];
+    bool pok[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int m = m0 + srow + 32 * p;
+        pok[p] = m < M;
+        const int mm = pok[p] ? m : 0;
+        pi[p] = mm / a.SW; pj[p] = mm - pi[p] * a.SW;
+    }
+    const int kchunks = a.Ci / BK;
+    const int ksteps = a.ntaps * kchunks;
+
+    h8 ra[4], rb[4];
+    auto load_tiles = [&](int ks) {
+        const int t = ks / kchunks, c0 = (ks - t * kchunks) * BK + chunk * 8;
+        const ConvTap tp = a.taps[t];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int iy = pi[p] + tp.dy, ix = pj[p] + tp.dx;
+            const bool ok = pok[p] & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
+            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok) v = *(const h8*)(xin + ((int64_t)iy * a.W + ix) * a.Ci + c0);
+            ra[p] = v;
+            const int co = co0 + srow + 32 * p;
+            h8 u = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (co < a.Co) u = *(const h8*)(wgt + ((int64_t)co * a.KT + tp.widx) * a.Ci + c0);
+            rb[p] = u;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = srow + 32 * p;
+            lds[buf][0][swz(row, chunk)] = ra[p];
+            lds[buf][1][swz(row, chunk)] = rb[p];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    const int frow = lane & 31, fk = lane >> 5;                                 // fragment row / k-group of this lane
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < ksteps) load_tiles(ks + 1);                                // global loads in flight under the MFMAs
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            h8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = lds[buf][0][swz(wm * 64 + i * 32 + frow, kk * 2 + fk)];
+                fb[i] = lds[buf][1][swz(wn * 64 + i * 32 + frow, kk * 2 + fk)];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (ks + 1 < ksteps) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulator element (row = (r&3) + 8(r>>2) + 4*fk, col = frow) of each 32x32 tile -------------
+    const float ns = a.noise ? a.noise_strength[0] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = co0 + wn * 64 + j * 32 + frow;
+        if (co >= a.Co) continue;
+        const float b = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (m >= M) continue;
+                const int si = m / a.SW, sj = m - si * a.SW;
+                const int oy = si * a.osy + a.ooy, ox = sj * a.osx + a.oox;
+                if (oy >= a.OH || ox >= a.OW) continue;
+                float v = acc[i][j][r];
+                if (a.noise) v = fmaf(a.noise[(int64_t)oy * a.OW + ox], ns, v);
+                v += b;
+                if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
+                v *= a.gain;
+                if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
+                a.y[(((int64_t)n * a.OH + oy) * a.OW + ox) * a.Co + co] = __float2half(v);
+            }
+    }
+}
+
+// ---- per-sample weight modulation + demodulation -> fp16, tap-major -------------------------------------------------
+// one block per (co, n): wm[i, t] = w[co, i, t] * s[n, i]; d = rsqrt(sum wm^2 + 1e-8) (if demodulate); out[n][co][t][i]
+__global__ void __launch_bounds__(256) modulate_weights_kernel(const float* __restrict__ w, const float* __restrict__ styles, __half* __restrict__ out,
+                                                               int Co, int Ci, int KT, int demodulate, float pre_scale)
+{
+    __shared__ float red[4];
+    const int co = blockIdx.x, n = blockIdx.y;
+    const float* wr = w + (int64_t)co * Ci * KT;
+    const float* s = styles + (int64_t)n * Ci;
+    const int total = Ci * KT;
+    float sq = 0.f;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const float v = wr[e] * pre_scale * s[e / KT];
+        sq = fmaf(v, v, sq);
+    }
+    float d = 1.f;
+    if (demodulate) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        d = rsqrtf(red[0] + red[1] + red[2] + red[3] + 1e-8f);
+    }
+    __half* o = out + ((int64_t)n * Co + co) * total;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {          // e enumerates the OUTPUT order [t][i]
+        const int t = e / Ci, i = e - t * Ci;
+        o[e] = __float2half(wr[i * KT + t] * pre_scale * s[i] * d);
+    }
+}
+
+// ---- 1x1 ToRGB on fp16 NHWC activations -> fp32 NCHW image (networks_stylegan2.py:355-359) ----------------------------
+// y[n, o, p] = clamp( sum_i x[n, p, i] * w[o, i] * s[n, i] + b[o] );  skinny (Co <= 8): pure streaming read of x.
+template <int CO>
+__global__ void __launch_bounds__(256) torgb_nhwc_kernel(const __half* __restrict__ x, const float* __restrict__ w, const float* __restrict__ styles,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int HW, int Ci, float clamp, int accumulate)
+{
+    extern __shared__ float wm[];                                    // [CO][Ci] modulated weights of this image
+    const int n = blockIdx.y;
+    for (int e = threadIdx.x; e < CO * Ci; e += blockDim.x) wm[e] = w[e] * styles[(int64_t)n * Ci + (e % Ci)];
+    __syncthreads();
+    const int lanes_per_px = Ci / 8;                                 // 16-byte vectors per pixel (Ci = 128 or 256 -> 16 or 32 lanes)
+    const int px_per_wave = 64 / lanes_per_px;
+    const int lane = threadIdx.x & 63, sub = lane % lanes_per_px, pw = lane / lanes_per_px;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const __half* xi = x + (int64_t)n * HW * Ci;
+    for (int p0 = wave_global * px_per_wave; p0 < HW; p0 += nwaves * px_per_wave) {
+        const int p = p0 + pw;
+        float acc[CO];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+        if (p < HW) {
+            const h8 v = *(const h8*)(xi + (int64_t)p * Ci + sub * 8);
+#pragma unroll
+            for (int o = 0; o < CO; ++o)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[o] = fmaf((float)v[e], wm[o * Ci + sub * 8 + e], acc[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < CO; ++o)
+            for (int s = 1; s < lanes_per_px; s <<= 1) acc[o] += __shfl_xor(acc[o], s, 64);
+        if (sub == 0 && p < HW) {
+#pragma unroll
+            for (int o = 0; o < CO; ++o) {
+                float v = acc[o] + (bias ? bias[o] : 0.f);
+                if (clamp >= 0.f) v = fminf(fmaxf(v, -clamp), clamp);
+                float* dst = y + ((int64_t)n * CO + o) * HW + p;
+                *dst = accumulate ? *dst + v : v;
+            }
+        }
+    }
+}
+
+} // namespace p3d
+
+using namespace p3d;
+
+extern "C" int p3d_modulate_weights(const float* weight, const float* styles, void* out_f16, int32_t n_img, int32_t co, int32_t ci,
+                                    int32_t taps, int32_t demodulate, float pre_scale, p3d_stream_t stream)
+{
+    P3D_REQUIRE(weight && styles && out_f16, "modulate_weights: null pointer");
+    P3D_REQUIRE(n_img >= 1 && co >= 1 && ci >= 1 && taps >= 1, "modulate_weights: bad sizes");
+    hipLaunchKernelGGL(modulate_weights_kernel, dim3(co, n_img), dim3(256), 0, (hipStream_t)stream, weight, styles, (__half*)out_f16, co, ci, taps, demodulate, pre_scale);
+    count_launch(FAM_CONV);
+    return check_launch("modulate_weights");
+}
+
+static int launch_conv(ConvArgs& a, hipStream_t s)
+{
+    const int M = a.SH * a.SW;
+    if (M <= 0) return P3D_OK;
+    dim3 grid((M + BM - 1) / BM, (a.Co + BN - 1) / BN, a.N);
+    hipLaunchKernelGGL(conv2d_nhwc_f16_kernel, grid, dim3(256), 0, s, a);
+    count_launch(FAM_CONV);
+    return check_launch("conv2d_nhwc_f16");
+}
+
+extern "C" int p3d_conv2d_nhwc_f16(const void* x, const void* w, void* y, const float* bias, const float* noise, const float* noise_strength,
+                                   int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
+                                   int32_t transposed_stride2, int32_t act, float gain, float clamp, p3d_stream_t stream)
+{
+    P3D_REQUIRE(x && w && y, "conv2d_nhwc_f16: null pointer");
+    P3D_REQUIRE(n_img >= 1 && h >= 1 && wdt >= 1 && co >= 1, "conv2d_nhwc_f16: bad sizes");
+    if (ci % BK != 0 && ci % 32 != 0) return fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc_f16: Ci=%d must be a multiple of 64", ci);
+    if (ci % BK != 0) return fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc_f16: Ci=%d must be a multiple of 64", ci);
+    P3D_REQUIRE((((uintptr_t)x) & 15u) == 0 && (((uintptr_t)w) & 15u) == 0, "conv2d_nhwc_f16: x and w must be 16-byte aligned");
+    ConvArgs a{};
+    a.x = (const __half*)x; a.w = (const __half*)w; a.y = (__half*)y; a.bias = bias; a.noise = noise; a.noise_strength = noise_strength;
+    a.N = n_img; a.H = h; a.W = wdt; a.Ci = ci; a.Co = co; a.KT = 9; a.w_img_stride = w_img_stride;
+    a.act = act; a.gain = gain; a.clamp = clamp;
+    hipStream_t s = (hipStream_t)stream;
+    if (!transposed_stride2) {                                       // correlation, padding 1: input offset = tap - 1
+        a.SH = h; a.SW = wdt; a.OH = h; a.OW = wdt; a.osy = a.osx = 1; a.ooy = a.oox = 0;
+        a.ntaps = 9;
+        for (int t = 0; t < 9; ++t) a.taps[t] = ConvTap{t / 3 - 1, t % 3 - 1, t};
+        return launch_conv(a, s);
+    }
+    // conv_transpose2d(stride 2, no padding): out[(2i+py), (2j+px)] = sum_{ky = py (mod 2), kx = px (mod 2)} x[i - (ky-py)/2, j - (kx-px)/2] w[ky, kx]
+    P3D_REQUIRE(!noise && !bias && act == 0, "conv2d_nhwc_f16: the transposed form has no epilogue (the FIR runs next)");
+    a.OH = 2 * h + 1; a.OW = 2 * wdt + 1; a.osy = a.osx = 2;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            a.ooy = py; a.oox = px;
+            a.SH = py ? h : h + 1; a.SW = px ? wdt : wdt + 1;
+            a.ntaps = 0;
+            for (int ky = py; ky < 3; ky += 2)
+                for (int kx = px; kx < 3; kx += 2)
+                    a.taps[a.ntaps++] = ConvTap{-(ky - py) / 2, -(kx - px) / 2, ky * 3 + kx};
+            int rc = launch_conv(a, s);
+            if (rc != P3D_OK) return rc;
+        }
+    return P3D_OK;
+}
+
+extern "C" int p3d_torgb_nhwc_f16(const void* x, const float* weight, const float* styles, const float* bias, float* y_nchw,
+                                  int32_t n_img, int32_t hw, int32_t ci, int32_t co, float clamp, int32_t accumulate, p3d_stream_t stream)
+{
+    P3D_REQUIRE(x && weight && styles && y_nchw, "torgb_nhwc_f16: null pointer");
+    if (!(ci == 64 || ci == 128 || ci == 256 || ci == 512) || co < 1 || co > 8 || co == 5 || co == 7)
+        return fail(P3D_ERR_UNSUPPORTED, "torgb_nhwc_f16: needs Ci in {64,128,256,512} and Co in {1,2,3,4,6,8} (got %d, %d)", ci, co);
+    hipStream_t s = (hipStream_t)stream;
+    int blocks = (hw / (64 / (ci / 8)) + 3) / 4;
+    if (blocks > kNumCU * 8 / n_img) blocks = kNumCU * 8 / n_img;
+    if (blocks < 1) blocks = 1;
+    const size_t sh = (size_t)co * ci * sizeof(float);
+#define P3D_RGB(C) case C: hipLaunchKernelGGL(torgb_nhwc_kernel<C>, dim3(blocks, n_img), dim3(256), sh, s, (const __half*)x, weight, styles, bias, y_nchw, hw, ci, clamp, accumulate); break;
+    switch (co) { P3D_RGB(1) P3D_RGB(2) P3D_RGB(3) P3D_RGB(4) P3D_RGB(6) P3D_RGB(8) }
+#undef P3D_RGB
+    count_launch(FAM_CONV);
+    return check_launch("torgb_nhwc_f16");
+}

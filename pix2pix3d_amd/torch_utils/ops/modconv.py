@@ -1,0 +1,122 @@
+"""Native inference path of the StyleGAN2 synthesis layers on fp16 channels-last activations.
+
+Not a module of the reference: it bundles what the reference spreads over ``modulated_conv2d`` (fused branch,
+training/networks_stylegan2.py:34-69, 81-91), ``conv2d_resample`` (:114-136), the noise add and ``bias_act``
+(networks_stylegan2.py:319-332) into calls of the MFMA implicit-GEMM kernels of libp3d_hip.so (csrc/conv2d.hip):
+``p3d_modulate_weights`` -> ``p3d_conv2d_nhwc_f16`` (+ ``upfirdn2d`` for the x2 layers) and ``p3d_torgb_nhwc_f16``.
+``SynthesisLayer`` / ``ToRGBLayer`` use it when ``layer_supported`` says so (device tensor, fp16, channels_last,
+inference, per-sample "fused" modulation); every other case keeps the generic operator route.
+"""
+import ctypes
+
+import torch
+
+from ... import _lib
+from . import upfirdn2d, bias_act
+
+enabled = True
+
+_vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+_lib.register('p3d_modulate_weights', ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp])
+_lib.register('p3d_conv2d_nhwc_f16', ctypes.c_int, [_vp] * 6 + [_i32] * 5 + [_i64, _i32, _i32, _f32, _f32, _vp])
+_lib.register('p3d_torgb_nhwc_f16', ctypes.c_int, [_vp] * 5 + [_i32] * 4 + [_f32, _i32, _vp])
+
+
+def _is_nhwc_f16(x):
+    return x.is_cuda and x.dtype == torch.float16 and x.ndim == 4 and x.is_contiguous(memory_format=torch.channels_last)
+
+
+def _no_grad_needed(*tensors):
+    return not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors))
+
+
+def layer_supported(x, weight, styles, noise_mode, fused_modconv, up):
+    """True when the native kernels cover this SynthesisLayer call."""
+    if not enabled or not _is_nhwc_f16(x) or not fused_modconv or up not in (1, 2):
+        return False
+    if tuple(weight.shape[2:]) != (3, 3) or noise_mode == 'random':
+        return False
+    return _no_grad_needed(x, weight, styles)
+
+
+def torgb_supported(x, weight, styles, fused_modconv):
+    if not enabled or not _is_nhwc_f16(x) or not fused_modconv or tuple(weight.shape[2:]) != (1, 1):
+        return False
+    return x.shape[1] in (64, 128, 256, 512) and weight.shape[0] in (1, 2, 3, 4, 6, 8) and _no_grad_needed(x, weight, styles)
+
+
+def modulate_weights(weight, styles, demodulate=True, pre_scale=1.0):
+    """weight [O,I,kh,kw] fp32, styles [N,I] -> fp16 [N][O][kh*kw][I], demodulation folded in."""
+    o, i, kh, kw = weight.shape
+    n = styles.shape[0]
+    w32 = weight.detach().float().contiguous()
+    s32 = styles.detach().float().contiguous()
+    out = torch.empty([n, o, kh * kw, i], dtype=torch.float16, device=weight.device)
+    code = _lib.lib().p3d_modulate_weights(_lib.ptr(w32), _lib.ptr(s32), _lib.ptr(out), n, o, i, kh * kw, int(demodulate), float(pre_scale), _lib.stream_of(out))
+    _lib.check(code, 'modulate_weights')
+    return out
+
+
+def _pad_channels(x, wmod, mult=64):
+    """Zero-pad Ci to a multiple of ``mult`` (only the 32-channel SR input needs it; the tensor is tiny)."""
+    ci = x.shape[1]
+    if ci % mult == 0:
+        return x, wmod
+    pad = mult - ci % mult
+    xp = torch.empty([x.shape[0], ci + pad, x.shape[2], x.shape[3]], dtype=x.dtype, device=x.device, memory_format=torch.channels_last).zero_()
+    xp[:, :ci] = x
+    wp = torch.zeros([*wmod.shape[:3], ci + pad], dtype=wmod.dtype, device=wmod.device)
+    wp[..., :ci] = wmod
+    return xp, wp
+
+
+def conv3x3(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None, act=0, gain=1.0, clamp=-1.0):
+    """x NHWC fp16 [N,Ci,H,W] (channels_last strides), wmod [N or 1][Co][9][Ci] fp16 -> NHWC fp16."""
+    assert _is_nhwc_f16(x) and wmod.dtype == torch.float16 and wmod.is_contiguous()
+    x, wmod = _pad_channels(x, wmod)
+    n, ci, h, w = x.shape
+    co = wmod.shape[1]
+    oh, ow = (2 * h + 1, 2 * w + 1) if transposed else (h, w)
+    y = torch.empty([n, co, oh, ow], dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+    stride = wmod.shape[1] * wmod.shape[2] * wmod.shape[3] if wmod.shape[0] == n and n > 1 else (0 if wmod.shape[0] == 1 else wmod.shape[1] * wmod.shape[2] * wmod.shape[3])
+    b32 = None if bias is None else bias.detach().float().contiguous()
+    nz = None if noise is None else noise.detach().float().contiguous()
+    ns = None if noise is None else noise_strength.detach().float().reshape(1).contiguous()
+    code = _lib.lib().p3d_conv2d_nhwc_f16(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns),
+                                          n, h, w, ci, co, stride, int(transposed), int(act), float(gain), float(clamp), _lib.stream_of(x))
+    _lib.check(code, 'conv2d_nhwc_f16')
+    return y
+
+
+def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=None, noise_strength=None, act='lrelu', act_gain=1.0, clamp=None):
+    """Whole SynthesisLayer body after the style affine: modulated 3x3 conv (x2 up when ``up == 2``) + noise + bias + act."""
+    wmod = modulate_weights(weight, styles, demodulate=True)
+    act_idx = {'linear': 0, 'lrelu': 1}.get(act)
+    clampv = -1.0 if clamp is None else float(clamp)
+    if up == 1 and act_idx is not None:
+        return conv3x3(x, wmod, bias=bias, noise=noise_const, noise_strength=noise_strength, act=act_idx, gain=act_gain, clamp=clampv)
+    if up == 1:
+        y = conv3x3(x, wmod, noise=noise_const, noise_strength=noise_strength)
+        return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
+    # x2: stride-2 transposed conv as four polyphase GEMMs, then the 4x4 low-pass with gain 4 (conv2d_resample.py:114-131)
+    y = conv3x3(x, wmod, transposed=True)
+    y = upfirdn2d.upfirdn2d(y, resample_filter, padding=[1, 1, 1, 1], gain=4)
+    if noise_const is not None:
+        y = y.add_((noise_const * noise_strength).to(y.dtype))
+    return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
+
+
+def torgb(x, weight, styles, bias, clamp=None, out=None):
+    """ToRGB: 1x1 modulated conv without demodulation + bias (+ clamp) -> fp32 NCHW; ``out`` accumulates (skip image)."""
+    n, ci, h, w = x.shape
+    co = weight.shape[0]
+    w32 = weight.detach().float().reshape(co, ci).contiguous()
+    s32 = styles.detach().float().contiguous()
+    b32 = None if bias is None else bias.detach().float().contiguous()
+    acc = out is not None
+    y = out if acc else torch.empty([n, co, h, w], dtype=torch.float32, device=x.device)
+    assert y.is_contiguous() and y.dtype == torch.float32
+    code = _lib.lib().p3d_torgb_nhwc_f16(_lib.ptr(x), _lib.ptr(w32), _lib.ptr(s32), _lib.ptr(b32), _lib.ptr(y), n, h * w, ci, co,
+                                         -1.0 if clamp is None else float(clamp), int(acc), _lib.stream_of(x))
+    _lib.check(code, 'torgb_nhwc_f16')
+    return y

@@ -9,7 +9,7 @@ import torch
 
 from ..torch_utils import misc
 from ..torch_utils import persistence
-from ..torch_utils.ops import conv2d_resample, upfirdn2d, bias_act, fma
+from ..torch_utils.ops import conv2d_resample, upfirdn2d, bias_act, fma, modconv
 
 
 @misc.profiled_function
@@ -215,9 +215,16 @@ class SynthesisLayer(torch.nn.Module):
             noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
         if self.use_noise and noise_mode == 'const':
             noise = self.noise_const * self.noise_strength
+        clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        if modconv.layer_supported(x, self.weight, styles, noise_mode, fused_modconv, self.up):
+            # fp16 channels-last inference: weight modulation, MFMA conv, noise, bias, activation in native kernels
+            const_noise = self.use_noise and noise_mode == 'const'
+            return modconv.synthesis_layer(x, self.weight, styles, self.bias, self.up, self.resample_filter,
+                                           noise_const=self.noise_const if const_noise else None,
+                                           noise_strength=self.noise_strength if const_noise else None,
+                                           act=self.activation, act_gain=self.act_gain * gain, clamp=clamp)
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
                              resample_filter=self.resample_filter, flip_weight=(self.up == 1), fused_modconv=fused_modconv)
-        clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=self.act_gain * gain, clamp=clamp)
 
     def extra_repr(self):
@@ -240,6 +247,8 @@ class ToRGBLayer(torch.nn.Module):
 
     def forward(self, x, w, fused_modconv=True):
         styles = self.affine(w) * self.weight_gain
+        if modconv.torgb_supported(x, self.weight, styles, fused_modconv):
+            return modconv.torgb(x, self.weight, styles, self.bias, clamp=self.conv_clamp)      # fp32 NCHW, bias + clamp fused
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
         return bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
 

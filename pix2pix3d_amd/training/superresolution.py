@@ -37,8 +37,13 @@ class _SuperresolutionBase(torch.nn.Module):
         return rgb
 
 
+sr_channels_last = True      # fp16 SR blocks run channels_last (the reference's `fp16_channels_last` knob, off there by default):
+                             # the layout the MFMA conv kernels of csrc/conv2d.hip consume
+
 def _two_blocks(self, cls0, cls1, channels, mid, out, res0, res1, img_channels, use_fp16, block_kwargs):
     clamp = 256 if use_fp16 else None
+    block_kwargs = dict(block_kwargs)
+    block_kwargs.setdefault('fp16_channels_last', sr_channels_last)
     self.block0 = cls0(channels, mid, w_dim=512, resolution=res0, img_channels=img_channels, is_last=False, use_fp16=use_fp16, conv_clamp=clamp, **block_kwargs)
     self.block1 = cls1(mid, out, w_dim=512, resolution=res1, img_channels=img_channels, is_last=True, use_fp16=use_fp16, conv_clamp=clamp, **block_kwargs)
 

@@ -1,0 +1,115 @@
+"""The MFMA implicit-GEMM modulated convolution (csrc/conv2d.hip) against fp32 torch convolutions of the same
+fp16-rounded operands.  fp16 storage, fp32 accumulation: tolerance 2e-3 relative-to-max on the conv output (one fp16
+rounding of the result), 1e-3 on the fp32 ToRGB output."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _nhwc(t):
+    return t.to(memory_format=torch.channels_last)
+
+
+def _ref_modulated(weight, styles, demod=True):
+    w = weight[None].float() * styles[:, None, :, None, None].float()
+    if demod:
+        w = w * (w.square().sum(dim=[2, 3, 4], keepdim=True) + 1e-8).rsqrt()
+    return w
+
+
+@pytest.mark.parametrize('ci,co,h,w', [(64, 128, 16, 16), (128, 128, 33, 20), (256, 96, 8, 40), (32, 256, 12, 12), (64, 200, 5, 7)])
+def test_modulate_and_conv3x3(hip_lib, ci, co, h, w):
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    from pix2pix3d_amd import _lib
+    torch.manual_seed(ci + co)
+    n = 3
+    x = _nhwc(torch.randn(n, ci, h, w, device='cuda').half())
+    weight = torch.randn(co, ci, 3, 3, device='cuda')
+    styles = torch.randn(n, ci, device='cuda') + 1
+    wmod = modconv.modulate_weights(weight, styles)
+    wref = _ref_modulated(weight, styles)                                   # [n, co, ci, 3, 3]
+    assert rel_err(wmod.float().cpu().numpy(), wref.permute(0, 1, 3, 4, 2).reshape(n, co, 9, ci).cpu().numpy()) < 1e-3
+    wq = wmod.float().reshape(n, co, 3, 3, ci).permute(0, 1, 4, 2, 3)       # the fp16-rounded weights the kernel sees
+    n0 = _lib.launch_count('conv')
+    y = modconv.conv3x3(x, wmod)
+    assert _lib.launch_count('conv') > n0 and y.is_contiguous(memory_format=torch.channels_last)
+    yr = torch.stack([F.conv2d(x[i:i + 1].float(), wq[i], padding=1)[0] for i in range(n)])
+    assert rel_err(y.float().cpu().numpy(), yr.cpu().numpy()) < 2e-3
+    # fused epilogue: noise, bias, lrelu, gain, clamp
+    bias = torch.randn(co, device='cuda')
+    noise = torch.randn(h, w, device='cuda')
+    strength = torch.tensor(0.3, device='cuda')
+    y2 = modconv.conv3x3(x, wmod, bias=bias, noise=noise, noise_strength=strength, act=1, gain=2 ** 0.5, clamp=1.5)
+    yr2 = (F.leaky_relu(yr + noise * strength + bias.view(1, -1, 1, 1), 0.2) * 2 ** 0.5).clamp(-1.5, 1.5)
+    assert rel_err(y2.float().cpu().numpy(), yr2.cpu().numpy()) < 2e-3
+    # shared (non-modulated) weights: stride 0 between images
+    y3 = modconv.conv3x3(x, wmod[:1])
+    yr3 = F.conv2d(x.float(), wq[0], padding=1)
+    assert rel_err(y3.float().cpu().numpy(), yr3.cpu().numpy()) < 2e-3
+
+
+@pytest.mark.parametrize('ci,co,h,w', [(64, 128, 8, 8), (128, 64, 17, 9), (32, 256, 16, 16)])
+def test_transposed_stride2_conv(hip_lib, ci, co, h, w):
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    torch.manual_seed(ci * co)
+    n = 2
+    x = _nhwc(torch.randn(n, ci, h, w, device='cuda').half())
+    weight = torch.randn(co, ci, 3, 3, device='cuda')
+    styles = torch.randn(n, ci, device='cuda') + 1
+    wmod = modconv.modulate_weights(weight, styles)
+    wq = wmod.float().reshape(n, co, 3, 3, ci).permute(0, 1, 4, 2, 3)       # [n, co, ci, 3, 3]
+    y = modconv.conv3x3(x, wmod, transposed=True)
+    assert tuple(y.shape) == (n, co, 2 * h + 1, 2 * w + 1)
+    yr = torch.stack([F.conv_transpose2d(x[i:i + 1].float(), wq[i].transpose(0, 1), stride=2)[0] for i in range(n)])
+    assert rel_err(y.float().cpu().numpy(), yr.cpu().numpy()) < 2e-3
+
+
+@pytest.mark.parametrize('ci,co', [(128, 3), (256, 6), (128, 1), (64, 4)])
+def test_torgb(hip_lib, ci, co):
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    torch.manual_seed(co)
+    n, h, w = 2, 24, 20
+    x = _nhwc(torch.randn(n, ci, h, w, device='cuda').half())
+    weight = torch.randn(co, ci, 1, 1, device='cuda')
+    styles = torch.randn(n, ci, device='cuda') / ci ** 0.5
+    bias = torch.randn(co, device='cuda')
+    y = modconv.torgb(x, weight, styles, bias, clamp=1.0)
+    yr = (torch.einsum('nihw,oi,ni->nohw', x.float(), weight[:, :, 0, 0], styles) + bias.view(1, -1, 1, 1)).clamp(-1, 1)
+    assert y.dtype == torch.float32 and rel_err(y.cpu().numpy(), yr.cpu().numpy()) < 1e-3
+    acc = torch.ones_like(y)
+    y2 = modconv.torgb(x, weight, styles, bias, clamp=1.0, out=acc)
+    assert y2 is acc and rel_err(acc.cpu().numpy(), (yr + 1).cpu().numpy()) < 1e-3
+
+
+def test_synthesis_layer_native_vs_generic(hip_lib):
+    """A whole fp16 channels-last SynthesisLayer / ToRGB through the native path equals the generic operator route."""
+    from pix2pix3d_amd.training.networks_stylegan2 import SynthesisLayer, ToRGBLayer
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    torch.manual_seed(0)
+    for up in (1, 2):
+        layer = SynthesisLayer(128, 64, w_dim=32, resolution=32 * up, up=up, conv_clamp=256, channels_last=True).cuda().eval().requires_grad_(False)
+        layer.noise_strength.fill_(0.2); layer.bias.normal_()
+        x = _nhwc(torch.randn(2, 128, 32, 32, device='cuda').half())
+        wl = torch.randn(2, 32, device='cuda')
+        for mode in ('const', 'none'):
+            with torch.no_grad():
+                modconv.enabled = True
+                y1 = layer(x, wl, noise_mode=mode, fused_modconv=True)
+                modconv.enabled = False
+                y0 = layer(x, wl, noise_mode=mode, fused_modconv=True)
+                modconv.enabled = True
+            assert y1.shape == y0.shape and rel_err(y1.float().cpu().numpy(), y0.float().cpu().numpy()) < 6e-3, (up, mode)
+    rgb = ToRGBLayer(128, 3, w_dim=32, conv_clamp=256, channels_last=True).cuda().eval().requires_grad_(False)
+    rgb.bias.normal_()
+    x = _nhwc(torch.randn(2, 128, 32, 32, device='cuda').half())
+    with torch.no_grad():
+        y1 = rgb(x, wl)
+        modconv.enabled = False
+        y0 = rgb(x, wl).float()
+        modconv.enabled = True
+    assert rel_err(y1.cpu().numpy(), y0.cpu().numpy()) < 6e-3
