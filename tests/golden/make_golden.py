@@ -299,6 +299,30 @@ def group_model():
 
 GROUPS['model'] = group_model
 
+
+def group_flrelu():
+    from torch_utils.ops import filtered_lrelu, upfirdn2d
+    g = torch.Generator().manual_seed(77)
+    cases = [dict(up=2, down=2, fu=12, fd=12, pad=[9, 10, 9, 10], clamp=None, flip=False), dict(up=1, down=1, fu=1, fd=1, pad=0, clamp=0.8, flip=False),
+             dict(up=2, down=1, fu=8, fd=1, pad=[3, 4, 3, 4], clamp=1.2, flip=True), dict(up=1, down=2, fu=1, fd=6, pad=[2, 3, 2, 3], clamp=None, flip=False)]
+    out = {'num': np.int64(len(cases))}
+    for i, cs in enumerate(cases):
+        x = torch.randn(2, 3, 10, 9, generator=g, dtype=torch.float64).requires_grad_(True)
+        b = torch.randn(3, generator=g, dtype=torch.float64)
+        fu = upfirdn2d.setup_filter(torch.randn(cs['fu'], generator=g).tolist()) if cs['fu'] > 1 else None
+        fd = upfirdn2d.setup_filter(torch.randn(cs['fd'], generator=g).tolist()) if cs['fd'] > 1 else None
+        y = filtered_lrelu._filtered_lrelu_ref(x, fu=fu, fd=fd, b=b, up=cs['up'], down=cs['down'], padding=cs['pad'], gain=1.3, slope=0.15, clamp=cs['clamp'], flip_filter=cs['flip'])
+        gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+        gx, = torch.autograd.grad(y, x, gy)
+        out.update({f'{i}.x': x, f'{i}.b': b, f'{i}.y': y, f'{i}.gy': gy, f'{i}.gx': gx,
+                    f'{i}.fu': fu if fu is not None else np.zeros([0], np.float32), f'{i}.fd': fd if fd is not None else np.zeros([0], np.float32),
+                    f'{i}.cfg': np.array([cs['up'], cs['down'], int(cs['flip'])]), f'{i}.pad': np.array(cs['pad'] if isinstance(cs['pad'], list) else [cs['pad']] * 4),
+                    f'{i}.clamp': np.float64(-1 if cs['clamp'] is None else cs['clamp'])})
+    save('ops_filtered_lrelu', **out)
+
+
+GROUPS['flrelu'] = group_flrelu
+
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GROUPS)
     for nm in names:

@@ -43,3 +43,16 @@ for name, ci, co, r, dt in [('sr.b1.conv0 T2', 256, 128, 256, torch.float16), ('
     xc, wc = x.to(memory_format=torch.channels_last), w.to(memory_format=torch.channels_last)
     res['plain NHWC'] = timeit(lambda: torch.nn.functional.conv_transpose2d(xc, wc, stride=2))
     print(name, dt, ' | '.join(f'{k}: {fl / t / 1e12:.1f} TF ({t * 1e3:.2f} ms)' for k, t in res.items()), flush=True)
+
+# ---- this repo's MFMA implicit-GEMM kernel on the SR shapes ----
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pix2pix3d_amd.torch_utils.ops import modconv
+for name, ci, co, r, tr in [('sr.b0.conv1', 256, 256, 256, False), ('sr.b1.conv1', 128, 128, 512, False), ('sr.b1.conv0 T2', 256, 128, 256, True), ('sr.b0.conv0 T2', 32, 256, 128, True)]:
+    x = torch.randn(N, ci, r, r, device='cuda').half().to(memory_format=torch.channels_last)
+    weight = torch.randn(co, ci, 3, 3, device='cuda'); styles = torch.randn(N, ci, device='cuda') + 1
+    wmod = modconv.modulate_weights(weight, styles)
+    bias = torch.randn(co, device='cuda')
+    fl = 2 * N * ci * co * 9 * r * r
+    t = timeit(lambda: modconv.conv3x3(x, wmod, transposed=tr, bias=None if tr else bias, act=0 if tr else 1, gain=1.414, clamp=-1 if tr else 256))
+    tm = timeit(lambda: modconv.modulate_weights(weight, styles))
+    print(f'p3d {name}: {fl / t / 1e12:.1f} TF ({t * 1e3:.3f} ms)   modulate_weights {tm * 1e6:.0f} us', flush=True)

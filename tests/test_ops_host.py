@@ -99,3 +99,40 @@ def test_fma_backward_unbroadcasts():
     b = torch.randn(2, 3, 1, 1, dtype=torch.float64, requires_grad=True)
     c = torch.randn(4, 4, dtype=torch.float64, requires_grad=True)
     assert torch.autograd.gradcheck(fma.fma, (a, b, c))
+
+
+def test_filtered_lrelu_cpu_path_matches_reference():
+    from pix2pix3d_amd.torch_utils.ops import filtered_lrelu
+    g = load_golden('ops_filtered_lrelu')
+    for i in range(int(g['num'])):
+        up, down, flip = g[f'{i}.cfg'].tolist()
+        fu, fd = g[f'{i}.fu'], g[f'{i}.fd']
+        x = torch.tensor(g[f'{i}.x'], requires_grad=True)
+        clamp = float(g[f'{i}.clamp'])
+        y = filtered_lrelu.filtered_lrelu(x, fu=None if fu.size == 0 else torch.tensor(fu), fd=None if fd.size == 0 else torch.tensor(fd), b=torch.tensor(g[f'{i}.b']),
+                                          up=up, down=down, padding=g[f'{i}.pad'].tolist(), gain=1.3, slope=0.15, clamp=None if clamp < 0 else clamp, flip_filter=bool(flip))
+        assert rel_err(y.detach().numpy(), g[f'{i}.y']) < 1e-6, i
+        gx, = torch.autograd.grad(y, x, torch.tensor(g[f'{i}.gy']))
+        assert rel_err(gx.numpy(), g[f'{i}.gx']) < 1e-6, i
+
+
+def test_dual_discriminator_forward_and_r1_on_cpu():
+    """D forward (north-star API) and the R1 double-backward path through conv2d_gradfix.no_weight_gradients."""
+    from pix2pix3d_amd.training.dual_discriminator import DualDiscriminator, SingleDiscriminator, filtered_resizing
+    torch.manual_seed(0)
+    D = DualDiscriminator(c_dim=25, img_resolution=32, img_channels=3, channel_base=512, channel_max=32, num_fp16_res=0, conv_clamp=None,
+                          block_kwargs=dict(freeze_layers=0), mapping_kwargs=dict(), epilogue_kwargs=dict(mbstd_group_size=2))
+    names = {n for n, _ in D.named_parameters()}
+    assert {'b32.fromrgb.weight', 'b8.skip.weight', 'b4.out.bias', 'mapping.fc7.weight'} <= names and 'resample_filter' in dict(D.named_buffers())
+    img = {'image': torch.randn(2, 3, 32, 32, requires_grad=True), 'image_raw': torch.randn(2, 3, 8, 8, requires_grad=True)}
+    c = torch.randn(2, 25)
+    logits = D(img, c)
+    assert logits.shape == (2, 1) and logits.dtype == torch.float32
+    with conv2d_gradfix.no_weight_gradients():
+        g_img, g_raw = torch.autograd.grad(logits.sum(), [img['image'], img['image_raw']], create_graph=True)
+    r1 = g_img.square().sum([1, 2, 3]) + g_raw.square().sum([1, 2, 3])
+    r1.mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in D.named_parameters() if 'b32.conv0.weight' in n)
+    assert filtered_resizing(img['image_raw'], 32, D.resample_filter, 'classic').shape == (2, 3, 32, 32)
+    S = SingleDiscriminator(c_dim=0, img_resolution=16, img_channels=3, channel_base=256, channel_max=16, num_fp16_res=0, conv_clamp=None)
+    assert S({'image': torch.randn(2, 3, 16, 16)}, None).shape == (2, 1)
