@@ -144,9 +144,10 @@ int p3d_modulate_weights(const float* weight, const float* styles, void* out_f16
  * transposed_stride2 = 0: 3x3 correlation, padding 1 -> y [N][H][W][Co]; optional epilogue
  *   v = acc + noise[H][W] * noise_strength[0] + bias[co]; act (0 linear, 1 lrelu 0.2); * gain; clamp (< 0 off).
  * transposed_stride2 = 1: conv_transpose2d(stride 2, padding 0) -> y [N][2H+1][2W+1][Co], no epilogue.
- * Ci must be a multiple of 64 (else P3D_ERR_UNSUPPORTED); fp32 accumulation.                        */
+ * zeros128: >= 128 bytes of zeros in device memory, 16-byte aligned (source of the border rows of the LDS-DMA
+ * staging).  Ci must be a multiple of 64 (else P3D_ERR_UNSUPPORTED); fp32 accumulation.              */
 int p3d_conv2d_nhwc_f16(const void* x, const void* w, void* y, const float* bias, const float* noise, const float* noise_strength,
-                        int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
+                        const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
                         int32_t transposed_stride2, int32_t act, float gain, float clamp, p3d_stream_t stream);
 
 /* x [N][HW][Ci] fp16 channels-last, weight [Co][Ci] fp32, styles [N][Ci] fp32 (weight gain already applied),

@@ -40,6 +40,7 @@ struct ConvArgs {
     const float* bias;     // [Co] or null
     const float* noise;    // [OH][OW] or null
     const float* noise_strength;   // device scalar (used when noise != null)
+    const __half* zeros;   // >= 128 bytes of zeros, 16-byte aligned: source of out-of-image / out-of-range rows
     int N, H, W, Ci, Co, KT;
     int64_t w_img_stride;  // elements between images' weight panels (0: shared weights)
     int SH, SW;            // sub-problem grid (pixels enumerated by this launch)
@@ -50,7 +51,9 @@ struct ConvArgs {
     float gain, clamp;     // clamp < 0: off
 };
 
-__device__ __forceinline__ int swz(int row, int chunk) { return row * (BK / 8) + (chunk ^ (row & 7)); }   // index in 16-B units
+// 16-B slot of (row, chunk).  Two 128-byte tile rows share one 256-byte LDS bank row, so the XOR key is (row >> 1) & 7:
+// the 16 rows a ds_read_b128 lane group touches then land on 16 distinct slots (row & 7 would leave a 2-way conflict).
+__device__ __forceinline__ int swz(int row, int chunk) { return row * (BK / 8) + (chunk ^ ((row >> 1) & 7)); }
 
 __global__ void __launch_bounds__(256, 2) conv2d_nhwc_f16_kernel(ConvArgs a)
 {
@@ -58,7 +61,16 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_f16_kernel(ConvArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;                                   // wave's 64x64 quadrant
     const int n = blockIdx.z;
-    const int m0 = blockIdx.x * BM, co0 = blockIdx.y * BN;
+    // XCD-aware tile order: workgroup L of a launch lands on XCD L % 8, each XCD with its own L2.  Consecutive slots
+    // of one XCD get the output-channel blocks of the SAME pixel tile (they share the A operand), and pixel tiles
+    // stride over XCDs, so an A neighbourhood is fetched into one L2 only.  Falls back to the plain order when the
+    // grid does not split evenly.
+    int mt = blockIdx.x, cb = blockIdx.y;
+    {
+        const int nmt = gridDim.x, ncb = gridDim.y, L = blockIdx.x + blockIdx.y * nmt;
+        if ((nmt & 7) == 0) { const int q = L >> 3, r = L & 7; cb = q % ncb; mt = (q / ncb) * 8 + r; }
+    }
+    const int m0 = mt * BM, co0 = cb * BN;
     const int M = a.SH * a.SW;
     const __half* xin = a.x + (int64_t)n * a.H * a.W * a.Ci;
     const __half* wgt = a.w + (int64_t)n * a.w_img_stride;
@@ -77,29 +89,26 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_f16_kernel(ConvArgs a)
     const int kchunks = a.Ci / BK;
     const int ksteps = a.ntaps * kchunks;
 
-    h8 ra[4], rb[4];
-    auto load_tiles = [&](int ks) {
-        const int t = ks / kchunks, c0 = (ks - t * kchunks) * BK + chunk * 8;
+    // Direct global -> LDS staging (global_load_lds_dwordx4): each wave instruction deposits 64 x 16 B = eight 128-byte
+    // rows linearly at a wave-uniform LDS base, so the XOR swizzle is applied on the SOURCE side: the lane that fills
+    // LDS slot (row, pos) fetches chunk pos ^ ((row >> 1) & 7) of that row.  Rows outside the image (or past the end of the
+    // pixel / channel range) read from a page of zeros instead.
+    const int src_chunk = chunk ^ ((srow >> 1) & 7);               // ((srow + 32p) >> 1) & 7 == (srow >> 1) & 7
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    auto stage = [&](int ks, int buf) {
+        const int cc = ks / a.ntaps, t = ks - cc * a.ntaps, c0 = cc * BK + src_chunk * 8;   // taps innermost: a block re-reads its 64-channel neighbourhood while it is L2-hot
         const ConvTap tp = a.taps[t];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int iy = pi[p] + tp.dy, ix = pj[p] + tp.dx;
             const bool ok = pok[p] & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
-            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok) v = *(const h8*)(xin + ((int64_t)iy * a.W + ix) * a.Ci + c0);
-            ra[p] = v;
+            const __half* src = ok ? xin + ((int64_t)iy * a.W + ix) * a.Ci + c0 : a.zeros;
+            const int row0 = (wave * 8 + 32 * p) * (BK / 8);      // first 16-B slot of this wave's 8-row group
+            __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)&lds[buf][0][row0], 16, 0, 0);
             const int co = co0 + srow + 32 * p;
-            h8 u = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (co < a.Co) u = *(const h8*)(wgt + ((int64_t)co * a.KT + tp.widx) * a.Ci + c0);
-            rb[p] = u;
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int row = srow + 32 * p;
-            lds[buf][0][swz(row, chunk)] = ra[p];
-            lds[buf][1][swz(row, chunk)] = rb[p];
+            const __half* wsrc = (co < a.Co) ? wgt + ((int64_t)co * a.KT + tp.widx) * a.Ci + c0 : a.zeros;
+            __builtin_amdgcn_global_load_lds((glb_ptr)wsrc, (lds_ptr)&lds[buf][1][row0], 16, 0, 0);
         }
     };
 
@@ -111,13 +120,12 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_f16_kernel(ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tiles(0);
-    store_tiles(0);
+    stage(0, 0);
     __syncthreads();
     const int frow = lane & 31, fk = lane >> 5;                                 // fragment row / k-group of this lane
     for (int ks = 0; ks < ksteps; ++ks) {
         const int buf = ks & 1;
-        if (ks + 1 < ksteps) load_tiles(ks + 1);                                // global loads in flight under the MFMAs
+        if (ks + 1 < ksteps) stage(ks + 1, buf ^ 1);                            // next tile streams into the other buffer under the MFMAs
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             h8 fa[2], fb[2];
@@ -132,8 +140,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_f16_kernel(ConvArgs a)
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        if (ks + 1 < ksteps) store_tiles(buf ^ 1);
-        __syncthreads();
+        __syncthreads();                                                        // drains the LDS-DMA (vmcnt) and fences the buffer swap
     }
 
     // ---- epilogue: accumulator element (row = (r&3) + 8(r>>2) + 4*fk, col = frow) of each 32x32 tile -------------
@@ -260,16 +267,16 @@ static int launch_conv(ConvArgs& a, hipStream_t s)
 }
 
 extern "C" int p3d_conv2d_nhwc_f16(const void* x, const void* w, void* y, const float* bias, const float* noise, const float* noise_strength,
-                                   int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
+                                   const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
                                    int32_t transposed_stride2, int32_t act, float gain, float clamp, p3d_stream_t stream)
 {
-    P3D_REQUIRE(x && w && y, "conv2d_nhwc_f16: null pointer");
+    P3D_REQUIRE(x && w && y && zeros128, "conv2d_nhwc_f16: null pointer");
     P3D_REQUIRE(n_img >= 1 && h >= 1 && wdt >= 1 && co >= 1, "conv2d_nhwc_f16: bad sizes");
     if (ci % BK != 0 && ci % 32 != 0) return fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc_f16: Ci=%d must be a multiple of 64", ci);
     if (ci % BK != 0) return fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc_f16: Ci=%d must be a multiple of 64", ci);
-    P3D_REQUIRE((((uintptr_t)x) & 15u) == 0 && (((uintptr_t)w) & 15u) == 0, "conv2d_nhwc_f16: x and w must be 16-byte aligned");
+    P3D_REQUIRE((((uintptr_t)x) & 15u) == 0 && (((uintptr_t)w) & 15u) == 0 && (((uintptr_t)zeros128) & 15u) == 0, "conv2d_nhwc_f16: x and w must be 16-byte aligned");
     ConvArgs a{};
-    a.x = (const __half*)x; a.w = (const __half*)w; a.y = (__half*)y; a.bias = bias; a.noise = noise; a.noise_strength = noise_strength;
+    a.x = (const __half*)x; a.w = (const __half*)w; a.y = (__half*)y; a.bias = bias; a.noise = noise; a.noise_strength = noise_strength; a.zeros = (const __half*)zeros128;
     a.N = n_img; a.H = h; a.W = wdt; a.Ci = ci; a.Co = co; a.KT = 9; a.w_img_stride = w_img_stride;
     a.act = act; a.gain = gain; a.clamp = clamp;
     hipStream_t s = (hipStream_t)stream;

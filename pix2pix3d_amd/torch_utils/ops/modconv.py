@@ -18,7 +18,16 @@ enabled = True
 
 _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 _lib.register('p3d_modulate_weights', ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp])
-_lib.register('p3d_conv2d_nhwc_f16', ctypes.c_int, [_vp] * 6 + [_i32] * 5 + [_i64, _i32, _i32, _f32, _f32, _vp])
+_lib.register('p3d_conv2d_nhwc_f16', ctypes.c_int, [_vp] * 7 + [_i32] * 5 + [_i64, _i32, _i32, _f32, _f32, _vp])
+
+_zero_pages = {}
+
+
+def _zeros_page(device):
+    z = _zero_pages.get(device)
+    if z is None:
+        z = _zero_pages[device] = torch.zeros(256, dtype=torch.float16, device=device)
+    return z
 _lib.register('p3d_torgb_nhwc_f16', ctypes.c_int, [_vp] * 5 + [_i32] * 4 + [_f32, _i32, _vp])
 
 
@@ -82,7 +91,7 @@ def conv3x3(x, wmod, transposed=False, bias=None, noise=None, noise_strength=Non
     b32 = None if bias is None else bias.detach().float().contiguous()
     nz = None if noise is None else noise.detach().float().contiguous()
     ns = None if noise is None else noise_strength.detach().float().reshape(1).contiguous()
-    code = _lib.lib().p3d_conv2d_nhwc_f16(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns),
+    code = _lib.lib().p3d_conv2d_nhwc_f16(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns), _lib.ptr(_zeros_page(x.device)),
                                           n, h, w, ci, co, stride, int(transposed), int(act), float(gain), float(clamp), _lib.stream_of(x))
     _lib.check(code, 'conv2d_nhwc_f16')
     return y

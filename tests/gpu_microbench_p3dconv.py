@@ -1,0 +1,19 @@
+import torch, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pix2pix3d_amd.torch_utils.ops import modconv
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); s = torch.cuda.Event(True); e = torch.cuda.Event(True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e-3
+N = 4
+for name, ci, co, r, tr in [('sr.b0.conv1', 256, 256, 256, False), ('sr.b1.conv1', 128, 128, 512, False), ('sr.b1.conv0 T2', 256, 128, 256, True), ('sr.b0.conv0 T2', 32, 256, 128, True)]:
+    x = torch.randn(N, ci, r, r, device='cuda').half().to(memory_format=torch.channels_last)
+    weight = torch.randn(co, ci, 3, 3, device='cuda'); styles = torch.randn(N, ci, device='cuda') + 1
+    wmod = modconv.modulate_weights(weight, styles)
+    bias = torch.randn(co, device='cuda')
+    fl = 2 * N * ci * co * 9 * r * r
+    t = timeit(lambda: modconv.conv3x3(x, wmod, transposed=tr, bias=None if tr else bias, act=0 if tr else 1, gain=1.414, clamp=-1 if tr else 256))
+    print(f'p3d {name}: {fl / t / 1e12:.1f} TF ({t * 1e3:.3f} ms)', flush=True)
