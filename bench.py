@@ -136,6 +136,13 @@ def main():
     for _ in range(max(args.warmup, 1)):
         out = step()
     torch.cuda.synchronize()
+    # vendor-library convolutions (small backbone layers) may still be compiling / selecting kernels on a fresh box:
+    # keep warming (untimed) until three consecutive steps agree within 5 %, at most 40 extra steps
+    hist = []
+    for _ in range(40):
+        t0 = time.perf_counter(); step(); torch.cuda.synchronize(); hist.append(time.perf_counter() - t0)
+        if len(hist) >= 3 and max(hist[-3:]) < 1.05 * min(hist[-3:]):
+            break
     assert out['image'].shape == (args.batch, 3, info['res'], info['res'])
 
     launch = 'eager'

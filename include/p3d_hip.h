@@ -92,6 +92,10 @@ typedef struct p3d_render_desc {
     int32_t white_back;
     float   ray_start, ray_end;           /* used when t_start/t_end are null                   */
     float   box_warp;
+    /* plane memory layout, in floats; all 0 = the default [N][3][H][W][32].  Texel (n, p, y, x) starts at
+     * n*image_stride + p*plane_stride + (y*W + x)*pixel_stride and holds 32 contiguous channels; e.g. a
+     * channels-last backbone output [N][H][W][96] is (image H*W*96, plane 32, pixel 96).                 */
+    int64_t image_stride, plane_stride, pixel_stride;
 } p3d_render_desc;
 
 int p3d_render_decoder_floats(void);     /* size of the packed decoder stream, in floats        */
@@ -136,19 +140,20 @@ int p3d_importance_sample(const float* z_coarse, const float* w_coarse, const fl
  *   ToRGB 1x1 modulated conv            training/networks_stylegan2.py:355-359                    */
 
 /* weight [Co][Ci][taps] fp32 (taps = kh*kw, PyTorch OIHW order), styles [N][Ci] fp32 ->
- * out [N][Co][taps][Ci] fp16 = weight * pre_scale * styles (* rsqrt(sum^2 + 1e-8) if demodulate). */
-int p3d_modulate_weights(const float* weight, const float* styles, void* out_f16, int32_t n_img, int32_t co, int32_t ci,
+ * out [N][Co][taps][Ci] (dtype fp16 or fp32) = weight * pre_scale * styles (* rsqrt(sum^2 + 1e-8) if demodulate). */
+int p3d_modulate_weights(const float* weight, const float* styles, void* out, int dtype, int32_t n_img, int32_t co, int32_t ci,
                          int32_t taps, int32_t demodulate, float pre_scale, p3d_stream_t stream);
 
-/* x [N][H][W][Ci] fp16, w [N or 1][Co][9][Ci] fp16 (w_img_stride elements between images, 0 = shared).
- * transposed_stride2 = 0: 3x3 correlation, padding 1 -> y [N][H][W][Co]; optional epilogue
+/* x [N][H][W][Ci], w [N or 1][Co][k*k][Ci] (w_img_stride elements between images, 0 = shared), both `dtype`
+ * (P3D_F16: v_mfma_f32_32x32x16_f16; P3D_F32: v_mfma_f32_32x32x2_f32, exact fp32), fp32 accumulation.
+ * transposed_stride2 = 0: k x k correlation (k = 1 or 3), "same" padding -> y [N][H][W][Co]; optional epilogue
  *   v = acc + noise[H][W] * noise_strength[0] + bias[co]; act (0 linear, 1 lrelu 0.2); * gain; clamp (< 0 off).
- * transposed_stride2 = 1: conv_transpose2d(stride 2, padding 0) -> y [N][2H+1][2W+1][Co], no epilogue.
+ * transposed_stride2 = 1 (k = 3): conv_transpose2d(stride 2, padding 0) -> y [N][2H+1][2W+1][Co], no epilogue.
  * zeros128: >= 128 bytes of zeros in device memory, 16-byte aligned (source of the border rows of the LDS-DMA
- * staging).  Ci must be a multiple of 64 (else P3D_ERR_UNSUPPORTED); fp32 accumulation.              */
-int p3d_conv2d_nhwc_f16(const void* x, const void* w, void* y, const float* bias, const float* noise, const float* noise_strength,
-                        const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
-                        int32_t transposed_stride2, int32_t act, float gain, float clamp, p3d_stream_t stream);
+ * staging).  Ci must be a multiple of 64 (fp16) / 32 (fp32), else P3D_ERR_UNSUPPORTED.             */
+int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype, const float* bias, const float* noise, const float* noise_strength,
+                    const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
+                    int32_t kernel_size, int32_t transposed_stride2, int32_t act, float gain, float clamp, p3d_stream_t stream);
 
 /* x [N][HW][Ci] fp16 channels-last, weight [Co][Ci] fp32, styles [N][Ci] fp32 (weight gain already applied),
  * bias [Co] or null -> y [N][Co][HW] fp32 (NCHW); accumulate != 0 adds into y (the skip-image sum).   */

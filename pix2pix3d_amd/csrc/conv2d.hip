@@ -29,38 +29,46 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BM = 128, BN = 128;          // block tile; the K step is one 128-byte row: 64 halfs or 32 floats
 
 struct ConvTap { int dy, dx, widx; };
 
 struct ConvArgs {
-    const __half* x;       // [N][H][W][Ci]
-    const __half* w;       // [N or 1][Co][KT][Ci]   (KT = taps in the weight tensor: 9 for 3x3)
-    __half* y;             // [N][OH][OW][Co]
+    const void* x;         // [N][H][W][Ci]           fp16 or fp32 (kernel template)
+    const void* w;         // [N or 1][Co][KT][Ci]    (KT = taps in the weight tensor: 9 for 3x3, 1 for 1x1)
+    void* y;               // [N][OH][OW][Co]
     const float* bias;     // [Co] or null
     const float* noise;    // [OH][OW] or null
     const float* noise_strength;   // device scalar (used when noise != null)
-    const __half* zeros;   // >= 128 bytes of zeros, 16-byte aligned: source of out-of-image / out-of-range rows
+    const void* zeros;     // >= 128 bytes of zeros, 16-byte aligned: source of out-of-image / out-of-range rows
     int N, H, W, Ci, Co, KT;
     int64_t w_img_stride;  // elements between images' weight panels (0: shared weights)
-    int SH, SW;            // sub-problem grid (pixels enumerated by this launch)
     int OH, OW;            // full output size
-    int osy, osx, ooy, oox;   // output pixel = (i * osy + ooy, j * osx + oox)
-    int ntaps; ConvTap taps[9];
+    int osy, osx;          // output pixel = (i * osy + ooy, j * osx + oox)
+    int ncls;              // sub-problems solved by this launch (1: plain conv; 4: parity classes of the stride-2 transposed conv)
+    struct Cls { int SH, SW, ooy, oox, ntaps; ConvTap taps[9]; } cls[4];     // plain conv uses cls[0] with up to 9 taps; transposed classes have <= 4
     int act;               // 0: none (linear), 1: lrelu(0.2)
     float gain, clamp;     // clamp < 0: off
 };
 
 // 16-B slot of (row, chunk).  Two 128-byte tile rows share one 256-byte LDS bank row, so the XOR key is (row >> 1) & 7:
 // the 16 rows a ds_read_b128 lane group touches then land on 16 distinct slots (row & 7 would leave a 2-way conflict).
-__device__ __forceinline__ int swz(int row, int chunk) { return row * (BK / 8) + (chunk ^ ((row >> 1) & 7)); }
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 8 + (chunk ^ ((row >> 1) & 7)); }
 
-__global__ void __launch_bounds__(256, 2) conv2d_nhwc_f16_kernel(ConvArgs a)
+template <class T> struct ConvTraits;
+template <> struct ConvTraits<__half> { static constexpr int BK = 64; };      // elements per 128-byte K row
+template <> struct ConvTraits<float>  { static constexpr int BK = 32; };
+
+template <class T>
+__global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
 {
-    __shared__ __attribute__((aligned(16))) h8 lds[2][2][BM * BK / 8];        // [buffer][A|B][row*8 + chunk]
+    constexpr int BK = ConvTraits<T>::BK;
+    constexpr int EPC = 16 / sizeof(T);                                        // elements per 16-byte chunk
+    __shared__ __attribute__((aligned(16))) f32x4 lds[2][2][BM * 8];          // [buffer][A|B][row*8 + chunk], 16-byte slots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;                                   // wave's 64x64 quadrant
-    const int n = blockIdx.z;
+    const int n = blockIdx.z / a.ncls;
+    const ConvArgs::Cls& kc = a.cls[blockIdx.z - n * a.ncls];
     // XCD-aware tile order: workgroup L of a launch lands on XCD L % 8, each XCD with its own L2.  Consecutive slots
     // of one XCD get the output-channel blocks of the SAME pixel tile (they share the A operand), and pixel tiles
     // stride over XCDs, so an A neighbourhood is fetched into one L2 only.  Falls back to the plain order when the
@@ -71,9 +79,10 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_f16_kernel(ConvArgs a)
         if ((nmt & 7) == 0) { const int q = L >> 3, r = L & 7; cb = q % ncb; mt = (q / ncb) * 8 + r; }
     }
     const int m0 = mt * BM, co0 = cb * BN;
-    const int M = a.SH * a.SW;
-    const __half* xin = a.x + (int64_t)n * a.H * a.W * a.Ci;
-    const __half* wgt = a.w + (int64_t)n * a.w_img_stride;
+    if (m0 >= kc.SH * kc.SW) return;                                           // classes of one launch differ slightly in size
+    const int M = kc.SH * kc.SW;
+    const T* xin = (const T*)a.x + (int64_t)n * a.H * a.W * a.Ci;
+    const T* wgt = (const T*)a.w + (int64_t)n * a.w_img_stride;
 
     // staging assignment: 8 threads cover one 128-byte row (64 halfs); 32 rows per pass, 4 passes for 128 rows
     const int chunk = tid & 7, srow = tid >> 3;
@@ -84,10 +93,11 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_f16_kernel(ConvArgs a)
         const int m = m0 + srow + 32 * p;
         pok[p] = m < M;
         const int mm = pok[p] ? m : 0;
-        pi[p] = mm / a.SW; pj[p] = mm - pi[p] * a.SW;
+        pi[p] = mm / kc.SW; pj[p] = mm - pi[p] * kc.SW;
     }
     const int kchunks = a.Ci / BK;
-    const int ksteps = a.ntaps * kchunks;
+    const int ntaps = kc.ntaps;
+    const int ksteps = ntaps * kchunks;
 
     // Direct global -> LDS staging (global_load_lds_dwordx4): each wave instruction deposits 64 x 16 B = eight 128-byte
     // rows linearly at a wave-uniform LDS base, so the XOR swizzle is applied on the SOURCE side: the lane that fills
@@ -97,17 +107,17 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_f16_kernel(ConvArgs a)
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
     auto stage = [&](int ks, int buf) {
-        const int cc = ks / a.ntaps, t = ks - cc * a.ntaps, c0 = cc * BK + src_chunk * 8;   // taps innermost: a block re-reads its 64-channel neighbourhood while it is L2-hot
-        const ConvTap tp = a.taps[t];
+        const int cc = ks / ntaps, t = ks - cc * ntaps, c0 = cc * BK + src_chunk * EPC;   // taps innermost: a block re-reads its 64-channel neighbourhood while it is L2-hot
+        const ConvTap tp = kc.taps[t];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int iy = pi[p] + tp.dy, ix = pj[p] + tp.dx;
             const bool ok = pok[p] & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
-            const __half* src = ok ? xin + ((int64_t)iy * a.W + ix) * a.Ci + c0 : a.zeros;
-            const int row0 = (wave * 8 + 32 * p) * (BK / 8);      // first 16-B slot of this wave's 8-row group
+            const T* src = ok ? xin + ((int64_t)iy * a.W + ix) * a.Ci + c0 : (const T*)a.zeros;
+            const int row0 = (wave * 8 + 32 * p) * 8;      // first 16-B slot of this wave's 8-row group
             __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)&lds[buf][0][row0], 16, 0, 0);
             const int co = co0 + srow + 32 * p;
-            const __half* wsrc = (co < a.Co) ? wgt + ((int64_t)co * a.KT + tp.widx) * a.Ci + c0 : a.zeros;
+            const T* wsrc = (co < a.Co) ? wgt + ((int64_t)co * a.KT + tp.widx) * a.Ci + c0 : (const T*)a.zeros;
             __builtin_amdgcn_global_load_lds((glb_ptr)wsrc, (lds_ptr)&lds[buf][1][row0], 16, 0, 0);
         }
     };
@@ -127,8 +137,8 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_f16_kernel(ConvArgs a)
         const int buf = ks & 1;
         if (ks + 1 < ksteps) stage(ks + 1, buf ^ 1);                            // next tile streams into the other buffer under the MFMAs
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            h8 fa[2], fb[2];
+        for (int kk = 0; kk < 4; ++kk) {                                        // 4 x 32 bytes of K per 128-byte row
+            f32x4 fa[2], fb[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 fa[i] = lds[buf][0][swz(wm * 64 + i * 32 + frow, kk * 2 + fk)];
@@ -137,8 +147,15 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_f16_kernel(ConvArgs a)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (sizeof(T) == 2) {                             // 8 halfs per lane = one 32x32x16 step
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, fa[i]), __builtin_bit_cast(h8, fb[j]), acc[i][j], 0, 0, 0);
+                    } else {                                                    // 4 floats per lane = four 32x32x2 steps; K order permuted identically in A and B
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+                    }
+                }
         }
         __syncthreads();                                                        // drains the LDS-DMA (vmcnt) and fences the buffer swap
     }
@@ -156,8 +173,8 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_f16_kernel(ConvArgs a)
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
                 if (m >= M) continue;
-                const int si = m / a.SW, sj = m - si * a.SW;
-                const int oy = si * a.osy + a.ooy, ox = sj * a.osx + a.oox;
+                const int si = m / kc.SW, sj = m - si * kc.SW;
+                const int oy = si * a.osy + kc.ooy, ox = sj * a.osx + kc.oox;
                 if (oy >= a.OH || ox >= a.OW) continue;
                 float v = acc[i][j][r];
                 if (a.noise) v = fmaf(a.noise[(int64_t)oy * a.OW + ox], ns, v);
@@ -165,14 +182,15 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_f16_kernel(ConvArgs a)
                 if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
                 v *= a.gain;
                 if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
-                a.y[(((int64_t)n * a.OH + oy) * a.OW + ox) * a.Co + co] = __float2half(v);
+                st((T*)a.y + (((int64_t)n * a.OH + oy) * a.OW + ox) * a.Co + co, v);
             }
     }
 }
 
 // ---- per-sample weight modulation + demodulation -> fp16, tap-major -------------------------------------------------
 // one block per (co, n): wm[i, t] = w[co, i, t] * s[n, i]; d = rsqrt(sum wm^2 + 1e-8) (if demodulate); out[n][co][t][i]
-__global__ void __launch_bounds__(256) modulate_weights_kernel(const float* __restrict__ w, const float* __restrict__ styles, __half* __restrict__ out,
+template <class T>
+__global__ void __launch_bounds__(256) modulate_weights_kernel(const float* __restrict__ w, const float* __restrict__ styles, T* __restrict__ out,
                                                                int Co, int Ci, int KT, int demodulate, float pre_scale)
 {
     __shared__ float red[4];
@@ -193,10 +211,10 @@ __global__ void __launch_bounds__(256) modulate_weights_kernel(const float* __re
         __syncthreads();
         d = rsqrtf(red[0] + red[1] + red[2] + red[3] + 1e-8f);
     }
-    __half* o = out + ((int64_t)n * Co + co) * total;
+    T* o = out + ((int64_t)n * Co + co) * total;
     for (int e = threadIdx.x; e < total; e += blockDim.x) {          // e enumerates the OUTPUT order [t][i]
         const int t = e / Ci, i = e - t * Ci;
-        o[e] = __float2half(wr[i * KT + t] * pre_scale * s[i] * d);
+        st(o + e, wr[i * KT + t] * pre_scale * s[i] * d);
     }
 }
 
@@ -246,61 +264,67 @@ __global__ void __launch_bounds__(256) torgb_nhwc_kernel(const __half* __restric
 
 using namespace p3d;
 
-extern "C" int p3d_modulate_weights(const float* weight, const float* styles, void* out_f16, int32_t n_img, int32_t co, int32_t ci,
+extern "C" int p3d_modulate_weights(const float* weight, const float* styles, void* out, int dtype, int32_t n_img, int32_t co, int32_t ci,
                                     int32_t taps, int32_t demodulate, float pre_scale, p3d_stream_t stream)
 {
-    P3D_REQUIRE(weight && styles && out_f16, "modulate_weights: null pointer");
+    P3D_REQUIRE(weight && styles && out, "modulate_weights: null pointer");
     P3D_REQUIRE(n_img >= 1 && co >= 1 && ci >= 1 && taps >= 1, "modulate_weights: bad sizes");
-    hipLaunchKernelGGL(modulate_weights_kernel, dim3(co, n_img), dim3(256), 0, (hipStream_t)stream, weight, styles, (__half*)out_f16, co, ci, taps, demodulate, pre_scale);
+    P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32, "modulate_weights: dtype must be fp16 or fp32");
+    if (dtype == P3D_F16) hipLaunchKernelGGL(modulate_weights_kernel<__half>, dim3(co, n_img), dim3(256), 0, (hipStream_t)stream, weight, styles, (__half*)out, co, ci, taps, demodulate, pre_scale);
+    else                  hipLaunchKernelGGL(modulate_weights_kernel<float>,  dim3(co, n_img), dim3(256), 0, (hipStream_t)stream, weight, styles, (float*)out, co, ci, taps, demodulate, pre_scale);
     count_launch(FAM_CONV);
     return check_launch("modulate_weights");
 }
 
-static int launch_conv(ConvArgs& a, hipStream_t s)
+static int launch_conv(ConvArgs& a, int dtype, hipStream_t s)
 {
-    const int M = a.SH * a.SW;
+    int M = 0;
+    for (int c = 0; c < a.ncls; ++c) M = a.cls[c].SH * a.cls[c].SW > M ? a.cls[c].SH * a.cls[c].SW : M;
     if (M <= 0) return P3D_OK;
-    dim3 grid((M + BM - 1) / BM, (a.Co + BN - 1) / BN, a.N);
-    hipLaunchKernelGGL(conv2d_nhwc_f16_kernel, grid, dim3(256), 0, s, a);
+    dim3 grid((M + BM - 1) / BM, (a.Co + BN - 1) / BN, a.N * a.ncls);
+    if (dtype == P3D_F16) hipLaunchKernelGGL(conv2d_nhwc_kernel<__half>, grid, dim3(256), 0, s, a);
+    else                  hipLaunchKernelGGL(conv2d_nhwc_kernel<float>, grid, dim3(256), 0, s, a);
     count_launch(FAM_CONV);
-    return check_launch("conv2d_nhwc_f16");
+    return check_launch("conv2d_nhwc");
 }
 
-extern "C" int p3d_conv2d_nhwc_f16(const void* x, const void* w, void* y, const float* bias, const float* noise, const float* noise_strength,
-                                   const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
-                                   int32_t transposed_stride2, int32_t act, float gain, float clamp, p3d_stream_t stream)
+extern "C" int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype, const float* bias, const float* noise, const float* noise_strength,
+                               const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
+                               int32_t kernel_size, int32_t transposed_stride2, int32_t act, float gain, float clamp, p3d_stream_t stream)
 {
-    P3D_REQUIRE(x && w && y && zeros128, "conv2d_nhwc_f16: null pointer");
-    P3D_REQUIRE(n_img >= 1 && h >= 1 && wdt >= 1 && co >= 1, "conv2d_nhwc_f16: bad sizes");
-    if (ci % BK != 0 && ci % 32 != 0) return fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc_f16: Ci=%d must be a multiple of 64", ci);
-    if (ci % BK != 0) return fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc_f16: Ci=%d must be a multiple of 64", ci);
-    P3D_REQUIRE((((uintptr_t)x) & 15u) == 0 && (((uintptr_t)w) & 15u) == 0 && (((uintptr_t)zeros128) & 15u) == 0, "conv2d_nhwc_f16: x and w must be 16-byte aligned");
+    P3D_REQUIRE(x && w && y && zeros128, "conv2d_nhwc: null pointer");
+    P3D_REQUIRE(n_img >= 1 && h >= 1 && wdt >= 1 && co >= 1, "conv2d_nhwc: bad sizes");
+    P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32, "conv2d_nhwc: dtype must be fp16 or fp32");
+    P3D_REQUIRE(kernel_size == 3 || (kernel_size == 1 && !transposed_stride2), "conv2d_nhwc: kernel 3x3, or 1x1 without upsampling");
+    const int bk = dtype == P3D_F16 ? 64 : 32;
+    if (ci % bk != 0) return fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc: Ci=%d must be a multiple of %d", ci, bk);
+    P3D_REQUIRE((((uintptr_t)x) & 15u) == 0 && (((uintptr_t)w) & 15u) == 0 && (((uintptr_t)zeros128) & 15u) == 0, "conv2d_nhwc: x, w and zeros128 must be 16-byte aligned");
     ConvArgs a{};
-    a.x = (const __half*)x; a.w = (const __half*)w; a.y = (__half*)y; a.bias = bias; a.noise = noise; a.noise_strength = noise_strength; a.zeros = (const __half*)zeros128;
-    a.N = n_img; a.H = h; a.W = wdt; a.Ci = ci; a.Co = co; a.KT = 9; a.w_img_stride = w_img_stride;
+    a.x = x; a.w = w; a.y = y; a.bias = bias; a.noise = noise; a.noise_strength = noise_strength; a.zeros = zeros128;
+    a.N = n_img; a.H = h; a.W = wdt; a.Ci = ci; a.Co = co; a.KT = kernel_size * kernel_size; a.w_img_stride = w_img_stride;
     a.act = act; a.gain = gain; a.clamp = clamp;
     hipStream_t s = (hipStream_t)stream;
-    if (!transposed_stride2) {                                       // correlation, padding 1: input offset = tap - 1
-        a.SH = h; a.SW = wdt; a.OH = h; a.OW = wdt; a.osy = a.osx = 1; a.ooy = a.oox = 0;
-        a.ntaps = 9;
-        for (int t = 0; t < 9; ++t) a.taps[t] = ConvTap{t / 3 - 1, t % 3 - 1, t};
-        return launch_conv(a, s);
+    if (!transposed_stride2) {                                       // correlation, "same" padding: input offset = tap - k/2
+        a.OH = h; a.OW = wdt; a.osy = a.osx = 1; a.ncls = 1;
+        a.cls[0].SH = h; a.cls[0].SW = wdt; a.cls[0].ooy = a.cls[0].oox = 0; a.cls[0].ntaps = a.KT;
+        for (int t = 0; t < a.KT; ++t) a.cls[0].taps[t] = ConvTap{t / kernel_size - kernel_size / 2, t % kernel_size - kernel_size / 2, t};
+        return launch_conv(a, dtype, s);
     }
     // conv_transpose2d(stride 2, no padding): out[(2i+py), (2j+px)] = sum_{ky = py (mod 2), kx = px (mod 2)} x[i - (ky-py)/2, j - (kx-px)/2] w[ky, kx]
-    P3D_REQUIRE(!noise && !bias && act == 0, "conv2d_nhwc_f16: the transposed form has no epilogue (the FIR runs next)");
-    a.OH = 2 * h + 1; a.OW = 2 * wdt + 1; a.osy = a.osx = 2;
+    // -> four dense sub-problems (4 / 2 / 2 / 1 taps), all in ONE launch so the grid fills the chip
+    P3D_REQUIRE(!noise && !bias && act == 0, "conv2d_nhwc: the transposed form has no epilogue (the FIR runs next)");
+    a.OH = 2 * h + 1; a.OW = 2 * wdt + 1; a.osy = a.osx = 2; a.ncls = 4;
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
-            a.ooy = py; a.oox = px;
-            a.SH = py ? h : h + 1; a.SW = px ? wdt : wdt + 1;
-            a.ntaps = 0;
+            ConvArgs::Cls& c = a.cls[py * 2 + px];
+            c.ooy = py; c.oox = px;
+            c.SH = py ? h : h + 1; c.SW = px ? wdt : wdt + 1;
+            c.ntaps = 0;
             for (int ky = py; ky < 3; ky += 2)
                 for (int kx = px; kx < 3; kx += 2)
-                    a.taps[a.ntaps++] = ConvTap{-(ky - py) / 2, -(kx - px) / 2, ky * 3 + kx};
-            int rc = launch_conv(a, s);
-            if (rc != P3D_OK) return rc;
+                    c.taps[c.ntaps++] = ConvTap{-(ky - py) / 2, -(kx - px) / 2, ky * 3 + kx};
         }
-    return P3D_OK;
+    return launch_conv(a, dtype, s);
 }
 
 extern "C" int p3d_torgb_nhwc_f16(const void* x, const float* weight, const float* styles, const float* bias, float* y_nchw,

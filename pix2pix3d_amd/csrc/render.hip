@@ -60,6 +60,7 @@ struct RenderArgs {
     float* dbg_wcoarse;       // optional [N*M][Sc-1] coarse weights
     unsigned* minmax;         // [2] ordered-uint encoded min / max of all sample depths
     int total_rays, rays_per_img, H, W, Sc, Sf;
+    int64_t plane_stride, pix_stride, img_stride;   // texel (n, p, y, x) starts at n*img_stride + p*plane_stride + (y*W + x)*pix_stride
     float ray_start, ray_end, coord_scale;
     int disparity, white_back, sem_sigmoid;
 };
@@ -134,11 +135,11 @@ __device__ __forceinline__ void gather_features(const RenderArgs& a, const float
         const float w10 = (vx1 & vy0) ? wx1 * wy0 : 0.f;    // ne
         const float w01 = (vx0 & vy1) ? wx0 * wy1 : 0.f;    // sw
         const float w11 = (vx1 & vy1) ? wx1 * wy1 : 0.f;    // se
-        const float* pl = img + (size_t)p * H * W * 32 + h * 16;
-        const f32x4* t00 = (const f32x4*)(pl + ((size_t)cy0 * W + cx0) * 32);
-        const f32x4* t10 = (const f32x4*)(pl + ((size_t)cy0 * W + cx1) * 32);
-        const f32x4* t01 = (const f32x4*)(pl + ((size_t)cy1 * W + cx0) * 32);
-        const f32x4* t11 = (const f32x4*)(pl + ((size_t)cy1 * W + cx1) * 32);
+        const float* pl = img + (size_t)p * a.plane_stride + h * 16;
+        const f32x4* t00 = (const f32x4*)(pl + ((size_t)cy0 * W + cx0) * a.pix_stride);
+        const f32x4* t10 = (const f32x4*)(pl + ((size_t)cy0 * W + cx1) * a.pix_stride);
+        const f32x4* t01 = (const f32x4*)(pl + ((size_t)cy1 * W + cx0) * a.pix_stride);
+        const f32x4* t11 = (const f32x4*)(pl + ((size_t)cy1 * W + cx1) * a.pix_stride);
         f32x4 v00[4], v10[4], v01[4], v11[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) { v00[q] = t00[q]; v10[q] = t10[q]; v01[q] = t01[q]; v11[q] = t11[q]; }
@@ -306,7 +307,7 @@ render_forward_kernel(RenderArgs a)
     const int g = min(ray0 + j, a.total_rays - 1);               // tail lanes shadow the last ray, never store
     const bool live = (ray0 + j) < a.total_rays;
     const int n_img = g / a.rays_per_img;
-    const float* img = a.planes + (size_t)n_img * 3 * a.H * a.W * 32;
+    const float* img = a.planes + (size_t)n_img * a.img_stride;
     const float ox = a.ray_o[g * 3 + 0], oy = a.ray_o[g * 3 + 1], oz = a.ray_o[g * 3 + 2];
     const float dx = a.ray_d[g * 3 + 0], dy = a.ray_d[g * 3 + 1], dz = a.ray_d[g * 3 + 2];
     const float cs = a.coord_scale;
@@ -459,7 +460,7 @@ sample_points_kernel(RenderArgs a, const float* coords, int pts_per_img, int tot
     for (int t = blockIdx.x * kWavesPerBlock + wave; t < tiles; t += gridDim.x * kWavesPerBlock) {
         const int p = min(t * 32 + j, total_pts - 1);
         const bool live = (t * 32 + j) < total_pts;
-        const float* img = a.planes + (size_t)(p / pts_per_img) * 3 * a.H * a.W * 32;
+        const float* img = a.planes + (size_t)(p / pts_per_img) * a.img_stride;
         const float cs = a.coord_scale;
         float feat[16];
         gather_features(a, img, h, cs * coords[(size_t)p * 3], cs * coords[(size_t)p * 3 + 1], cs * coords[(size_t)p * 3 + 2], feat);
@@ -569,6 +570,7 @@ static int check_render_common(const p3d_render_desc* d)
     P3D_REQUIRE(d->n_nets == 1 || d->n_nets == 2, "render: n_nets must be 1 or 2 (got %d)", d->n_nets);
     P3D_REQUIRE(d->plane_h >= 1 && d->plane_w >= 1, "render: bad plane size");
     P3D_REQUIRE(d->box_warp != 0.f, "render: box_warp must be non-zero");
+    P3D_REQUIRE(d->pixel_stride == 0 || (d->pixel_stride % 4 == 0 && d->plane_stride % 4 == 0 && d->image_stride % 4 == 0), "render: plane strides must keep texels 16-byte aligned");
     return P3D_OK;
 }
 
@@ -610,6 +612,8 @@ static void fill_args(RenderArgs& a, const p3d_render_desc* d)
     a.H = d->plane_h; a.W = d->plane_w; a.Sc = d->depth_resolution; a.Sf = d->depth_resolution_importance;
     a.ray_start = d->ray_start; a.ray_end = d->ray_end; a.coord_scale = 2.f / d->box_warp;
     a.disparity = d->disparity_space_sampling; a.white_back = d->white_back; a.sem_sigmoid = d->semantic_sigmoid;
+    if (d->pixel_stride > 0) { a.plane_stride = d->plane_stride; a.pix_stride = d->pixel_stride; a.img_stride = d->image_stride; }
+    else { a.plane_stride = (int64_t)a.H * a.W * 32; a.pix_stride = 32; a.img_stride = 3 * a.plane_stride; }
 }
 
 extern "C" int p3d_render_forward(const float* planes_cl, const float* decoder, const float* ray_o, const float* ray_d,

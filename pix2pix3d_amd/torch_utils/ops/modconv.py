@@ -1,11 +1,11 @@
-"""Native inference path of the StyleGAN2 synthesis layers on fp16 channels-last activations.
+"""Native inference path of the StyleGAN2 synthesis layers on channels-last activations (fp16 or fp32).
 
 Not a module of the reference: it bundles what the reference spreads over ``modulated_conv2d`` (fused branch,
 training/networks_stylegan2.py:34-69, 81-91), ``conv2d_resample`` (:114-136), the noise add and ``bias_act``
 (networks_stylegan2.py:319-332) into calls of the MFMA implicit-GEMM kernels of libp3d_hip.so (csrc/conv2d.hip):
-``p3d_modulate_weights`` -> ``p3d_conv2d_nhwc_f16`` (+ ``upfirdn2d`` for the x2 layers) and ``p3d_torgb_nhwc_f16``.
-``SynthesisLayer`` / ``ToRGBLayer`` use it when ``layer_supported`` says so (device tensor, fp16, channels_last,
-inference, per-sample "fused" modulation); every other case keeps the generic operator route.
+``p3d_modulate_weights`` -> ``p3d_conv2d_nhwc`` (+ ``upfirdn2d`` for the x2 layers) and ``p3d_torgb_nhwc_f16``.
+``SynthesisLayer`` / ``ToRGBLayer`` use it when ``layer_supported`` says so (device tensor, channels_last, inference,
+per-sample "fused" modulation, enough pixels to fill 128-row MFMA tiles); every other case keeps the generic route.
 """
 import ctypes
 
@@ -17,8 +17,10 @@ from . import upfirdn2d, bias_act
 enabled = True
 
 _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
-_lib.register('p3d_modulate_weights', ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp])
-_lib.register('p3d_conv2d_nhwc_f16', ctypes.c_int, [_vp] * 7 + [_i32] * 5 + [_i64, _i32, _i32, _f32, _f32, _vp])
+_lib.register('p3d_modulate_weights', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _i32, _i32, _i32, _i32, _i32, _f32, _vp])
+_lib.register('p3d_conv2d_nhwc', ctypes.c_int, [_vp] * 3 + [ctypes.c_int] + [_vp] * 4 + [_i32] * 5 + [_i64, _i32, _i32, _i32, _f32, _f32, _vp])
+
+min_pixels = 1024            # below this an image does not fill enough 128-pixel tiles; the generic route handles it
 
 _zero_pages = {}
 
@@ -26,13 +28,17 @@ _zero_pages = {}
 def _zeros_page(device):
     z = _zero_pages.get(device)
     if z is None:
-        z = _zero_pages[device] = torch.zeros(256, dtype=torch.float16, device=device)
+        z = _zero_pages[device] = torch.zeros(256, dtype=torch.float32, device=device)
     return z
 _lib.register('p3d_torgb_nhwc_f16', ctypes.c_int, [_vp] * 5 + [_i32] * 4 + [_f32, _i32, _vp])
 
 
+def _is_nhwc(x, dtypes=(torch.float16, torch.float32)):
+    return x.is_cuda and x.dtype in dtypes and x.ndim == 4 and x.is_contiguous(memory_format=torch.channels_last)
+
+
 def _is_nhwc_f16(x):
-    return x.is_cuda and x.dtype == torch.float16 and x.ndim == 4 and x.is_contiguous(memory_format=torch.channels_last)
+    return _is_nhwc(x, (torch.float16,))
 
 
 def _no_grad_needed(*tensors):
@@ -41,33 +47,36 @@ def _no_grad_needed(*tensors):
 
 def layer_supported(x, weight, styles, noise_mode, fused_modconv, up):
     """True when the native kernels cover this SynthesisLayer call."""
-    if not enabled or not _is_nhwc_f16(x) or not fused_modconv or up not in (1, 2):
+    if not enabled or not _is_nhwc(x) or not fused_modconv or up not in (1, 2):
         return False
-    if tuple(weight.shape[2:]) != (3, 3) or noise_mode == 'random':
+    if tuple(weight.shape[2:]) != (3, 3) or noise_mode == 'random' or x.shape[2] * x.shape[3] < min_pixels:
         return False
     return _no_grad_needed(x, weight, styles)
 
 
 def torgb_supported(x, weight, styles, fused_modconv):
-    if not enabled or not _is_nhwc_f16(x) or not fused_modconv or tuple(weight.shape[2:]) != (1, 1):
+    if not enabled or not _is_nhwc(x) or not fused_modconv or tuple(weight.shape[2:]) != (1, 1) or not _no_grad_needed(x, weight, styles):
         return False
-    return x.shape[1] in (64, 128, 256, 512) and weight.shape[0] in (1, 2, 3, 4, 6, 8) and _no_grad_needed(x, weight, styles)
+    if x.dtype == torch.float16 and x.shape[1] in (64, 128, 256, 512) and weight.shape[0] in (1, 2, 3, 4, 6, 8):
+        return True                                   # skinny streaming kernel
+    return x.shape[2] * x.shape[3] >= min_pixels and x.shape[1] % (64 if x.dtype == torch.float16 else 32) == 0      # 1x1 through the MFMA kernel
 
 
-def modulate_weights(weight, styles, demodulate=True, pre_scale=1.0):
-    """weight [O,I,kh,kw] fp32, styles [N,I] -> fp16 [N][O][kh*kw][I], demodulation folded in."""
+def modulate_weights(weight, styles, demodulate=True, pre_scale=1.0, dtype=torch.float16):
+    """weight [O,I,kh,kw] fp32, styles [N,I] -> ``dtype`` [N][O][kh*kw][I], demodulation folded in."""
     o, i, kh, kw = weight.shape
     n = styles.shape[0]
     w32 = weight.detach().float().contiguous()
     s32 = styles.detach().float().contiguous()
-    out = torch.empty([n, o, kh * kw, i], dtype=torch.float16, device=weight.device)
-    code = _lib.lib().p3d_modulate_weights(_lib.ptr(w32), _lib.ptr(s32), _lib.ptr(out), n, o, i, kh * kw, int(demodulate), float(pre_scale), _lib.stream_of(out))
+    out = torch.empty([n, o, kh * kw, i], dtype=dtype, device=weight.device)
+    code = _lib.lib().p3d_modulate_weights(_lib.ptr(w32), _lib.ptr(s32), _lib.ptr(out), _lib.DTYPE_CODE[dtype], n, o, i, kh * kw, int(demodulate), float(pre_scale), _lib.stream_of(out))
     _lib.check(code, 'modulate_weights')
     return out
 
 
-def _pad_channels(x, wmod, mult=64):
-    """Zero-pad Ci to a multiple of ``mult`` (only the 32-channel SR input needs it; the tensor is tiny)."""
+def _pad_channels(x, wmod):
+    """Zero-pad Ci to a whole 128-byte K row (only the 32-channel fp16 SR input needs it; that tensor is tiny)."""
+    mult = 64 if x.dtype == torch.float16 else 32
     ci = x.shape[1]
     if ci % mult == 0:
         return x, wmod
@@ -79,27 +88,33 @@ def _pad_channels(x, wmod, mult=64):
     return xp, wp
 
 
-def conv3x3(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None, act=0, gain=1.0, clamp=-1.0):
-    """x NHWC fp16 [N,Ci,H,W] (channels_last strides), wmod [N or 1][Co][9][Ci] fp16 -> NHWC fp16."""
-    assert _is_nhwc_f16(x) and wmod.dtype == torch.float16 and wmod.is_contiguous()
+def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None, act=0, gain=1.0, clamp=-1.0):
+    """x NHWC [N,Ci,H,W] (channels_last strides), wmod [N or 1][Co][k*k][Ci] of the same dtype -> NHWC, same dtype.
+    k*k = 9: 3x3 "same" correlation, or (transposed) the stride-2 transposed conv [N,Co,2H+1,2W+1]; k*k = 1: 1x1."""
+    assert _is_nhwc(x) and wmod.dtype == x.dtype and wmod.is_contiguous() and wmod.shape[2] in (1, 9)
     x, wmod = _pad_channels(x, wmod)
     n, ci, h, w = x.shape
-    co = wmod.shape[1]
+    co, k = wmod.shape[1], (3 if wmod.shape[2] == 9 else 1)
     oh, ow = (2 * h + 1, 2 * w + 1) if transposed else (h, w)
-    y = torch.empty([n, co, oh, ow], dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
-    stride = wmod.shape[1] * wmod.shape[2] * wmod.shape[3] if wmod.shape[0] == n and n > 1 else (0 if wmod.shape[0] == 1 else wmod.shape[1] * wmod.shape[2] * wmod.shape[3])
+    y = torch.empty([n, co, oh, ow], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    assert wmod.shape[0] in (1, n)
+    stride = 0 if wmod.shape[0] == 1 else wmod.shape[1] * wmod.shape[2] * wmod.shape[3]
     b32 = None if bias is None else bias.detach().float().contiguous()
     nz = None if noise is None else noise.detach().float().contiguous()
     ns = None if noise is None else noise_strength.detach().float().reshape(1).contiguous()
-    code = _lib.lib().p3d_conv2d_nhwc_f16(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns), _lib.ptr(_zeros_page(x.device)),
-                                          n, h, w, ci, co, stride, int(transposed), int(act), float(gain), float(clamp), _lib.stream_of(x))
-    _lib.check(code, 'conv2d_nhwc_f16')
+    code = _lib.lib().p3d_conv2d_nhwc(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), _lib.DTYPE_CODE[x.dtype], _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns),
+                                      _lib.ptr(_zeros_page(x.device)), n, h, w, ci, co, stride, k, int(transposed), int(act), float(gain), float(clamp),
+                                      _lib.stream_of(x))
+    _lib.check(code, 'conv2d_nhwc')
     return y
+
+
+conv3x3 = conv2d
 
 
 def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=None, noise_strength=None, act='lrelu', act_gain=1.0, clamp=None):
     """Whole SynthesisLayer body after the style affine: modulated 3x3 conv (x2 up when ``up == 2``) + noise + bias + act."""
-    wmod = modulate_weights(weight, styles, demodulate=True)
+    wmod = modulate_weights(weight, styles, demodulate=True, dtype=x.dtype)
     act_idx = {'linear': 0, 'lrelu': 1}.get(act)
     clampv = -1.0 if clamp is None else float(clamp)
     if up == 1 and act_idx is not None:
@@ -116,9 +131,15 @@ def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=No
 
 
 def torgb(x, weight, styles, bias, clamp=None, out=None):
-    """ToRGB: 1x1 modulated conv without demodulation + bias (+ clamp) -> fp32 NCHW; ``out`` accumulates (skip image)."""
+    """ToRGB: 1x1 modulated conv without demodulation + bias (+ clamp).  fp16 activations with a handful of output
+    channels take the streaming kernel (-> fp32 NCHW, optionally accumulated into ``out``); wide outputs (the 96-channel
+    tri-plane image of the backbone) go through the MFMA kernel as a 1x1 conv and stay channels-last."""
     n, ci, h, w = x.shape
     co = weight.shape[0]
+    if not (x.dtype == torch.float16 and ci in (64, 128, 256, 512) and co in (1, 2, 3, 4, 6, 8)):
+        wmod = modulate_weights(weight, styles, demodulate=False, dtype=x.dtype)
+        y = conv2d(x, wmod, bias=bias, clamp=-1.0 if clamp is None else float(clamp))
+        return y if out is None else out.add_(y)
     w32 = weight.detach().float().reshape(co, ci).contiguous()
     s32 = styles.detach().float().contiguous()
     b32 = None if bias is None else bias.detach().float().contiguous()

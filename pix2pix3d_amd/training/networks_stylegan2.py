@@ -216,6 +216,8 @@ class SynthesisLayer(torch.nn.Module):
         if self.use_noise and noise_mode == 'const':
             noise = self.noise_const * self.noise_strength
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        if native_channels_last and fused_modconv is True and x.is_cuda and not torch.is_grad_enabled() and not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)      # e.g. the output of a small generic-route layer feeding a native one
         if modconv.layer_supported(x, self.weight, styles, noise_mode, fused_modconv, self.up):
             # fp16 channels-last inference: weight modulation, MFMA conv, noise, bias, activation in native kernels
             const_noise = self.use_noise and noise_mode == 'const'
@@ -256,6 +258,9 @@ class ToRGBLayer(torch.nn.Module):
         return f'in_channels={self.in_channels:d}, out_channels={self.out_channels:d}, w_dim={self.w_dim:d}'
 
 
+native_channels_last = True     # run device inference channels-last so every 3x3 / 1x1 layer takes the native kernels (csrc/conv2d.hip)
+
+
 def _block_mode(block, ws, force_fp32, fused_modconv):
     """Shared dtype / layout / modconv-mode decision of the synthesis blocks (:421-430)."""
     if ws.device.type != 'cuda':
@@ -266,6 +271,8 @@ def _block_mode(block, ws, force_fp32, fused_modconv):
         fused_modconv = block.fused_modconv_default
     if fused_modconv == 'inference_only':
         fused_modconv = (not block.training)
+    if native_channels_last and modconv.enabled and ws.device.type == 'cuda' and fused_modconv is True and not torch.is_grad_enabled():
+        fmt = torch.channels_last          # inference on the device: the layout the MFMA conv kernels consume (any dtype)
     return dtype, fmt, fused_modconv
 
 
@@ -309,7 +316,7 @@ class SynthesisBlock(torch.nn.Module):
         dtype, fmt, fused_modconv = _block_mode(self, ws, force_fp32, fused_modconv)
 
         if self.in_channels == 0:
-            x = self.const.to(dtype=dtype, memory_format=fmt).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
+            x = self.const.to(dtype=dtype).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1]).contiguous(memory_format=fmt)
         else:
             misc.assert_shape(x, [None, self.in_channels, self.resolution // self._in_div, self.resolution // self._in_div])
             x = x.to(dtype=dtype, memory_format=fmt)
@@ -330,7 +337,10 @@ class SynthesisBlock(torch.nn.Module):
             img = upfirdn2d.upsample2d(img, self.resample_filter)
         if self.is_last or self.architecture == 'skip':
             y = self.torgb(x, next(w_iter), fused_modconv=fused_modconv)
-            y = y.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+            if fmt == torch.channels_last and y.dtype == torch.float32 and y.shape[1] > 8:
+                pass                       # wide fp32 skip image (the tri-planes) stays channels-last: the ray-marcher reads it in place
+            else:
+                y = y.to(dtype=torch.float32, memory_format=torch.contiguous_format)
             img = img.add_(y) if img is not None else y
 
         assert x.dtype == dtype

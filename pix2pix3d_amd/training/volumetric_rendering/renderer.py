@@ -25,7 +25,8 @@ class _RenderDesc(ctypes.Structure):          # p3d_render_desc (include/p3d_hip
     _fields_ = [('n_img', ctypes.c_int32), ('rays_per_img', ctypes.c_int32), ('plane_h', ctypes.c_int32), ('plane_w', ctypes.c_int32),
                 ('n_nets', ctypes.c_int32), ('semantic_sigmoid', ctypes.c_int32), ('depth_resolution', ctypes.c_int32),
                 ('depth_resolution_importance', ctypes.c_int32), ('disparity_space_sampling', ctypes.c_int32), ('white_back', ctypes.c_int32),
-                ('ray_start', ctypes.c_float), ('ray_end', ctypes.c_float), ('box_warp', ctypes.c_float)]
+                ('ray_start', ctypes.c_float), ('ray_end', ctypes.c_float), ('box_warp', ctypes.c_float),
+                ('image_stride', ctypes.c_int64), ('plane_stride', ctypes.c_int64), ('pixel_stride', ctypes.c_int64)]
 
 
 _vp, _i32, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
@@ -106,9 +107,18 @@ class _FusedContext:
         lib = _lib.lib()
         n, k, c, h, w = planes.shape
         assert k == 3 and c == 32
-        src = _f32c(planes)
-        self.planes_cl = torch.empty([n, 3, h, w, 32], dtype=torch.float32, device=planes.device)
-        _lib.check(lib.p3d_planes_to_channels_last(_lib.ptr(src), _lib.ptr(self.planes_cl), n, h, w, _lib.stream_of(src)), 'planes_to_channels_last')
+        self.strides = (0, 0, 0)
+        st = planes.stride()
+        if planes.dtype == torch.float32 and st[2] == 1 and st[1] == 32 and st[4] >= 96 and st[3] == w * st[4] and st[0] == h * st[3] and st[4] % 4 == 0 \
+                and planes.data_ptr() % 16 == 0:
+            # already texel-major (a channels-last [N,96,H,W] backbone output viewed as [N,3,32,H,W]): read it in place
+            self.planes_cl = planes.detach()
+            self.strides = (st[0], st[1], st[4])
+            src = self.planes_cl
+        else:
+            src = _f32c(planes)
+            self.planes_cl = torch.empty([n, 3, h, w, 32], dtype=torch.float32, device=planes.device)
+            _lib.check(lib.p3d_planes_to_channels_last(_lib.ptr(src), _lib.ptr(self.planes_cl), n, h, w, _lib.stream_of(src)), 'planes_to_channels_last')
         self.packed = torch.empty([lib.p3d_render_decoder_floats()], dtype=torch.float32, device=planes.device)
         ws = []
         for fc1, fc2 in nets:
@@ -122,7 +132,7 @@ class _FusedContext:
         return _RenderDesc(self.n, rays_per_img, self.h, self.w, self.n_nets, int(self.sem_sigmoid),
                            int(options.get('depth_resolution', 0)), int(options.get('depth_resolution_importance', 0)),
                            int(bool(options.get('disparity_space_sampling', False))), int(bool(options.get('white_back', False))),
-                           float(start), float(end), float(options['box_warp']))
+                           float(start), float(end), float(options['box_warp']), *self.strides)
 
 
 class ImportanceRenderer(torch.nn.Module):

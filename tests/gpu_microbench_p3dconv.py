@@ -17,3 +17,13 @@ for name, ci, co, r, tr in [('sr.b0.conv1', 256, 256, 256, False), ('sr.b1.conv1
     fl = 2 * N * ci * co * 9 * r * r
     t = timeit(lambda: modconv.conv3x3(x, wmod, transposed=tr, bias=None if tr else bias, act=0 if tr else 1, gain=1.414, clamp=-1 if tr else 256))
     print(f'p3d {name}: {fl / t / 1e12:.1f} TF ({t * 1e3:.3f} ms)', flush=True)
+
+for name, ci, co, r, tr in [('bb.b64.conv1', 512, 512, 64, False), ('bb.b128.conv1', 256, 256, 128, False), ('bb.b256.conv1', 128, 128, 256, False),
+                            ('bb.b128.conv0 T2', 512, 256, 64, True), ('bb.b256.conv0 T2', 256, 128, 128, True)]:
+    x = torch.randn(N, ci, r, r, device='cuda').to(memory_format=torch.channels_last)
+    weight = torch.randn(co, ci, 3, 3, device='cuda'); styles = torch.randn(N, ci, device='cuda') + 1
+    wmod = modconv.modulate_weights(weight, styles, dtype=torch.float32)
+    bias = torch.randn(co, device='cuda')
+    fl = 2 * N * ci * co * 9 * r * r
+    t = timeit(lambda: modconv.conv2d(x, wmod, transposed=tr, bias=None if tr else bias, act=0 if tr else 1, gain=1.414))
+    print(f'p3d fp32 {name}: {fl / t / 1e12:.1f} TF ({t * 1e3:.3f} ms)', flush=True)

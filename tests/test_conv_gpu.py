@@ -22,6 +22,31 @@ def _ref_modulated(weight, styles, demod=True):
     return w
 
 
+@pytest.mark.parametrize('ci,co,h,w', [(64, 96, 16, 16), (128, 128, 9, 20), (32, 130, 12, 12)])
+@pytest.mark.parametrize('k', [3, 1])
+def test_fp32_conv_is_exact_fp32(hip_lib, ci, co, h, w, k):
+    """fp32 variant (v_mfma_f32_32x32x2_f32): plain, transposed and 1x1 against torch fp64 references; error is fp32 rounding."""
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    torch.manual_seed(ci + co + k)
+    n = 2
+    x = _nhwc(torch.randn(n, ci, h, w, device='cuda'))
+    weight = torch.randn(co, ci, k, k, device='cuda')
+    styles = torch.randn(n, ci, device='cuda') + 1
+    wmod = modconv.modulate_weights(weight, styles, demodulate=(k == 3), dtype=torch.float32)
+    wq = wmod.double().reshape(n, co, k, k, ci).permute(0, 1, 4, 2, 3)
+    wref = _ref_modulated(weight.double(), styles.double(), demod=(k == 3))
+    assert rel_err(wq.cpu().numpy(), wref.cpu().numpy()) < 1e-6
+    bias = torch.randn(co, device='cuda')
+    y = modconv.conv2d(x, wmod, bias=bias, act=1, gain=1.3, clamp=2.0)
+    yr = torch.stack([F.conv2d(x[i:i + 1].double(), wq[i], padding=k // 2)[0] for i in range(n)])
+    yr = (F.leaky_relu(yr + bias.double().view(1, -1, 1, 1), 0.2) * 1.3).clamp(-2, 2)
+    assert y.dtype == torch.float32 and rel_err(y.cpu().numpy(), yr.cpu().numpy()) < 1e-5          # fp32 accumulation over K = 9*Ci terms
+    if k == 3:
+        yt = modconv.conv2d(x, wmod, transposed=True)
+        ytr = torch.stack([F.conv_transpose2d(x[i:i + 1].double(), wq[i].transpose(0, 1), stride=2)[0] for i in range(n)])
+        assert rel_err(yt.cpu().numpy(), ytr.cpu().numpy()) < 1e-5
+
+
 @pytest.mark.parametrize('ci,co,h,w', [(64, 128, 16, 16), (128, 128, 33, 20), (256, 96, 8, 40), (32, 256, 12, 12), (64, 200, 5, 7)])
 def test_modulate_and_conv3x3(hip_lib, ci, co, h, w):
     from pix2pix3d_amd.torch_utils.ops import modconv
@@ -104,6 +129,25 @@ def test_synthesis_layer_native_vs_generic(hip_lib):
                 y0 = layer(x, wl, noise_mode=mode, fused_modconv=True)
                 modconv.enabled = True
             assert y1.shape == y0.shape and rel_err(y1.float().cpu().numpy(), y0.float().cpu().numpy()) < 6e-3, (up, mode)
+    # fp32 layers (the tri-plane backbone) through the fp32 MFMA kernel, incl. a wide ToRGB (1x1 through the same kernel)
+    for up in (1, 2):
+        layer = SynthesisLayer(64, 64, w_dim=32, resolution=32 * up, up=up).cuda().eval().requires_grad_(False)
+        layer.noise_strength.fill_(0.2); layer.bias.normal_()
+        x = _nhwc(torch.randn(2, 64, 32, 32, device='cuda'))
+        wl = torch.randn(2, 32, device='cuda')
+        with torch.no_grad():
+            y1 = layer(x, wl, noise_mode='const', fused_modconv=True)
+            modconv.enabled = False
+            y0 = layer(x, wl, noise_mode='const', fused_modconv=True)
+            modconv.enabled = True
+        assert y1.dtype == torch.float32 and rel_err(y1.cpu().numpy(), y0.cpu().numpy()) < 2e-5, up
+    wide = ToRGBLayer(64, 96, w_dim=32).cuda().eval().requires_grad_(False)
+    with torch.no_grad():
+        y1 = wide(x, wl)
+        modconv.enabled = False
+        y0 = wide(x, wl)
+        modconv.enabled = True
+    assert rel_err(y1.cpu().numpy(), y0.cpu().numpy()) < 2e-5
     rgb = ToRGBLayer(128, 3, w_dim=32, conv_clamp=256, channels_last=True).cuda().eval().requires_grad_(False)
     rgb.bias.normal_()
     x = _nhwc(torch.randn(2, 128, 32, 32, device='cuda').half())
