@@ -140,9 +140,10 @@ int p3d_importance_sample(const float* z_coarse, const float* w_coarse, const fl
  *   ToRGB 1x1 modulated conv            training/networks_stylegan2.py:355-359                    */
 
 /* weight [Co][Ci][taps] fp32 (taps = kh*kw, PyTorch OIHW order), styles [N][Ci] fp32 ->
- * out [N][Co][taps][Ci] (dtype fp16 or fp32) = weight * pre_scale * styles (* rsqrt(sum^2 + 1e-8) if demodulate). */
+ * out (dtype fp16 or fp32) = weight * pre_scale * styles (* rsqrt(sum^2 + 1e-8) if demodulate), laid out
+ * [N][Co][taps][Ci] (tap-major K, what p3d_conv2d_nhwc consumes) or, with oihw_order != 0, [N][Co][Ci][taps].   */
 int p3d_modulate_weights(const float* weight, const float* styles, void* out, int dtype, int32_t n_img, int32_t co, int32_t ci,
-                         int32_t taps, int32_t demodulate, float pre_scale, p3d_stream_t stream);
+                         int32_t taps, int32_t demodulate, float pre_scale, int32_t oihw_order, p3d_stream_t stream);
 
 /* x [N][H][W][Ci], w [N or 1][Co][k*k][Ci] (w_img_stride elements between images, 0 = shared), both `dtype`
  * (P3D_F16: v_mfma_f32_32x32x16_f16; P3D_F32: v_mfma_f32_32x32x2_f32, exact fp32), fp32 accumulation.

@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
 // one block per (co, n): wm[i, t] = w[co, i, t] * s[n, i]; d = rsqrt(sum wm^2 + 1e-8) (if demodulate); out[n][co][t][i]
 template <class T>
 __global__ void __launch_bounds__(256) modulate_weights_kernel(const float* __restrict__ w, const float* __restrict__ styles, T* __restrict__ out,
-                                                               int Co, int Ci, int KT, int demodulate, float pre_scale)
+                                                               int Co, int Ci, int KT, int demodulate, float pre_scale, int oihw)
 {
     __shared__ float red[4];
     const int co = blockIdx.x, n = blockIdx.y;
@@ -212,6 +212,10 @@ __global__ void __launch_bounds__(256) modulate_weights_kernel(const float* __re
         d = rsqrtf(red[0] + red[1] + red[2] + red[3] + 1e-8f);
     }
     T* o = out + ((int64_t)n * Co + co) * total;
+    if (oihw) {                                                      // keep the source order [i][t] (GEMM route of the small layers)
+        for (int e = threadIdx.x; e < total; e += blockDim.x) st(o + e, wr[e] * pre_scale * s[e / KT] * d);
+        return;
+    }
     for (int e = threadIdx.x; e < total; e += blockDim.x) {          // e enumerates the OUTPUT order [t][i]
         const int t = e / Ci, i = e - t * Ci;
         st(o + e, wr[i * KT + t] * pre_scale * s[i] * d);
@@ -265,13 +269,13 @@ __global__ void __launch_bounds__(256) torgb_nhwc_kernel(const __half* __restric
 using namespace p3d;
 
 extern "C" int p3d_modulate_weights(const float* weight, const float* styles, void* out, int dtype, int32_t n_img, int32_t co, int32_t ci,
-                                    int32_t taps, int32_t demodulate, float pre_scale, p3d_stream_t stream)
+                                    int32_t taps, int32_t demodulate, float pre_scale, int32_t oihw_order, p3d_stream_t stream)
 {
     P3D_REQUIRE(weight && styles && out, "modulate_weights: null pointer");
     P3D_REQUIRE(n_img >= 1 && co >= 1 && ci >= 1 && taps >= 1, "modulate_weights: bad sizes");
     P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32, "modulate_weights: dtype must be fp16 or fp32");
-    if (dtype == P3D_F16) hipLaunchKernelGGL(modulate_weights_kernel<__half>, dim3(co, n_img), dim3(256), 0, (hipStream_t)stream, weight, styles, (__half*)out, co, ci, taps, demodulate, pre_scale);
-    else                  hipLaunchKernelGGL(modulate_weights_kernel<float>,  dim3(co, n_img), dim3(256), 0, (hipStream_t)stream, weight, styles, (float*)out, co, ci, taps, demodulate, pre_scale);
+    if (dtype == P3D_F16) hipLaunchKernelGGL(modulate_weights_kernel<__half>, dim3(co, n_img), dim3(256), 0, (hipStream_t)stream, weight, styles, (__half*)out, co, ci, taps, demodulate, pre_scale, oihw_order);
+    else                  hipLaunchKernelGGL(modulate_weights_kernel<float>,  dim3(co, n_img), dim3(256), 0, (hipStream_t)stream, weight, styles, (float*)out, co, ci, taps, demodulate, pre_scale, oihw_order);
     count_launch(FAM_CONV);
     return check_launch("modulate_weights");
 }

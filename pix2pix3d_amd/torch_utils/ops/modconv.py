@@ -17,10 +17,13 @@ from . import upfirdn2d, bias_act
 enabled = True
 
 _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
-_lib.register('p3d_modulate_weights', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _i32, _i32, _i32, _i32, _i32, _f32, _vp])
+_lib.register('p3d_modulate_weights', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp])
 _lib.register('p3d_conv2d_nhwc', ctypes.c_int, [_vp] * 3 + [ctypes.c_int] + [_vp] * 4 + [_i32] * 5 + [_i64, _i32, _i32, _i32, _f32, _f32, _vp])
 
-min_pixels = 1024            # below this an image does not fill enough 128-pixel tiles; the generic route handles it
+min_pixels = 1               # every layer takes this module (the vendor conv library is never entered: its choices for the small
+                             # layers — naive kernels on a fresh box — cost milliseconds)
+gemm_max_pixels = 1024       # layers whose input has at most this many pixels per image cannot fill 128-pixel MFMA tiles: they run as
+                             # im2col/col2im + one batched library GEMM per layer (weight-bandwidth bound, tens of microseconds)
 
 _zero_pages = {}
 
@@ -59,17 +62,18 @@ def torgb_supported(x, weight, styles, fused_modconv):
         return False
     if x.dtype == torch.float16 and x.shape[1] in (64, 128, 256, 512) and weight.shape[0] in (1, 2, 3, 4, 6, 8):
         return True                                   # skinny streaming kernel
-    return x.shape[2] * x.shape[3] >= min_pixels and x.shape[1] % (64 if x.dtype == torch.float16 else 32) == 0      # 1x1 through the MFMA kernel
+    return x.shape[2] * x.shape[3] <= gemm_max_pixels or x.shape[1] % (64 if x.dtype == torch.float16 else 32) == 0    # small: GEMM; else 1x1 through the MFMA kernel
 
 
-def modulate_weights(weight, styles, demodulate=True, pre_scale=1.0, dtype=torch.float16):
-    """weight [O,I,kh,kw] fp32, styles [N,I] -> ``dtype`` [N][O][kh*kw][I], demodulation folded in."""
+def modulate_weights(weight, styles, demodulate=True, pre_scale=1.0, dtype=torch.float16, oihw=False):
+    """weight [O,I,kh,kw] fp32, styles [N,I] -> ``dtype`` [N][O][kh*kw][I] (or [N][O][I][kh*kw] with ``oihw``), demodulation folded in."""
     o, i, kh, kw = weight.shape
     n = styles.shape[0]
     w32 = weight.detach().float().contiguous()
     s32 = styles.detach().float().contiguous()
-    out = torch.empty([n, o, kh * kw, i], dtype=dtype, device=weight.device)
-    code = _lib.lib().p3d_modulate_weights(_lib.ptr(w32), _lib.ptr(s32), _lib.ptr(out), _lib.DTYPE_CODE[dtype], n, o, i, kh * kw, int(demodulate), float(pre_scale), _lib.stream_of(out))
+    out = torch.empty([n, o, i, kh * kw] if oihw else [n, o, kh * kw, i], dtype=dtype, device=weight.device)
+    code = _lib.lib().p3d_modulate_weights(_lib.ptr(w32), _lib.ptr(s32), _lib.ptr(out), _lib.DTYPE_CODE[dtype], n, o, i, kh * kw, int(demodulate), float(pre_scale),
+                                           int(oihw), _lib.stream_of(out))
     _lib.check(code, 'modulate_weights')
     return out
 
@@ -112,18 +116,41 @@ def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None
 conv3x3 = conv2d
 
 
+def _small_layer(x, weight, styles, up):
+    """Per-sample modulated 3x3 conv (or its stride-2 transposed form) for images too small for the MFMA tiles: the
+    classic lowering to ONE batched GEMM per layer.  up == 1: im2col (F.unfold) then W[n] @ cols[n]; up == 2:
+    (W[n]^T arranged [Co*9, Ci]) @ x[n] then col2im (F.fold, stride 2) -> [N, Co, 2H+1, 2W+1].  NCHW in and out."""
+    n, ci, h, w = x.shape
+    co = weight.shape[0]
+    xc = x.contiguous()
+    if up == 1:
+        wm = modulate_weights(weight, styles, demodulate=True, dtype=x.dtype, oihw=True).reshape(n, co, ci * 9)
+        cols = torch.nn.functional.unfold(xc, kernel_size=3, padding=1)                     # [N, Ci*9, H*W]
+        return torch.bmm(wm, cols).reshape(n, co, h, w)
+    wm = modulate_weights(weight, styles, demodulate=True, dtype=x.dtype, oihw=False)       # [N, Co, 9, Ci]
+    cols = torch.bmm(wm.reshape(n, co * 9, ci), xc.reshape(n, ci, h * w))                  # [N, Co*9, H*W]
+    return torch.nn.functional.fold(cols, output_size=(2 * h + 1, 2 * w + 1), kernel_size=3, stride=2)
+
+
 def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=None, noise_strength=None, act='lrelu', act_gain=1.0, clamp=None):
     """Whole SynthesisLayer body after the style affine: modulated 3x3 conv (x2 up when ``up == 2``) + noise + bias + act."""
+    if x.shape[2] * x.shape[3] <= gemm_max_pixels:
+        y = _small_layer(x, weight, styles, up)
+        if up == 2:
+            y = upfirdn2d.upfirdn2d(y, resample_filter, padding=[1, 1, 1, 1], gain=4)
+        if noise_const is not None:
+            y = y.add_((noise_const * noise_strength).to(y.dtype))
+        return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
     wmod = modulate_weights(weight, styles, demodulate=True, dtype=x.dtype)
     act_idx = {'linear': 0, 'lrelu': 1}.get(act)
     clampv = -1.0 if clamp is None else float(clamp)
     if up == 1 and act_idx is not None:
-        return conv3x3(x, wmod, bias=bias, noise=noise_const, noise_strength=noise_strength, act=act_idx, gain=act_gain, clamp=clampv)
+        return conv2d(x, wmod, bias=bias, noise=noise_const, noise_strength=noise_strength, act=act_idx, gain=act_gain, clamp=clampv)
     if up == 1:
-        y = conv3x3(x, wmod, noise=noise_const, noise_strength=noise_strength)
+        y = conv2d(x, wmod, noise=noise_const, noise_strength=noise_strength)
         return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
     # x2: stride-2 transposed conv as four polyphase GEMMs, then the 4x4 low-pass with gain 4 (conv2d_resample.py:114-131)
-    y = conv3x3(x, wmod, transposed=True)
+    y = conv2d(x, wmod, transposed=True)
     y = upfirdn2d.upfirdn2d(y, resample_filter, padding=[1, 1, 1, 1], gain=4)
     if noise_const is not None:
         y = y.add_((noise_const * noise_strength).to(y.dtype))
@@ -136,6 +163,11 @@ def torgb(x, weight, styles, bias, clamp=None, out=None):
     tri-plane image of the backbone) go through the MFMA kernel as a 1x1 conv and stay channels-last."""
     n, ci, h, w = x.shape
     co = weight.shape[0]
+    if h * w <= gemm_max_pixels and not (x.dtype == torch.float16 and co <= 8):
+        wm = modulate_weights(weight, styles, demodulate=False, dtype=x.dtype).reshape(n, co, ci)
+        y = torch.bmm(wm, x.contiguous().reshape(n, ci, h * w)).reshape(n, co, h, w)
+        y = bias_act.bias_act(y, None if bias is None else bias.to(y.dtype), clamp=clamp)
+        return y if out is None else out.add_(y)
     if not (x.dtype == torch.float16 and ci in (64, 128, 256, 512) and co in (1, 2, 3, 4, 6, 8)):
         wmod = modulate_weights(weight, styles, demodulate=False, dtype=x.dtype)
         y = conv2d(x, wmod, bias=bias, clamp=-1.0 if clamp is None else float(clamp))

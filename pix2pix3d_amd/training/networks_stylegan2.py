@@ -337,10 +337,9 @@ class SynthesisBlock(torch.nn.Module):
             img = upfirdn2d.upsample2d(img, self.resample_filter)
         if self.is_last or self.architecture == 'skip':
             y = self.torgb(x, next(w_iter), fused_modconv=fused_modconv)
-            if fmt == torch.channels_last and y.dtype == torch.float32 and y.shape[1] > 8:
-                pass                       # wide fp32 skip image (the tri-planes) stays channels-last: the ray-marcher reads it in place
-            else:
-                y = y.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+            wide_cl = fmt == torch.channels_last and y.shape[1] > 8 and y.shape[1] % 4 == 0
+            # a wide skip image (the 96-channel tri-planes) stays channels-last end to end: the ray-marcher reads it in place
+            y = y.to(dtype=torch.float32, memory_format=torch.channels_last if wide_cl else torch.contiguous_format)
             img = img.add_(y) if img is not None else y
 
         assert x.dtype == dtype
