@@ -96,6 +96,8 @@ typedef struct p3d_render_desc {
      * n*image_stride + p*plane_stride + (y*W + x)*pixel_stride and holds 32 contiguous channels; e.g. a
      * channels-last backbone output [N][H][W][96] is (image H*W*96, plane 32, pixel 96).                 */
     int64_t image_stride, plane_stride, pixel_stride;
+    int32_t raster_order;                 /* != 0: ray m of an image is pixel (m / R, m % R) of an R x R raster (R*R = rays_per_img):
+                                             lets the kernel assign 16 x 16 pixel blocks to workgroups for L2 locality  */
 } p3d_render_desc;
 
 int p3d_render_decoder_floats(void);     /* size of the packed decoder stream, in floats        */

@@ -59,7 +59,7 @@ struct RenderArgs {
     float* dbg_fine;          // optional [N*M][Sf] sorted fine depths
     float* dbg_wcoarse;       // optional [N*M][Sc-1] coarse weights
     unsigned* minmax;         // [2] ordered-uint encoded min / max of all sample depths
-    int total_rays, rays_per_img, H, W, Sc, Sf;
+    int total_rays, rays_per_img, res, H, W, Sc, Sf;          // res: image side when the rays form a res x res raster (else 0)
     int64_t plane_stride, pix_stride, img_stride;   // texel (n, p, y, x) starts at n*img_stride + p*plane_stride + (y*W + x)*pix_stride
     float ray_start, ray_end, coord_scale;
     int disparity, white_back, sem_sigmoid;
@@ -302,10 +302,31 @@ render_forward_kernel(RenderArgs a)
     const int SN = NNETS - 1;                                    // density comes from the last net (triplane_cond.py:958)
     const int Sc = a.Sc, Sf = a.Sf;
 
-    const int ray0 = (blockIdx.x * kWavesPerBlock + wave) * 32;
+    // ---- ray -> (workgroup, wave, lane) assignment -------------------------------------------------------------
+    // Rays of one pixel COLUMN project onto the same texels of the (x,z) plane, rays of one pixel ROW onto the same
+    // texels of the (z,y) plane.  Workgroup b runs on XCD b % 8 (private L2), so when the image is R x R with
+    // R = 16 * ns and ns | 8, XCD k is given the 16-pixel-wide column strip k % ns of every image: the (x,z) texels a
+    // strip needs (~1 MB per image) stay in that XCD's L2 for all its rows instead of being re-fetched by 8 L2s.
+    // A workgroup is a 16 x 16 pixel block, a wave two 16-pixel rows of it (same row => same (z,y) texels: one fetch
+    // serves 16 lanes).  Any other shape falls back to consecutive rays.
+    int ray0 = (blockIdx.x * kWavesPerBlock + wave) * 32;        // linear assignment (and the bound for 'live')
+    int g_lane = ray0 + j;
+    {
+        const int R = a.res;
+        const int ns = R >> 4;
+        if (R > 0 && (R & 15) == 0 && ns <= 8 && (8 % ns) == 0 && a.rays_per_img == R * R && ((a.total_rays / 256) & 7) == 0) {
+            const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+            const int strip = xcd % ns, sub = xcd / ns, per = 8 / ns;         // `per` XCDs share a strip
+            const int blk = slot * per + sub;                                 // (image, row block) index within the strip
+            const int n_i = blk / ns, rb = blk - n_i * ns;                    // ns row blocks of 16 rows per image
+            const int row = rb * 16 + wave * 2 + (j >> 4), col = strip * 16 + (j & 15);
+            g_lane = n_i * a.rays_per_img + row * R + col;
+            ray0 = 0;                                                         // every lane is a real ray in this mode
+        }
+    }
     if (ray0 >= a.total_rays) return;
-    const int g = min(ray0 + j, a.total_rays - 1);               // tail lanes shadow the last ray, never store
-    const bool live = (ray0 + j) < a.total_rays;
+    const int g = min(g_lane, a.total_rays - 1);                 // tail lanes shadow the last ray, never store
+    const bool live = g_lane < a.total_rays;
     const int n_img = g / a.rays_per_img;
     const float* img = a.planes + (size_t)n_img * a.img_stride;
     const float ox = a.ray_o[g * 3 + 0], oy = a.ray_o[g * 3 + 1], oz = a.ray_o[g * 3 + 2];
@@ -337,16 +358,17 @@ render_forward_kernel(RenderArgs a)
 
     // ------------------------------ phase B: importance depths, sorted --------------------------------
     for (int r = 0; r < 32; ++r) {
-        const int gr = min(ray0 + r, a.total_rays - 1);                          // wave-uniform
+        const int gr = __shfl(g, r, 64);                                         // global index of the wave's r-th ray (wave-uniform)
+        const bool r_live = __shfl((int)live, r, 64) != 0;
         const float w_i = (lane < Sc - 1) ? tile[lane * kPitch + r] : 0.f;
         const float z_i = (lane < Sc) ? coarse_depth(a, gr, lane, a.u_coarse[(size_t)gr * Sc + lane]) : 0.f;
         const float u   = (lane < Sf) ? a.u_fine[(size_t)gr * Sf + lane] : 2.f;
-        if (a.dbg_wcoarse && lane < Sc - 1 && ray0 + r < a.total_rays) a.dbg_wcoarse[(size_t)gr * (Sc - 1) + lane] = w_i;
+        if (a.dbg_wcoarse && lane < Sc - 1 && r_live) a.dbg_wcoarse[(size_t)gr * (Sc - 1) + lane] = w_i;
         float zf = importance_depth(Sc, Sf, lane, w_i, z_i, u, sA, sB);
         zf = bitonic_sort64(zf, lane);
         wave_sync();
         if (lane < Sf) tile[lane * kPitch + r] = zf;
-        if (a.dbg_fine && lane < Sf && ray0 + r < a.total_rays) a.dbg_fine[(size_t)gr * Sf + lane] = zf;
+        if (a.dbg_fine && lane < Sf && r_live) a.dbg_fine[(size_t)gr * Sf + lane] = zf;
     }
     wave_sync();
 
@@ -639,6 +661,7 @@ extern "C" int p3d_render_forward(const float* planes_cl, const float* decoder, 
     a.t_start = t_start; a.t_end = t_end; a.feat = feat; a.depth = depth; a.wsum = wsum;
     a.dbg_fine = dbg_fine; a.dbg_wcoarse = dbg_wcoarse; a.minmax = minmax_ws;
     a.total_rays = (int)total; a.rays_per_img = d->rays_per_img;
+    { int r = 1; while (r * r < d->rays_per_img) ++r; a.res = (r * r == d->rays_per_img && d->raster_order) ? r : 0; }
     hipStream_t s = (hipStream_t)stream;
     const size_t lds_bytes = (size_t)(kDecoderFloats + kWavesPerBlock * kWaveTile) * sizeof(float);
     const int blocks = (int)((total + kWavesPerBlock * 32 - 1) / (kWavesPerBlock * 32));

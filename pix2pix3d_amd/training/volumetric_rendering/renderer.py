@@ -26,7 +26,7 @@ class _RenderDesc(ctypes.Structure):          # p3d_render_desc (include/p3d_hip
                 ('n_nets', ctypes.c_int32), ('semantic_sigmoid', ctypes.c_int32), ('depth_resolution', ctypes.c_int32),
                 ('depth_resolution_importance', ctypes.c_int32), ('disparity_space_sampling', ctypes.c_int32), ('white_back', ctypes.c_int32),
                 ('ray_start', ctypes.c_float), ('ray_end', ctypes.c_float), ('box_warp', ctypes.c_float),
-                ('image_stride', ctypes.c_int64), ('plane_stride', ctypes.c_int64), ('pixel_stride', ctypes.c_int64)]
+                ('image_stride', ctypes.c_int64), ('plane_stride', ctypes.c_int64), ('pixel_stride', ctypes.c_int64), ('raster_order', ctypes.c_int32)]
 
 
 _vp, _i32, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
@@ -128,11 +128,11 @@ class _FusedContext:
         self._keep = ws
         self.n_nets, self.sem_sigmoid, self.n, self.h, self.w = len(nets), sem_sigmoid, n, h, w
 
-    def desc(self, options, rays_per_img=1, start=0.0, end=0.0):
+    def desc(self, options, rays_per_img=1, start=0.0, end=0.0, raster=False):
         return _RenderDesc(self.n, rays_per_img, self.h, self.w, self.n_nets, int(self.sem_sigmoid),
                            int(options.get('depth_resolution', 0)), int(options.get('depth_resolution_importance', 0)),
                            int(bool(options.get('disparity_space_sampling', False))), int(bool(options.get('white_back', False))),
-                           float(start), float(end), float(options['box_warp']), *self.strides)
+                           float(start), float(end), float(options['box_warp']), *self.strides, int(raster))
 
 
 class ImportanceRenderer(torch.nn.Module):
@@ -347,7 +347,8 @@ def fused_render(planes, decoder, ray_origins, ray_directions, opt, u_coarse, u_
     mm = torch.empty([2], device=dev, dtype=torch.int32)
     dbg_f = torch.empty([n * m, sf], device=dev, dtype=torch.float32) if debug else None
     dbg_w = torch.empty([n * m, sc - 1], device=dev, dtype=torch.float32) if debug else None
-    d = ctx.desc(opt, rays_per_img=m, start=0.0 if auto else opt['ray_start'], end=0.0 if auto else opt['ray_end'])
+    # raster=True is a pure scheduling hint (which wave takes which ray); results never depend on it
+    d = ctx.desc(opt, rays_per_img=m, start=0.0 if auto else opt['ray_start'], end=0.0 if auto else opt['ray_end'], raster=True)
     with _lib.kernel_timer('render_forward', feat):
         code = _lib.lib().p3d_render_forward(_lib.ptr(ctx.planes_cl), _lib.ptr(ctx.packed), _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(uc), _lib.ptr(uf),
                                              _lib.ptr(t0), _lib.ptr(t1), ctypes.byref(d), _lib.ptr(feat), _lib.ptr(depth), _lib.ptr(wsum),
