@@ -61,7 +61,8 @@ struct RenderArgs {
     unsigned* minmax;         // [2] ordered-uint encoded min / max of all sample depths
     int total_rays, rays_per_img, res, H, W, Sc, Sf;          // res: image side when the rays form a res x res raster (else 0)
     int64_t plane_stride, pix_stride, img_stride;   // texel (n, p, y, x) starts at n*img_stride + p*plane_stride + (y*W + x)*pix_stride
-    float ray_start, ray_end, coord_scale;
+    unsigned plane_bytes, pix_bytes, img_bytes, planes_total_bytes;   // the same strides in bytes (everything fits 32 bits, checked on the host)
+    float ray_start, ray_end, coord_scale, lin_step;
     int disparity, white_back, sem_sigmoid;
 };
 
@@ -76,11 +77,15 @@ __device__ __forceinline__ unsigned order_key(float f) {
 __device__ __forceinline__ float order_unkey(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
+// Hardware transcendentals (v_exp_f32 = 2^x, v_log_f32 = log2, ~1 ulp): two instructions per exp/log instead of the
+// range-checked library expansions; arguments here are always in the safe range (no denormal inputs matter).
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 __device__ __forceinline__ float softplus20(float x) {      // torch.nn.Softplus(beta=1, threshold=20)
-    return x > 20.f ? x : __logf(1.f + __expf(x));
+    return x > 20.f ? x : fast_log(1.f + fast_exp(x));
 }
 __device__ __forceinline__ float sigmoid_clamped(float x) {  // sigmoid(x) * (1 + 2*0.001) - 0.001
-    return __builtin_amdgcn_rcpf(1.f + __expf(-x)) * 1.002f - 0.001f;
+    return fmaf(__builtin_amdgcn_rcpf(1.f + fast_exp(-x)), 1.002f, -0.001f);
 }
 
 // Depth of coarse sample i on ray g (renderer.py:169-192), fp32 with the same operation order.
@@ -100,13 +105,14 @@ __device__ __forceinline__ float coarse_depth(const RenderArgs& a, int g, int i,
         t = t + u * step;
         return 1.f / (1.f / a.ray_start * (1.f - t) + 1.f / a.ray_end * t);
     }
-    const float step = (a.ray_end - a.ray_start) / (float)(S - 1);          // torch.linspace, fp32
+    const float step = a.lin_step;                                          // (ray_end - ray_start) / (S - 1) in fp32, as torch.linspace
     const float lin = (i < S / 2) ? a.ray_start + step * (float)i : a.ray_end - step * (float)(S - i - 1);
     return lin + u * step;
 }
 
 // ---- tri-plane gather: mean over planes of the bilinear sample, channels [16h, 16h+16) ------------
-__device__ __forceinline__ void gather_features(const RenderArgs& a, const float* __restrict__ img, int h,
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ void gather_features(const RenderArgs& a, rsrc_t rsrc, unsigned img_off, int h,
                                                 float px, float py, float pz, float (&feat)[16])
 {
     const int W = a.W, H = a.H;
@@ -135,14 +141,20 @@ __device__ __forceinline__ void gather_features(const RenderArgs& a, const float
         const float w10 = (vx1 & vy0) ? wx1 * wy0 : 0.f;    // ne
         const float w01 = (vx0 & vy1) ? wx0 * wy1 : 0.f;    // sw
         const float w11 = (vx1 & vy1) ? wx1 * wy1 : 0.f;    // se
-        const float* pl = img + (size_t)p * a.plane_stride + h * 16;
-        const f32x4* t00 = (const f32x4*)(pl + ((size_t)cy0 * W + cx0) * a.pix_stride);
-        const f32x4* t10 = (const f32x4*)(pl + ((size_t)cy0 * W + cx1) * a.pix_stride);
-        const f32x4* t01 = (const f32x4*)(pl + ((size_t)cy1 * W + cx0) * a.pix_stride);
-        const f32x4* t11 = (const f32x4*)(pl + ((size_t)cy1 * W + cx1) * a.pix_stride);
+        // 32-bit byte offsets into one buffer resource (wave-uniform descriptor): no 64-bit address arithmetic per tap
+        const unsigned pbase = img_off + (unsigned)p * a.plane_bytes + (unsigned)h * 64u;
+        const unsigned o00 = pbase + __umul24(__umul24(cy0, W) + cx0, a.pix_bytes);
+        const unsigned o10 = pbase + __umul24(__umul24(cy0, W) + cx1, a.pix_bytes);
+        const unsigned o01 = pbase + __umul24(__umul24(cy1, W) + cx0, a.pix_bytes);
+        const unsigned o11 = pbase + __umul24(__umul24(cy1, W) + cx1, a.pix_bytes);
         f32x4 v00[4], v10[4], v01[4], v11[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { v00[q] = t00[q]; v10[q] = t10[q]; v01[q] = t01[q]; v11[q] = t11[q]; }
+        for (int q = 0; q < 4; ++q) {
+            v00[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o00 + 16 * q, 0, 0));
+            v10[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o10 + 16 * q, 0, 0));
+            v01[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o01 + 16 * q, 0, 0));
+            v11[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o11 + 16 * q, 0, 0));
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -328,7 +340,8 @@ render_forward_kernel(RenderArgs a)
     const int g = min(g_lane, a.total_rays - 1);                 // tail lanes shadow the last ray, never store
     const bool live = g_lane < a.total_rays;
     const int n_img = g / a.rays_per_img;
-    const float* img = a.planes + (size_t)n_img * a.img_stride;
+    const rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.planes, 0, a.planes_total_bytes, 0x00020000);
+    const unsigned img = (unsigned)n_img * a.img_bytes;
     const float ox = a.ray_o[g * 3 + 0], oy = a.ray_o[g * 3 + 1], oz = a.ray_o[g * 3 + 2];
     const float dx = a.ray_d[g * 3 + 0], dy = a.ray_d[g * 3 + 1], dz = a.ray_d[g * 3 + 2];
     const float cs = a.coord_scale;
@@ -340,13 +353,13 @@ render_forward_kernel(RenderArgs a)
         for (int i = 0; i < Sc; ++i) {
             const float z = coarse_depth(a, g, i, uc[i]);
             float feat[16];
-            gather_features(a, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
+            gather_features(a, rsrc, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
             f32x16 h0, h1;
             mlp_layer1(lds, SN, lane, h, feat, h0, h1);
             const float sigma = mlp_sigma(lds, h, h0, h1);
             if (i > 0) {
                 const float dens = softplus20(0.5f * (s_prev + sigma) - 1.f);
-                const float alpha = 1.f - __expf(-dens * (z - z_prev));
+                const float alpha = 1.f - fast_exp(-dens * (z - z_prev));
                 const float w = alpha * T;
                 T *= (1.f - alpha + 1e-10f);
                 if (h == 0) tile[(i - 1) * kPitch + j] = w;
@@ -390,7 +403,7 @@ render_forward_kernel(RenderArgs a)
         else        { ++jf; zf = (jf < Sf) ? tile[jf * kPitch + j] : INFINITY; }
 
         float feat[16];
-        gather_features(a, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
+        gather_features(a, rsrc, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
         // The density net goes first: its sigma closes interval k-1 (weight w), after which every net's
         // colours are folded into the accumulators as soon as its layer 2 retires — only `prev` (the
         // other end of the midpoint rule) stays live across samples.
@@ -405,7 +418,7 @@ render_forward_kernel(RenderArgs a)
                 if (k == 0) z_first = z;
                 else {
                     const float dens = softplus20(0.5f * (s_prev + sigma) - 1.f);
-                    const float alpha = 1.f - __expf(-dens * (z - z_prev));
+                    const float alpha = 1.f - fast_exp(-dens * (z - z_prev));
                     const float w = alpha * T;
                     T *= (1.f - alpha + 1e-10f);
                     hw = 0.5f * w;
@@ -478,14 +491,15 @@ sample_points_kernel(RenderArgs a, const float* coords, int pts_per_img, int tot
     }
     __syncthreads();
     const int SN = NNETS - 1;
+    const rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.planes, 0, a.planes_total_bytes, 0x00020000);
     const int tiles = (total_pts + 31) / 32;
     for (int t = blockIdx.x * kWavesPerBlock + wave; t < tiles; t += gridDim.x * kWavesPerBlock) {
         const int p = min(t * 32 + j, total_pts - 1);
         const bool live = (t * 32 + j) < total_pts;
-        const float* img = a.planes + (size_t)(p / pts_per_img) * a.img_stride;
+        const unsigned img = (unsigned)(p / pts_per_img) * a.img_bytes;
         const float cs = a.coord_scale;
         float feat[16];
-        gather_features(a, img, h, cs * coords[(size_t)p * 3], cs * coords[(size_t)p * 3 + 1], cs * coords[(size_t)p * 3 + 2], feat);
+        gather_features(a, rsrc, img, h, cs * coords[(size_t)p * 3], cs * coords[(size_t)p * 3 + 1], cs * coords[(size_t)p * 3 + 2], feat);
 #pragma unroll
         for (int n = 0; n < NNETS; ++n) {
             f32x16 h0, h1, o;
@@ -592,6 +606,11 @@ static int check_render_common(const p3d_render_desc* d)
     P3D_REQUIRE(d->n_nets == 1 || d->n_nets == 2, "render: n_nets must be 1 or 2 (got %d)", d->n_nets);
     P3D_REQUIRE(d->plane_h >= 1 && d->plane_w >= 1, "render: bad plane size");
     P3D_REQUIRE(d->box_warp != 0.f, "render: box_warp must be non-zero");
+    {   // 32-bit buffer addressing: the whole plane tensor must span < 2 GiB, a pixel stride < 64 KiB (24-bit multiplies)
+        const int64_t istr = d->pixel_stride > 0 ? d->image_stride : (int64_t)3 * d->plane_h * d->plane_w * 32;
+        if ((int64_t)d->n_img * istr * 4 >= ((int64_t)1 << 31) || (int64_t)d->plane_h * d->plane_w >= (1 << 24) || d->pixel_stride * 4 >= (1 << 16))
+            return fail(P3D_ERR_UNSUPPORTED, "render: plane tensor too large for 32-bit buffer addressing (%lld images)", (long long)d->n_img);
+    }
     P3D_REQUIRE(d->pixel_stride == 0 || (d->pixel_stride % 4 == 0 && d->plane_stride % 4 == 0 && d->image_stride % 4 == 0), "render: plane strides must keep texels 16-byte aligned");
     return P3D_OK;
 }
@@ -633,9 +652,12 @@ static void fill_args(RenderArgs& a, const p3d_render_desc* d)
 {
     a.H = d->plane_h; a.W = d->plane_w; a.Sc = d->depth_resolution; a.Sf = d->depth_resolution_importance;
     a.ray_start = d->ray_start; a.ray_end = d->ray_end; a.coord_scale = 2.f / d->box_warp;
+    a.lin_step = a.Sc > 1 ? (d->ray_end - d->ray_start) / (float)(a.Sc - 1) : 0.f;
     a.disparity = d->disparity_space_sampling; a.white_back = d->white_back; a.sem_sigmoid = d->semantic_sigmoid;
     if (d->pixel_stride > 0) { a.plane_stride = d->plane_stride; a.pix_stride = d->pixel_stride; a.img_stride = d->image_stride; }
     else { a.plane_stride = (int64_t)a.H * a.W * 32; a.pix_stride = 32; a.img_stride = 3 * a.plane_stride; }
+    a.plane_bytes = (unsigned)(a.plane_stride * 4); a.pix_bytes = (unsigned)(a.pix_stride * 4); a.img_bytes = (unsigned)(a.img_stride * 4);
+    a.planes_total_bytes = (unsigned)((int64_t)d->n_img * a.img_stride * 4);
 }
 
 extern "C" int p3d_render_forward(const float* planes_cl, const float* decoder, const float* ray_o, const float* ray_d,
