@@ -163,6 +163,18 @@ int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype, const floa
 int p3d_torgb_nhwc_f16(const void* x, const float* weight, const float* styles, const float* bias, float* y_nchw,
                        int32_t n_img, int32_t hw, int32_t ci, int32_t co, float clamp, int32_t accumulate, p3d_stream_t stream);
 
+/* ---- 4x4 FIR + layer epilogue, channels-last --------------------------------------------------
+ * The tail of every x2 synthesis layer in one pass: upfirdn2d(up = down = 1, 4x4 filter f [4][4] fp32 contiguous,
+ * gain) (torch_utils/ops/conv2d_resample.py:128) followed by "+ noise" and bias_act (networks_stylegan2.py:319-332):
+ *   y = clamp(act(fir(x) + noise[out_h][out_w] * noise_strength[0] + bias[c]) * act_gain)
+ * x [N][in_h][in_w][C] -> y [N][out_h][out_w][C], dtype fp16 or fp32, out = in + pad0 + pad1 - 3 (pad1 implied by the
+ * sizes).  act: 1 linear, 3 lrelu(alpha) (bias_act.py:23-33 indices); bias / noise may be null; clamp < 0 = off.
+ * C must be a multiple of 64 (fp16) / 32 (fp32), else P3D_ERR_UNSUPPORTED.                              */
+int p3d_fir4_bias_act_nhwc(const void* x, const float* f, void* y, int dtype, int32_t n_img, int32_t c, int32_t in_h, int32_t in_w,
+                           int32_t pad_x0, int32_t pad_y0, int32_t out_h, int32_t out_w, int32_t flip, float gain,
+                           const float* bias, const float* noise, const float* noise_strength, int32_t act, float alpha, float act_gain,
+                           float clamp, p3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

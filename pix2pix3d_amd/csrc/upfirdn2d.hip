@@ -222,6 +222,100 @@ __global__ void __launch_bounds__(256) upfirdn2d_cl_kernel(UpfirArgs a)
     }
 }
 
+// ---- channels-last 4x4 FIR with the layer epilogue fused (LDS-tiled) ---------------------------------------------------
+// The x2 synthesis layers end with: transposed conv -> this FIR (up = down = 1, 4x4, gain 4) -> + noise -> bias_act
+// (conv2d_resample.py:128, networks_stylegan2.py:319-332).  One block = 16 x 16 output pixels x 128 bytes of channels
+// (64 halfs / 32 floats): the 19 x 19 input footprint is staged once in LDS, each thread slides a 4-column window
+// down 8 rows for one 16-byte channel chunk (44 LDS reads for 8 outputs instead of 128), then applies
+// v = fir + noise*strength + bias -> lrelu -> * act_gain -> clamp and stores — the activation never makes a second trip
+// through HBM.
+struct FirEpilogue { const float* bias; const float* noise; const float* noise_strength; int act; float alpha, act_gain, clamp; };
+
+template <class T>
+__global__ void __launch_bounds__(256) fir4_cl_fused_kernel(UpfirArgs a, FirEpilogue ep)
+{
+    constexpr int VEC = 16 / sizeof(T);            // elements per 16-byte chunk
+    constexpr int CB = 8 * VEC;                    // channels per block (128 bytes)
+    constexpr int TI = 19;                         // input tile side for a 16 x 16 output tile and 4 taps
+    typedef Pack16<T> P;
+    __shared__ P tile[TI * TI * 8];
+    const int tiles_x = (a.out_w + 15) / 16, tiles_y = (a.out_h + 15) / 16;
+    int b = blockIdx.x;
+    const int cblk = b % (a.C / CB); b /= (a.C / CB);
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int n = b / tiles_y;
+    const int ox0 = tx * 16, oy0 = ty * 16;
+    const int ix0 = ox0 - a.pad_x0, iy0 = oy0 - a.pad_y0;
+    const T* img = (const T*)a.x + (int64_t)n * a.isn + cblk * CB;
+    const int chunk = threadIdx.x & 7;
+    for (int e = threadIdx.x >> 3; e < TI * TI; e += 32) {
+        const int r = e / TI, c = e - r * TI;
+        const int iy = iy0 + r, ix = ix0 + c;
+        P v;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) st(&v.v[k], (typename Acc<T>::type)0);
+        if ((iy >= 0) & (iy < a.in_h) & (ix >= 0) & (ix < a.in_w)) v = *(const P*)(img + (int64_t)iy * a.isy + (int64_t)ix * a.isx + chunk * VEC);
+        tile[e * 8 + chunk] = v;
+    }
+    float fr[4][4];
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            const int fx = a.flip ? kx : 3 - kx, fy = a.flip ? ky : 3 - ky;
+            fr[ky][kx] = a.f[fx * a.fsx + fy * a.fsy] * a.gain;
+        }
+    __syncthreads();
+    const int x = (threadIdx.x >> 3) & 15, yh = threadIdx.x >> 7;
+    float acc[8][VEC];
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[o][k] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 11; ++r) {                 // input rows yh*8 .. yh*8+10 feed output rows yh*8 .. yh*8+7
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            const P v = tile[((yh * 8 + r) * TI + x + kx) * 8 + chunk];
+            float vf[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) vf[k] = (float)ld(&v.v[k]);
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky) {
+                const int o = r - ky;              // output row (within the strip) this input row contributes to with tap ky
+                if (o >= 0 && o < 8) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[o][k] = fmaf(vf[k], fr[ky][kx], acc[o][k]);
+                }
+            }
+        }
+    }
+    const int ox = ox0 + x;
+    if (ox >= a.out_w) return;
+    const int c0 = cblk * CB + chunk * VEC;
+    float bias[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) bias[k] = ep.bias ? ep.bias[c0 + k] : 0.f;
+    const float ns = ep.noise ? ep.noise_strength[0] : 0.f;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        const int oy = oy0 + yh * 8 + o;
+        if (oy >= a.out_h) break;
+        const float nz = ep.noise ? ep.noise[(int64_t)oy * a.out_w + ox] * ns : 0.f;
+        P outv;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float v = acc[o][k] + nz + bias[k];
+            if (ep.act == 3) v = v > 0.f ? v : v * ep.alpha;
+            v *= ep.act_gain;
+            if (ep.clamp >= 0.f) v = fminf(fmaxf(v, -ep.clamp), ep.clamp);
+            st(&outv.v[k], (typename Acc<T>::type)v);
+        }
+        *(P*)((T*)a.y + (int64_t)n * a.osn + (int64_t)oy * a.osy + (int64_t)ox * a.osx + c0) = outv;
+    }
+}
+
 template <class T>
 static bool try_channels_last(const UpfirArgs& a, hipStream_t s)
 {
@@ -313,4 +407,32 @@ extern "C" int p3d_upfirdn2d(const void* x, const float* f, void* y, int dtype,
         case P3D_F64: return launch_upfirdn2d<double>(a, s);
     }
     return fail(P3D_ERR_ARGUMENT, "upfirdn2d: unknown dtype %d", dtype);
+}
+
+extern "C" int p3d_fir4_bias_act_nhwc(const void* x, const float* f, void* y, int dtype, int32_t n_img, int32_t c, int32_t in_h, int32_t in_w,
+                                      int32_t pad_x0, int32_t pad_y0, int32_t out_h, int32_t out_w, int32_t flip, float gain,
+                                      const float* bias, const float* noise, const float* noise_strength, int32_t act, float alpha, float act_gain,
+                                      float clamp, p3d_stream_t stream)
+{
+    using namespace p3d;
+    P3D_REQUIRE(x && f && y, "fir4_bias_act_nhwc: null pointer");
+    P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32, "fir4_bias_act_nhwc: dtype must be fp16 or fp32");
+    P3D_REQUIRE(act == 1 || act == 3, "fir4_bias_act_nhwc: act must be linear (1) or lrelu (3)");
+    const int cb = dtype == P3D_F16 ? 64 : 32;
+    if (c % cb != 0) return fail(P3D_ERR_UNSUPPORTED, "fir4_bias_act_nhwc: C=%d must be a multiple of %d", c, cb);
+    P3D_REQUIRE(((((uintptr_t)x) | ((uintptr_t)y)) & 15u) == 0, "fir4_bias_act_nhwc: x and y must be 16-byte aligned");
+    UpfirArgs a{};
+    a.x = x; a.f = f; a.y = y; a.in_w = in_w; a.in_h = in_h; a.C = c; a.N = n_img;
+    a.isc = 1; a.isx = c; a.isy = (int64_t)in_w * c; a.isn = (int64_t)in_h * in_w * c;
+    a.osc = 1; a.osx = c; a.osy = (int64_t)out_w * c; a.osn = (int64_t)out_h * out_w * c;
+    a.fw = a.fh = 4; a.fsx = 1; a.fsy = 4; a.out_w = out_w; a.out_h = out_h;
+    a.up_x = a.up_y = a.down_x = a.down_y = 1; a.pad_x0 = pad_x0; a.pad_y0 = pad_y0; a.flip = flip ? 1 : 0; a.gain = gain;
+    FirEpilogue ep{bias, noise, noise_strength, act, alpha, act_gain, clamp};
+    const int64_t blocks = (int64_t)n_img * ((out_h + 15) / 16) * ((out_w + 15) / 16) * (c / cb);
+    P3D_REQUIRE(blocks > 0 && blocks < (1ll << 31), "fir4_bias_act_nhwc: bad launch size");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == P3D_F16) hipLaunchKernelGGL(fir4_cl_fused_kernel<__half>, dim3((unsigned)blocks), dim3(256), 0, s, a, ep);
+    else                  hipLaunchKernelGGL(fir4_cl_fused_kernel<float>,  dim3((unsigned)blocks), dim3(256), 0, s, a, ep);
+    count_launch(FAM_UPFIRDN);
+    return check_launch("fir4_bias_act_nhwc");
 }

@@ -20,6 +20,8 @@ _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.
 _lib.register('p3d_modulate_weights', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp])
 _lib.register('p3d_conv2d_nhwc', ctypes.c_int, [_vp] * 3 + [ctypes.c_int] + [_vp] * 4 + [_i32] * 5 + [_i64, _i32, _i32, _i32, _f32, _f32, _vp])
 
+_lib.register('p3d_fir4_bias_act_nhwc', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int] + [_i32] * 9 + [_f32, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _vp])
+
 min_pixels = 1               # every layer takes this module (the vendor conv library is never entered: its choices for the small
                              # layers — naive kernels on a fresh box — cost milliseconds)
 gemm_max_pixels = 1024       # layers whose input has at most this many pixels per image cannot fill 128-pixel MFMA tiles: they run as
@@ -48,21 +50,32 @@ def _no_grad_needed(*tensors):
     return not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors))
 
 
+def _dense_dev(x):
+    return x.is_cuda and x.dtype in (torch.float16, torch.float32) and x.ndim == 4 and (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last))
+
+
+def is_small(x):
+    """Images this small run as one batched GEMM (any dense layout); larger ones need channels_last for the MFMA kernel."""
+    return x.shape[2] * x.shape[3] <= gemm_max_pixels
+
+
 def layer_supported(x, weight, styles, noise_mode, fused_modconv, up):
     """True when the native kernels cover this SynthesisLayer call."""
-    if not enabled or not _is_nhwc(x) or not fused_modconv or up not in (1, 2):
+    if not enabled or not fused_modconv or up not in (1, 2) or not _dense_dev(x):
         return False
-    if tuple(weight.shape[2:]) != (3, 3) or noise_mode == 'random' or x.shape[2] * x.shape[3] < min_pixels:
+    if tuple(weight.shape[2:]) != (3, 3) or noise_mode == 'random' or not (is_small(x) or _is_nhwc(x)):
         return False
     return _no_grad_needed(x, weight, styles)
 
 
 def torgb_supported(x, weight, styles, fused_modconv):
-    if not enabled or not _is_nhwc(x) or not fused_modconv or tuple(weight.shape[2:]) != (1, 1) or not _no_grad_needed(x, weight, styles):
+    if not enabled or not fused_modconv or tuple(weight.shape[2:]) != (1, 1) or not _dense_dev(x) or not _no_grad_needed(x, weight, styles):
         return False
-    if x.dtype == torch.float16 and x.shape[1] in (64, 128, 256, 512) and weight.shape[0] in (1, 2, 3, 4, 6, 8):
+    if _is_nhwc_f16(x) and x.shape[1] in (64, 128, 256, 512) and weight.shape[0] in (1, 2, 3, 4, 6, 8):
         return True                                   # skinny streaming kernel
-    return x.shape[2] * x.shape[3] <= gemm_max_pixels or x.shape[1] % (64 if x.dtype == torch.float16 else 32) == 0    # small: GEMM; else 1x1 through the MFMA kernel
+    if is_small(x):
+        return True                                   # batched GEMM
+    return _is_nhwc(x) and x.shape[1] % (64 if x.dtype == torch.float16 else 32) == 0      # 1x1 through the MFMA kernel
 
 
 def modulate_weights(weight, styles, demodulate=True, pre_scale=1.0, dtype=torch.float16, oihw=False):
@@ -134,7 +147,7 @@ def _small_layer(x, weight, styles, up):
 
 def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=None, noise_strength=None, act='lrelu', act_gain=1.0, clamp=None):
     """Whole SynthesisLayer body after the style affine: modulated 3x3 conv (x2 up when ``up == 2``) + noise + bias + act."""
-    if x.shape[2] * x.shape[3] <= gemm_max_pixels:
+    if is_small(x):
         y = _small_layer(x, weight, styles, up)
         if up == 2:
             y = upfirdn2d.upfirdn2d(y, resample_filter, padding=[1, 1, 1, 1], gain=4)
@@ -151,10 +164,27 @@ def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=No
         return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
     # x2: stride-2 transposed conv as four polyphase GEMMs, then the 4x4 low-pass with gain 4 (conv2d_resample.py:114-131)
     y = conv2d(x, wmod, transposed=True)
+    if act_idx is not None and tuple(resample_filter.shape) == (4, 4) and y.shape[1] % (64 if y.dtype == torch.float16 else 32) == 0:
+        return fir4_bias_act(y, resample_filter, bias, noise_const, noise_strength, act, act_gain, clampv)     # FIR + noise + bias + act in one pass
     y = upfirdn2d.upfirdn2d(y, resample_filter, padding=[1, 1, 1, 1], gain=4)
     if noise_const is not None:
         y = y.add_((noise_const * noise_strength).to(y.dtype))
     return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
+
+
+def fir4_bias_act(y, f, bias, noise, noise_strength, act, act_gain, clamp):
+    """4x4 FIR (pad 1, gain 4) + noise + bias + activation on an NHWC tensor [N,C,2H+1,2W+1] -> [N,C,2H,2W]."""
+    n, c, ih, iw = y.shape
+    out = torch.empty([n, c, ih - 1, iw - 1], dtype=y.dtype, device=y.device, memory_format=torch.channels_last)
+    f32 = f.detach().float().contiguous()
+    b32 = None if bias is None else bias.detach().float().contiguous()
+    nz = None if noise is None else noise.detach().float().contiguous()
+    ns = None if noise is None else noise_strength.detach().float().reshape(1).contiguous()
+    code = _lib.lib().p3d_fir4_bias_act_nhwc(_lib.ptr(y), _lib.ptr(f32), _lib.ptr(out), _lib.DTYPE_CODE[y.dtype], n, c, ih, iw, 1, 1, ih - 1, iw - 1, 0, 4.0,
+                                             _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns), {'linear': 1, 'lrelu': 3}[act], 0.2, float(act_gain), float(clamp),
+                                             _lib.stream_of(y))
+    _lib.check(code, 'fir4_bias_act_nhwc')
+    return out
 
 
 def torgb(x, weight, styles, bias, clamp=None, out=None):
@@ -163,7 +193,7 @@ def torgb(x, weight, styles, bias, clamp=None, out=None):
     tri-plane image of the backbone) go through the MFMA kernel as a 1x1 conv and stay channels-last."""
     n, ci, h, w = x.shape
     co = weight.shape[0]
-    if h * w <= gemm_max_pixels and not (x.dtype == torch.float16 and co <= 8):
+    if is_small(x) and not (_is_nhwc_f16(x) and ci in (64, 128, 256, 512) and co in (1, 2, 3, 4, 6, 8)):
         wm = modulate_weights(weight, styles, demodulate=False, dtype=x.dtype).reshape(n, co, ci)
         y = torch.bmm(wm, x.contiguous().reshape(n, ci, h * w)).reshape(n, co, h, w)
         y = bias_act.bias_act(y, None if bias is None else bias.to(y.dtype), clamp=clamp)

@@ -216,7 +216,8 @@ class SynthesisLayer(torch.nn.Module):
         if self.use_noise and noise_mode == 'const':
             noise = self.noise_const * self.noise_strength
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
-        if native_channels_last and fused_modconv is True and x.is_cuda and not torch.is_grad_enabled() and not x.is_contiguous(memory_format=torch.channels_last):
+        if native_channels_last and fused_modconv is True and x.is_cuda and not torch.is_grad_enabled() and not modconv.is_small(x) \
+                and not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)      # e.g. the output of a small generic-route layer feeding a native one
         if modconv.layer_supported(x, self.weight, styles, noise_mode, fused_modconv, self.up):
             # fp16 channels-last inference: weight modulation, MFMA conv, noise, bias, activation in native kernels
