@@ -223,42 +223,58 @@ __global__ void __launch_bounds__(256) modulate_weights_kernel(const float* __re
 }
 
 // ---- 1x1 ToRGB on fp16 NHWC activations -> fp32 NCHW image (networks_stylegan2.py:355-359) ----------------------------
-// y[n, o, p] = clamp( sum_i x[n, p, i] * w[o, i] * s[n, i] + b[o] );  skinny (Co <= 8): pure streaming read of x.
-template <int CO>
+// y[n, o, p] = clamp( sum_i x[n, p, i] * w[o, i] * s[n, i] + b[o] ): a skinny GEMM (Co <= 8) whose cost is reading x once.
+// One wave = 32 pixels per step on v_mfma_f32_32x32x16_f16: A = the pixels' channel vectors loaded straight from
+// global memory in fragment layout (16 B per lane per K step, all K steps of a tile in flight together), B = the
+// per-image modulated weights padded to 32 columns and held in registers for the whole kernel.  Output channel o is
+// column o of the accumulator: lanes o < Co store four float4 (4 consecutive pixels each) into the NCHW image.
+template <int KSTEPS>
 __global__ void __launch_bounds__(256) torgb_nhwc_kernel(const __half* __restrict__ x, const float* __restrict__ w, const float* __restrict__ styles,
-                                                         const float* __restrict__ bias, float* __restrict__ y, int HW, int Ci, float clamp, int accumulate)
+                                                         const float* __restrict__ bias, float* __restrict__ y, int HW, int Co, float clamp, int accumulate)
 {
-    extern __shared__ float wm[];                                    // [CO][Ci] modulated weights of this image
+    constexpr int Ci = KSTEPS * 16;
     const int n = blockIdx.y;
-    for (int e = threadIdx.x; e < CO * Ci; e += blockDim.x) wm[e] = w[e] * styles[(int64_t)n * Ci + (e % Ci)];
-    __syncthreads();
-    const int lanes_per_px = Ci / 8;                                 // 16-byte vectors per pixel (Ci = 128 or 256 -> 16 or 32 lanes)
-    const int px_per_wave = 64 / lanes_per_px;
-    const int lane = threadIdx.x & 63, sub = lane % lanes_per_px, pw = lane / lanes_per_px;
-    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-    const __half* xi = x + (int64_t)n * HW * Ci;
-    for (int p0 = wave_global * px_per_wave; p0 < HW; p0 += nwaves * px_per_wave) {
-        const int p = p0 + pw;
-        float acc[CO];
+    const int lane = threadIdx.x & 63, col = lane & 31, kg = lane >> 5;
+    h8 bw[KSTEPS];
 #pragma unroll
-        for (int o = 0; o < CO; ++o) acc[o] = 0.f;
-        if (p < HW) {
-            const h8 v = *(const h8*)(xi + (int64_t)p * Ci + sub * 8);
+    for (int k = 0; k < KSTEPS; ++k)
 #pragma unroll
-            for (int o = 0; o < CO; ++o)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[o] = fmaf((float)v[e], wm[o * Ci + sub * 8 + e], acc[o]);
+        for (int e = 0; e < 8; ++e) {
+            const int ci = k * 16 + kg * 8 + e;
+            bw[k][e] = (col < Co) ? (_Float16)(w[col * Ci + ci] * styles[(int64_t)n * Ci + ci]) : (_Float16)0.f;
         }
+    const float b = (bias && col < Co) ? bias[col] : 0.f;
+    const __half* xi = x + (int64_t)n * HW * Ci;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (int p0 = wave_global * 32; p0 < HW; p0 += nwaves * 32) {
+        const int p = min(p0 + col, HW - 1);                           // fragment row = pixel
+        h8 fa[KSTEPS];
 #pragma unroll
-        for (int o = 0; o < CO; ++o)
-            for (int s = 1; s < lanes_per_px; s <<= 1) acc[o] += __shfl_xor(acc[o], s, 64);
-        if (sub == 0 && p < HW) {
+        for (int k = 0; k < KSTEPS; ++k) fa[k] = *(const h8*)(xi + (int64_t)p * Ci + k * 16 + kg * 8);
+        f32x16 acc;
 #pragma unroll
-            for (int o = 0; o < CO; ++o) {
-                float v = acc[o] + (bias ? bias[o] : 0.f);
-                if (clamp >= 0.f) v = fminf(fmaxf(v, -clamp), clamp);
-                float* dst = y + ((int64_t)n * CO + o) * HW + p;
-                *dst = accumulate ? *dst + v : v;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < KSTEPS; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[k], bw[k], acc, 0, 0, 0);
+        if (col < Co) {
+            float* dst = y + ((int64_t)n * Co + col) * HW + p0 + 4 * kg;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                              // rows 8q + 4kg + {0..3}
+                const int pp = p0 + 8 * q + 4 * kg;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[q * 4 + e] + b;
+                    if (clamp >= 0.f) t = fminf(fmaxf(t, -clamp), clamp);
+                    v[e] = t;
+                }
+                if (pp + 3 < HW) {
+                    f32x4* d4 = (f32x4*)(dst + 8 * q);
+                    if (accumulate) { const f32x4 o = *d4; v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
+                    *d4 = v;
+                } else {
+                    for (int e = 0; e < 4; ++e) if (pp + e < HW) dst[8 * q + e] = accumulate ? dst[8 * q + e] + v[e] : v[e];
+                }
             }
         }
     }
@@ -335,15 +351,15 @@ extern "C" int p3d_torgb_nhwc_f16(const void* x, const float* weight, const floa
                                   int32_t n_img, int32_t hw, int32_t ci, int32_t co, float clamp, int32_t accumulate, p3d_stream_t stream)
 {
     P3D_REQUIRE(x && weight && styles && y_nchw, "torgb_nhwc_f16: null pointer");
-    if (!(ci == 64 || ci == 128 || ci == 256 || ci == 512) || co < 1 || co > 8 || co == 5 || co == 7)
-        return fail(P3D_ERR_UNSUPPORTED, "torgb_nhwc_f16: needs Ci in {64,128,256,512} and Co in {1,2,3,4,6,8} (got %d, %d)", ci, co);
+    if (!(ci == 64 || ci == 128 || ci == 256) || co < 1 || co > 32 || (hw & 3))
+        return fail(P3D_ERR_UNSUPPORTED, "torgb_nhwc_f16: needs Ci in {64,128,256}, Co <= 32, H*W a multiple of 4 (got %d, %d, %d)", ci, co, hw);
     hipStream_t s = (hipStream_t)stream;
-    int blocks = (hw / (64 / (ci / 8)) + 3) / 4;
-    if (blocks > kNumCU * 8 / n_img) blocks = kNumCU * 8 / n_img;
+    int blocks = (hw / 32 + 3) / 4;
+    const int cap = kNumCU * 8 / (n_img > 0 ? n_img : 1);
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    const size_t sh = (size_t)co * ci * sizeof(float);
-#define P3D_RGB(C) case C: hipLaunchKernelGGL(torgb_nhwc_kernel<C>, dim3(blocks, n_img), dim3(256), sh, s, (const __half*)x, weight, styles, bias, y_nchw, hw, ci, clamp, accumulate); break;
-    switch (co) { P3D_RGB(1) P3D_RGB(2) P3D_RGB(3) P3D_RGB(4) P3D_RGB(6) P3D_RGB(8) }
+#define P3D_RGB(K) case K * 16: hipLaunchKernelGGL(torgb_nhwc_kernel<K>, dim3(blocks, n_img), dim3(256), 0, s, (const __half*)x, weight, styles, bias, y_nchw, hw, co, clamp, accumulate); break;
+    switch (ci) { P3D_RGB(4) P3D_RGB(8) P3D_RGB(16) }
 #undef P3D_RGB
     count_launch(FAM_CONV);
     return check_launch("torgb_nhwc_f16");

@@ -71,7 +71,7 @@ def layer_supported(x, weight, styles, noise_mode, fused_modconv, up):
 def torgb_supported(x, weight, styles, fused_modconv):
     if not enabled or not fused_modconv or tuple(weight.shape[2:]) != (1, 1) or not _dense_dev(x) or not _no_grad_needed(x, weight, styles):
         return False
-    if _is_nhwc_f16(x) and x.shape[1] in (64, 128, 256, 512) and weight.shape[0] in (1, 2, 3, 4, 6, 8):
+    if _is_nhwc_f16(x) and x.shape[1] in (64, 128, 256) and weight.shape[0] <= 32 and (x.shape[2] * x.shape[3]) % 4 == 0:
         return True                                   # skinny streaming kernel
     if is_small(x):
         return True                                   # batched GEMM
@@ -193,12 +193,12 @@ def torgb(x, weight, styles, bias, clamp=None, out=None):
     tri-plane image of the backbone) go through the MFMA kernel as a 1x1 conv and stay channels-last."""
     n, ci, h, w = x.shape
     co = weight.shape[0]
-    if is_small(x) and not (_is_nhwc_f16(x) and ci in (64, 128, 256, 512) and co in (1, 2, 3, 4, 6, 8)):
+    if is_small(x) and not (_is_nhwc_f16(x) and ci in (64, 128, 256) and co <= 32 and (h * w) % 4 == 0):
         wm = modulate_weights(weight, styles, demodulate=False, dtype=x.dtype).reshape(n, co, ci)
         y = torch.bmm(wm, x.contiguous().reshape(n, ci, h * w)).reshape(n, co, h, w)
         y = bias_act.bias_act(y, None if bias is None else bias.to(y.dtype), clamp=clamp)
         return y if out is None else out.add_(y)
-    if not (x.dtype == torch.float16 and ci in (64, 128, 256, 512) and co in (1, 2, 3, 4, 6, 8)):
+    if not (x.dtype == torch.float16 and ci in (64, 128, 256) and co <= 32 and (h * w) % 4 == 0):
         wmod = modulate_weights(weight, styles, demodulate=False, dtype=x.dtype)
         y = conv2d(x, wmod, bias=bias, clamp=-1.0 if clamp is None else float(clamp))
         return y if out is None else out.add_(y)
