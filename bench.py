@@ -207,6 +207,13 @@ def main():
         samples_per_launch = args.batch * nrr * nrr * args.depth
         render_s = render_kernel_ms * 1e-3
         achieved = samples_per_launch * BYTES_PER_SAMPLE / render_s / 1e9 if render_s > 0 else 0.0
+        traffic = None                                              # memory-side bytes per launch from the committed PMC pass (same workload only)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'render_pmc.json')))
+            if args.batch == 4 and args.depth == 128 and nrr == 128:
+                traffic = pmc['traffic_bytes_per_launch']
+        except (OSError, KeyError, ValueError):
+            pass
         line = {
             'metric': 'rendered img/s (512^2, 128 depth)' if args.depth == 128 else f'rendered img/s (512^2, {args.depth} depth)',
             'value': round(imgs / elapsed, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -219,7 +226,7 @@ def main():
             'stage_ms': {k: round(v, 3) for k, v in stage_ms.items()},
             'conv_tflops': round(FLOP_PER_IMG * args.batch / ((stage_ms['backbone'] + stage_ms['sr']) * 1e-3) / 1e12, 2) if stage_ms['backbone'] + stage_ms['sr'] > 0 else None,
             'roofline': {'kernel': 'render_forward_kernel (fused tri-plane ray-marcher)', 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                          'ms_per_launch': round(render_kernel_ms, 4), 'launches_timed': len(kern), 'units_per_launch': samples_per_launch, 'bytes_per_unit': BYTES_PER_SAMPLE},
             'cpu_baseline': cpu,
         }
