@@ -21,6 +21,7 @@
 // image border), so a tile may straddle image rows.  blockIdx.x walks pixel tiles fastest with the image index in
 // blockIdx.z, so concurrently resident blocks share one image's weight panel (1.2 MB, L2-resident).
 #include "p3d_common.h"
+#include <stdlib.h>
 
 namespace p3d {
 
@@ -187,6 +188,139 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
     }
 }
 
+// ---- 3x3 "same" convolution with halo reuse ---------------------------------------------------------------------------
+// Same GEMM tiling as above, but the A operand of a block — an 8 x 16 pixel patch — is staged ONCE per 128-byte channel
+// chunk as a (8+2) x (16+2) pixel slab; the nine taps then read shifted windows of that slab straight from LDS.  Global /
+// L2 traffic per K step drops from 32 KB (A + B tile) to 16 KB of weights + 1/9 of a 23 KB slab, and every activation
+// byte is fetched from HBM once per output-channel block instead of nine times.
+constexpr int PH = 8, PW = 16;                      // pixel patch of a block (PH * PW == BM)
+constexpr int SLAB_W = PW + 2, SLAB_ROWS = (PH + 2) * (PW + 2);          // 18, 180 slab pixels
+constexpr int SLAB_SLOTS = ((SLAB_ROWS + 7) / 8) * 8 * 8;                // padded to whole 8-row DMA groups, 16-byte slots
+
+template <class T>
+__global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(ConvArgs a)
+{
+    constexpr int BK = ConvTraits<T>::BK;
+    constexpr int EPC = 16 / sizeof(T);
+    __shared__ __attribute__((aligned(16))) f32x4 slab[2][SLAB_SLOTS];       // [buffer][slab pixel * 8 + chunk]
+    __shared__ __attribute__((aligned(16))) f32x4 wt[2][BN * 8];             // [buffer][co row * 8 + chunk]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n = blockIdx.z;
+    const int tiles_x = (a.W + PW - 1) / PW;
+    int mt = blockIdx.x, cb = blockIdx.y;
+    {
+        const int nmt = gridDim.x, ncb = gridDim.y, L = blockIdx.x + blockIdx.y * nmt;
+        if ((nmt & 7) == 0) { const int q = L >> 3, r = L & 7; cb = q % ncb; mt = (q / ncb) * 8 + r; }
+    }
+    const int ty = mt / tiles_x, tx = mt - ty * tiles_x;
+    const int oy0 = ty * PH, ox0 = tx * PW, co0 = cb * BN;
+    const T* xin = (const T*)a.x + (int64_t)n * a.H * a.W * a.Ci;
+    const T* wgt = (const T*)a.w + (int64_t)n * a.w_img_stride;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+
+    const int pos = tid & 7, grow = tid >> 3;                               // DMA lane: slot position / row within the 32-row pass
+    const int kchunks = a.Ci / BK;
+    auto stage_slab = [&](int cc, int buf) {
+#pragma unroll
+        for (int p = 0; p < (SLAB_SLOTS / 8 + 31) / 32; ++p) {              // 6 passes of 32 slab rows
+            const int row = grow + 32 * p;
+            if (row >= SLAB_SLOTS / 8) break;                               // wave-uniform: rows of a wave are contiguous groups of 8
+            const int sr = row / SLAB_W, sc = row - sr * SLAB_W;
+            const int iy = oy0 - 1 + sr, ix = ox0 - 1 + sc;
+            const bool ok = (row < SLAB_ROWS) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
+            const int src_chunk = pos ^ ((row >> 1) & 7);
+            const T* src = ok ? xin + ((int64_t)iy * a.W + ix) * a.Ci + cc * BK + src_chunk * EPC : (const T*)a.zeros;
+            __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)&slab[buf][(row - (grow & 7)) * 8], 16, 0, 0);
+        }
+    };
+    auto stage_w = [&](int cc, int t, int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = grow + 32 * p, co = co0 + row;
+            const int src_chunk = pos ^ ((row >> 1) & 7);
+            const T* src = (co < a.Co) ? wgt + ((int64_t)co * 9 + t) * a.Ci + cc * BK + src_chunk * EPC : (const T*)a.zeros;
+            __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)&wt[buf][(wave * 8 + 32 * p) * 8], 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment rows of this lane: MFMA row r of tile i is patch pixel (py, px) = (wm*4 + i*2 + r/16, r%16)
+    const int frow = lane & 31, fk = lane >> 5;
+    int arow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) arow[i] = (wm * 4 + i * 2 + (frow >> 4) + 1) * SLAB_W + (frow & 15) + 1;    // slab pixel under tap (0,0)
+
+    stage_slab(0, 0);
+    stage_w(0, 0, 0);
+    __syncthreads();
+    const int ksteps = 9 * kchunks;
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int cc = ks / 9, t = ks - cc * 9;
+        const int wb = ks & 1, sb = cc & 1;
+        if (ks + 1 < ksteps) {
+            const int cc1 = (ks + 1) / 9, t1 = (ks + 1) - cc1 * 9;
+            stage_w(cc1, t1, wb ^ 1);
+            if (t == 0 && cc + 1 < kchunks) stage_slab(cc + 1, sb ^ 1);     // next chunk's slab streams in under this chunk's nine taps
+        }
+        const int toff = (t / 3 - 1) * SLAB_W + (t % 3 - 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int sr = arow[i] + toff;
+                fa[i] = slab[sb][sr * 8 + ((kk * 2 + fk) ^ ((sr >> 1) & 7))];
+                fb[i] = wt[wb][swz(wn * 64 + i * 32 + frow, kk * 2 + fk)];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (sizeof(T) == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, fa[i]), __builtin_bit_cast(h8, fb[j]), acc[i][j], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+        __syncthreads();
+    }
+
+    const float ns = a.noise ? a.noise_strength[0] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = co0 + wn * 64 + j * 32 + frow;
+        if (co >= a.Co) continue;
+        const float b = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mrow = (r & 3) + 8 * (r >> 2) + 4 * fk;             // accumulator row within the 32-row tile
+                const int oy = oy0 + wm * 4 + i * 2 + (mrow >> 4), ox = ox0 + (mrow & 15);
+                if (oy >= a.H || ox >= a.W) continue;
+                float v = acc[i][j][r];
+                if (a.noise) v = fmaf(a.noise[(int64_t)oy * a.W + ox], ns, v);
+                v += b;
+                if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
+                v *= a.gain;
+                if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
+                st((T*)a.y + (((int64_t)n * a.H + oy) * a.W + ox) * a.Co + co, v);
+            }
+    }
+}
+
 // ---- per-sample weight modulation + demodulation -> fp16, tap-major -------------------------------------------------
 // one block per (co, n): wm[i, t] = w[co, i, t] * s[n, i]; d = rsqrt(sum wm^2 + 1e-8) (if demodulate); out[n][co][t][i]
 template <class T>
@@ -328,6 +462,14 @@ extern "C" int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype,
         a.OH = h; a.OW = wdt; a.osy = a.osx = 1; a.ncls = 1;
         a.cls[0].SH = h; a.cls[0].SW = wdt; a.cls[0].ooy = a.cls[0].oox = 0; a.cls[0].ntaps = a.KT;
         for (int t = 0; t < a.KT; ++t) a.cls[0].taps[t] = ConvTap{t / kernel_size - kernel_size / 2, t % kernel_size - kernel_size / 2, t};
+        static const bool no_halo = getenv("P3D_CONV_NO_HALO") != nullptr;
+        if (kernel_size == 3 && h >= PH && wdt >= PW && !no_halo) {       // halo-reuse kernel for the plain 3x3 layers
+            dim3 grid(((h + PH - 1) / PH) * ((wdt + PW - 1) / PW), (co + BN - 1) / BN, n_img);
+            if (dtype == P3D_F16) hipLaunchKernelGGL(conv3x3_halo_kernel<__half>, grid, dim3(256), 0, s, a);
+            else                  hipLaunchKernelGGL(conv3x3_halo_kernel<float>, grid, dim3(256), 0, s, a);
+            count_launch(FAM_CONV);
+            return check_launch("conv3x3_halo");
+        }
         return launch_conv(a, dtype, s);
     }
     // conv_transpose2d(stride 2, no padding): out[(2i+py), (2j+px)] = sum_{ky = py (mod 2), kx = px (mod 2)} x[i - (ky-py)/2, j - (kx-px)/2] w[ky, kx]
