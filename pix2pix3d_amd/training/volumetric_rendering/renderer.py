@@ -19,6 +19,7 @@ from . import math_utils
 from .ray_marcher import MipRayMarcher2
 
 fused_policy = 'auto'          # 'auto' | 'require' | 'never'
+fused_training = True          # graphs that need gradients: fused forward + recompute-in-backward (see _FusedRenderFn)
 
 
 class _RenderDesc(ctypes.Structure):          # p3d_render_desc (include/p3d_hip.h)
@@ -148,8 +149,8 @@ class ImportanceRenderer(torch.nn.Module):
             return 'fused_policy == never'
         if planes.device.type != 'cuda':
             return 'CPU tensors'
-        if needs_grad:
-            return 'autograd graph requested (fused backward not available yet)'
+        if needs_grad and not fused_training:
+            return 'autograd graph requested and fused_training is off'
         if planes.ndim != 5 or planes.shape[1] != 3 or planes.shape[2] != 32:
             return f'planes shape {tuple(planes.shape)} is not [N,3,32,H,W]'
         if options.get('density_noise', 0) > 0:
@@ -168,7 +169,7 @@ class ImportanceRenderer(torch.nn.Module):
                                                   or any(p.requires_grad for p in decoder.parameters()))
         reason = self._fused_reason(planes, decoder, rendering_options, needs_grad)
         if reason is None:
-            out = self._forward_fused(planes, decoder, ray_origins, ray_directions, rendering_options)
+            out = self._forward_fused(planes, decoder, ray_origins, ray_directions, rendering_options, needs_grad)
             if out is not None:
                 return out
             reason = 'sample counts outside the fused kernel envelope (<= 64 coarse, 1..64 fine)'
@@ -185,7 +186,7 @@ class ImportanceRenderer(torch.nn.Module):
             t1[~ok] = t0[ok].max()
         return t0, t1
 
-    def _forward_fused(self, planes, decoder, ray_origins, ray_directions, opt):
+    def _forward_fused(self, planes, decoder, ray_origins, ray_directions, opt, needs_grad=False):
         n, m, _ = ray_origins.shape
         sc, sf = int(opt['depth_resolution']), int(opt['depth_resolution_importance'])
         if not (4 <= sc <= 64 and 1 <= sf <= 64):
@@ -200,6 +201,9 @@ class ImportanceRenderer(torch.nn.Module):
         else:   # tensor-limits branch: rand_like of the permuted [S,N,M,1] linspace fills in ITS memory order (:184-186)
             u_c = torch.rand([sc, n, m, 1], device=dev, dtype=torch.float32).permute(1, 2, 0, 3)
         u_f = torch.rand([n * m, sf], device=dev, dtype=torch.float32)
+        if needs_grad:
+            params = [p for p in decoder.parameters()]
+            return _FusedRenderFn.apply(self, decoder, opt, u_c, u_f, t0, t1, planes, ray_origins, ray_directions, *params)
         return fused_render(planes, decoder, ray_origins, ray_directions, opt, u_c, u_f, t0, t1)
 
     # ------------------------------------------------------------------------------------------------
@@ -323,6 +327,56 @@ def importance_sample_native(z_coarse, w_coarse, u_fine, sort=False):
     code = _lib.lib().p3d_importance_sample(_lib.ptr(z), _lib.ptr(w), _lib.ptr(u), _lib.ptr(out), z.shape[0], z.shape[1], u.shape[1], int(sort), _lib.stream_of(z))
     _lib.check(code, 'importance_sample')
     return out
+
+
+class _replay_draws:
+    """Make torch.rand_like / torch.rand hand back given tensors, in order (the renderer's two uniform draws)."""
+
+    def __init__(self, *draws):
+        self.draws = list(draws)
+
+    def __enter__(self):
+        self._rl, self._r = torch.rand_like, torch.rand
+        it = iter(self.draws)
+        torch.rand_like = lambda t, *a, **k: next(it).to(t.device).reshape(t.shape)
+        torch.rand = lambda *a, **k: next(it)
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand_like, torch.rand = self._rl, self._r
+
+
+class _FusedRenderFn(torch.autograd.Function):
+    """Training-mode rendering: the FORWARD is the fused kernel (nothing per-sample is kept — the reference holds
+    ~1.2 GB of sampled features per image for autograd); the BACKWARD re-runs the differentiable tensor-op renderer on
+    the same planes / decoder / rays / uniforms under autograd and back-propagates the incoming gradients through it
+    (recompute-in-backward).  Gradients are therefore exactly those of the tensor-op path; a fused backward kernel
+    (atomics into the plane gradients) is the planned replacement."""
+
+    @staticmethod
+    def forward(ctx, renderer, decoder, opt, u_c, u_f, t0, t1, planes, ray_o, ray_d, *params):
+        out = fused_render(planes, decoder, ray_o, ray_d, opt, u_c, u_f, t0, t1)
+        if out is None:
+            raise RuntimeError('fused training render: sample counts outside the kernel envelope')
+        ctx.renderer, ctx.decoder, ctx.opt = renderer, decoder, opt
+        ctx.save_for_backward(u_c, u_f, planes, ray_o, ray_d)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_feat, g_depth, g_wsum):
+        u_c, u_f, planes, ray_o, ray_d = ctx.saved_tensors
+        params = [p for p in ctx.decoder.parameters()]
+        with torch.enable_grad():
+            pl = planes.detach().requires_grad_(ctx.needs_input_grad[7])
+            ro = ray_o.detach().requires_grad_(ctx.needs_input_grad[8])
+            rd = ray_d.detach().requires_grad_(ctx.needs_input_grad[9])
+            with _replay_draws(u_c, u_f):
+                feat, depth, wsum = ctx.renderer._forward_tensor_ops(pl, ctx.decoder, ro, rd, ctx.opt)
+            wanted = [t for t in [pl, ro, rd] + params if t.requires_grad]
+            grads = torch.autograd.grad([feat, depth, wsum], wanted, [g_feat, g_depth, g_wsum], allow_unused=True)
+        it = iter(grads)
+        res = [next(it) if t.requires_grad else None for t in [pl, ro, rd] + params]
+        return (None,) * 7 + tuple(res)
 
 
 def fused_render(planes, decoder, ray_origins, ray_directions, opt, u_coarse, u_fine, t_start=None, t_end=None, debug=False):

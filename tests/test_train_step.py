@@ -54,7 +54,17 @@ def test_training_gradients_match_reference_on_cpu():
 def test_training_gradients_match_reference_on_gpu(hip_lib):
     """Same step on the device: bias_act / upfirdn2d gradient kernels are HIP, convolutions' gradients ATen."""
     from pix2pix3d_amd import _lib
-    n0 = (_lib.launch_count('bias_act'), _lib.launch_count('upfirdn2d'))
+    from pix2pix3d_amd.training.volumetric_rendering import renderer as rmod
+    n0 = (_lib.launch_count('bias_act'), _lib.launch_count('upfirdn2d'), _lib.launch_count('render'))
+    assert rmod.fused_training
     g, G, loss = _run('cuda')
     assert _lib.launch_count('bias_act') > n0[0] and _lib.launch_count('upfirdn2d') > n0[1]
+    assert _lib.launch_count('render') == n0[2] + 1, 'training forward did not go through the fused ray-marcher'
     _check(g, G, loss, 2e-3)
+    # and the all-tensor-op route gives the same gradients
+    rmod.fused_training = False
+    try:
+        g2, G2, loss2 = _run('cuda')
+    finally:
+        rmod.fused_training = True
+    _check(g2, G2, loss2, 2e-3)
