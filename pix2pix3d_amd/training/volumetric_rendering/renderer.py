@@ -143,14 +143,14 @@ class ImportanceRenderer(torch.nn.Module):
         self.plane_axes = generate_planes()
 
     # ------------------------------------------------------------------------------------------------
-    def _fused_reason(self, planes, decoder, options, needs_grad):
+    def _fused_reason(self, planes, decoder, options, needs_grad, trainable=True):
         """None when the fused kernel applies, else why not."""
         if fused_policy == 'never':
             return 'fused_policy == never'
         if planes.device.type != 'cuda':
             return 'CPU tensors'
-        if needs_grad and not fused_training:
-            return 'autograd graph requested and fused_training is off'
+        if needs_grad and not (fused_training and trainable):
+            return 'autograd graph requested (no fused backward for this entry point / fused_training is off)'
         if planes.ndim != 5 or planes.shape[1] != 3 or planes.shape[2] != 32:
             return f'planes shape {tuple(planes.shape)} is not [N,3,32,H,W]'
         if options.get('density_noise', 0) > 0:
@@ -239,7 +239,7 @@ class ImportanceRenderer(torch.nn.Module):
         self.plane_axes = self.plane_axes.to(sample_coordinates.device)
         needs_grad = torch.is_grad_enabled() and (planes.requires_grad or sample_coordinates.requires_grad
                                                   or any(p.requires_grad for p in decoder.parameters()))
-        reason = self._fused_reason(planes, decoder, options, needs_grad)
+        reason = self._fused_reason(planes, decoder, options, needs_grad, trainable=False)
         if reason is None:
             n, p, _ = sample_coordinates.shape
             ctx = _FusedContext(planes, _decoder_nets(decoder))
