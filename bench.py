@@ -191,12 +191,16 @@ def main():
     handles += hook(G.backbone.synthesis, 'backbone') + hook(G.renderer, 'render')
     handles += hook(G.superresolution, 'sr') + hook(G.superresolution_semantic, 'sr')
     n_prof = min(args.steps, 10)
-    _lib.kernel_events['render_forward'] = []
+    for k in ('render_forward', 'conv_f16', 'conv_f32', 'conv_flops'):
+        _lib.kernel_events[k] = []
     for _ in range(n_prof):
         step()
     torch.cuda.synchronize()
     kern = _lib.kernel_events.pop('render_forward')
     render_kernel_ms = sum(a.elapsed_time(b) for a, b in kern) / max(len(kern), 1)
+    conv_ms = {k: sum(a.elapsed_time(b) for a, b in _lib.kernel_events.pop(k)) / n_prof for k in ('conv_f16', 'conv_f32')}
+    flops = _lib.kernel_events.pop('conv_flops')
+    conv_fl = {'conv_f16': sum(f for d, f in flops if 'float16' in d) / n_prof, 'conv_f32': sum(f for d, f in flops if 'float32' in d) / n_prof}
     for h in handles:
         h.remove()
     stage_ms = {k: (sum(a.elapsed_time(b) for a, b in v) / n_prof if v else 0.0) for k, v in stage_events.items()}
@@ -228,6 +232,9 @@ def main():
             'roofline': {'kernel': 'render_forward_kernel (fused tri-plane ray-marcher)', 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                          'ms_per_launch': round(render_kernel_ms, 4), 'launches_timed': len(kern), 'units_per_launch': samples_per_launch, 'bytes_per_unit': BYTES_PER_SAMPLE},
+            'mfma_conv': {k: {'ms_per_step': round(conv_ms[k], 3), 'tflops': round(conv_fl[k] / (conv_ms[k] * 1e-3) / 1e12, 1) if conv_ms[k] > 0 else None,
+                              'frac_of_peak': round(conv_fl[k] / (conv_ms[k] * 1e-3) / 1e12 / (2500.0 if k == 'conv_f16' else 157.3), 3) if conv_ms[k] > 0 else None}
+                          for k in ('conv_f16', 'conv_f32')},
             'cpu_baseline': cpu,
         }
         print(json.dumps(line), flush=True)

@@ -159,7 +159,8 @@ int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype, const floa
                     int32_t kernel_size, int32_t transposed_stride2, int32_t act, float gain, float clamp, p3d_stream_t stream);
 
 /* x [N][HW][Ci] fp16 channels-last, weight [Co][Ci] fp32, styles [N][Ci] fp32 (weight gain already applied),
- * bias [Co] or null -> y [N][Co][HW] fp32 (NCHW); accumulate != 0 adds into y (the skip-image sum).   */
+ * bias [Co] or null -> y [N][Co][HW] fp32 (NCHW); accumulate != 0 adds into y (the skip-image sum).
+ * Ci in {64, 128, 256}, Co <= 32, HW a multiple of 4, else P3D_ERR_UNSUPPORTED (wide outputs: p3d_conv2d_nhwc, k = 1). */
 int p3d_torgb_nhwc_f16(const void* x, const float* weight, const float* styles, const float* bias, float* y_nchw,
                        int32_t n_img, int32_t hw, int32_t ci, int32_t co, float clamp, int32_t accumulate, p3d_stream_t stream);
 

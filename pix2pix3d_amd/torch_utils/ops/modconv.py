@@ -119,10 +119,14 @@ def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None
     b32 = None if bias is None else bias.detach().float().contiguous()
     nz = None if noise is None else noise.detach().float().contiguous()
     ns = None if noise is None else noise_strength.detach().float().reshape(1).contiguous()
-    code = _lib.lib().p3d_conv2d_nhwc(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), _lib.DTYPE_CODE[x.dtype], _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns),
-                                      _lib.ptr(_zeros_page(x.device)), n, h, w, ci, co, stride, k, int(transposed), int(act), float(gain), float(clamp),
-                                      _lib.stream_of(x))
+    with _lib.kernel_timer('conv_f16' if x.dtype == torch.float16 else 'conv_f32', x):
+        code = _lib.lib().p3d_conv2d_nhwc(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), _lib.DTYPE_CODE[x.dtype], _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns),
+                                          _lib.ptr(_zeros_page(x.device)), n, h, w, ci, co, stride, k, int(transposed), int(act), float(gain), float(clamp),
+                                          _lib.stream_of(x))
     _lib.check(code, 'conv2d_nhwc')
+    log = _lib.kernel_events.get('conv_flops')
+    if log is not None:                                  # bench.py: FLOPs of the launches it is timing (2*Ci*Co*k*k per output / input pixel)
+        log.append((str(x.dtype), 2.0 * n * ci * co * k * k * h * w))
     return y
 
 
