@@ -321,6 +321,144 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(ConvArgs a)
     }
 }
 
+// ---- 3x3 conv, 256-pixel tile, three-stage weight pipeline (fp16) ---------------------------------------------------------
+// The two-stage kernels above wait for the whole prefetch at every barrier, so a K step costs one L2 round trip however
+// little compute it holds.  This variant (what the big fp16 super-resolution layers run) keeps the halo slab idea but
+//   * doubles the pixel tile to 16 x 16 (512 threads, 8 waves as 4 x 2; weight traffic per FLOP halves),
+//   * rings the weight tiles through THREE LDS buffers: at step k the tile of step k+2 is issued, and the barrier at the
+//     end of step k only waits for the tile of step k+1 — a counted `s_waitcnt vmcnt(n)` with n = the LDS-DMA instructions
+//     this wave issued during step k (they are the youngest), followed by a bare `s_barrier` (a `__syncthreads()` would
+//     drain the queue to zero),
+//   * keeps two slab buffers; the next channel chunk's slab is issued at tap 0 and is forced to land by the next counted
+//     wait, eight steps before its first use.
+// LDS: 2 x 41.5 KB slabs + 3 x 16 KB weights = 131 KB -> one block (2 waves per SIMD) per CU.
+constexpr int QH = 16, QW = 16;                     // pixel patch (QH * QW = 256)
+constexpr int QSLAB_W = QW + 2, QSLAB_ROWS = (QH + 2) * (QW + 2);        // 18, 324
+constexpr int QSLAB_GROUPS = (QSLAB_ROWS + 7) / 8;                       // 41 DMA groups of 8 slab pixels
+constexpr int QSLAB_SLOTS = QSLAB_GROUPS * 64;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+__global__ void __launch_bounds__(512, 2) conv3x3_q256_f16_kernel(ConvArgs a)
+{
+    // ONE __shared__ object on purpose: with two, hipcc drains vmcnt to 0 before the first ds_read of every step and the
+    // counted waits below are moot (cdna_hip_programming.md, 'three .s-level traps' (a))
+    __shared__ __attribute__((aligned(16))) f32x4 lds[2 * QSLAB_SLOTS + 3 * BN * 8];
+    f32x4* const slab0 = lds;
+    f32x4* const wt0 = lds + 2 * QSLAB_SLOTS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                                   // 4 x 2 waves, 64 x 64 outputs each
+    const int n = blockIdx.z;
+    const int tiles_x = (a.W + QW - 1) / QW;
+    int mt = blockIdx.x, cb = blockIdx.y;
+    {
+        const int nmt = gridDim.x, ncb = gridDim.y, L = blockIdx.x + blockIdx.y * nmt;
+        if ((nmt & 7) == 0) { const int q = L >> 3, r = L & 7; cb = q % ncb; mt = (q / ncb) * 8 + r; }
+    }
+    const int ty = mt / tiles_x, tx = mt - ty * tiles_x;
+    const int oy0 = ty * QH, ox0 = tx * QW, co0 = cb * BN;
+    const __half* xin = (const __half*)a.x + (int64_t)n * a.H * a.W * a.Ci;
+    const __half* wgt = (const __half*)a.w + (int64_t)n * a.w_img_stride;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const int pos = lane & 7, lrow = lane >> 3;                                // DMA lane within its 8-row group
+    const int kchunks = a.Ci / 64;
+
+    // slab groups are dealt round-robin to the 8 waves: wave w stages groups w, w+8, ...  (6 for w = 0, else 5)
+    auto stage_slab = [&](int cc, int buf) {
+        for (int gidx = wave; gidx < QSLAB_GROUPS; gidx += 8) {
+            const int row = gidx * 8 + lrow;
+            const int sr = row / QSLAB_W, sc = row - sr * QSLAB_W;
+            const int iy = oy0 - 1 + sr, ix = ox0 - 1 + sc;
+            const bool ok = (row < QSLAB_ROWS) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
+            const int src_chunk = pos ^ ((row >> 1) & 7);
+            const __half* src = ok ? xin + ((int64_t)iy * a.W + ix) * a.Ci + cc * 64 + src_chunk * 8 : (const __half*)a.zeros;
+            __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(slab0 + buf * QSLAB_SLOTS + gidx * 64), 16, 0, 0);
+        }
+    };
+    auto stage_w = [&](int cc, int t, int buf) {                               // 128 rows: 16 groups, 2 per wave
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int gidx = wave * 2 + p, row = gidx * 8 + lrow, co = co0 + row;
+            const int src_chunk = pos ^ ((row >> 1) & 7);
+            const __half* src = (co < a.Co) ? wgt + ((int64_t)co * 9 + t) * a.Ci + cc * 64 + src_chunk * 8 : (const __half*)a.zeros;
+            __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(wt0 + buf * (BN * 8) + gidx * 64), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int frow = lane & 31, fk = lane >> 5;
+    int arow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) arow[i] = (wm * 4 + i * 2 + (frow >> 4) + 1) * QSLAB_W + (frow & 15) + 1;
+
+    const int ksteps = 9 * kchunks;
+    stage_slab(0, 0);
+    stage_w(0, 0, 0);
+    if (ksteps > 1) stage_w(0, 1, 1);
+    wait_vmcnt<2>();                                                            // everything but the youngest weight tile
+    __builtin_amdgcn_s_barrier();
+    const bool six = (wave == 0);                                               // wave 0 stages 6 slab groups, the others 5
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int cc = ks / 9, t = ks - cc * 9;
+        const int wb = ks % 3, sb = cc & 1;
+        const bool slab_now = (t == 0) && (cc + 1 < kchunks);
+        if (slab_now) stage_slab(cc + 1, sb ^ 1);
+        const bool w_now = ks + 2 < ksteps;
+        if (w_now) { const int cc2 = (ks + 2) / 9, t2 = (ks + 2) - cc2 * 9; stage_w(cc2, t2, (ks + 2) % 3); }
+        const int toff = (t / 3 - 1) * QSLAB_W + (t % 3 - 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int sr = arow[i] + toff;
+                fa[i] = slab0[sb * QSLAB_SLOTS + sr * 8 + ((kk * 2 + fk) ^ ((sr >> 1) & 7))];
+                fb[i] = wt0[wb * (BN * 8) + swz(wn * 64 + i * 32 + frow, kk * 2 + fk)];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, fa[i]), __builtin_bit_cast(h8, fb[j]), acc[i][j], 0, 0, 0);
+        }
+        // the tile of step ks+1 was issued one step ago: everything older than this step's own issues must have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (slab_now) { if (six) { if (w_now) wait_vmcnt<8>(); else wait_vmcnt<6>(); } else { if (w_now) wait_vmcnt<7>(); else wait_vmcnt<5>(); } }
+        else          { if (w_now) wait_vmcnt<2>(); else wait_vmcnt<0>(); }
+        __builtin_amdgcn_s_barrier();
+    }
+
+    const float ns = a.noise ? a.noise_strength[0] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = co0 + wn * 64 + j * 32 + frow;
+        if (co >= a.Co) continue;
+        const float b = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mrow = (r & 3) + 8 * (r >> 2) + 4 * fk;
+                const int oy = oy0 + wm * 4 + i * 2 + (mrow >> 4), ox = ox0 + (mrow & 15);
+                if (oy >= a.H || ox >= a.W) continue;
+                float v = acc[i][j][r];
+                if (a.noise) v = fmaf(a.noise[(int64_t)oy * a.W + ox], ns, v);
+                v += b;
+                if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
+                v *= a.gain;
+                if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
+                ((__half*)a.y)[(((int64_t)n * a.H + oy) * a.W + ox) * a.Co + co] = __float2half(v);
+            }
+    }
+}
+
 // ---- per-sample weight modulation + demodulation -> fp16, tap-major -------------------------------------------------
 // one block per (co, n): wm[i, t] = w[co, i, t] * s[n, i]; d = rsqrt(sum wm^2 + 1e-8) (if demodulate); out[n][co][t][i]
 template <class T>
@@ -463,6 +601,15 @@ extern "C" int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype,
         a.cls[0].SH = h; a.cls[0].SW = wdt; a.cls[0].ooy = a.cls[0].oox = 0; a.cls[0].ntaps = a.KT;
         for (int t = 0; t < a.KT; ++t) a.cls[0].taps[t] = ConvTap{t / kernel_size - kernel_size / 2, t % kernel_size - kernel_size / 2, t};
         static const bool no_halo = getenv("P3D_CONV_NO_HALO") != nullptr;
+        static const bool no_q256 = getenv("P3D_CONV_NO_Q256") != nullptr;
+        if (kernel_size == 3 && dtype == P3D_F16 && h >= 64 && wdt >= 64 && !no_halo && !no_q256) {     // big fp16 layers: 256-pixel tiles, 3-stage weights
+            static hipError_t attr = hipFuncSetAttribute((const void*)conv3x3_q256_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 0);
+            (void)attr;
+            dim3 grid(((h + QH - 1) / QH) * ((wdt + QW - 1) / QW), (co + BN - 1) / BN, n_img);
+            hipLaunchKernelGGL(conv3x3_q256_f16_kernel, grid, dim3(512), 0, s, a);
+            count_launch(FAM_CONV);
+            return check_launch("conv3x3_q256_f16");
+        }
         if (kernel_size == 3 && h >= PH && wdt >= PW && !no_halo) {       // halo-reuse kernel for the plain 3x3 layers
             dim3 grid(((h + PH - 1) / PH) * ((wdt + PW - 1) / PW), (co + BN - 1) / BN, n_img);
             if (dtype == P3D_F16) hipLaunchKernelGGL(conv3x3_halo_kernel<__half>, grid, dim3(256), 0, s, a);
