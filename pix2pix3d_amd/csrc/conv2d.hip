@@ -362,28 +362,46 @@ __global__ void __launch_bounds__(512, 2) conv3x3_q256_f16_kernel(ConvArgs a)
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
     const int pos = lane & 7, lrow = lane >> 3;                                // DMA lane within its 8-row group
-    const int kchunks = a.Ci / 64;
+    const int kpairs = a.Ci / 128;                                             // the loop body covers TWO 64-channel chunks (18 taps)
+    char* const lds_b = (char*)lds;
+    constexpr int SLAB_BYTES = QSLAB_SLOTS * 16, WT_BYTES = BN * 8 * 16, WT_BASE = 2 * SLAB_BYTES;
 
-    // slab groups are dealt round-robin to the 8 waves: wave w stages groups w, w+8, ...  (6 for w = 0, else 5)
+    // ---- everything lane-dependent is computed ONCE; a K step then costs a handful of scalar adds (the first version spent
+    //      ~110 VALU + ~90 SALU instructions per 16 MFMAs on addresses and was issue-bound, not MFMA-bound)
+    // weight DMA: piece p of this wave fills tile rows (wave*2+p)*8 .. +7; byte offset of the lane's 16 bytes inside tap 0 / chunk 0
+    unsigned woff[2];
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) {
+        const int row = (wave * 2 + p2) * 8 + lrow;
+        woff[p2] = (unsigned)(((co0 + row) * 9 * a.Ci + (pos ^ ((row >> 1) & 7)) * 8) * 2);
+    }
+    const char* const wgt_b = (const char*)wgt;
+    // slab DMA: groups wave, wave+8, ... (6 for wave 0, else 5); out-of-image pixels read the zero line
+    unsigned soff[6]; bool sok[6];
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+        const int row = (wave + 8 * g) * 8 + lrow;
+        const int sr = row / QSLAB_W, sc = row - sr * QSLAB_W;
+        const int iy = oy0 - 1 + sr, ix = ox0 - 1 + sc;
+        sok[g] = (row < QSLAB_ROWS) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
+        soff[g] = (unsigned)(((iy * a.W + ix) * a.Ci + (pos ^ ((sc >> 1) & 7)) * 8) * 2);     // keyed on the slab COLUMN (see below)
+    }
+    const char* const xin_b = (const char*)xin;
+    const int nslab = (wave == 0) ? 6 : 5;
     auto stage_slab = [&](int cc, int buf) {
-        for (int gidx = wave; gidx < QSLAB_GROUPS; gidx += 8) {
-            const int row = gidx * 8 + lrow;
-            const int sr = row / QSLAB_W, sc = row - sr * QSLAB_W;
-            const int iy = oy0 - 1 + sr, ix = ox0 - 1 + sc;
-            const bool ok = (row < QSLAB_ROWS) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
-            const int src_chunk = pos ^ ((row >> 1) & 7);
-            const __half* src = ok ? xin + ((int64_t)iy * a.W + ix) * a.Ci + cc * 64 + src_chunk * 8 : (const __half*)a.zeros;
-            __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(slab0 + buf * QSLAB_SLOTS + gidx * 64), 16, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            if (g < nslab) {
+                const char* src = sok[g] ? xin_b + soff[g] + cc * 128 : (const char*)a.zeros;
+                __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(lds_b + buf * SLAB_BYTES + (wave + 8 * g) * 1024), 16, 0, 0);
+            }
         }
     };
-    auto stage_w = [&](int cc, int t, int buf) {                               // 128 rows: 16 groups, 2 per wave
+    auto stage_w = [&](int cc, int t, int slot) {
+        const char* base = wgt_b + (t * a.Ci + cc * 64) * 2;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int gidx = wave * 2 + p, row = gidx * 8 + lrow, co = co0 + row;
-            const int src_chunk = pos ^ ((row >> 1) & 7);
-            const __half* src = (co < a.Co) ? wgt + ((int64_t)co * 9 + t) * a.Ci + cc * 64 + src_chunk * 8 : (const __half*)a.zeros;
-            __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(wt0 + buf * (BN * 8) + gidx * 64), 16, 0, 0);
-        }
+        for (int p2 = 0; p2 < 2; ++p2)
+            __builtin_amdgcn_global_load_lds((glb_ptr)(base + woff[p2]), (lds_ptr)(lds_b + WT_BASE + slot * WT_BYTES + (wave * 2 + p2) * 1024), 16, 0, 0);
     };
 
     f32x16 acc[2][2];
@@ -394,68 +412,116 @@ __global__ void __launch_bounds__(512, 2) conv3x3_q256_f16_kernel(ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int frow = lane & 31, fk = lane >> 5;
-    int arow[2];
+    // fragment addresses (LDS byte offsets).  A: pixel (wm*4 + 2i + frow/16, frow%16) of the patch, tap (ty, tx) -> slab row
+    // arowm + i*36 + ty*18 + tx; its 16-byte chunk c sits at slot position c ^ key with key from the slab COLUMN, so the 16
+    // lanes one ds_read_b128 cycle serves (8 pixels of a patch row + 8 of the next) hit 16 distinct bank quads although the
+    // slab pitch is 18.  Only tx changes the key: 3 x 4 lane constants; i, ty and the slab buffer are immediates.
+    const int acol = frow & 15;
+    const int arowm = (wm * 4 + (frow >> 4)) * QSLAB_W + acol;
+    int preA[3][4], preB[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) arow[i] = (wm * 4 + i * 2 + (frow >> 4) + 1) * QSLAB_W + (frow & 15) + 1;
+    for (int tx2 = 0; tx2 < 3; ++tx2)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            preA[tx2][kk] = (arowm + tx2) * 128 + (((kk * 2 + fk) ^ (((acol + tx2) >> 1) & 7)) << 4);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) preB[kk] = WT_BASE + swz(wn * 64 + frow, kk * 2 + fk) * 16;
 
-    const int ksteps = 9 * kchunks;
+    f32x4 fa[2][2], fb[2][2];
+    auto load_frags = [&](int buf, int t, int kk, f32x4* pa, f32x4* pb) {      // buf, t, kk are compile-time after unrolling
+        const int ty2 = t / 3, tx2 = t - ty2 * 3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            pa[i] = *(const f32x4*)(lds_b + preA[tx2][kk] + (buf * SLAB_BYTES + (i * 2 * QSLAB_W + ty2 * QSLAB_W) * 128));
+            pb[i] = *(const f32x4*)(lds_b + preB[kk] + ((t % 3) * WT_BYTES + i * 32 * 128));
+        }
+    };
+
+    // Software pipeline.  Fragments are double-buffered in registers (the reads of sub-step kk+1 fly under the MFMAs of kk).
+    // The block-wide rendezvous sits in the MIDDLE of a step (before kk = 2), where every wave still holds prefetched
+    // fragments: there tile ks+1 (issued at the same point one step earlier) must have landed, and everyone has finished
+    // reading tile ks-1, whose ring slot takes the DMA of tile ks+2.  Nine taps and three slots: the slot index is t % 3, a
+    // compile-time constant of the unrolled body.  The slab of the next channel chunk rides along at tap 0.
     stage_slab(0, 0);
     stage_w(0, 0, 0);
-    if (ksteps > 1) stage_w(0, 1, 1);
-    wait_vmcnt<2>();                                                            // everything but the youngest weight tile
+    stage_w(0, 1, 1);
+    wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    const bool six = (wave == 0);                                               // wave 0 stages 6 slab groups, the others 5
-    for (int ks = 0; ks < ksteps; ++ks) {
-        const int cc = ks / 9, t = ks - cc * 9;
-        const int wb = ks % 3, sb = cc & 1;
-        const bool slab_now = (t == 0) && (cc + 1 < kchunks);
-        if (slab_now) stage_slab(cc + 1, sb ^ 1);
-        const bool w_now = ks + 2 < ksteps;
-        if (w_now) { const int cc2 = (ks + 2) / 9, t2 = (ks + 2) - cc2 * 9; stage_w(cc2, t2, (ks + 2) % 3); }
-        const int toff = (t / 3 - 1) * QSLAB_W + (t % 3 - 1);
+    load_frags(0, 0, 0, fa[0], fb[0]);
+    for (int cp = 0; cp < kpairs; ++cp) {
+        const bool more = cp + 1 < kpairs;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            f32x4 fa[2], fb[2];
+        for (int h = 0; h < 2; ++h) {
+            const int cc = cp * 2 + h;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int sr = arow[i] + toff;
-                fa[i] = slab0[sb * QSLAB_SLOTS + sr * 8 + ((kk * 2 + fk) ^ ((sr >> 1) & 7))];
-                fb[i] = wt0[wb * (BN * 8) + swz(wn * 64 + i * 32 + frow, kk * 2 + fk)];
+            for (int t = 0; t < 9; ++t) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int cur = kk & 1, nxt = cur ^ 1;
+                    if (kk == 2) {
+                        wait_vmcnt<0>();
+                        __builtin_amdgcn_s_barrier();
+                        if (t < 7) stage_w(cc, t + 2, (t + 2) % 3);
+                        else if (h == 0 || more) stage_w(cc + 1, t - 7, (t + 2) % 3);
+                        if (t == 0 && (h == 0 || more)) stage_slab(cc + 1, h ^ 1);
+                    }
+                    if (kk < 3) load_frags(h, t, kk + 1, fa[nxt], fb[nxt]);
+                    else if (t < 8) load_frags(h, t + 1, 0, fa[nxt], fb[nxt]);
+                    else if (h == 0 || more) load_frags(h ^ 1, 0, 0, fa[nxt], fb[nxt]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, fa[cur][i]), __builtin_bit_cast(h8, fb[cur][j]), acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, fa[i]), __builtin_bit_cast(h8, fb[j]), acc[i][j], 0, 0, 0);
         }
-        // the tile of step ks+1 was issued one step ago: everything older than this step's own issues must have landed
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (slab_now) { if (six) { if (w_now) wait_vmcnt<8>(); else wait_vmcnt<6>(); } else { if (w_now) wait_vmcnt<7>(); else wait_vmcnt<5>(); } }
-        else          { if (w_now) wait_vmcnt<2>(); else wait_vmcnt<0>(); }
-        __builtin_amdgcn_s_barrier();
     }
+    __syncthreads();                                                            // every wave is done with the slabs and tiles
 
+    // Epilogue through LDS (the loop's last barrier has retired every fragment read, so the slabs are free): each lane holds
+    // ONE channel of 64 pixels, which as direct stores is 64 two-byte writes per lane.  Instead the finished tile is laid out
+    // [256 pixels][128 channels] (pitch 136 halfs: the fk = 1 half-wave lands 16 banks away) and leaves as 16-byte stores,
+    // 16 lanes per pixel = the pixel's whole 256-byte channel run.
+    constexpr int OP = 136;
+    __half* const ot = (__half*)lds;
+    float* const nz = (float*)(ot + 256 * OP);                                   // the tile's noise (256 floats), if any
     const float ns = a.noise ? a.noise_strength[0] : 0.f;
+    if (a.noise) {
+        if (tid < 256) {
+            const int oy = oy0 + (tid >> 4), ox = ox0 + (tid & 15);
+            nz[tid] = (oy < a.H && ox < a.W) ? a.noise[(int64_t)oy * a.W + ox] * ns : 0.f;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int co = co0 + wn * 64 + j * 32 + frow;
-        if (co >= a.Co) continue;
-        const float b = a.bias ? a.bias[co] : 0.f;
+        const int cl = wn * 64 + j * 32 + frow, co = co0 + cl;
+        const float b = (a.bias && co < a.Co) ? a.bias[co] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int mrow = (r & 3) + 8 * (r >> 2) + 4 * fk;
-                const int oy = oy0 + wm * 4 + i * 2 + (mrow >> 4), ox = ox0 + (mrow & 15);
-                if (oy >= a.H || ox >= a.W) continue;
+                const int p = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;   // pixel within the 16 x 16 tile, row-major
                 float v = acc[i][j][r];
-                if (a.noise) v = fmaf(a.noise[(int64_t)oy * a.W + ox], ns, v);
+                if (a.noise) v += nz[p];
                 v += b;
                 if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
                 v *= a.gain;
                 if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
-                ((__half*)a.y)[(((int64_t)n * a.H + oy) * a.W + ox) * a.Co + co] = __float2half(v);
+                ot[p * OP + cl] = __float2half(v);
             }
+    }
+    __syncthreads();
+    __half* const yout = (__half*)a.y + (int64_t)n * a.H * a.W * a.Co;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = it * 512 + tid, p = idx >> 4, ch = idx & 15;
+        const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15), co = co0 + ch * 8;
+        if (oy < a.H && ox < a.W && co < a.Co)
+            *(f32x4*)(yout + ((int64_t)oy * a.W + ox) * a.Co + co) = *(const f32x4*)(ot + p * OP + ch * 8);
     }
 }
 
@@ -602,7 +668,7 @@ extern "C" int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype,
         for (int t = 0; t < a.KT; ++t) a.cls[0].taps[t] = ConvTap{t / kernel_size - kernel_size / 2, t % kernel_size - kernel_size / 2, t};
         static const bool no_halo = getenv("P3D_CONV_NO_HALO") != nullptr;
         static const bool no_q256 = getenv("P3D_CONV_NO_Q256") != nullptr;
-        if (kernel_size == 3 && dtype == P3D_F16 && h >= 64 && wdt >= 64 && !no_halo && !no_q256) {     // big fp16 layers: 256-pixel tiles, 3-stage weights
+        if (kernel_size == 3 && dtype == P3D_F16 && h >= 64 && wdt >= 64 && ci % 128 == 0 && co % BN == 0 && (((uintptr_t)y) & 15u) == 0 && !no_halo && !no_q256) {     // big fp16 layers: 256-pixel tiles, 3-stage weights
             static hipError_t attr = hipFuncSetAttribute((const void*)conv3x3_q256_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 0);
             (void)attr;
             dim3 grid(((h + QH - 1) / QH) * ((wdt + QW - 1) / QW), (co + BN - 1) / BN, n_img);

@@ -27,3 +27,13 @@ for name, ci, co, r, tr in [('bb.b64.conv1', 512, 512, 64, False), ('bb.b128.con
     fl = 2 * N * ci * co * 9 * r * r
     t = timeit(lambda: modconv.conv2d(x, wmod, transposed=tr, bias=None if tr else bias, act=0 if tr else 1, gain=1.414))
     print(f'p3d fp32 {name}: {fl / t / 1e12:.1f} TF ({t * 1e3:.3f} ms)', flush=True)
+
+from pix2pix3d_amd.torch_utils.ops import upfirdn2d as _up
+f4 = _up.setup_filter([1, 3, 3, 1], device='cuda')
+for name, c, r, dt in [('sr.b1 fir 512^2x128 f16', 128, 512, torch.float16), ('sr.b0 fir 256^2x256 f16', 256, 256, torch.float16), ('bb.b256 fir 256^2x128 f32', 128, 256, torch.float32)]:
+    y = torch.randn(N, c, r + 1, r + 1, device='cuda').to(dt).to(memory_format=torch.channels_last)
+    bias = torch.randn(c, device='cuda'); nz = torch.randn(r, r, device='cuda'); ns = torch.full([], 0.1, device='cuda')
+    t = timeit(lambda: modconv.fir4_bias_act(y, f4, bias, nz, ns, 'lrelu', 1.414, 256.0))
+    es = y.element_size()
+    gb = N * c * ((r + 1) ** 2 + r * r) * es / 1e9
+    print(f'p3d {name}: {t * 1e3:.3f} ms, {gb / t / 1e3:.2f} TB/s (algorithmic read+write)', flush=True)
