@@ -85,40 +85,46 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
     const T* xin = (const T*)a.x + (int64_t)n * a.H * a.W * a.Ci;
     const T* wgt = (const T*)a.w + (int64_t)n * a.w_img_stride;
 
-    // staging assignment: 8 threads cover one 128-byte row (64 halfs); 32 rows per pass, 4 passes for 128 rows
+    // staging assignment: 8 threads cover one 128-byte row (64 halfs); 32 rows per pass, 4 passes for 128 rows.
+    // Everything lane-dependent is computed once: per K step a DMA source costs one add, four compares and a select.
     const int chunk = tid & 7, srow = tid >> 3;
-    int pi[4], pj[4];
-    bool pok[4];
+    const int src_chunk = chunk ^ ((srow >> 1) & 7);               // ((srow + 32p) >> 1) & 7 == (srow >> 1) & 7
+    int pi[4], pj[4], poff[4], woff[4];
+    bool pok[4], wok[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int m = m0 + srow + 32 * p;
         pok[p] = m < M;
         const int mm = pok[p] ? m : 0;
         pi[p] = mm / kc.SW; pj[p] = mm - pi[p] * kc.SW;
+        poff[p] = ((pi[p] * a.W + pj[p]) * a.Ci + src_chunk * EPC) * (int)sizeof(T);      // < 2^31: one image's activations
+        const int co = co0 + srow + 32 * p;
+        wok[p] = co < a.Co;
+        woff[p] = (co * a.KT * a.Ci + src_chunk * EPC) * (int)sizeof(T);
     }
     const int kchunks = a.Ci / BK;
     const int ntaps = kc.ntaps;
-    const int ksteps = ntaps * kchunks;
 
     // Direct global -> LDS staging (global_load_lds_dwordx4): each wave instruction deposits 64 x 16 B = eight 128-byte
     // rows linearly at a wave-uniform LDS base, so the XOR swizzle is applied on the SOURCE side: the lane that fills
     // LDS slot (row, pos) fetches chunk pos ^ ((row >> 1) & 7) of that row.  Rows outside the image (or past the end of the
     // pixel / channel range) read from a page of zeros instead.
-    const int src_chunk = chunk ^ ((srow >> 1) & 7);               // ((srow + 32p) >> 1) & 7 == (srow >> 1) & 7
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
-    auto stage = [&](int ks, int buf) {
-        const int cc = ks / ntaps, t = ks - cc * ntaps, c0 = cc * BK + src_chunk * EPC;   // taps innermost: a block re-reads its 64-channel neighbourhood while it is L2-hot
+    const char* const xin_b = (const char*)xin;
+    const char* const wgt_b = (const char*)wgt;
+    auto stage = [&](int cc, int t, int buf) {                     // taps innermost: a block re-reads its channel chunk while it is L2-hot
         const ConvTap tp = kc.taps[t];
+        const int xs = ((tp.dy * a.W + tp.dx) * a.Ci + cc * BK) * (int)sizeof(T);
+        const int ws = (tp.widx * a.Ci + cc * BK) * (int)sizeof(T);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int iy = pi[p] + tp.dy, ix = pj[p] + tp.dx;
             const bool ok = pok[p] & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
-            const T* src = ok ? xin + ((int64_t)iy * a.W + ix) * a.Ci + c0 : (const T*)a.zeros;
+            const char* src = ok ? xin_b + (poff[p] + xs) : (const char*)a.zeros;
             const int row0 = (wave * 8 + 32 * p) * 8;      // first 16-B slot of this wave's 8-row group
             __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)&lds[buf][0][row0], 16, 0, 0);
-            const int co = co0 + srow + 32 * p;
-            const T* wsrc = (co < a.Co) ? wgt + ((int64_t)co * a.KT + tp.widx) * a.Ci + c0 : (const T*)a.zeros;
+            const char* wsrc = wok[p] ? wgt_b + (woff[p] + ws) : (const char*)a.zeros;
             __builtin_amdgcn_global_load_lds((glb_ptr)wsrc, (lds_ptr)&lds[buf][1][row0], 16, 0, 0);
         }
     };
@@ -131,60 +137,140 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    stage(0, 0);
+    stage(0, 0, 0);
     __syncthreads();
     const int frow = lane & 31, fk = lane >> 5;                                 // fragment row / k-group of this lane
-    for (int ks = 0; ks < ksteps; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < ksteps) stage(ks + 1, buf ^ 1);                            // next tile streams into the other buffer under the MFMAs
+    int pa[2][4], pb[2][4];                                                     // fragment slots of this lane (buffer 0)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {                                        // 4 x 32 bytes of K per 128-byte row
-            f32x4 fa[2], fb[2];
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fa[i] = lds[buf][0][swz(wm * 64 + i * 32 + frow, kk * 2 + fk)];
-                fb[i] = lds[buf][1][swz(wn * 64 + i * 32 + frow, kk * 2 + fk)];
+        for (int kk = 0; kk < 4; ++kk) {
+            pa[i][kk] = swz(wm * 64 + i * 32 + frow, kk * 2 + fk);
+            pb[i][kk] = swz(wn * 64 + i * 32 + frow, kk * 2 + fk);
+        }
+    int buf = 0;
+    for (int cc = 0; cc < kchunks; ++cc)
+        for (int t = 0; t < ntaps; ++t) {
+            {                                                                   // next tile streams into the other buffer under the MFMAs
+                int t2 = t + 1, cc2 = cc;
+                if (t2 == ntaps) { t2 = 0; ++cc2; }
+                if (cc2 < kchunks) stage(cc2, t2, buf ^ 1);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int kk = 0; kk < 4; ++kk) {                                    // 4 x 32 bytes of K per 128-byte row
+                f32x4 fa[2], fb[2];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if constexpr (sizeof(T) == 2) {                             // 8 halfs per lane = one 32x32x16 step
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, fa[i]), __builtin_bit_cast(h8, fb[j]), acc[i][j], 0, 0, 0);
-                    } else {                                                    // 4 floats per lane = four 32x32x2 steps; K order permuted identically in A and B
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-                    }
+                for (int i = 0; i < 2; ++i) {
+                    fa[i] = lds[buf][0][pa[i][kk]];
+                    fb[i] = lds[buf][1][pb[i][kk]];
                 }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if constexpr (sizeof(T) == 2) {                         // 8 halfs per lane = one 32x32x16 step
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, fa[i]), __builtin_bit_cast(h8, fb[j]), acc[i][j], 0, 0, 0);
+                        } else {                                                // 4 floats per lane = four 32x32x2 steps; K order permuted identically in A and B
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+                        }
+                    }
+            }
+            __syncthreads();                                                    // drains the LDS-DMA (vmcnt) and fences the buffer swap
+            buf ^= 1;
         }
-        __syncthreads();                                                        // drains the LDS-DMA (vmcnt) and fences the buffer swap
-    }
 
     // ---- epilogue: accumulator element (row = (r&3) + 8(r>>2) + 4*fk, col = frow) of each 32x32 tile -------------
     const float ns = a.noise ? a.noise_strength[0] : 0.f;
+    if constexpr (sizeof(T) == 2) {
+        // fp16: a lane holds ONE channel of 64 output pixels — as direct stores, 64 two-byte writes.  The tile is transposed
+        // through LDS instead ([128 pixels][128 channels], pitch 136 halfs so the fk = 1 half-wave lands 16 banks away) and
+        // leaves as 16-byte stores, 16 lanes per pixel = that pixel's whole 256-byte channel run; the pixel -> (y, x)
+        // division is done 8 times per lane, not 64.  (The loop's last barrier has retired every fragment read.)
+        constexpr int OP = 136;
+        __half* const ot = (__half*)lds;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int co = co0 + wn * 64 + j * 32 + frow;
-        if (co >= a.Co) continue;
-        const float b = a.bias ? a.bias[co] : 0.f;
+        for (int j = 0; j < 2; ++j) {
+            const int cl = wn * 64 + j * 32 + frow, co = co0 + cl;
+            const float b = (a.bias && co < a.Co) ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    float v = acc[i][j][r] + b;
+                    if (!a.noise) {                                             // (with noise the activation waits for the read-back pass)
+                        if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
+                        v *= a.gain;
+                        if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
+                    }
+                    ot[ml * OP + cl] = __float2half(v);
+                }
+        }
+        __syncthreads();
+        __half* const yout = (__half*)a.y + (int64_t)n * a.OH * a.OW * a.Co;
+        const bool vec_ok = ((a.Co & 7) == 0) && ((((uintptr_t)a.y) & 15u) == 0);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 256 + tid, ml = idx >> 4, ch = idx & 15;
+            const int m = m0 + ml, co = co0 + ch * 8;
+            if (m >= M || co >= a.Co) continue;
+            const int si = m / kc.SW, sj = m - si * kc.SW;
+            const int oy = si * a.osy + kc.ooy, ox = sj * a.osx + kc.oox;
+            if (oy >= a.OH || ox >= a.OW) continue;
+            f32x4 pk = *(const f32x4*)(ot + ml * OP + ch * 8);
+            if (a.noise) {                                                      // rare here (the big noisy layers take the halo kernels)
+                const float nz = a.noise[(int64_t)oy * a.OW + ox] * ns;
+                h8 hv = __builtin_bit_cast(h8, pk);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = (float)hv[e] + nz;
+                    if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
+                    v *= a.gain;
+                    if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
+                    hv[e] = (_Float16)v;
+                }
+                pk = __builtin_bit_cast(f32x4, hv);
+            }
+            __half* dst = yout + ((int64_t)oy * a.OW + ox) * a.Co + co;
+            if (vec_ok) *(f32x4*)dst = pk;
+            else {
+                const h8 hv = __builtin_bit_cast(h8, pk);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (co + e < a.Co) ((_Float16*)dst)[e] = hv[e];
+            }
+        }
+    } else {
+        int opix[2][16];                                                        // output pixel offset of each accumulator row (or -1)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                if (m >= M) continue;
                 const int si = m / kc.SW, sj = m - si * kc.SW;
                 const int oy = si * a.osy + kc.ooy, ox = sj * a.osx + kc.oox;
-                if (oy >= a.OH || ox >= a.OW) continue;
-                float v = acc[i][j][r];
-                if (a.noise) v = fmaf(a.noise[(int64_t)oy * a.OW + ox], ns, v);
-                v += b;
-                if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
-                v *= a.gain;
-                if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
-                st((T*)a.y + (((int64_t)n * a.OH + oy) * a.OW + ox) * a.Co + co, v);
+                opix[i][r] = (m < M && oy < a.OH && ox < a.OW) ? oy * a.OW + ox : -1;
             }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int co = co0 + wn * 64 + j * 32 + frow;
+            if (co >= a.Co) continue;
+            const float b = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (opix[i][r] < 0) continue;
+                    float v = acc[i][j][r];
+                    if (a.noise) v = fmaf(a.noise[opix[i][r]], ns, v);
+                    v += b;
+                    if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
+                    v *= a.gain;
+                    if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
+                    st((T*)a.y + ((int64_t)n * a.OH * a.OW + opix[i][r]) * a.Co + co, v);
+                }
+        }
     }
 }
 
@@ -344,8 +430,6 @@ __global__ void __launch_bounds__(512, 2) conv3x3_q256_f16_kernel(ConvArgs a)
     // ONE __shared__ object on purpose: with two, hipcc drains vmcnt to 0 before the first ds_read of every step and the
     // counted waits below are moot (cdna_hip_programming.md, 'three .s-level traps' (a))
     __shared__ __attribute__((aligned(16))) f32x4 lds[2 * QSLAB_SLOTS + 3 * BN * 8];
-    f32x4* const slab0 = lds;
-    f32x4* const wt0 = lds + 2 * QSLAB_SLOTS;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;                                   // 4 x 2 waves, 64 x 64 outputs each
     const int n = blockIdx.z;
@@ -432,8 +516,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_q256_f16_kernel(ConvArgs a)
         const int ty2 = t / 3, tx2 = t - ty2 * 3;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            pa[i] = *(const f32x4*)(lds_b + preA[tx2][kk] + (buf * SLAB_BYTES + (i * 2 * QSLAB_W + ty2 * QSLAB_W) * 128));
-            pb[i] = *(const f32x4*)(lds_b + preB[kk] + ((t % 3) * WT_BYTES + i * 32 * 128));
+            // issued as opaque asm so that the compiler's own s_waitcnt (always lgkmcnt(0) here) stays out of the way: the
+            // waits are the counted ones written next to the MFMAs below
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pa[i]) : "v"(preA[tx2][kk]), "n"(buf * SLAB_BYTES + (i * 2 * QSLAB_W + ty2 * QSLAB_W) * 128) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pb[i]) : "v"(preB[kk]), "n"((t % 3) * WT_BYTES + i * 32 * 128) : "memory");
         }
     };
 
@@ -465,9 +551,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_q256_f16_kernel(ConvArgs a)
                         else if (h == 0 || more) stage_w(cc + 1, t - 7, (t + 2) % 3);
                         if (t == 0 && (h == 0 || more)) stage_slab(cc + 1, h ^ 1);
                     }
-                    if (kk < 3) load_frags(h, t, kk + 1, fa[nxt], fb[nxt]);
-                    else if (t < 8) load_frags(h, t + 1, 0, fa[nxt], fb[nxt]);
-                    else if (h == 0 || more) load_frags(h ^ 1, 0, 0, fa[nxt], fb[nxt]);
+                    if (kk < 3) { load_frags(h, t, kk + 1, fa[nxt], fb[nxt]); asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); }
+                    else if (t < 8) { load_frags(h, t + 1, 0, fa[nxt], fb[nxt]); asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); }
+                    else if (h == 0 || more) { load_frags(h ^ 1, 0, 0, fa[nxt], fb[nxt]); asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); }
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
