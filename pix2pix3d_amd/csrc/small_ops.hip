@@ -1,0 +1,161 @@
+// Launch-count diet for the low-resolution half of the synthesis network (4^2 .. 32^2) and the style affines.
+// These layers hold almost no arithmetic — at batch 4 they are pure launch latency: the torch route spent ~14 launches on
+// one 3x3 layer (weight scaling, addmm, layout copies, per-sample im2col, bmm, noise add, bias_act) and the whole group
+// cost more than the ray-marcher.  Here:
+//   p3d_fc_forward      : FullyConnectedLayer (networks_stylegan2.py:96-130) in one launch — weight gain, bias gain,
+//                         activation and an output scale (ToRGB's weight_gain, :356) folded in.
+//   p3d_im2col3x3       : the 3x3 / pad 1 patch matrix of the whole batch in one launch, from any NCHW-indexable layout.
+//   p3d_noise_bias_act  : + noise * strength, + bias, activation, gain, clamp on a [N, C, HW] tensor in one pass
+//                         (networks_stylegan2.py:326-332 after the GEMM).
+#include "p3d_common.h"
+
+namespace p3d {
+
+// ---- fully connected: y[n, o] = act((x[n, :] . W[o, :]) * wg + b[o] * bg) * act_gain * out_scale ---------------------
+// One wave per output feature: the wave streams W[o, :] once (coalesced float4), keeps the (few) input rows in LDS and
+// reduces with DPP-free shuffles.  n_rows <= 16.
+constexpr int FC_MAXN = 16;
+__global__ void __launch_bounds__(256) fc_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                 float* __restrict__ y, int n_rows, int in_f, int out_f, float wg, float bg,
+                                                 int act, float alpha, float act_gain, float out_scale)
+{
+    extern __shared__ float xs[];                                   // [n_rows][in_f]
+    for (int e = threadIdx.x * 4; e < n_rows * in_f; e += 256 * 4) *(float4*)(xs + e) = *(const float4*)(x + e);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + wave;
+    if (o >= out_f) return;
+    float acc[FC_MAXN];
+#pragma unroll
+    for (int n = 0; n < FC_MAXN; ++n) acc[n] = 0.f;
+    const float* wr = w + (int64_t)o * in_f;
+    for (int k = lane * 4; k < in_f; k += 256) {
+        const float4 wv = *(const float4*)(wr + k);
+#pragma unroll
+        for (int n = 0; n < FC_MAXN; ++n) {
+            if (n < n_rows) {
+                const float4 xv = *(const float4*)(xs + n * in_f + k);
+                acc[n] = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, acc[n]))));
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < FC_MAXN; ++n) {
+        if (n < n_rows) {
+            float v = acc[n];
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+            acc[n] = v;
+        }
+    }
+    if (lane == 0) {
+        const float bias = b ? b[o] * bg : 0.f;
+#pragma unroll
+        for (int n = 0; n < FC_MAXN; ++n) {
+            if (n < n_rows) {
+                float v = fmaf(acc[n], wg, bias);
+                if (act == 3) v = v > 0.f ? v : v * alpha;
+                y[(int64_t)n * out_f + o] = v * act_gain * out_scale;
+            }
+        }
+    }
+}
+
+// ---- im2col, 3x3, pad 1: cols[n][ci*9 + t][p] = x[n, ci, py + t/3 - 1, px + t%3 - 1] -------------------------------
+// x is addressed through element strides (NCHW-contiguous or channels-last alike); one thread per (n, ci, p) writes the
+// nine taps, so the nine stores of a wave are each a coalesced run along p.
+__global__ void __launch_bounds__(256) im2col3x3_kernel(const float* __restrict__ x, float* __restrict__ cols, int N, int C, int H, int W,
+                                                        int64_t sn, int64_t sc, int64_t sy, int64_t sx)
+{
+    const int HW = H * W;
+    const int64_t total = (int64_t)N * C * HW;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int p = (int)(e % HW);
+    const int64_t nc = e / HW;
+    const int c = (int)(nc % C), n = (int)(nc / C);
+    const int py = p / W, px = p - py * W;
+    const float* xb = x + n * sn + c * sc;
+    float* cb = cols + ((int64_t)n * C + c) * 9 * HW + p;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int iy = py + t / 3 - 1, ix = px + t % 3 - 1;
+        const bool ok = (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
+        cb[(int64_t)t * HW] = ok ? xb[iy * sy + ix * sx] : 0.f;
+    }
+}
+
+// ---- y[n, c, p] = clamp(act(y + noise[p] * strength + bias[c]) * gain) -------------------------------------------------
+__global__ void __launch_bounds__(256) noise_bias_act_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ noise,
+                                                             const float* __restrict__ noise_strength, const float* __restrict__ bias,
+                                                             int64_t total, int C, int HW, int act, float alpha, float gain, float clamp)
+{
+    const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= total) return;
+    const float ns = noise ? noise_strength[0] : 0.f;
+    const int p = (int)(e % HW);                                     // HW % 4 == 0: the four elements share n and c
+    const int c = (int)((e / HW) % C);
+    const float b = bias ? bias[c] : 0.f;
+    float4 v = *(const float4*)(x + e);
+    float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float t = r[k] + b;
+        if (noise) t = fmaf(noise[p + k], ns, r[k]) + b;
+        if (act == 3) t = t > 0.f ? t : t * alpha;
+        t *= gain;
+        if (clamp >= 0.f) t = fminf(fmaxf(t, -clamp), clamp);
+        r[k] = t;
+    }
+    *(float4*)(y + e) = make_float4(r[0], r[1], r[2], r[3]);
+}
+
+} // namespace p3d
+
+extern "C" int p3d_fc_forward(const float* x, const float* w, const float* b, float* y, int32_t n_rows, int32_t in_features,
+                              int32_t out_features, float weight_gain, float bias_gain, int32_t act, float alpha, float act_gain,
+                              float out_scale, p3d_stream_t stream)
+{
+    using namespace p3d;
+    P3D_REQUIRE(x && w && y, "fc_forward: null pointer");
+    P3D_REQUIRE(n_rows >= 1 && n_rows <= FC_MAXN, "fc_forward: n_rows=%d outside [1, %d]", n_rows, FC_MAXN);
+    P3D_REQUIRE(in_features >= 4 && in_features % 4 == 0 && out_features >= 1, "fc_forward: in_features must be a positive multiple of 4");
+    P3D_REQUIRE(act == 1 || act == 3, "fc_forward: act must be linear (1) or lrelu (3)");
+    P3D_REQUIRE(((((uintptr_t)x) | ((uintptr_t)w)) & 15u) == 0, "fc_forward: x and w must be 16-byte aligned");
+    const size_t shm = (size_t)n_rows * in_features * sizeof(float);
+    P3D_REQUIRE(shm <= 64 * 1024, "fc_forward: n_rows * in_features too large for the LDS stage");
+    hipLaunchKernelGGL(fc_kernel, dim3((out_features + 3) / 4), dim3(256), shm, (hipStream_t)stream, x, w, b, y, n_rows, in_features,
+                       out_features, weight_gain, bias_gain, act, alpha, act_gain, out_scale);
+    count_launch(FAM_AUX);
+    return check_launch("fc_forward");
+}
+
+extern "C" int p3d_im2col3x3(const float* x, float* cols, int32_t n_img, int32_t c, int32_t h, int32_t w, int64_t stride_n, int64_t stride_c,
+                             int64_t stride_y, int64_t stride_x, p3d_stream_t stream)
+{
+    using namespace p3d;
+    P3D_REQUIRE(x && cols, "im2col3x3: null pointer");
+    P3D_REQUIRE(n_img >= 1 && c >= 1 && h >= 1 && w >= 1, "im2col3x3: bad sizes");
+    const int64_t total = (int64_t)n_img * c * h * w;
+    P3D_REQUIRE(total < (1ll << 31) * 256, "im2col3x3: too large");
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, cols, n_img, c, h, w,
+                       stride_n, stride_c, stride_y, stride_x);
+    count_launch(FAM_AUX);
+    return check_launch("im2col3x3");
+}
+
+extern "C" int p3d_noise_bias_act(const float* x, float* y, const float* noise, const float* noise_strength, const float* bias, int32_t n_img,
+                                  int32_t c, int32_t hw, int32_t act, float alpha, float gain, float clamp, p3d_stream_t stream)
+{
+    using namespace p3d;
+    P3D_REQUIRE(x && y, "noise_bias_act: null pointer");
+    P3D_REQUIRE(n_img >= 1 && c >= 1 && hw >= 4 && hw % 4 == 0, "noise_bias_act: hw must be a positive multiple of 4");
+    P3D_REQUIRE(act == 1 || act == 3, "noise_bias_act: act must be linear (1) or lrelu (3)");
+    P3D_REQUIRE(!noise || noise_strength, "noise_bias_act: noise needs its strength");
+    P3D_REQUIRE(((((uintptr_t)x) | ((uintptr_t)y)) & 15u) == 0, "noise_bias_act: x and y must be 16-byte aligned");
+    const int64_t total = (int64_t)n_img * c * hw;
+    hipLaunchKernelGGL(noise_bias_act_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, noise,
+                       noise_strength, bias, total, c, hw, act, alpha, gain, clamp);
+    count_launch(FAM_AUX);
+    return check_launch("noise_bias_act");
+}

@@ -21,6 +21,9 @@ _lib.register('p3d_modulate_weights', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int
 _lib.register('p3d_conv2d_nhwc', ctypes.c_int, [_vp] * 3 + [ctypes.c_int] + [_vp] * 4 + [_i32] * 5 + [_i64, _i32, _i32, _i32, _f32, _f32, _vp])
 
 _lib.register('p3d_fir4_bias_act_nhwc', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int] + [_i32] * 9 + [_f32, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _vp])
+_lib.register('p3d_fc_forward', ctypes.c_int, [_vp] * 4 + [_i32] * 3 + [_f32, _f32, _i32, _f32, _f32, _f32, _vp])
+_lib.register('p3d_im2col3x3', ctypes.c_int, [_vp, _vp] + [_i32] * 4 + [_i64] * 4 + [_vp])
+_lib.register('p3d_noise_bias_act', ctypes.c_int, [_vp] * 5 + [_i32] * 4 + [_f32, _f32, _f32, _vp])
 
 min_pixels = 1               # every layer takes this module (the vendor conv library is never entered: its choices for the small
                              # layers — naive kernels on a fresh box — cost milliseconds)
@@ -133,19 +136,60 @@ def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None
 conv3x3 = conv2d
 
 
+def fc_supported(x, weight, bias, activation):
+    """FullyConnectedLayer calls the one-launch kernel covers: a few fp32 rows on the device, inference."""
+    return (enabled and x.is_cuda and x.ndim == 2 and x.dtype == torch.float32 and 1 <= x.shape[0] <= 16 and x.shape[1] % 4 == 0
+            and x.shape[0] * x.shape[1] <= 16384 and activation in ('linear', 'lrelu') and weight.dtype == torch.float32
+            and _no_grad_needed(x, weight, bias))
+
+
+def fc(x, weight, bias, weight_gain, bias_gain, activation='linear', out_scale=1.0):
+    """act((x @ weight.T) * weight_gain + bias * bias_gain) * def_gain * out_scale in one launch (networks_stylegan2.py:113-127)."""
+    n, out_f = x.shape[0], weight.shape[0]
+    x32 = x.detach().contiguous()
+    w32 = weight.detach().contiguous()
+    b32 = None if bias is None else bias.detach().float().contiguous()
+    y = torch.empty([n, out_f], dtype=torch.float32, device=x.device)
+    act_gain = bias_act.activation_funcs[activation].def_gain
+    code = _lib.lib().p3d_fc_forward(_lib.ptr(x32), _lib.ptr(w32), _lib.ptr(b32), _lib.ptr(y), n, x.shape[1], out_f, float(weight_gain), float(bias_gain),
+                                     {'linear': 1, 'lrelu': 3}[activation], 0.2, float(act_gain), float(out_scale), _lib.stream_of(x))
+    _lib.check(code, 'fc_forward')
+    return y
+
+
+def im2col3x3(x):
+    """[N, C, H, W] fp32 in any dense layout -> [N, C*9, H*W] (= F.unfold(x, 3, padding=1)), one launch for the batch."""
+    n, c, h, w = x.shape
+    cols = torch.empty([n, c * 9, h * w], dtype=torch.float32, device=x.device)
+    code = _lib.lib().p3d_im2col3x3(_lib.ptr(x), _lib.ptr(cols), n, c, h, w, x.stride(0), x.stride(1), x.stride(2), x.stride(3), _lib.stream_of(x))
+    _lib.check(code, 'im2col3x3')
+    return cols
+
+
+def noise_bias_act(y, bias, noise, noise_strength, act, act_gain, clamp):
+    """In place on a contiguous fp32 [N, C, H, W]: + noise * strength, + bias, activation, gain, clamp (networks_stylegan2.py:326-332)."""
+    n, c, h, w = y.shape
+    b32 = None if bias is None else bias.detach().float().contiguous()
+    nz = None if noise is None else noise.detach().float().contiguous()
+    ns = None if noise is None else noise_strength.detach().float().reshape(1).contiguous()
+    code = _lib.lib().p3d_noise_bias_act(_lib.ptr(y), _lib.ptr(y), _lib.ptr(nz), _lib.ptr(ns), _lib.ptr(b32), n, c, h * w, {'linear': 1, 'lrelu': 3}[act], 0.2,
+                                         float(act_gain), -1.0 if clamp is None else float(clamp), _lib.stream_of(y))
+    _lib.check(code, 'noise_bias_act')
+    return y
+
+
 def _small_layer(x, weight, styles, up):
     """Per-sample modulated 3x3 conv (or its stride-2 transposed form) for images too small for the MFMA tiles: the
-    classic lowering to ONE batched GEMM per layer.  up == 1: im2col (F.unfold) then W[n] @ cols[n]; up == 2:
-    (W[n]^T arranged [Co*9, Ci]) @ x[n] then col2im (F.fold, stride 2) -> [N, Co, 2H+1, 2W+1].  NCHW in and out."""
+    classic lowering to ONE batched GEMM per layer.  up == 1: im2col then W[n] @ cols[n]; up == 2: (W[n]^T arranged
+    [Co*9, Ci]) @ x[n] then col2im (F.fold, stride 2) -> [N, Co, 2H+1, 2W+1].  Any dense layout in, NCHW out."""
     n, ci, h, w = x.shape
     co = weight.shape[0]
-    xc = x.contiguous()
     if up == 1:
         wm = modulate_weights(weight, styles, demodulate=True, dtype=x.dtype, oihw=True).reshape(n, co, ci * 9)
-        cols = torch.nn.functional.unfold(xc, kernel_size=3, padding=1)                     # [N, Ci*9, H*W]
+        cols = im2col3x3(x) if x.dtype == torch.float32 else torch.nn.functional.unfold(x.contiguous(), kernel_size=3, padding=1)   # [N, Ci*9, H*W]
         return torch.bmm(wm, cols).reshape(n, co, h, w)
     wm = modulate_weights(weight, styles, demodulate=True, dtype=x.dtype, oihw=False)       # [N, Co, 9, Ci]
-    cols = torch.bmm(wm.reshape(n, co * 9, ci), xc.reshape(n, ci, h * w))                  # [N, Co*9, H*W]
+    cols = torch.bmm(wm.reshape(n, co * 9, ci), x.contiguous().reshape(n, ci, h * w))      # [N, Co*9, H*W]
     return torch.nn.functional.fold(cols, output_size=(2 * h + 1, 2 * w + 1), kernel_size=3, stride=2)
 
 
@@ -155,6 +199,8 @@ def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=No
         y = _small_layer(x, weight, styles, up)
         if up == 2:
             y = upfirdn2d.upfirdn2d(y, resample_filter, padding=[1, 1, 1, 1], gain=4)
+        if y.dtype == torch.float32 and act in ('linear', 'lrelu') and (y.shape[2] * y.shape[3]) % 4 == 0 and y.is_contiguous():
+            return noise_bias_act(y, bias, noise_const, noise_strength, act, act_gain, clamp)
         if noise_const is not None:
             y = y.add_((noise_const * noise_strength).to(y.dtype))
         return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)

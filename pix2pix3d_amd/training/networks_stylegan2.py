@@ -79,7 +79,14 @@ class FullyConnectedLayer(torch.nn.Module):
         self.weight_gain = lr_multiplier / np.sqrt(in_features)
         self.bias_gain = lr_multiplier
 
-    def forward(self, x):
+    def forward(self, x, out_scale=1):
+        """``out_scale`` multiplies the result (ToRGBLayer folds its weight gain in here instead of a separate launch)."""
+        if modconv.fc_supported(x, self.weight, self.bias, self.activation):
+            return modconv.fc(x, self.weight, self.bias, self.weight_gain, self.bias_gain, self.activation, out_scale)
+        y = self._forward(x)
+        return y if out_scale == 1 else y * out_scale
+
+    def _forward(self, x):
         w = self.weight.to(x.dtype) * self.weight_gain
         b = self.bias
         if b is not None:
@@ -249,7 +256,7 @@ class ToRGBLayer(torch.nn.Module):
         self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
 
     def forward(self, x, w, fused_modconv=True):
-        styles = self.affine(w) * self.weight_gain
+        styles = self.affine(w, out_scale=self.weight_gain)
         if modconv.torgb_supported(x, self.weight, styles, fused_modconv):
             return modconv.torgb(x, self.weight, styles, self.bias, clamp=self.conv_clamp)      # fp32 NCHW, bias + clamp fused
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
@@ -273,7 +280,9 @@ def _block_mode(block, ws, force_fp32, fused_modconv):
     if fused_modconv == 'inference_only':
         fused_modconv = (not block.training)
     if native_channels_last and modconv.enabled and ws.device.type == 'cuda' and fused_modconv is True and not torch.is_grad_enabled():
-        fmt = torch.channels_last          # inference on the device: the layout the MFMA conv kernels consume (any dtype)
+        # inference on the device: channels-last is the layout the MFMA conv kernels consume (any dtype); the low-resolution
+        # blocks run as batched GEMMs on plain NCHW and are left alone (a layout round trip per layer is pure launch latency)
+        fmt = torch.channels_last if block.resolution ** 2 > modconv.gemm_max_pixels else torch.contiguous_format
     return dtype, fmt, fused_modconv
 
 
@@ -320,7 +329,10 @@ class SynthesisBlock(torch.nn.Module):
             x = self.const.to(dtype=dtype).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1]).contiguous(memory_format=fmt)
         else:
             misc.assert_shape(x, [None, self.in_channels, self.resolution // self._in_div, self.resolution // self._in_div])
-            x = x.to(dtype=dtype, memory_format=fmt)
+            if fmt == torch.channels_last and native_channels_last and modconv.is_small(x) and x.is_cuda and not torch.is_grad_enabled():
+                x = x.to(dtype=dtype)     # first MFMA-sized block: its x2 layer still takes the GEMM route on NCHW; conv1 converts
+            else:
+                x = x.to(dtype=dtype, memory_format=fmt)
 
         if self.in_channels == 0:
             x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
@@ -341,6 +353,8 @@ class SynthesisBlock(torch.nn.Module):
             wide_cl = fmt == torch.channels_last and y.shape[1] > 8 and y.shape[1] % 4 == 0
             # a wide skip image (the 96-channel tri-planes) stays channels-last end to end: the ray-marcher reads it in place
             y = y.to(dtype=torch.float32, memory_format=torch.channels_last if wide_cl else torch.contiguous_format)
+            if img is not None and wide_cl and not img.is_contiguous(memory_format=torch.channels_last):
+                img = img.contiguous(memory_format=torch.channels_last)     # the skip image turns channels-last where the blocks do
             img = img.add_(y) if img is not None else y
 
         assert x.dtype == dtype

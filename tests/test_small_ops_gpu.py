@@ -1,0 +1,95 @@
+"""One-launch helpers of the low-resolution layers (csrc/small_ops.hip) against plain torch fp32 / fp64 references:
+``fc`` vs the FullyConnectedLayer formula, ``im2col3x3`` vs F.unfold (bit-exact: pure data movement), ``noise_bias_act`` vs the
+noise add + bias_act composition, and a whole small SynthesisLayer / block against the generic (tensor-op) route."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('n,in_f,out_f', [(4, 512, 512), (1, 512, 96), (16, 64, 33), (3, 516, 7)])
+@pytest.mark.parametrize('act', ['linear', 'lrelu'])
+def test_fc_matches_formula(hip_lib, n, in_f, out_f, act):
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    torch.manual_seed(n + in_f + out_f)
+    x = torch.randn(n, in_f, device='cuda')
+    w = torch.randn(out_f, in_f, device='cuda')
+    b = torch.randn(out_f, device='cuda')
+    wg, bg, scale = 1 / np.sqrt(in_f), 0.5, 0.37
+    assert modconv.fc_supported(x, w, b, act)
+    y = modconv.fc(x, w, b, wg, bg, act, out_scale=scale)
+    ref = x.double() @ (w.double() * wg).t() + b.double() * bg
+    if act == 'lrelu':
+        ref = F.leaky_relu(ref, 0.2) * np.sqrt(2)
+    ref = ref * scale
+    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < 2e-6       # fp32 accumulation order only
+    y0 = modconv.fc(x, w, None, wg, bg, act)
+    ref0 = x.double() @ (w.double() * wg).t()
+    if act == 'lrelu':
+        ref0 = F.leaky_relu(ref0, 0.2) * np.sqrt(2)
+    assert rel_err(y0.cpu().numpy(), ref0.cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize('layout', ['nchw', 'nhwc'])
+@pytest.mark.parametrize('n,c,h,w', [(4, 512, 4, 4), (2, 37, 9, 5), (1, 8, 32, 32)])
+def test_im2col_is_unfold(hip_lib, layout, n, c, h, w):
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    torch.manual_seed(c + h)
+    x = torch.randn(n, c, h, w, device='cuda')
+    if layout == 'nhwc':
+        x = x.to(memory_format=torch.channels_last)
+    cols = modconv.im2col3x3(x)
+    ref = F.unfold(x.contiguous(), kernel_size=3, padding=1)
+    assert cols.shape == ref.shape
+    assert torch.equal(cols, ref)                                    # data movement: bit-exact
+
+
+@pytest.mark.parametrize('act', ['linear', 'lrelu'])
+@pytest.mark.parametrize('with_noise', [False, True])
+@pytest.mark.parametrize('clamp', [None, 0.7])
+def test_noise_bias_act(hip_lib, act, with_noise, clamp):
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    torch.manual_seed(5)
+    n, c, h, w = 3, 21, 6, 10
+    y = torch.randn(n, c, h, w, device='cuda')
+    bias = torch.randn(c, device='cuda')
+    noise = torch.randn(h, w, device='cuda') if with_noise else None
+    ns = torch.tensor(0.31, device='cuda') if with_noise else None
+    ref = y.double()
+    if with_noise:
+        ref = ref + noise.double() * ns.double()
+    ref = ref + bias.double().reshape(1, -1, 1, 1)
+    if act == 'lrelu':
+        ref = F.leaky_relu(ref, 0.2)
+    ref = ref * 1.4
+    if clamp is not None:
+        ref = ref.clamp(-clamp, clamp)
+    out = modconv.noise_bias_act(y.clone(), bias, noise, ns, act, 1.4, clamp)
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize('res,up', [(8, 1), (16, 2), (32, 1), (32, 2)])
+def test_small_synthesis_layer_matches_generic_route(hip_lib, res, up):
+    """A low-resolution SynthesisLayer through the launch-diet route vs the same module with the native path disabled."""
+    from pix2pix3d_amd.training import networks_stylegan2 as ns2
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    torch.manual_seed(res + up)
+    layer = ns2.SynthesisLayer(48, 40, w_dim=64, resolution=res, up=up).cuda().eval()
+    with torch.no_grad():
+        layer.noise_strength.fill_(0.2)
+        layer.bias.normal_()
+    x = torch.randn(2, 48, res // up, res // up, device='cuda')
+    w = torch.randn(2, 64, device='cuda')
+    with torch.no_grad():
+        y = layer(x, w, noise_mode='const')
+        modconv.enabled = False
+        try:
+            ref = layer(x, w, noise_mode='const')
+        finally:
+            modconv.enabled = True
+    assert y.shape == ref.shape
+    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < 1e-5
