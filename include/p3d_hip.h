@@ -179,7 +179,8 @@ int p3d_fir4_bias_act_nhwc(const void* x, const float* f, void* y, int dtype, in
 /* ---- low-resolution layers and style affines: launch-count diet (csrc/small_ops.hip) -----------
  * p3d_fc_forward: FullyConnectedLayer.forward (training/networks_stylegan2.py:113-127) in one launch:
  *   y[n][o] = act((sum_i x[n][i] * w[o][i]) * weight_gain + b[o] * bias_gain) * act_gain * out_scale
- * x [n_rows][in] (n_rows <= 16), w [out][in], b [out] or null, fp32 contiguous; act 1 = linear, 3 = lrelu(alpha).
+ * x [n_rows][in] (n_rows <= 16, rows x_row_stride elements apart: a column of the ws tensor is read in place), w [out][in],
+ * b [out] or null, fp32; act 1 = linear, 3 = lrelu(alpha).
  * out_scale carries a constant the caller multiplies the result by (ToRGBLayer's weight_gain, :356).
  *
  * p3d_im2col3x3: the patch matrix torch.nn.functional.unfold(x, 3, padding=1) of the whole batch,
@@ -189,11 +190,17 @@ int p3d_fir4_bias_act_nhwc(const void* x, const float* f, void* y, int dtype, in
  * p3d_noise_bias_act: the tail of SynthesisLayer.forward after the convolution (:326-332) on y [n_img][c][hw] fp32:
  *   y = clamp(act(x + noise[hw] * noise_strength[0] + bias[c]) * gain);  hw % 4 == 0; x may equal y; noise / bias may be null. */
 int p3d_fc_forward(const float* x, const float* w, const float* b, float* y, int32_t n_rows, int32_t in_features, int32_t out_features,
-                   float weight_gain, float bias_gain, int32_t act, float alpha, float act_gain, float out_scale, p3d_stream_t stream);
+                   int64_t x_row_stride, float weight_gain, float bias_gain, int32_t act, float alpha, float act_gain, float out_scale, p3d_stream_t stream);
 int p3d_im2col3x3(const float* x, float* cols, int32_t n_img, int32_t c, int32_t h, int32_t w, int64_t stride_n, int64_t stride_c,
                   int64_t stride_y, int64_t stride_x, p3d_stream_t stream);
 int p3d_noise_bias_act(const float* x, float* y, const float* noise, const float* noise_strength, const float* bias, int32_t n_img,
                        int32_t c, int32_t hw, int32_t act, float alpha, float gain, float clamp, p3d_stream_t stream);
+
+/* RaySampler.forward (training/volumetric_rendering/ray_sampler.py:24-62) in one launch: cam2world [n_cam][4][4], intrinsics
+ * [n_cam][3][3] (normalised fx, fy, cx, cy, skew), fp32 contiguous -> origins, dirs [n_cam][R*R][3] fp32, rays row-major,
+ * directions unit length (norm clamped at 1e-12 like F.normalize).                                                        */
+int p3d_ray_sample(const float* cam2world, const float* intrinsics, float* origins, float* dirs, int32_t n_cam, int32_t resolution,
+                   p3d_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -16,11 +16,14 @@ namespace p3d {
 // reduces with DPP-free shuffles.  n_rows <= 16.
 constexpr int FC_MAXN = 16;
 __global__ void __launch_bounds__(256) fc_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
-                                                 float* __restrict__ y, int n_rows, int in_f, int out_f, float wg, float bg,
+                                                 float* __restrict__ y, int n_rows, int in_f, int out_f, int64_t x_stride, float wg, float bg,
                                                  int act, float alpha, float act_gain, float out_scale)
 {
     extern __shared__ float xs[];                                   // [n_rows][in_f]
-    for (int e = threadIdx.x * 4; e < n_rows * in_f; e += 256 * 4) *(float4*)(xs + e) = *(const float4*)(x + e);
+    for (int e = threadIdx.x * 4; e < n_rows * in_f; e += 256 * 4) {
+        const int n = e / in_f, k = e - n * in_f;
+        *(float4*)(xs + e) = *(const float4*)(x + n * x_stride + k);
+    }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int o = blockIdx.x * 4 + wave;
@@ -110,10 +113,55 @@ __global__ void __launch_bounds__(256) noise_bias_act_kernel(const float* __rest
     *(float4*)(y + e) = make_float4(r[0], r[1], r[2], r[3]);
 }
 
+// ---- pixel-centre rays (training/volumetric_rendering/ray_sampler.py:24-62): one thread per ray --------------------------
+// Pixel (row i, col j) -> image coords ((j+.5)/R, (i+.5)/R) -> camera-frame point at z = 1 (OpenCV intrinsics with skew)
+// -> world space through cam2world -> unit direction from the camera origin.  Same operation order as the tensor-op form.
+__global__ void __launch_bounds__(256) ray_sample_kernel(const float* __restrict__ c2w, const float* __restrict__ intr, float* __restrict__ origins,
+                                                         float* __restrict__ dirs, int N, int R)
+{
+    const int M = R * R;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= N * M) return;
+    const int n = e / M, m = e - n * M;
+    const int i = m / R, j = m - i * R;
+    const float* K = intr + n * 9;
+    const float* C = c2w + n * 16;
+    const float fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
+    const float inv = 1.f / (float)R, half = 0.5f / (float)R;
+    const float x_img = (float)j * inv + half, y_img = (float)i * inv + half;
+    const float x_cam = (x_img - cx + cy * sk / fy - sk * y_img / fy) / fx;
+    const float y_cam = (y_img - cy) / fy;
+    float d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float wk = C[k * 4 + 0] * x_cam + C[k * 4 + 1] * y_cam + C[k * 4 + 2] + C[k * 4 + 3];
+        d[k] = wk - C[k * 4 + 3];
+    }
+    const float nrm = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        origins[(int64_t)e * 3 + k] = C[k * 4 + 3];
+        dirs[(int64_t)e * 3 + k] = d[k] / nrm;
+    }
+}
+
 } // namespace p3d
 
+extern "C" int p3d_ray_sample(const float* cam2world, const float* intrinsics, float* origins, float* dirs, int32_t n_cam, int32_t resolution,
+                              p3d_stream_t stream)
+{
+    using namespace p3d;
+    P3D_REQUIRE(cam2world && intrinsics && origins && dirs, "ray_sample: null pointer");
+    P3D_REQUIRE(n_cam >= 1 && resolution >= 1 && (int64_t)n_cam * resolution * resolution < (1ll << 31), "ray_sample: bad sizes");
+    const int total = n_cam * resolution * resolution;
+    hipLaunchKernelGGL(ray_sample_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, cam2world, intrinsics, origins, dirs,
+                       n_cam, resolution);
+    count_launch(FAM_AUX);
+    return check_launch("ray_sample");
+}
+
 extern "C" int p3d_fc_forward(const float* x, const float* w, const float* b, float* y, int32_t n_rows, int32_t in_features,
-                              int32_t out_features, float weight_gain, float bias_gain, int32_t act, float alpha, float act_gain,
+                              int32_t out_features, int64_t x_row_stride, float weight_gain, float bias_gain, int32_t act, float alpha, float act_gain,
                               float out_scale, p3d_stream_t stream)
 {
     using namespace p3d;
@@ -121,11 +169,11 @@ extern "C" int p3d_fc_forward(const float* x, const float* w, const float* b, fl
     P3D_REQUIRE(n_rows >= 1 && n_rows <= FC_MAXN, "fc_forward: n_rows=%d outside [1, %d]", n_rows, FC_MAXN);
     P3D_REQUIRE(in_features >= 4 && in_features % 4 == 0 && out_features >= 1, "fc_forward: in_features must be a positive multiple of 4");
     P3D_REQUIRE(act == 1 || act == 3, "fc_forward: act must be linear (1) or lrelu (3)");
-    P3D_REQUIRE(((((uintptr_t)x) | ((uintptr_t)w)) & 15u) == 0, "fc_forward: x and w must be 16-byte aligned");
+    P3D_REQUIRE(((((uintptr_t)x) | ((uintptr_t)w)) & 15u) == 0 && x_row_stride % 4 == 0, "fc_forward: x, its rows and w must be 16-byte aligned");
     const size_t shm = (size_t)n_rows * in_features * sizeof(float);
     P3D_REQUIRE(shm <= 64 * 1024, "fc_forward: n_rows * in_features too large for the LDS stage");
     hipLaunchKernelGGL(fc_kernel, dim3((out_features + 3) / 4), dim3(256), shm, (hipStream_t)stream, x, w, b, y, n_rows, in_features,
-                       out_features, weight_gain, bias_gain, act, alpha, act_gain, out_scale);
+                       out_features, x_row_stride, weight_gain, bias_gain, act, alpha, act_gain, out_scale);
     count_launch(FAM_AUX);
     return check_launch("fc_forward");
 }

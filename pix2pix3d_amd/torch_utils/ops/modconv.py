@@ -21,7 +21,7 @@ _lib.register('p3d_modulate_weights', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int
 _lib.register('p3d_conv2d_nhwc', ctypes.c_int, [_vp] * 3 + [ctypes.c_int] + [_vp] * 4 + [_i32] * 5 + [_i64, _i32, _i32, _i32, _f32, _f32, _vp])
 
 _lib.register('p3d_fir4_bias_act_nhwc', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int] + [_i32] * 9 + [_f32, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _vp])
-_lib.register('p3d_fc_forward', ctypes.c_int, [_vp] * 4 + [_i32] * 3 + [_f32, _f32, _i32, _f32, _f32, _f32, _vp])
+_lib.register('p3d_fc_forward', ctypes.c_int, [_vp] * 4 + [_i32] * 3 + [_i64, _f32, _f32, _i32, _f32, _f32, _f32, _vp])
 _lib.register('p3d_im2col3x3', ctypes.c_int, [_vp, _vp] + [_i32] * 4 + [_i64] * 4 + [_vp])
 _lib.register('p3d_noise_bias_act', ctypes.c_int, [_vp] * 5 + [_i32] * 4 + [_f32, _f32, _f32, _vp])
 
@@ -57,16 +57,19 @@ def _dense_dev(x):
     return x.is_cuda and x.dtype in (torch.float16, torch.float32) and x.ndim == 4 and (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last))
 
 
-def is_small(x):
+gemm_max_pixels_up = 256     # the x2 layers leave the GEMM route earlier: col2im of a 65^2 image costs more than the four polyphase MFMA GEMMs
+
+
+def is_small(x, up=1):
     """Images this small run as one batched GEMM (any dense layout); larger ones need channels_last for the MFMA kernel."""
-    return x.shape[2] * x.shape[3] <= gemm_max_pixels
+    return x.shape[2] * x.shape[3] <= (gemm_max_pixels if up == 1 else gemm_max_pixels_up)
 
 
 def layer_supported(x, weight, styles, noise_mode, fused_modconv, up):
     """True when the native kernels cover this SynthesisLayer call."""
     if not enabled or not fused_modconv or up not in (1, 2) or not _dense_dev(x):
         return False
-    if tuple(weight.shape[2:]) != (3, 3) or noise_mode == 'random' or not (is_small(x) or _is_nhwc(x)):
+    if tuple(weight.shape[2:]) != (3, 3) or noise_mode == 'random' or not (is_small(x, up) or _is_nhwc(x)):
         return False
     return _no_grad_needed(x, weight, styles)
 
@@ -146,12 +149,14 @@ def fc_supported(x, weight, bias, activation):
 def fc(x, weight, bias, weight_gain, bias_gain, activation='linear', out_scale=1.0):
     """act((x @ weight.T) * weight_gain + bias * bias_gain) * def_gain * out_scale in one launch (networks_stylegan2.py:113-127)."""
     n, out_f = x.shape[0], weight.shape[0]
-    x32 = x.detach().contiguous()
+    x32 = x.detach()
+    if x32.stride(1) != 1 or x32.stride(0) % 4 != 0 or x32.data_ptr() % 16 != 0:
+        x32 = x32.contiguous()
     w32 = weight.detach().contiguous()
     b32 = None if bias is None else bias.detach().float().contiguous()
     y = torch.empty([n, out_f], dtype=torch.float32, device=x.device)
     act_gain = bias_act.activation_funcs[activation].def_gain
-    code = _lib.lib().p3d_fc_forward(_lib.ptr(x32), _lib.ptr(w32), _lib.ptr(b32), _lib.ptr(y), n, x.shape[1], out_f, float(weight_gain), float(bias_gain),
+    code = _lib.lib().p3d_fc_forward(_lib.ptr(x32), _lib.ptr(w32), _lib.ptr(b32), _lib.ptr(y), n, x.shape[1], out_f, x32.stride(0) if n > 1 else x.shape[1], float(weight_gain), float(bias_gain),
                                      {'linear': 1, 'lrelu': 3}[activation], 0.2, float(act_gain), float(out_scale), _lib.stream_of(x))
     _lib.check(code, 'fc_forward')
     return y
@@ -195,7 +200,7 @@ def _small_layer(x, weight, styles, up):
 
 def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=None, noise_strength=None, act='lrelu', act_gain=1.0, clamp=None):
     """Whole SynthesisLayer body after the style affine: modulated 3x3 conv (x2 up when ``up == 2``) + noise + bias + act."""
-    if is_small(x):
+    if is_small(x, up):
         y = _small_layer(x, weight, styles, up)
         if up == 2:
             y = upfirdn2d.upfirdn2d(y, resample_filter, padding=[1, 1, 1, 1], gain=4)

@@ -220,10 +220,8 @@ class SynthesisLayer(torch.nn.Module):
         noise = None
         if self.use_noise and noise_mode == 'random':
             noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
-        if self.use_noise and noise_mode == 'const':
-            noise = self.noise_const * self.noise_strength
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
-        if native_channels_last and fused_modconv is True and x.is_cuda and not torch.is_grad_enabled() and not modconv.is_small(x) \
+        if native_channels_last and fused_modconv is True and x.is_cuda and not torch.is_grad_enabled() and not modconv.is_small(x, self.up) \
                 and not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)      # e.g. the output of a small generic-route layer feeding a native one
         if modconv.layer_supported(x, self.weight, styles, noise_mode, fused_modconv, self.up):
@@ -233,6 +231,8 @@ class SynthesisLayer(torch.nn.Module):
                                            noise_const=self.noise_const if const_noise else None,
                                            noise_strength=self.noise_strength if const_noise else None,
                                            act=self.activation, act_gain=self.act_gain * gain, clamp=clamp)
+        if self.use_noise and noise_mode == 'const':
+            noise = self.noise_const * self.noise_strength
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
                              resample_filter=self.resample_filter, flip_weight=(self.up == 1), fused_modconv=fused_modconv)
         return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=self.act_gain * gain, clamp=clamp)
@@ -329,7 +329,7 @@ class SynthesisBlock(torch.nn.Module):
             x = self.const.to(dtype=dtype).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1]).contiguous(memory_format=fmt)
         else:
             misc.assert_shape(x, [None, self.in_channels, self.resolution // self._in_div, self.resolution // self._in_div])
-            if fmt == torch.channels_last and native_channels_last and modconv.is_small(x) and x.is_cuda and not torch.is_grad_enabled():
+            if fmt == torch.channels_last and native_channels_last and modconv.is_small(x, self._in_div) and x.is_cuda and not torch.is_grad_enabled():
                 x = x.to(dtype=dtype)     # first MFMA-sized block: its x2 layer still takes the GEMM route on NCHW; conv1 converts
             else:
                 x = x.to(dtype=dtype, memory_format=fmt)

@@ -93,3 +93,24 @@ def test_small_synthesis_layer_matches_generic_route(hip_lib, res, up):
             modconv.enabled = True
     assert y.shape == ref.shape
     assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('res', [8, 64, 128])
+def test_native_ray_sampler_matches_tensor_ops(hip_lib, res):
+    from pix2pix3d_amd.training.volumetric_rendering import ray_sampler
+    torch.manual_seed(res)
+    n = 3
+    c2w = torch.eye(4, device='cuda')[None].repeat(n, 1, 1)
+    q, _ = torch.linalg.qr(torch.randn(n, 3, 3, device='cuda'))
+    c2w[:, :3, :3] = q
+    c2w[:, :3, 3] = torch.randn(n, 3, device='cuda') * 2.7
+    k = torch.tensor([[4.26, 0.03, 0.5], [0, 4.1, 0.48], [0, 0, 1]], device='cuda')[None].repeat(n, 1, 1)
+    rs = ray_sampler.RaySampler()
+    o, d = rs(c2w, k, res)
+    ray_sampler.native = False
+    try:
+        o_ref, d_ref = rs(c2w, k, res)
+    finally:
+        ray_sampler.native = True
+    assert torch.equal(o, o_ref)
+    assert (d - d_ref).abs().max().item() < 2e-6
