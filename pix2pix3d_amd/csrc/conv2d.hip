@@ -165,17 +165,17 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
                     fb[i] = lds[buf][1][pb[i][kk]];
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int e = 0; e < (sizeof(T) == 2 ? 1 : 4); ++e)              // fp32: e outermost, so consecutive MFMAs never share an accumulator
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        if constexpr (sizeof(T) == 2) {                         // 8 halfs per lane = one 32x32x16 step
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, fa[i]), __builtin_bit_cast(h8, fb[j]), acc[i][j], 0, 0, 0);
-                        } else {                                                // 4 floats per lane = four 32x32x2 steps; K order permuted identically in A and B
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
+                        for (int j = 0; j < 2; ++j) {
+                            if constexpr (sizeof(T) == 2) {                     // 8 halfs per lane = one 32x32x16 step
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, fa[i]), __builtin_bit_cast(h8, fb[j]), acc[i][j], 0, 0, 0);
+                            } else {                                            // 4 floats per lane = four 32x32x2 steps; K order permuted identically in A and B
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+                            }
                         }
-                    }
             }
             __syncthreads();                                                    // drains the LDS-DMA (vmcnt) and fences the buffer swap
             buf ^= 1;
@@ -368,17 +368,17 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(ConvArgs a)
                 fb[i] = wt[wb][swz(wn * 64 + i * 32 + frow, kk * 2 + fk)];
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int e = 0; e < (sizeof(T) == 2 ? 1 : 4); ++e)                  // fp32: e outermost, so consecutive MFMAs never share an accumulator
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if constexpr (sizeof(T) == 2) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, fa[i]), __builtin_bit_cast(h8, fb[j]), acc[i][j], 0, 0, 0);
-                    } else {
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
+                    for (int j = 0; j < 2; ++j) {
+                        if constexpr (sizeof(T) == 2) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, fa[i]), __builtin_bit_cast(h8, fb[j]), acc[i][j], 0, 0, 0);
+                        } else {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+                        }
                     }
-                }
         }
         __syncthreads();
     }

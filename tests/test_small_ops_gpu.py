@@ -114,3 +114,25 @@ def test_native_ray_sampler_matches_tensor_ops(hip_lib, res):
         ray_sampler.native = True
     assert torch.equal(o, o_ref)
     assert (d - d_ref).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('separable', [True, False])
+@pytest.mark.parametrize('size', [17, 40, 97])
+def test_fused_fir_any_filter(hip_lib, dtype, separable, size):
+    """4x4 FIR + noise + bias + lrelu in one pass (csrc/upfirdn2d.hip): rank-1 filters take the two-pass branch, anything else the
+    16-tap branch; both against upfirdn2d + the explicit epilogue, on sizes that leave partial tiles and partial tile groups."""
+    from pix2pix3d_amd.torch_utils.ops import modconv, upfirdn2d
+    torch.manual_seed(size)
+    c = 64
+    f = upfirdn2d.setup_filter([1, 3, 3, 1], device='cuda') if separable else torch.rand(4, 4, device='cuda') / 8
+    x = torch.randn(2, c, size + 1, size + 1, device='cuda').to(dtype).to(memory_format=torch.channels_last)
+    bias = torch.randn(c, device='cuda')
+    noise = torch.randn(size, size, device='cuda')
+    ns = torch.tensor(0.3, device='cuda')
+    y = modconv.fir4_bias_act(x, f, bias, noise, ns, 'lrelu', 1.3, 2.5)
+    ref = upfirdn2d.upfirdn2d(x.float().contiguous(), f, padding=[1, 1, 1, 1], gain=4).double()
+    ref = ref + (noise * ns).double() + bias.double().reshape(1, -1, 1, 1)
+    ref = (F.leaky_relu(ref, 0.2) * 1.3).clamp(-2.5, 2.5)
+    assert y.shape == ref.shape and y.dtype == dtype
+    assert rel_err(y.float().cpu().numpy(), ref.cpu().numpy()) < (2e-3 if dtype == torch.float16 else 1e-5)
