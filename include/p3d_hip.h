@@ -149,14 +149,16 @@ int p3d_modulate_weights(const float* weight, const float* styles, void* out, in
 
 /* x [N][H][W][Ci], w [N or 1][Co][k*k][Ci] (w_img_stride elements between images, 0 = shared), both `dtype`
  * (P3D_F16: v_mfma_f32_32x32x16_f16; P3D_F32: v_mfma_f32_32x32x2_f32, exact fp32), fp32 accumulation.
- * transposed_stride2 = 0: k x k correlation (k = 1 or 3), "same" padding -> y [N][H][W][Co]; optional epilogue
+ * resample = 0: k x k correlation (k = 1 or 3), "same" padding -> y [N][H][W][Co]; optional epilogue
  *   v = acc + noise[H][W] * noise_strength[0] + bias[co]; act (0 linear, 1 lrelu 0.2); * gain; clamp (< 0 off).
- * transposed_stride2 = 1 (k = 3): conv_transpose2d(stride 2, padding 0) -> y [N][2H+1][2W+1][Co], no epilogue.
+ * resample = 1 (k = 3): conv_transpose2d(stride 2, padding 0) -> y [N][2H+1][2W+1][Co], no epilogue.
+ * resample = 2: valid (unpadded) correlation at stride 2 -> y [N][(H-k)/2+1][(W-k)/2+1][Co] with the epilogue: the strided
+ * conv conv2d_resample runs after its low-pass FIR in the down-2 layers (conv2d_resample.py:108-111).
  * zeros128: >= 128 bytes of zeros in device memory, 16-byte aligned (source of the border rows of the LDS-DMA
  * staging).  Ci must be a multiple of 64 (fp16) / 32 (fp32), else P3D_ERR_UNSUPPORTED.             */
 int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype, const float* bias, const float* noise, const float* noise_strength,
                     const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
-                    int32_t kernel_size, int32_t transposed_stride2, int32_t act, float gain, float clamp, p3d_stream_t stream);
+                    int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, p3d_stream_t stream);
 
 /* x [N][HW][Ci] fp16 channels-last, weight [Co][Ci] fp32, styles [N][Ci] fp32 (weight gain already applied),
  * bias [Co] or null -> y [N][Co][HW] fp32 (NCHW); accumulate != 0 adds into y (the skip-image sum).
@@ -183,16 +185,18 @@ int p3d_fir4_bias_act_nhwc(const void* x, const float* f, void* y, int dtype, in
  * b [out] or null, fp32; act 1 = linear, 3 = lrelu(alpha).
  * out_scale carries a constant the caller multiplies the result by (ToRGBLayer's weight_gain, :356).
  *
- * p3d_im2col3x3: the patch matrix torch.nn.functional.unfold(x, 3, padding=1) of the whole batch,
- *   cols[n][c * 9 + ky * 3 + kx][y * w + x] = x[n, c, y + ky - 1, x + kx - 1] (0 outside),
- * x fp32 addressed by ELEMENT strides (NCHW or channels-last storage), cols fp32 contiguous.
+ * p3d_im2col3x3: the 3x3 patch matrix of the whole batch,
+ *   cols[n][c * 9 + ky * 3 + kx][oy * ow + ox] = x[n, c, oy * stride + ky - pad, ox * stride + kx - pad] (0 outside),
+ * oh = (h + 2 pad - 3) / stride + 1.  pad 1 / stride 1 = torch.nn.functional.unfold(x, 3, padding=1); pad 0 / stride 2 feeds the
+ * valid stride-2 conv of the down-2 layers (conv2d_resample.py:108-111).  x fp32 addressed by ELEMENT strides (NCHW or
+ * channels-last storage), cols fp32 contiguous.
  *
  * p3d_noise_bias_act: the tail of SynthesisLayer.forward after the convolution (:326-332) on y [n_img][c][hw] fp32:
  *   y = clamp(act(x + noise[hw] * noise_strength[0] + bias[c]) * gain);  hw % 4 == 0; x may equal y; noise / bias may be null. */
 int p3d_fc_forward(const float* x, const float* w, const float* b, float* y, int32_t n_rows, int32_t in_features, int32_t out_features,
                    int64_t x_row_stride, float weight_gain, float bias_gain, int32_t act, float alpha, float act_gain, float out_scale, p3d_stream_t stream);
-int p3d_im2col3x3(const float* x, float* cols, int32_t n_img, int32_t c, int32_t h, int32_t w, int64_t stride_n, int64_t stride_c,
-                  int64_t stride_y, int64_t stride_x, p3d_stream_t stream);
+int p3d_im2col3x3(const float* x, float* cols, int32_t n_img, int32_t c, int32_t h, int32_t w, int32_t pad, int32_t stride,
+                  int64_t stride_n, int64_t stride_c, int64_t stride_y, int64_t stride_x, p3d_stream_t stream);
 int p3d_noise_bias_act(const float* x, float* y, const float* noise, const float* noise_strength, const float* bias, int32_t n_img,
                        int32_t c, int32_t hw, int32_t act, float alpha, float gain, float clamp, p3d_stream_t stream);
 

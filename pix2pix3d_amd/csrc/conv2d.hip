@@ -46,6 +46,7 @@ struct ConvArgs {
     int64_t w_img_stride;  // elements between images' weight panels (0: shared weights)
     int OH, OW;            // full output size
     int osy, osx;          // output pixel = (i * osy + ooy, j * osx + oox)
+    int isy, isx;          // input pixel of tap (dy, dx) = (i * isy + dy, j * isx + dx)   (2 for the stride-2 'down' convolution)
     int ncls;              // sub-problems solved by this launch (1: plain conv; 4: parity classes of the stride-2 transposed conv)
     struct Cls { int SH, SW, ooy, oox, ntaps; ConvTap taps[9]; } cls[4];     // plain conv uses cls[0] with up to 9 taps; transposed classes have <= 4
     int act;               // 0: none (linear), 1: lrelu(0.2)
@@ -97,6 +98,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
         pok[p] = m < M;
         const int mm = pok[p] ? m : 0;
         pi[p] = mm / kc.SW; pj[p] = mm - pi[p] * kc.SW;
+        pi[p] *= a.isy; pj[p] *= a.isx;                                                     // from here on: the tap-(0,0) input pixel
         poff[p] = ((pi[p] * a.W + pj[p]) * a.Ci + src_chunk * EPC) * (int)sizeof(T);      // < 2^31: one image's activations
         const int co = co0 + srow + 32 * p;
         wok[p] = co < a.Co;
@@ -735,8 +737,10 @@ static int launch_conv(ConvArgs& a, int dtype, hipStream_t s)
 
 extern "C" int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype, const float* bias, const float* noise, const float* noise_strength,
                                const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
-                               int32_t kernel_size, int32_t transposed_stride2, int32_t act, float gain, float clamp, p3d_stream_t stream)
+                               int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, p3d_stream_t stream)
 {
+    const bool transposed_stride2 = (resample == 1), down2 = (resample == 2);
+    P3D_REQUIRE(resample >= 0 && resample <= 2, "conv2d_nhwc: resample must be 0 (same), 1 (transposed x2) or 2 (valid, stride 2)");
     P3D_REQUIRE(x && w && y && zeros128, "conv2d_nhwc: null pointer");
     P3D_REQUIRE(n_img >= 1 && h >= 1 && wdt >= 1 && co >= 1, "conv2d_nhwc: bad sizes");
     P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32, "conv2d_nhwc: dtype must be fp16 or fp32");
@@ -747,8 +751,15 @@ extern "C" int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype,
     ConvArgs a{};
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.noise = noise; a.noise_strength = noise_strength; a.zeros = zeros128;
     a.N = n_img; a.H = h; a.W = wdt; a.Ci = ci; a.Co = co; a.KT = kernel_size * kernel_size; a.w_img_stride = w_img_stride;
-    a.act = act; a.gain = gain; a.clamp = clamp;
+    a.act = act; a.gain = gain; a.clamp = clamp; a.isy = a.isx = 1;
     hipStream_t s = (hipStream_t)stream;
+    if (down2) {                                                     // valid (unpadded) correlation at stride 2: conv2d_resample.py:108-111 after its FIR
+        P3D_REQUIRE(h >= kernel_size && wdt >= kernel_size, "conv2d_nhwc: image smaller than the kernel");
+        a.OH = (h - kernel_size) / 2 + 1; a.OW = (wdt - kernel_size) / 2 + 1; a.osy = a.osx = 1; a.isy = a.isx = 2; a.ncls = 1;
+        a.cls[0].SH = a.OH; a.cls[0].SW = a.OW; a.cls[0].ooy = a.cls[0].oox = 0; a.cls[0].ntaps = a.KT;
+        for (int t = 0; t < a.KT; ++t) a.cls[0].taps[t] = ConvTap{t / kernel_size, t % kernel_size, t};
+        return launch_conv(a, dtype, s);
+    }
     if (!transposed_stride2) {                                       // correlation, "same" padding: input offset = tap - k/2
         a.OH = h; a.OW = wdt; a.osy = a.osx = 1; a.ncls = 1;
         a.cls[0].SH = h; a.cls[0].SW = wdt; a.cls[0].ooy = a.cls[0].oox = 0; a.cls[0].ntaps = a.KT;

@@ -64,25 +64,26 @@ __global__ void __launch_bounds__(256) fc_kernel(const float* __restrict__ x, co
     }
 }
 
-// ---- im2col, 3x3, pad 1: cols[n][ci*9 + t][p] = x[n, ci, py + t/3 - 1, px + t%3 - 1] -------------------------------
-// x is addressed through element strides (NCHW-contiguous or channels-last alike); one thread per (n, ci, p) writes the
-// nine taps, so the nine stores of a wave are each a coalesced run along p.
+// ---- im2col, 3x3: cols[n][ci*9 + t][p] = x[n, ci, oy*stride + t/3 - pad, ox*stride + t%3 - pad] ------------------------
+// x is addressed through element strides (NCHW-contiguous or channels-last alike); one thread per (n, ci, output pixel) writes
+// the nine taps, so the nine stores of a wave are each a coalesced run along p.  pad 1 / stride 1 is F.unfold(x, 3, padding=1);
+// pad 0 / stride 2 is the patch matrix of the valid stride-2 conv that follows the low-pass in the down-2 layers.
 __global__ void __launch_bounds__(256) im2col3x3_kernel(const float* __restrict__ x, float* __restrict__ cols, int N, int C, int H, int W,
-                                                        int64_t sn, int64_t sc, int64_t sy, int64_t sx)
+                                                        int OH, int OW, int pad, int stride, int64_t sn, int64_t sc, int64_t sy, int64_t sx)
 {
-    const int HW = H * W;
+    const int HW = OH * OW;
     const int64_t total = (int64_t)N * C * HW;
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     const int p = (int)(e % HW);
     const int64_t nc = e / HW;
     const int c = (int)(nc % C), n = (int)(nc / C);
-    const int py = p / W, px = p - py * W;
+    const int py = p / OW, px = p - py * OW;
     const float* xb = x + n * sn + c * sc;
     float* cb = cols + ((int64_t)n * C + c) * 9 * HW + p;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        const int iy = py + t / 3 - 1, ix = px + t % 3 - 1;
+        const int iy = py * stride + t / 3 - pad, ix = px * stride + t % 3 - pad;
         const bool ok = (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
         cb[(int64_t)t * HW] = ok ? xb[iy * sy + ix * sx] : 0.f;
     }
@@ -178,16 +179,19 @@ extern "C" int p3d_fc_forward(const float* x, const float* w, const float* b, fl
     return check_launch("fc_forward");
 }
 
-extern "C" int p3d_im2col3x3(const float* x, float* cols, int32_t n_img, int32_t c, int32_t h, int32_t w, int64_t stride_n, int64_t stride_c,
-                             int64_t stride_y, int64_t stride_x, p3d_stream_t stream)
+extern "C" int p3d_im2col3x3(const float* x, float* cols, int32_t n_img, int32_t c, int32_t h, int32_t w, int32_t pad, int32_t stride,
+                             int64_t stride_n, int64_t stride_c, int64_t stride_y, int64_t stride_x, p3d_stream_t stream)
 {
     using namespace p3d;
     P3D_REQUIRE(x && cols, "im2col3x3: null pointer");
     P3D_REQUIRE(n_img >= 1 && c >= 1 && h >= 1 && w >= 1, "im2col3x3: bad sizes");
-    const int64_t total = (int64_t)n_img * c * h * w;
+    P3D_REQUIRE((pad == 0 || pad == 1) && (stride == 1 || stride == 2), "im2col3x3: pad must be 0 or 1, stride 1 or 2");
+    const int oh = (h + 2 * pad - 3) / stride + 1, ow = (w + 2 * pad - 3) / stride + 1;
+    P3D_REQUIRE(h + 2 * pad >= 3 && w + 2 * pad >= 3, "im2col3x3: image smaller than the window");
+    const int64_t total = (int64_t)n_img * c * oh * ow;
     P3D_REQUIRE(total < (1ll << 31) * 256, "im2col3x3: too large");
     hipLaunchKernelGGL(im2col3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, cols, n_img, c, h, w,
-                       stride_n, stride_c, stride_y, stride_x);
+                       oh, ow, pad, stride, stride_n, stride_c, stride_y, stride_x);
     count_launch(FAM_AUX);
     return check_launch("im2col3x3");
 }

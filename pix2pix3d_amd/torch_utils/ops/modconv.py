@@ -22,7 +22,7 @@ _lib.register('p3d_conv2d_nhwc', ctypes.c_int, [_vp] * 3 + [ctypes.c_int] + [_vp
 
 _lib.register('p3d_fir4_bias_act_nhwc', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int] + [_i32] * 9 + [_f32, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _vp])
 _lib.register('p3d_fc_forward', ctypes.c_int, [_vp] * 4 + [_i32] * 3 + [_i64, _f32, _f32, _i32, _f32, _f32, _f32, _vp])
-_lib.register('p3d_im2col3x3', ctypes.c_int, [_vp, _vp] + [_i32] * 4 + [_i64] * 4 + [_vp])
+_lib.register('p3d_im2col3x3', ctypes.c_int, [_vp, _vp] + [_i32] * 6 + [_i64] * 4 + [_vp])
 _lib.register('p3d_noise_bias_act', ctypes.c_int, [_vp] * 5 + [_i32] * 4 + [_f32, _f32, _f32, _vp])
 
 min_pixels = 1               # every layer takes this module (the vendor conv library is never entered: its choices for the small
@@ -111,14 +111,16 @@ def _pad_channels(x, wmod):
     return xp, wp
 
 
-def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None, act=0, gain=1.0, clamp=-1.0):
+def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None, act=0, gain=1.0, clamp=-1.0, down=1):
     """x NHWC [N,Ci,H,W] (channels_last strides), wmod [N or 1][Co][k*k][Ci] of the same dtype -> NHWC, same dtype.
-    k*k = 9: 3x3 "same" correlation, or (transposed) the stride-2 transposed conv [N,Co,2H+1,2W+1]; k*k = 1: 1x1."""
+    k*k = 9: 3x3 "same" correlation, or (transposed) the stride-2 transposed conv [N,Co,2H+1,2W+1], or (down=2) the valid
+    stride-2 correlation [N,Co,(H-3)//2+1,(W-3)//2+1]; k*k = 1: 1x1."""
     assert _is_nhwc(x) and wmod.dtype == x.dtype and wmod.is_contiguous() and wmod.shape[2] in (1, 9)
+    assert down in (1, 2) and not (transposed and down == 2)
     x, wmod = _pad_channels(x, wmod)
     n, ci, h, w = x.shape
     co, k = wmod.shape[1], (3 if wmod.shape[2] == 9 else 1)
-    oh, ow = (2 * h + 1, 2 * w + 1) if transposed else (h, w)
+    oh, ow = (2 * h + 1, 2 * w + 1) if transposed else (((h - k) // 2 + 1, (w - k) // 2 + 1) if down == 2 else (h, w))
     y = torch.empty([n, co, oh, ow], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     assert wmod.shape[0] in (1, n)
     stride = 0 if wmod.shape[0] == 1 else wmod.shape[1] * wmod.shape[2] * wmod.shape[3]
@@ -127,16 +129,89 @@ def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None
     ns = None if noise is None else noise_strength.detach().float().reshape(1).contiguous()
     with _lib.kernel_timer('conv_f16' if x.dtype == torch.float16 else 'conv_f32', x):
         code = _lib.lib().p3d_conv2d_nhwc(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), _lib.DTYPE_CODE[x.dtype], _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns),
-                                          _lib.ptr(_zeros_page(x.device)), n, h, w, ci, co, stride, k, int(transposed), int(act), float(gain), float(clamp),
+                                          _lib.ptr(_zeros_page(x.device)), n, h, w, ci, co, stride, k, (1 if transposed else (2 if down == 2 else 0)), int(act), float(gain), float(clamp),
                                           _lib.stream_of(x))
     _lib.check(code, 'conv2d_nhwc')
     log = _lib.kernel_events.get('conv_flops')
     if log is not None:                                  # bench.py: FLOPs of the launches it is timing (2*Ci*Co*k*k per output / input pixel)
-        log.append((str(x.dtype), 2.0 * n * ci * co * k * k * h * w))
+        log.append((str(x.dtype), 2.0 * n * ci * co * k * k * (oh * ow if down == 2 else h * w)))
     return y
 
 
 conv3x3 = conv2d
+
+
+_plain_weights = {}
+
+
+def plain_layer_supported(x, weight, up, down, activation):
+    """Conv2dLayer calls (networks_stylegan2.py:135-188) the native kernels cover: inference on the device, 1x1 / 3x3, down in {1, 2}."""
+    if not enabled or up != 1 or down not in (1, 2) or not _dense_dev(x) or activation not in ('linear', 'lrelu'):
+        return False
+    k = weight.shape[2]
+    if weight.shape[2] != weight.shape[3] or k not in (1, 3):
+        return False
+    if x.shape[2] * x.shape[3] <= gemm_max_pixels and (x.dtype != torch.float32 or (x.shape[2] * x.shape[3]) % (4 * down * down) != 0):
+        return False                                     # the small (GEMM) route is fp32 and wants hw % 4 == 0 after decimation
+    return _no_grad_needed(x, weight)
+
+
+def _plain_small(x, weight, bias, weight_gain, resample_filter, down, padding, act, act_gain, clamp):
+    """Low-resolution Conv2dLayer: one library GEMM with shared weights, [Co, Ci*k*k] @ [N, Ci*k*k, OH*OW] (im2col in one launch)."""
+    co, ci, k, _ = weight.shape
+    n, _, h, w = x.shape
+    key = (weight.data_ptr(), weight._version, 'gemm', float(weight_gain))
+    wm = _plain_weights.get((id(weight), 'gemm'))
+    if wm is None or wm[0] != key:
+        wm = (key, (weight.detach().float() * float(weight_gain)).reshape(co, ci * k * k).contiguous())
+        _plain_weights[(id(weight), 'gemm')] = wm
+    wm = wm[1]
+    fw = resample_filter.shape[-1]
+    p0, p1 = padding + (fw - down + 1) // 2, padding + (fw - down) // 2
+    if k == 1:
+        if down == 2:
+            x = upfirdn2d.upfirdn2d(x, resample_filter, down=down, padding=[p0, p1, p0, p1])
+        oh, ow = x.shape[2], x.shape[3]
+        cols = x.contiguous().reshape(n, ci, oh * ow)
+    elif down == 1:
+        oh, ow = h, w
+        cols = im2col3x3(x)
+    else:
+        x = upfirdn2d.upfirdn2d(x, resample_filter, padding=[p0, p1, p0, p1])
+        oh, ow = (x.shape[2] - 3) // 2 + 1, (x.shape[3] - 3) // 2 + 1
+        cols = im2col3x3(x, pad=0, stride=2)
+    y = torch.matmul(wm, cols).reshape(n, co, oh, ow)
+    return noise_bias_act(y, bias, None, None, act, act_gain, clamp)
+
+
+def plain_layer(x, weight, bias, weight_gain, resample_filter, down, padding, act, act_gain, clamp):
+    """Conv2dLayer.forward on the MFMA kernels: weight * gain re-laid tap-major once per weight version (shared across the
+    batch), then conv2d_resample's routing (conv2d_resample.py:96-136): plain "same" conv; down = 2 with a 3x3: low-pass FIR
+    at full rate then the valid stride-2 conv; down = 2 with a 1x1: FIR + decimate, then the 1x1.  Bias, activation, gain
+    and clamp ride in the conv epilogue.  Input any dense layout, output channels-last."""
+    co, ci, k, _ = weight.shape
+    if x.shape[2] * x.shape[3] <= gemm_max_pixels:
+        return _plain_small(x, weight, bias, weight_gain, resample_filter, down, padding, act, act_gain, clamp)
+    key = (weight.data_ptr(), weight._version, x.dtype, float(weight_gain))
+    wmod = _plain_weights.get(id(weight))
+    if wmod is None or wmod[0] != key:
+        ones = torch.ones([1, ci], dtype=torch.float32, device=weight.device)
+        wmod = (key, modulate_weights(weight, ones, demodulate=False, pre_scale=float(weight_gain), dtype=x.dtype))
+        _plain_weights[id(weight)] = wmod
+    wmod = wmod[1]
+    x = x.contiguous(memory_format=torch.channels_last)
+    act_idx = {'linear': 0, 'lrelu': 1}[act]
+    clampv = -1.0 if clamp is None else float(clamp)
+    if down == 1:
+        assert padding == k // 2
+        return conv2d(x, wmod, bias=bias, act=act_idx, gain=act_gain, clamp=clampv)
+    fw = resample_filter.shape[-1]
+    p0, p1 = padding + (fw - down + 1) // 2, padding + (fw - down) // 2
+    if k == 1:
+        x = upfirdn2d.upfirdn2d(x, resample_filter, down=down, padding=[p0, p1, p0, p1])
+        return conv2d(x, wmod, bias=bias, act=act_idx, gain=act_gain, clamp=clampv)
+    x = upfirdn2d.upfirdn2d(x, resample_filter, padding=[p0, p1, p0, p1])
+    return conv2d(x, wmod, bias=bias, act=act_idx, gain=act_gain, clamp=clampv, down=2)
 
 
 def fc_supported(x, weight, bias, activation):
@@ -162,11 +237,12 @@ def fc(x, weight, bias, weight_gain, bias_gain, activation='linear', out_scale=1
     return y
 
 
-def im2col3x3(x):
-    """[N, C, H, W] fp32 in any dense layout -> [N, C*9, H*W] (= F.unfold(x, 3, padding=1)), one launch for the batch."""
+def im2col3x3(x, pad=1, stride=1):
+    """[N, C, H, W] fp32 in any dense layout -> [N, C*9, OH*OW] (pad 1, stride 1: = F.unfold(x, 3, padding=1)), one launch for the batch."""
     n, c, h, w = x.shape
-    cols = torch.empty([n, c * 9, h * w], dtype=torch.float32, device=x.device)
-    code = _lib.lib().p3d_im2col3x3(_lib.ptr(x), _lib.ptr(cols), n, c, h, w, x.stride(0), x.stride(1), x.stride(2), x.stride(3), _lib.stream_of(x))
+    oh, ow = (h + 2 * pad - 3) // stride + 1, (w + 2 * pad - 3) // stride + 1
+    cols = torch.empty([n, c * 9, oh * ow], dtype=torch.float32, device=x.device)
+    code = _lib.lib().p3d_im2col3x3(_lib.ptr(x), _lib.ptr(cols), n, c, h, w, pad, stride, x.stride(0), x.stride(1), x.stride(2), x.stride(3), _lib.stream_of(x))
     _lib.check(code, 'im2col3x3')
     return cols
 

@@ -128,6 +128,10 @@ class Conv2dLayer(torch.nn.Module):
                 self.bias = None
 
     def forward(self, x, gain=1):
+        clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        if modconv.plain_layer_supported(x, self.weight, self.up, self.down, self.activation):
+            return modconv.plain_layer(x, self.weight, self.bias, self.weight_gain, self.resample_filter, self.down, self.padding,
+                                       self.activation, self.act_gain * gain, clamp)
         w = self.weight * self.weight_gain
         b = self.bias.to(x.dtype) if self.bias is not None else None
         x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
@@ -458,6 +462,9 @@ class DiscriminatorBlock(torch.nn.Module):
             force_fp32 = True
         dtype = torch.float16 if self.use_fp16 and not force_fp32 else torch.float32
         fmt = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
+        probe = x if x is not None else img
+        if native_channels_last and modconv.enabled and probe.is_cuda and not torch.is_grad_enabled() and self.resolution ** 2 > modconv.gemm_max_pixels:
+            fmt = torch.channels_last      # inference on the device: the layout the MFMA conv kernels consume and produce
         if x is not None:
             misc.assert_shape(x, [None, self.in_channels, self.resolution, self.resolution])
             x = x.to(dtype=dtype, memory_format=fmt)

@@ -33,6 +33,13 @@ class EqualConv2d(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros(out_channel)) if bias else None
 
     def forward(self, input):
+        co, ci, kh, kw = self.weight.shape
+        if self.padding == 0 and tuple(input.shape[2:]) == (kh, kw):
+            # the Encoder's 4x4 projector sees a 4x4 image: a plain matrix product (and no trip through the vendor conv library)
+            y = input.reshape(input.shape[0], ci * kh * kw) @ (self.weight * self.scale).reshape(co, ci * kh * kw).t()
+            if self.bias is not None:
+                y = y + self.bias
+            return y.reshape(input.shape[0], co, 1, 1)
         return F.conv2d(input, self.weight * self.scale, bias=self.bias, stride=self.stride, padding=self.padding)
 
     def __repr__(self):

@@ -34,6 +34,13 @@ def test_fc_matches_formula(hip_lib, n, in_f, out_f, act):
     assert rel_err(y0.cpu().numpy(), ref0.cpu().numpy()) < 2e-6
 
 
+@pytest.mark.parametrize('h,w', [(9, 9), (17, 12)])
+def test_im2col_strided_is_unfold(hip_lib, h, w):
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    x = torch.randn(2, 5, h, w, device='cuda').to(memory_format=torch.channels_last)
+    assert torch.equal(modconv.im2col3x3(x, pad=0, stride=2), F.unfold(x.contiguous(), kernel_size=3, padding=0, stride=2))
+
+
 @pytest.mark.parametrize('layout', ['nchw', 'nhwc'])
 @pytest.mark.parametrize('n,c,h,w', [(4, 512, 4, 4), (2, 37, 9, 5), (1, 8, 32, 32)])
 def test_im2col_is_unfold(hip_lib, layout, n, c, h, w):
@@ -136,3 +143,29 @@ def test_fused_fir_any_filter(hip_lib, dtype, separable, size):
     ref = (F.leaky_relu(ref, 0.2) * 1.3).clamp(-2.5, 2.5)
     assert y.shape == ref.shape and y.dtype == dtype
     assert rel_err(y.float().cpu().numpy(), ref.cpu().numpy()) < (2e-3 if dtype == torch.float16 else 1e-5)
+
+
+@pytest.mark.parametrize('cin,cout,k,down,res', [(64, 64, 3, 1, 64), (64, 128, 3, 2, 64), (64, 128, 1, 2, 64), (6, 64, 1, 1, 64), (96, 40, 3, 2, 50),
+                                                 (48, 40, 3, 1, 16), (48, 40, 3, 2, 16), (48, 40, 1, 2, 8), (40, 24, 3, 2, 4)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_plain_conv2d_layer_native_route(hip_lib, cin, cout, k, down, res, dtype):
+    """Conv2dLayer (the Encoder / discriminator building block) on the MFMA kernels vs the same module on the generic route:
+    "same" 3x3, FIR + valid stride-2 3x3, FIR-decimate + 1x1 (skip branch), 1x1 fromrgb with 6 input channels."""
+    from pix2pix3d_amd.training import networks_stylegan2 as ns2
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    torch.manual_seed(cin + cout + k + down)
+    layer = ns2.Conv2dLayer(cin, cout, kernel_size=k, activation='lrelu', down=down, conv_clamp=256 if dtype == torch.float16 else None).cuda().eval()
+    with torch.no_grad():
+        layer.bias.normal_()
+    x = torch.randn(2, cin, res, res, device='cuda').to(dtype)
+    with torch.no_grad():
+        if not modconv.plain_layer_supported(x, layer.weight, 1, down, 'lrelu'):
+            pytest.skip('low-resolution GEMM route is fp32 only')
+        y = layer(x, gain=0.7)
+        modconv.enabled = False
+        try:
+            ref = layer(x.float(), gain=0.7)            # fp32 reference of the same (fp16-rounded) input
+        finally:
+            modconv.enabled = True
+    assert y.shape == ref.shape and y.dtype == dtype
+    assert rel_err(y.float().cpu().numpy(), ref.cpu().numpy()) < (3e-3 if dtype == torch.float16 else 1e-5)
