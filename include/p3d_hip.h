@@ -124,6 +124,28 @@ int p3d_render_forward(const float* planes_cl, const float* decoder, const float
                        const p3d_render_desc* desc, float* feat, float* depth, float* wsum, uint32_t* minmax_ws,
                        float* dbg_fine, float* dbg_wcoarse, p3d_stream_t stream);
 
+/* ---- backward of p3d_render_forward (training configs) ------------------------------------------
+ * What autograd derives for ImportanceRenderer.forward (renderer.py:88-140) in the reference, as two recomputing launches
+ * (csrc/render_bwd.hip): the forward sweep again, driven by g_feat, hands every sample its compositing scalars on a tape; a
+ * point-wise pass re-evaluates gather + MLPs per sample and back-propagates on the matrix cores.  Importance depths are constants
+ * (renderer.py:198, 211).  Gradients w.r.t. the rays and w.r.t. the depth output are not produced (the training losses use
+ * neither; the host falls back to the tensor-op formulation if asked for them).
+ *   decoder_bwd : p3d_render_bwd_decoder_floats() floats from p3d_pack_decoder_bwd (same raw parameters as p3d_pack_decoder)
+ *   g_feat [N*M][32*n_nets] = dL/dfeat, g_wsum [N*M] = dL/dwsum or null; rays / uniforms / limits exactly as in the forward call
+ *   tape_intervals [N*M][S-1][4], tape_samples [N*M][S][4] fp32 scratch (S = S_c + S_f), 16-byte aligned
+ *   d_planes_cl [N][3][H][W][32] <- dL/dplanes (channels-last, zeroed here, accumulated with atomics)
+ *   d_decoder [p3d_render_grad_decoder_floats()] <- per net (stride 4260 floats): dW1 [64][32] @0, db1 [64] @2048, dW2 [33][64]
+ *   @2112, db2 [33] @4224, gradients of the EFFECTIVE weights w * lr_mul / sqrt(fan_in), b * lr_mul (multiply by the same gains
+ *   for the raw parameters).                                                                                              */
+int p3d_render_bwd_decoder_floats(void);
+int p3d_render_grad_decoder_floats(void);
+int p3d_pack_decoder_bwd(const float* w1_a, const float* w2_a, const float* w1_b, const float* w2_b, int32_t n_nets, float lr_mul,
+                         float* packed_bwd, p3d_stream_t stream);
+int p3d_render_backward(const float* planes_cl, const float* decoder, const float* decoder_bwd, const float* ray_o, const float* ray_d,
+                        const float* u_coarse, const float* u_fine, const float* t_start, const float* t_end,
+                        const p3d_render_desc* desc, const float* g_feat, const float* g_wsum, float* tape_intervals, float* tape_samples,
+                        float* d_planes_cl, float* d_decoder, p3d_stream_t stream);
+
 /* coords [N*P][3] -> rgb [N*P][32*n_nets], sigma [N*P]  (G.sample / G.sample_mixed, extract_mesh) */
 int p3d_sample_points(const float* planes_cl, const float* decoder, const float* coords, const p3d_render_desc* desc,
                       int32_t pts_per_img, float* rgb, float* sigma, p3d_stream_t stream);

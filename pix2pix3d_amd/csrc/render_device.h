@@ -1,0 +1,499 @@
+// Device-side pieces of the fused tri-plane ray-marcher shared by render.hip (inference / forward) and render_bwd.hip
+// (training: forward with tape + point-wise backward).  See render.hip for the mapping notes.
+#pragma once
+#include "p3d_common.h"
+#include <math.h>
+
+namespace p3d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4  __attribute__((ext_vector_type(4)));
+
+// ---- decoder stream layout (floats); identical in the packed global buffer and in LDS ------------
+constexpr int kNetStride = 4096;                 // per net: 64 MFMA steps x 64 lanes
+constexpr int OFF_B1   = 2 * kNetStride;         // [net][half][32]  hidden biases in accumulator order
+constexpr int OFF_B2   = OFF_B1 + 128;           // [net][half][16]  colour biases in accumulator order
+constexpr int OFF_W2S  = OFF_B2 + 64;            // [half][32]       density row of the density net
+constexpr int OFF_B2S  = OFF_W2S + 64;           // [1]              density bias
+constexpr int kDecoderFloats = 8464;             // padded to 16 floats
+constexpr int kPitch = 33;                       // LDS pitch of the per-wave [sample][ray] tile
+constexpr int kMaxS = 64;                        // max coarse / fine samples per ray
+constexpr int kWaveTile = kMaxS * kPitch + 128;  // + two 64-float scratch rows
+constexpr int kWavesPerBlock = 8;
+
+struct RenderArgs {
+    const float* planes;      // [N][3][H][W][32]
+    const float* decoder;     // kDecoderFloats, see p3d_pack_decoder
+    const float* ray_o;       // [N*M][3]
+    const float* ray_d;       // [N*M][3]
+    const float* u_coarse;    // [N*M][Sc]
+    const float* u_fine;      // [N*M][Sf]
+    const float* t_start;     // optional [N*M] per-ray limits ('auto' ray range), else null
+    const float* t_end;
+    float* feat;              // [N*M][n_nets*32]
+    float* depth;             // [N*M]   (unclamped; p3d_render_clamp_depth finishes it)
+    float* wsum;              // [N*M]
+    float* dbg_fine;          // optional [N*M][Sf] sorted fine depths
+    float* dbg_wcoarse;       // optional [N*M][Sc-1] coarse weights
+    // training tape (render_bwd.hip): upstream gradients in, per-interval / per-sample records out
+    const float* g_feat;      // [N*M][n_nets*32] dL/dfeat
+    const float* g_wsum;      // optional [N*M] dL/dwsum
+    float* tape_i;            // [N*M][S-1][4]  alpha, T (before the interval), colour part of dL/dw, sigma_mid
+    float* tape_s;            // [N*M][S][4]    z, 0.5 (w[k-1] + w[k]), dL/dsigma_k, unused
+    unsigned* minmax;         // [2] ordered-uint encoded min / max of all sample depths
+    int total_rays, rays_per_img, res, H, W, Sc, Sf;          // res: image side when the rays form a res x res raster (else 0)
+    int64_t plane_stride, pix_stride, img_stride;   // texel (n, p, y, x) starts at n*img_stride + p*plane_stride + (y*W + x)*pix_stride
+    unsigned plane_bytes, pix_bytes, img_bytes, planes_total_bytes;   // the same strides in bytes (everything fits 32 bits, checked on the host)
+    float ray_start, ray_end, coord_scale, lin_step;
+    int disparity, white_back, sem_sigmoid;
+};
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ unsigned order_key(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float order_unkey(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+// Hardware transcendentals (v_exp_f32 = 2^x, v_log_f32 = log2, ~1 ulp): two instructions per exp/log instead of the
+// range-checked library expansions; arguments here are always in the safe range (no denormal inputs matter).
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ float softplus20(float x) {      // torch.nn.Softplus(beta=1, threshold=20)
+    return x > 20.f ? x : fast_log(1.f + fast_exp(x));
+}
+__device__ __forceinline__ float sigmoid_clamped(float x) {  // sigmoid(x) * (1 + 2*0.001) - 0.001
+    return fmaf(__builtin_amdgcn_rcpf(1.f + fast_exp(-x)), 1.002f, -0.001f);
+}
+
+// Depth of coarse sample i on ray g (renderer.py:169-192), fp32 with the same operation order.
+__device__ __forceinline__ float coarse_depth(const RenderArgs& a, int g, int i, float u)
+{
+#pragma clang fp contract(off)
+    const int S = a.Sc;
+    if (a.t_start) {                                      // tensor limits: math_utils.linspace (math_utils.py:101-118)
+        const float s = a.t_start[g], e = a.t_end[g];
+        const float t = (float)i / (float)(S - 1);
+        const float z = s + t * (e - s);
+        return z + u * ((e - s) / (float)(S - 1));
+    }
+    if (a.disparity) {
+        const float step = 1.f / (float)(S - 1);
+        float t = (i < S / 2) ? 0.f + step * (float)i : 1.f - step * (float)(S - i - 1);
+        t = t + u * step;
+        return 1.f / (1.f / a.ray_start * (1.f - t) + 1.f / a.ray_end * t);
+    }
+    const float step = a.lin_step;                                          // (ray_end - ray_start) / (S - 1) in fp32, as torch.linspace
+    const float lin = (i < S / 2) ? a.ray_start + step * (float)i : a.ray_end - step * (float)(S - i - 1);
+    return lin + u * step;
+}
+
+// ---- tri-plane gather: mean over planes of the bilinear sample, channels [16h, 16h+16) ------------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ void gather_features(const RenderArgs& a, rsrc_t rsrc, unsigned img_off, int h,
+                                                float px, float py, float pz, float (&feat)[16])
+{
+    const int W = a.W, H = a.H;
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        // inverse plane bases (renderer.py:23-53): plane 0 -> (x, y), plane 1 -> (x, z), plane 2 -> (z, x)
+        const float gx = (p == 2) ? pz : px;
+        const float gy = (p == 0) ? py : (p == 1 ? pz : px);
+        // grid_sample(align_corners=False): pixel = ((g + 1) * size - 1) / 2, zero padding
+        float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+        float iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+        ix = fminf(fmaxf(ix, -2.f), (float)W + 1.f);       // keeps the int conversion sane; all taps of a
+        iy = fminf(fmaxf(iy, -2.f), (float)H + 1.f);       // clamped coordinate are out of range anyway
+        const float fx = floorf(ix), fy = floorf(iy);
+        const int x0 = (int)fx, y0 = (int)fy;
+        const float wx1 = ix - fx, wx0 = (fx + 1.f) - ix;
+        const float wy1 = iy - fy, wy0 = (fy + 1.f) - iy;
+        const bool vx0 = (x0 >= 0) & (x0 < W), vx1 = (x0 + 1 >= 0) & (x0 + 1 < W);
+        const bool vy0 = (y0 >= 0) & (y0 < H), vy1 = (y0 + 1 >= 0) & (y0 + 1 < H);
+        const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x0 + 1, 0), W - 1);
+        const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y0 + 1, 0), H - 1);
+        const float w00 = (vx0 & vy0) ? wx0 * wy0 : 0.f;    // nw
+        const float w10 = (vx1 & vy0) ? wx1 * wy0 : 0.f;    // ne
+        const float w01 = (vx0 & vy1) ? wx0 * wy1 : 0.f;    // sw
+        const float w11 = (vx1 & vy1) ? wx1 * wy1 : 0.f;    // se
+        // 32-bit byte offsets into one buffer resource (wave-uniform descriptor): no 64-bit address arithmetic per tap
+        const unsigned pbase = img_off + (unsigned)p * a.plane_bytes + (unsigned)h * 64u;
+        const unsigned o00 = pbase + __umul24(__umul24(cy0, W) + cx0, a.pix_bytes);
+        const unsigned o10 = pbase + __umul24(__umul24(cy0, W) + cx1, a.pix_bytes);
+        const unsigned o01 = pbase + __umul24(__umul24(cy1, W) + cx0, a.pix_bytes);
+        const unsigned o11 = pbase + __umul24(__umul24(cy1, W) + cx1, a.pix_bytes);
+        f32x4 v00[4], v10[4], v01[4], v11[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v00[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o00 + 16 * q, 0, 0));
+            v10[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o10 + 16 * q, 0, 0));
+            v01[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o01 + 16 * q, 0, 0));
+            v11[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o11 + 16 * q, 0, 0));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s = v00[q][e] * w00;
+                s = fmaf(v10[q][e], w10, s);
+                s = fmaf(v01[q][e], w01, s);
+                s = fmaf(v11[q][e], w11, s);
+                acc[q * 4 + e] += s;
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) feat[c] = acc[c] * (1.f / 3.f);
+}
+
+// ---- decoder pieces -------------------------------------------------------------------------------
+// Layer 1 of net `n` for this wave's 32 samples: returns the 64 hidden units (post-softplus) as two
+// accumulator tiles; lane (j,h) holds hidden unit 32t + (r&3) + 8(r>>2) + 4h of sample j in tile[t][r].
+__device__ __forceinline__ void mlp_layer1(const float* lds, int n, int lane, int h, const float (&feat)[16],
+                                           f32x16& h0, f32x16& h1)
+{
+    const f32x4* b1 = (const f32x4*)(lds + OFF_B1 + (n * 2 + h) * 32);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v0 = b1[q], v1 = b1[4 + q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h0[q * 4 + e] = v0[e]; h1[q * 4 + e] = v1[e]; }
+    }
+    const f32x4* wv = (const f32x4*)(lds + n * kNetStride) + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 a0 = wv[q * 64], a1 = wv[(4 + q) * 64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], feat[q * 4 + e], h0, 0, 0, 0);
+            h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], feat[q * 4 + e], h1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { h0[r] = softplus20(h0[r]); h1[r] = softplus20(h1[r]); }
+}
+
+// Layer 2 colour rows (decoder outputs 1..32) of net `n`: lane (j,h) gets channel (r&3)+8(r>>2)+4h in out[r].
+__device__ __forceinline__ void mlp_layer2(const float* lds, int n, int lane, int h, const f32x16& h0, const f32x16& h1, f32x16& out)
+{
+    const f32x4* b2 = (const f32x4*)(lds + OFF_B2 + (n * 2 + h) * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = b2[q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[q * 4 + e] = v[e];
+    }
+    const f32x4* wv = (const f32x4*)(lds + n * kNetStride) + 8 * 64 + lane;      // steps 32..63
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const f32x4 a = wv[q * 64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int s = q * 4 + e;
+            const float b = (s < 16) ? h0[s] : h1[s - 16];
+            out = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b, out, 0, 0, 0);
+        }
+    }
+}
+
+// Density row (decoder output 0) of the density net from its hidden units; reduced over the two halves.
+__device__ __forceinline__ float mlp_sigma(const float* lds, int h, const f32x16& h0, const f32x16& h1)
+{
+    const f32x4* w = (const f32x4*)(lds + OFF_W2S + h * 32);
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v0 = w[q], v1 = w[4 + q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s = fmaf(v0[e], h0[q * 4 + e], s); s = fmaf(v1[e], h1[q * 4 + e], s); }
+    }
+    s += __shfl_xor(s, 32, 64);
+    return s + lds[OFF_B2S];
+}
+
+// ---- importance sampling for one ray, wave-cooperative (renderer.py:194-253) ----------------------
+// lane i holds coarse weight w_i (i < Sc-1) and coarse depth z_i (i < Sc); lane j returns fine depth j
+// (unsorted), +inf for j >= Sf.  sA / sB: two 64-float LDS scratch rows of this wave.
+__device__ __forceinline__ float importance_depth(int Sc, int Sf, int lane, float w_i, float z_i, float u, float* sA, float* sB)
+{
+#pragma clang fp contract(off)
+    const float ninf = -INFINITY;
+    const float wi  = (lane < Sc - 1) ? w_i : ninf;
+    float wl = __shfl_up(wi, 1, 64);  if (lane == 0) wl = ninf;
+    const float mp = fmaxf(wl, wi);                        // max_pool1d(k=2, s=1, pad=1): Sc values
+    const float mpn = __shfl_down(mp, 1, 64);
+    const float ap = (mp + mpn) / 2.f;                     // avg_pool1d(k=2, s=1): Sc-1 values
+    const float wk = (ap + 0.01f) + 1e-5f;                 // "+ 0.01" then sample_pdf's "+ eps"
+    const float zn = __shfl_down(z_i, 1, 64);
+    const float zmid = 0.5f * (z_i + zn);                  // bins: Sc-1 midpoints
+    const int nw = Sc - 3;                                 // pdf entries = smoothed[1:-1]
+    wave_sync();
+    if (lane >= 1 && lane <= nw) sA[lane - 1] = wk;
+    if (lane <= Sc - 2) sB[lane] = zmid;
+    wave_sync();
+    float total = 0.f;
+    for (int k = 0; k < nw; ++k) total = total + sA[k];
+    wave_sync();
+    if (lane < nw) sA[lane] = sA[lane] / total;
+    wave_sync();
+    // cdf_0 = 0, cdf_{k+1} = cdf_k + pdf_k (Sc-2 entries); inds = #{cdf <= u} (searchsorted right=True)
+    float cdf = 0.f, cb = 0.f, zb = sB[0], ca = 0.f, za = 0.f;
+    bool found = false;
+    for (int k = 0; k <= nw; ++k) {
+        if (k > 0) cdf = cdf + sA[k - 1];
+        const float zk = sB[k];
+        if (cdf <= u) { cb = cdf; zb = zk; }
+        else if (!found) { ca = cdf; za = zk; found = true; }
+    }
+    if (!found) { ca = cb; za = zb; }                      // above clamps to the last bin
+    float denom = ca - cb;
+    if (denom < 1e-5f) denom = 1.f;
+    const float t = (u - cb) / denom;
+    const float z = zb + t * (za - zb);
+    return (lane < Sf) ? z : INFINITY;
+}
+
+__device__ __forceinline__ float bitonic_sort64(float v, int lane)
+{
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const float o = __shfl_xor(v, j, 64);
+            const bool up = ((lane & k) == 0);
+            const bool lower = ((lane & j) == 0);
+            v = (lower == up) ? fminf(v, o) : fmaxf(v, o);
+        }
+    }
+    return v;
+}
+
+// ---- the fused kernel -------------------------------------------------------------------------------
+// TAPE = false: the inference / forward kernel.  TAPE = true: the same sweep driven by dL/dfeat instead of writing feat: it records, per
+// ray, what the point-wise backward kernel needs (sample depth, colour weight 0.5 (w[k-1] + w[k]), dL/dsigma_k) — see render_bwd.hip.
+template <int NNETS, bool TAPE>
+__global__ void __launch_bounds__(kWavesPerBlock * 64, 2)
+render_forward_kernel(RenderArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+
+    {   // decoder stream -> LDS (straight copy, 16 B per lane)
+        const f32x4* src = (const f32x4*)a.decoder;
+        f32x4* dst = (f32x4*)lds;
+        for (int i = tid; i < kDecoderFloats / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    float* tile = lds + kDecoderFloats + wave * kWaveTile;      // [sample][kPitch] coarse weights, then fine depths
+    float* sA = tile + kMaxS * kPitch;
+    float* sB = sA + 64;
+    const int SN = NNETS - 1;                                    // density comes from the last net (triplane_cond.py:958)
+    const int Sc = a.Sc, Sf = a.Sf;
+
+    // ---- ray -> (workgroup, wave, lane) assignment -------------------------------------------------------------
+    // Rays of one pixel COLUMN project onto the same texels of the (x,z) plane, rays of one pixel ROW onto the same
+    // texels of the (z,y) plane.  Workgroup b runs on XCD b % 8 (private L2), so when the image is R x R with
+    // R = 16 * ns and ns | 8, XCD k is given the 16-pixel-wide column strip k % ns of every image: the (x,z) texels a
+    // strip needs (~1 MB per image) stay in that XCD's L2 for all its rows instead of being re-fetched by 8 L2s.
+    // A workgroup is a 16 x 16 pixel block, a wave two 16-pixel rows of it (same row => same (z,y) texels: one fetch
+    // serves 16 lanes).  Any other shape falls back to consecutive rays.
+    int ray0 = (blockIdx.x * kWavesPerBlock + wave) * 32;        // linear assignment (and the bound for 'live')
+    int g_lane = ray0 + j;
+    {
+        const int R = a.res;
+        const int ns = R >> 4;
+        if (R > 0 && (R & 15) == 0 && ns <= 8 && (8 % ns) == 0 && a.rays_per_img == R * R && ((a.total_rays / 256) & 7) == 0) {
+            const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+            const int strip = xcd % ns, sub = xcd / ns, per = 8 / ns;         // `per` XCDs share a strip
+            const int blk = slot * per + sub;                                 // (image, row block) index within the strip
+            const int n_i = blk / ns, rb = blk - n_i * ns;                    // ns row blocks of 16 rows per image
+            const int row = rb * 16 + wave * 2 + (j >> 4), col = strip * 16 + (j & 15);
+            g_lane = n_i * a.rays_per_img + row * R + col;
+            ray0 = 0;                                                         // every lane is a real ray in this mode
+        }
+    }
+    if (ray0 >= a.total_rays) return;
+    const int g = min(g_lane, a.total_rays - 1);                 // tail lanes shadow the last ray, never store
+    const bool live = g_lane < a.total_rays;
+    const int n_img = g / a.rays_per_img;
+    const rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.planes, 0, a.planes_total_bytes, 0x00020000);
+    const unsigned img = (unsigned)n_img * a.img_bytes;
+    const float ox = a.ray_o[g * 3 + 0], oy = a.ray_o[g * 3 + 1], oz = a.ray_o[g * 3 + 2];
+    const float dx = a.ray_d[g * 3 + 0], dy = a.ray_d[g * 3 + 1], dz = a.ray_d[g * 3 + 2];
+    const float cs = a.coord_scale;
+    const float* uc = a.u_coarse + (size_t)g * Sc;
+
+    // ------------------------------ phase A: coarse densities -> weights ------------------------------
+    {
+        float T = 1.f, z_prev = 0.f, s_prev = 0.f;
+        for (int i = 0; i < Sc; ++i) {
+            const float z = coarse_depth(a, g, i, uc[i]);
+            float feat[16];
+            gather_features(a, rsrc, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
+            f32x16 h0, h1;
+            mlp_layer1(lds, SN, lane, h, feat, h0, h1);
+            const float sigma = mlp_sigma(lds, h, h0, h1);
+            if (i > 0) {
+                const float dens = softplus20(0.5f * (s_prev + sigma) - 1.f);
+                const float alpha = 1.f - fast_exp(-dens * (z - z_prev));
+                const float w = alpha * T;
+                T *= (1.f - alpha + 1e-10f);
+                if (h == 0) tile[(i - 1) * kPitch + j] = w;
+            }
+            z_prev = z; s_prev = sigma;
+        }
+    }
+    wave_sync();
+
+    // ------------------------------ phase B: importance depths, sorted --------------------------------
+    for (int r = 0; r < 32; ++r) {
+        const int gr = __shfl(g, r, 64);                                         // global index of the wave's r-th ray (wave-uniform)
+        const bool r_live = __shfl((int)live, r, 64) != 0;
+        const float w_i = (lane < Sc - 1) ? tile[lane * kPitch + r] : 0.f;
+        const float z_i = (lane < Sc) ? coarse_depth(a, gr, lane, a.u_coarse[(size_t)gr * Sc + lane]) : 0.f;
+        const float u   = (lane < Sf) ? a.u_fine[(size_t)gr * Sf + lane] : 2.f;
+        if (a.dbg_wcoarse && lane < Sc - 1 && r_live) a.dbg_wcoarse[(size_t)gr * (Sc - 1) + lane] = w_i;
+        float zf = importance_depth(Sc, Sf, lane, w_i, z_i, u, sA, sB);
+        zf = bitonic_sort64(zf, lane);
+        wave_sync();
+        if (lane < Sf) tile[lane * kPitch + r] = zf;
+        if (a.dbg_fine && lane < Sf && r_live) a.dbg_fine[(size_t)gr * Sf + lane] = zf;
+    }
+    wave_sync();
+
+    // ------------------------------ phase C: merged decode + composite --------------------------------
+    float acc[NNETS][16], prev[NNETS][16];       // TAPE: acc holds dL/dC (= 2 dL/dfeat) of this lane's 16 channels per net
+#pragma unroll
+    for (int n = 0; n < NNETS; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[n][r] = TAPE ? 2.f * a.g_feat[(size_t)g * (NNETS * 32) + n * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
+            prev[n][r] = 0.f;
+        }
+    float4* const tape_i = TAPE ? (float4*)a.tape_i + (size_t)g * (Sc + Sf - 1) : nullptr;
+    float4* const tape_s = TAPE ? (float4*)a.tape_s + (size_t)g * (Sc + Sf) : nullptr;
+    float T = 1.f, z_prev = 0.f, s_prev = 0.f, w_sum = 0.f, wz_sum = 0.f, z_first = 0.f;
+    int ic = 0, jf = 0;
+    float zc = coarse_depth(a, g, 0, uc[0]);
+    float zf = (Sf > 0) ? tile[j] : INFINITY;
+    const int S = Sc + Sf;
+    for (int k = 0; k < S; ++k) {
+        const bool take_c = (zc <= zf);
+        const float z = take_c ? zc : zf;
+        if (take_c) { ++ic; zc = (ic < Sc) ? coarse_depth(a, g, ic, uc[ic]) : INFINITY; }
+        else        { ++jf; zf = (jf < Sf) ? tile[jf * kPitch + j] : INFINITY; }
+
+        float feat[16];
+        gather_features(a, rsrc, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
+        // The density net goes first: its sigma closes interval k-1 (weight w), after which every net's
+        // colours are folded into the accumulators as soon as its layer 2 retires — only `prev` (the
+        // other end of the midpoint rule) stays live across samples.
+        float sigma = 0.f, hw = 0.f;
+        float t_alpha = 0.f, t_T = 0.f, t_sm = 0.f, t_A = 0.f;               // TAPE: record of interval k-1
+#pragma unroll
+        for (int idx = 0; idx < NNETS; ++idx) {
+            const int n = (idx == 0) ? SN : idx - 1;
+            f32x16 h0, h1, o;
+            mlp_layer1(lds, n, lane, h, feat, h0, h1);
+            if (idx == 0) {
+                sigma = mlp_sigma(lds, h, h0, h1);
+                if (k == 0) z_first = z;
+                else {
+                    const float dens = softplus20(0.5f * (s_prev + sigma) - 1.f);
+                    const float alpha = 1.f - fast_exp(-dens * (z - z_prev));
+                    const float w = alpha * T;
+                    if (TAPE) { t_alpha = alpha; t_T = T; t_sm = 0.5f * (s_prev + sigma); }
+                    T *= (1.f - alpha + 1e-10f);
+                    hw = 0.5f * w;
+                    w_sum += w;
+                    wz_sum = fmaf(w, 0.5f * (z_prev + z), wz_sum);
+                }
+            }
+            mlp_layer2(lds, n, lane, h, h0, h1, o);
+            const bool squash = (n == 0) || (NNETS == 1) || a.sem_sigmoid;     // raw logits for the label net (triplane_cond.py:960-964)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float c = squash ? sigmoid_clamped(o[r]) : o[r];
+                if (TAPE) t_A = fmaf(acc[n][r], prev[n][r] + c, t_A);          // dL/dw of interval k-1, colour part: sum_ch dC (c[k-1] + c[k]) / 2
+                else      acc[n][r] = fmaf(hw, prev[n][r] + c, acc[n][r]);     // hw == 0 for the first sample
+                prev[n][r] = c;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (TAPE) {
+            t_A += __shfl_xor(t_A, 32, 64);
+            if (h == 0 && live) {
+                tape_s[k] = make_float4(z, 0.f, 0.f, 0.f);
+                if (k > 0) tape_i[k - 1] = make_float4(t_alpha, t_T, 0.5f * t_A, t_sm);
+            }
+        }
+        z_prev = z; s_prev = sigma;
+    }
+    if (TAPE) {
+        // ---- backward of the compositing (ray_marcher.py:25-57), one ray per lane, walking the intervals back to front:
+        //   w_i = alpha_i T_i,  T_i = prod_{j<i} (1 - alpha_j + 1e-10)  =>  dL/dalpha_i = dw_i T_i - (sum_{j>i} dw_j w_j) / (1 - alpha_i + 1e-10)
+        //   alpha = 1 - exp(-dens delta), dens = softplus(sigma_mid - 1)  =>  dL/dsigma_mid = dL/dalpha * delta (1 - alpha) sigmoid(sigma_mid - 1)
+        // and hands every SAMPLE its share: dL/dsigma_k = (dsm[k-1] + dsm[k]) / 2, colour weight (w[k-1] + w[k]) / 2.
+        float sum_dc = 0.f;
+#pragma unroll
+        for (int n = 0; n < NNETS; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum_dc += acc[n][r];
+        sum_dc += __shfl_xor(sum_dc, 32, 64);
+        if (h == 0 && live) {
+            const float base = (a.g_wsum ? a.g_wsum[g] : 0.f) - (a.white_back ? sum_dc : 0.f);
+            float suffix = 0.f, dsm_next = 0.f, w_next = 0.f;
+            float z_hi = tape_s[S - 1].x;
+            for (int i = S - 2; i >= 0; --i) {
+                const float4 rec = tape_i[i];
+                const float z_lo = tape_s[i].x;
+                const float alpha = rec.x, Ti = rec.y, w = alpha * Ti;
+                const float dw = rec.z + base;
+                const float dalpha = dw * Ti - suffix / (1.f - alpha + 1e-10f);
+                suffix = fmaf(dw, w, suffix);
+                const float x = rec.w - 1.f;
+                const float sg = x > 20.f ? 1.f : __builtin_amdgcn_rcpf(1.f + fast_exp(-x));
+                const float dsm = dalpha * (z_hi - z_lo) * (1.f - alpha) * sg;
+                tape_s[i + 1] = make_float4(z_hi, 0.5f * (w + w_next), 0.5f * (dsm + dsm_next), 0.f);
+                dsm_next = dsm; w_next = w; z_hi = z_lo;
+            }
+            tape_s[0] = make_float4(z_hi, 0.5f * w_next, 0.5f * dsm_next, 0.f);
+        }
+        return;
+    }
+
+    // ------------------------------ epilogue --------------------------------------------------------
+    const float bg = a.white_back ? (1.f - w_sum) : 0.f;
+    if (live) {
+        float* dst = a.feat + (size_t)g * (NNETS * 32);
+#pragma unroll
+        for (int n = 0; n < NNETS; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                 // accumulator rows 8q + 4h + {0..3}: one 16-B store
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (acc[n][q * 4 + e] + bg) * 2.f - 1.f;
+                *(f32x4*)(dst + n * 32 + q * 8 + h * 4) = v;
+            }
+        if (h == 0) {
+            a.depth[g] = wz_sum / w_sum;                  // NaN when nothing was hit; finished by the clamp pass
+            a.wsum[g] = w_sum;
+        }
+    }
+    // global depth range (ray_marcher.py:50 clamps to min/max over the WHOLE depth tensor)
+    float zmin = live ? z_first : INFINITY, zmax = live ? z_prev : -INFINITY;
+#pragma unroll
+    for (int s = 16; s > 0; s >>= 1) { zmin = fminf(zmin, __shfl_xor(zmin, s, 64)); zmax = fmaxf(zmax, __shfl_xor(zmax, s, 64)); }
+    if (lane == 0) { atomicMin(a.minmax, order_key(zmin)); atomicMax(a.minmax + 1, order_key(zmax)); }
+}
+
+
+} // namespace p3d

@@ -20,6 +20,7 @@ from .ray_marcher import MipRayMarcher2
 
 fused_policy = 'auto'          # 'auto' | 'require' | 'never'
 fused_training = True          # graphs that need gradients: fused forward + recompute-in-backward (see _FusedRenderFn)
+fused_backward = True          # ... with the backward on the device kernels of csrc/render_bwd.hip (False: replay the tensor-op renderer)
 
 
 class _RenderDesc(ctypes.Structure):          # p3d_render_desc (include/p3d_hip.h)
@@ -34,6 +35,10 @@ _vp, _i32, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
 _lib.register('p3d_render_decoder_floats', ctypes.c_int, [])
 _lib.register('p3d_planes_to_channels_last', ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp])
 _lib.register('p3d_pack_decoder', ctypes.c_int, [_vp] * 8 + [_i32, _f32, _vp, _vp])
+_lib.register('p3d_render_bwd_decoder_floats', ctypes.c_int, [])
+_lib.register('p3d_render_grad_decoder_floats', ctypes.c_int, [])
+_lib.register('p3d_pack_decoder_bwd', ctypes.c_int, [_vp] * 4 + [ctypes.c_int32, ctypes.c_float, _vp, _vp])
+_lib.register('p3d_render_backward', ctypes.c_int, [_vp] * 9 + [ctypes.POINTER(_RenderDesc)] + [_vp] * 6 + [_vp])
 _lib.register('p3d_render_forward', ctypes.c_int, [_vp] * 8 + [ctypes.POINTER(_RenderDesc)] + [_vp] * 6 + [_vp])
 _lib.register('p3d_sample_points', ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(_RenderDesc), _i32, _vp, _vp, _vp])
 _lib.register('p3d_importance_sample', ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp])
@@ -359,6 +364,8 @@ class _FusedRenderFn(torch.autograd.Function):
         if out is None:
             raise RuntimeError('fused training render: sample counts outside the kernel envelope')
         ctx.renderer, ctx.decoder, ctx.opt = renderer, decoder, opt
+        ctx.limits = (t0, t1)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(u_c, u_f, planes, ray_o, ray_d)
         return out
 
@@ -366,6 +373,17 @@ class _FusedRenderFn(torch.autograd.Function):
     def backward(ctx, g_feat, g_depth, g_wsum):
         u_c, u_f, planes, ray_o, ray_d = ctx.saved_tensors
         params = [p for p in ctx.decoder.parameters()]
+        rays_need_grad = ctx.needs_input_grad[8] or ctx.needs_input_grad[9]
+        if fused_backward and g_depth is None and not rays_need_grad and g_feat is not None:
+            g_planes, g_params = fused_render_backward(planes, ctx.decoder, ray_o, ray_d, ctx.opt, u_c, u_f, ctx.limits[0], ctx.limits[1], g_feat, g_wsum)
+            return (None,) * 7 + (g_planes if ctx.needs_input_grad[7] else None, None, None) + tuple(g_params)
+        # depth gradients / ray gradients: the differentiable tensor-op renderer, replayed on the same draws
+        n, m = ray_o.shape[0], ray_o.shape[1]
+        dev = planes.device
+        nch = 32 * len(_decoder_nets(ctx.decoder)[0])
+        g_feat = torch.zeros([n, m, nch], device=dev) if g_feat is None else g_feat
+        g_depth = torch.zeros([n, m, 1], device=dev) if g_depth is None else g_depth
+        g_wsum = torch.zeros([n, m, 1], device=dev) if g_wsum is None else g_wsum
         with torch.enable_grad():
             pl = planes.detach().requires_grad_(ctx.needs_input_grad[7])
             ro = ray_o.detach().requires_grad_(ctx.needs_input_grad[8])
@@ -377,6 +395,52 @@ class _FusedRenderFn(torch.autograd.Function):
         it = iter(grads)
         res = [next(it) if t.requires_grad else None for t in [pl, ro, rd] + params]
         return (None,) * 7 + tuple(res)
+
+
+def fused_render_backward(planes, decoder, ray_origins, ray_directions, opt, u_coarse, u_fine, t_start, t_end, g_feat, g_wsum=None):
+    """dL/dplanes (same shape and layout class as ``planes``) and dL/d(decoder parameters) (in ``decoder.parameters()`` order) of the
+    fused render, by the two recomputing launches of csrc/render_bwd.hip."""
+    info = _decoder_nets(decoder)
+    nets, lr_mul, _ = info
+    lib = _lib.lib()
+    n, m, _ = ray_origins.shape
+    sc, sf = int(opt['depth_resolution']), int(opt['depth_resolution_importance'])
+    s_all = sc + sf
+    dev = planes.device
+    ctx = _FusedContext(planes, info)
+    packed_bwd = torch.empty([lib.p3d_render_bwd_decoder_floats()], dtype=torch.float32, device=dev)
+    w1s = [_f32c(fc1.weight) for fc1, _ in nets] + [None]
+    w2s = [_f32c(fc2.weight) for _, fc2 in nets] + [None]
+    _lib.check(lib.p3d_pack_decoder_bwd(_lib.ptr(w1s[0]), _lib.ptr(w2s[0]), _lib.ptr(w1s[1]), _lib.ptr(w2s[1]), len(nets), lr_mul, _lib.ptr(packed_bwd),
+                                        _lib.stream_of(packed_bwd)), 'pack_decoder_bwd')
+    auto = t_start is not None
+    t0 = _f32c(t_start).reshape(-1) if auto else None
+    t1 = _f32c(t_end).reshape(-1) if auto else None
+    ro, rd, uc, uf = _f32c(ray_origins), _f32c(ray_directions), _f32c(u_coarse), _f32c(u_fine)
+    gf = _f32c(g_feat)
+    gw = None if g_wsum is None else _f32c(g_wsum).reshape(-1)
+    tape_i = torch.empty([n * m, s_all - 1, 4], dtype=torch.float32, device=dev)
+    tape_s = torch.empty([n * m, s_all, 4], dtype=torch.float32, device=dev)
+    d_planes = torch.empty([n, 3, ctx.h, ctx.w, 32], dtype=torch.float32, device=dev)
+    d_dec = torch.empty([lib.p3d_render_grad_decoder_floats()], dtype=torch.float32, device=dev)
+    d = ctx.desc(opt, rays_per_img=m, start=0.0 if auto else opt['ray_start'], end=0.0 if auto else opt['ray_end'], raster=True)
+    code = lib.p3d_render_backward(_lib.ptr(ctx.planes_cl), _lib.ptr(ctx.packed), _lib.ptr(packed_bwd), _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(uc), _lib.ptr(uf),
+                                   _lib.ptr(t0), _lib.ptr(t1), ctypes.byref(d), _lib.ptr(gf), _lib.ptr(gw), _lib.ptr(tape_i), _lib.ptr(tape_s),
+                                   _lib.ptr(d_planes), _lib.ptr(d_dec), _lib.stream_of(d_planes))
+    _lib.check(code, 'render_backward')
+    g_planes = d_planes.permute(0, 1, 4, 2, 3)                    # [N, 3, 32, H, W] view of the channels-last gradient
+    if planes.dim() == 5 and planes.is_contiguous():
+        g_planes = g_planes.contiguous()
+    stride = lib.p3d_render_grad_decoder_floats() // 2
+    by_param = {}
+    for i, (fc1, fc2) in enumerate(nets):
+        g = d_dec[i * stride:(i + 1) * stride]
+        by_param[id(fc1.weight)] = g[0:2048].reshape(64, 32) * fc1.weight_gain
+        by_param[id(fc1.bias)] = g[2048:2112] * fc1.bias_gain
+        by_param[id(fc2.weight)] = g[2112:4224].reshape(33, 64) * fc2.weight_gain
+        by_param[id(fc2.bias)] = g[4224:4257] * fc2.bias_gain
+    g_params = [by_param.get(id(p)) if p.requires_grad else None for p in decoder.parameters()]
+    return g_planes, g_params
 
 
 def fused_render(planes, decoder, ray_origins, ray_directions, opt, u_coarse, u_fine, t_start=None, t_end=None, debug=False):
