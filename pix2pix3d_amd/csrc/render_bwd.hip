@@ -66,33 +66,51 @@ __device__ __forceinline__ void read_row16(const float* p, float (&v)[16])
     }
 }
 
-// d planes: the transpose of gather_features.  Lane (j, h) holds dL/dfeature of channels acc_row(r, h) (four runs of four).
-__device__ __forceinline__ void scatter_features(const RenderArgs& a, float* __restrict__ d_planes, size_t img_off, int h,
-                                                 float px, float py, float pz, const f32x16& df)
+// d planes: the transpose of gather_features, with COALESCED atomics.  Scattering straight from the accumulator layout (lane = ray)
+// makes every atomic instruction touch 32 texel lines with 2 dwords each, and the L2 serialises them: 1.2 G atomics ran at 20 G/s
+// (61 of the kernel's 64 ms).  Instead the wave parks dL/dfeature as [ray][feature] in LDS together with each ray's 12 tap offsets
+// and weights, and then walks the 384 (ray, tap) pairs two at a time with lane = CHANNEL: an atomic instruction is two full
+// 128-byte texel lines, one request each.
+__device__ __forceinline__ void scatter_features(const RenderArgs& a, float* __restrict__ d_planes, unsigned img_off, int lane, bool live,
+                                                 float px, float py, float pz, const f32x16& df, float* Tdf, unsigned* Toff, float* Tw)
 {
     const int W = a.W, H = a.H;
+    const int j = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        const float gx = (p == 2) ? pz : px;
-        const float gy = (p == 0) ? py : (p == 1 ? pz : px);
-        float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
-        float iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
-        ix = fminf(fmaxf(ix, -2.f), (float)W + 1.f);
-        iy = fminf(fmaxf(iy, -2.f), (float)H + 1.f);
-        const float fx = floorf(ix), fy = floorf(iy);
-        const int x0 = (int)fx, y0 = (int)fy;
-        const float wx1 = ix - fx, wx0 = (fx + 1.f) - ix;
-        const float wy1 = iy - fy, wy0 = (fy + 1.f) - iy;
-        float* const plane = d_planes + img_off + (size_t)p * H * W * 32;
+    for (int q = 0; q < 4; ++q) {                                  // accumulator rows 8q + 4h + {0..3}: one 16-byte store
+        f32x4 v; v[0] = df[4 * q]; v[1] = df[4 * q + 1]; v[2] = df[4 * q + 2]; v[3] = df[4 * q + 3];
+        *(f32x4*)(Tdf + j * TP + 8 * q + 4 * h) = v;
+    }
+    if (h == 0) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int x = x0 + (t & 1), y = y0 + (t >> 1);
-            if ((x < 0) | (x >= W) | (y < 0) | (y >= H)) continue;          // zero padding: the tap never contributed
-            const float w = ((t & 1) ? wx1 : wx0) * ((t >> 1) ? wy1 : wy0) * (1.f / 3.f);
-            float* tex = plane + ((size_t)y * W + x) * 32 + 4 * h;
+        for (int p = 0; p < 3; ++p) {
+            const float gx = (p == 2) ? pz : px;
+            const float gy = (p == 0) ? py : (p == 1 ? pz : px);
+            float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+            float iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+            ix = fminf(fmaxf(ix, -2.f), (float)W + 1.f);
+            iy = fminf(fmaxf(iy, -2.f), (float)H + 1.f);
+            const float fx = floorf(ix), fy = floorf(iy);
+            const int x0 = (int)fx, y0 = (int)fy;
+            const float wx1 = ix - fx, wx0 = (fx + 1.f) - ix;
+            const float wy1 = iy - fy, wy0 = (fy + 1.f) - iy;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) unsafeAtomicAdd(tex + (r & 3) + 8 * (r >> 2), w * df[r]);
+            for (int t = 0; t < 4; ++t) {
+                const int x = x0 + (t & 1), y = y0 + (t >> 1);
+                const bool ok = live & (x >= 0) & (x < W) & (y >= 0) & (y < H);     // zero padding: such a tap never contributed
+                const float w = ((t & 1) ? wx1 : wx0) * ((t >> 1) ? wy1 : wy0) * (1.f / 3.f);
+                Tw[(p * 4 + t) * 32 + j] = ok ? w : 0.f;
+                Toff[(p * 4 + t) * 32 + j] = ok ? img_off + (unsigned)((p * H + y) * W + x) * 32u : 0u;
+            }
         }
+    }
+    wave_sync();
+    const int c = lane & 31;
+#pragma unroll 4
+    for (int it = 0; it < 192; ++it) {                              // 12 taps x 16 ray pairs; each half-wave serves one (ray, tap)
+        const int slot = (it >> 4) * 32 + ((it & 15) << 1) + (lane >> 5);
+        const float w = Tw[slot];
+        if (w != 0.f) unsafeAtomicAdd(d_planes + Toff[slot] + c, w * Tdf[(slot & 31) * TP + c]);
     }
 }
 
@@ -126,7 +144,7 @@ render_backward_kernel(RenderArgs a, const float* __restrict__ bwd_stream, float
     const int n_img = g / a.rays_per_img;
     const rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.planes, 0, a.planes_total_bytes, 0x00020000);
     const unsigned img = (unsigned)n_img * a.img_bytes;
-    const size_t dimg = (size_t)n_img * 3 * a.H * a.W * 32;       // d_planes is always the compact [N][3][H][W][32]
+    const unsigned dimg = (unsigned)n_img * 3u * (unsigned)(a.H * a.W) * 32u;    // d_planes is always the compact [N][3][H][W][32] (< 2^29 floats, checked on the host)
     const float ox = a.ray_o[g * 3 + 0], oy = a.ray_o[g * 3 + 1], oz = a.ray_o[g * 3 + 2];
     const float dx = a.ray_d[g * 3 + 0], dy = a.ray_d[g * 3 + 1], dz = a.ray_d[g * 3 + 2];
     const float cs = a.coord_scale;
@@ -278,7 +296,8 @@ render_backward_kernel(RenderArgs a, const float* __restrict__ bwd_stream, float
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (live) scatter_features(a, d_planes, dimg, h, px, py, pz, df);
+        wave_sync();                                              // T_x / T_do are free again: the scatter reuses them
+        scatter_features(a, d_planes, dimg, lane, live, px, py, pz, df, Tx, (unsigned*)Tdo, Tdo + 384);
     }
 
     // ---- weight gradients leave through atomics (effective-weight gradients; the host applies the layer gains)
