@@ -167,7 +167,10 @@ render_backward_kernel(RenderArgs a, const float* __restrict__ bwd_stream, float
             for (int r = 0; r < 16; ++r) { aW2[n][t][r] = 0.f; aW1[n][t][r] = 0.f; }
     }
 
-    for (int k = 0; k < S; ++k) {
+    // the pass is order-free over samples: small launches split every ray's samples over gridDim.y blocks so that all CUs get work
+    const int k_per = (S + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int k_begin = (int)blockIdx.y * k_per, k_end = min(S, k_begin + k_per);
+    for (int k = k_begin; k < k_end; ++k) {
         const float4 rec = tape[k];                               // z, colour weight, dL/dsigma
         const float z = rec.x, wgt = live ? rec.y : 0.f, dsig = live ? rec.z : 0.f;
         const float px = cs * fmaf(z, dx, ox), py = cs * fmaf(z, dy, oy), pz = cs * fmaf(z, dz, oz);
@@ -402,14 +405,16 @@ extern "C" int p3d_render_backward(const float* planes_cl, const float* decoder,
     {
         const size_t lds_bytes = (size_t)(kDecoderFloats + kBwdFloats + kBwdWaves * kBwdWaveLds) * sizeof(float);
         const int blocks = (int)((total + kBwdWaves * 32 - 1) / (kBwdWaves * 32));
+        int splits = 1;                                                  // one block per CU at a time: aim for >= 2 rounds of blocks
+        while (blocks * splits < 2 * kNumCU && splits < 8) splits *= 2;
         if (d->n_nets == 1) {
             static hipError_t once1 = hipFuncSetAttribute((const void*)render_backward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (once1 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_backward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(once1));
-            hipLaunchKernelGGL(render_backward_kernel<1>, dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, a, decoder_bwd, d_planes_cl, d_decoder);
+            hipLaunchKernelGGL(render_backward_kernel<1>, dim3(blocks, splits), dim3(kBwdWaves * 64), lds_bytes, s, a, decoder_bwd, d_planes_cl, d_decoder);
         } else {
             static hipError_t once2 = hipFuncSetAttribute((const void*)render_backward_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (once2 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_backward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(once2));
-            hipLaunchKernelGGL(render_backward_kernel<2>, dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, a, decoder_bwd, d_planes_cl, d_decoder);
+            hipLaunchKernelGGL(render_backward_kernel<2>, dim3(blocks, splits), dim3(kBwdWaves * 64), lds_bytes, s, a, decoder_bwd, d_planes_cl, d_decoder);
         }
     }
     count_launch(FAM_RENDER);
