@@ -4,11 +4,12 @@ Host-side mirror of training/volumetric_rendering/renderer.py:88-253 (``Importan
 constructor, ``forward(planes, decoder, ray_origins, ray_directions, rendering_options)`` and
 ``run_model(...)`` signatures, same ``rendering_options`` keys, same RNG draws in the same order.
 
-Device tensors without autograd run ONE fused HIP kernel (csrc/render.hip through
-``p3d_render_forward`` / ``p3d_sample_points``).  CPU tensors — and graphs that need gradients,
-until the fused backward lands — run the tensor-op restatement below (``_forward_tensor_ops``),
-which is also what the reference does on every device.  ``fused_policy = 'require'`` turns any
-silent use of the tensor-op path on a device tensor into an error.
+Device tensors run ONE fused HIP kernel (csrc/render.hip through ``p3d_render_forward`` /
+``p3d_sample_points``); graphs that need gradients get the same forward and a fused backward
+(csrc/render_bwd.hip through ``p3d_render_backward``, see ``_FusedRenderFn``).  CPU tensors run the
+tensor-op restatement below (``_forward_tensor_ops``), which is also what the reference does on every
+device.  ``fused_policy = 'require'`` turns any silent use of the tensor-op path on a device tensor
+into an error.
 """
 import ctypes
 
@@ -352,11 +353,11 @@ class _replay_draws:
 
 
 class _FusedRenderFn(torch.autograd.Function):
-    """Training-mode rendering: the FORWARD is the fused kernel (nothing per-sample is kept — the reference holds
-    ~1.2 GB of sampled features per image for autograd); the BACKWARD re-runs the differentiable tensor-op renderer on
-    the same planes / decoder / rays / uniforms under autograd and back-propagates the incoming gradients through it
-    (recompute-in-backward).  Gradients are therefore exactly those of the tensor-op path; a fused backward kernel
-    (atomics into the plane gradients) is the planned replacement."""
+    """Training-mode rendering: the FORWARD is the fused kernel and keeps nothing per-sample (the reference holds ~1.2 GB of
+    sampled features per image for autograd); the BACKWARD recomputes on the device — ``p3d_render_backward``: the forward
+    sweep again with a tape, then a point-wise MFMA backward (csrc/render_bwd.hip) — and returns gradients for the planes and
+    the decoder parameters.  If a gradient w.r.t. the rays or the depth output is requested (no training loss does), or with
+    ``fused_backward = False``, it replays the differentiable tensor-op renderer on the same draws under autograd instead."""
 
     @staticmethod
     def forward(ctx, renderer, decoder, opt, u_c, u_f, t0, t1, planes, ray_o, ray_d, *params):
