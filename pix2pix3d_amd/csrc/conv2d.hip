@@ -526,14 +526,17 @@ __global__ void __launch_bounds__(512, 2) conv3x3_q256_f16_kernel(ConvArgs a)
     };
 
     // Software pipeline.  Fragments are double-buffered in registers (the reads of sub-step kk+1 fly under the MFMAs of kk).
-    // The block-wide rendezvous sits in the MIDDLE of a step (before kk = 2), where every wave still holds prefetched
-    // fragments: there tile ks+1 (issued at the same point one step earlier) must have landed, and everyone has finished
-    // reading tile ks-1, whose ring slot takes the DMA of tile ks+2.  Nine taps and three slots: the slot index is t % 3, a
-    // compile-time constant of the unrolled body.  The slab of the next channel chunk rides along at tap 0.
+    // ONE block-wide rendezvous per step, at kk = 3, after the step's last fragment reads have landed (lgkmcnt(0)): everyone is
+    // then done with tile ks, so its ring slot takes the DMA of tile ks+3 at once, and the same point waits for tile ks+1 — issued
+    // TWO steps earlier, while the group issued one step earlier (tile ks+2, plus a slab after tap 0) stays in flight under a
+    // counted vmcnt.  Two full steps of flight out of three 16 KB slots; PMC on the previous one-step version: 46 % of the wave
+    // cycles waiting at vmcnt(0) + barrier.  Nine taps and three slots: the slot index is t % 3, a compile-time constant of the
+    // unrolled body.  The slab of the next channel chunk rides along at tap 0.
     stage_slab(0, 0);
     stage_w(0, 0, 0);
     stage_w(0, 1, 1);
-    wait_vmcnt<0>();
+    stage_w(0, 2, 2);
+    wait_vmcnt<2>();                                                            // slab 0, tiles 0 and 1 (tile 2 stays in flight)
     __builtin_amdgcn_s_barrier();
     load_frags(0, 0, 0, fa[0], fb[0]);
     for (int cp = 0; cp < kpairs; ++cp) {
@@ -541,22 +544,27 @@ __global__ void __launch_bounds__(512, 2) conv3x3_q256_f16_kernel(ConvArgs a)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int cc = cp * 2 + h;
+            const bool next_chunk = (h == 0) || more;                           // chunk cc + 1 exists
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int cur = kk & 1, nxt = cur ^ 1;
-                    if (kk == 2) {
-                        wait_vmcnt<0>();
-                        __builtin_amdgcn_s_barrier();
-                        if (t < 7) stage_w(cc, t + 2, (t + 2) % 3);
-                        else if (h == 0 || more) stage_w(cc + 1, t - 7, (t + 2) % 3);
-                        if (t == 0 && (h == 0 || more)) stage_slab(cc + 1, h ^ 1);
-                    }
                     if (kk < 3) { load_frags(h, t, kk + 1, fa[nxt], fb[nxt]); asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); }
-                    else if (t < 8) { load_frags(h, t + 1, 0, fa[nxt], fb[nxt]); asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); }
-                    else if (h == 0 || more) { load_frags(h ^ 1, 0, 0, fa[nxt], fb[nxt]); asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); }
-                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this step's last fragments are in registers
+                        // what may stay in flight: the group issued one step ago = tile ks+2 (if any) + the slab issued at tap 0
+                        const bool t2 = (t < 7) || next_chunk;                  // tile ks+2 exists
+                        if (t == 1 && next_chunk) { if (nslab == 6) wait_vmcnt<8>(); else wait_vmcnt<7>(); }
+                        else if (t2) wait_vmcnt<2>();
+                        else wait_vmcnt<0>();
+                        __builtin_amdgcn_s_barrier();
+                        if (t < 6) stage_w(cc, t + 3, t % 3);                   // tile ks+3 -> the slot tile ks just left
+                        else if (next_chunk) stage_w(cc + 1, t - 6, t % 3);
+                        if (t == 0 && next_chunk) stage_slab(cc + 1, h ^ 1);
+                        if (t < 8) load_frags(h, t + 1, 0, fa[nxt], fb[nxt]);
+                        else if (next_chunk) load_frags(h ^ 1, 0, 0, fa[nxt], fb[nxt]);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
