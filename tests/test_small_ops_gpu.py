@@ -169,3 +169,30 @@ def test_plain_conv2d_layer_native_route(hip_lib, cin, cout, k, down, res, dtype
             modconv.enabled = True
     assert y.shape == ref.shape and y.dtype == dtype
     assert rel_err(y.float().cpu().numpy(), ref.cpu().numpy()) < (3e-3 if dtype == torch.float16 else 1e-5)
+
+
+@pytest.mark.parametrize('num_fp16_res', [0, 2])
+def test_discriminator_and_encoder_forward_on_native_convs(hip_lib, num_fp16_res):
+    """DualDiscriminator.forward (and with it every DiscriminatorBlock / Conv2dLayer variant: fromrgb, 3x3, down-2 3x3, down-2 1x1
+    skip, low-resolution GEMM route, 4x4 epilogue) under no_grad on the device = the native conv route, against the same module with
+    the native route switched off (ATen convolutions)."""
+    from pix2pix3d_amd.training.dual_discriminator import DualDiscriminator
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    from pix2pix3d_amd import _lib
+    torch.manual_seed(3)
+    D = DualDiscriminator(c_dim=25, img_resolution=128, img_channels=3, channel_base=4096, channel_max=128, num_fp16_res=num_fp16_res,
+                          conv_clamp=256 if num_fp16_res else None, block_kwargs=dict(freeze_layers=0), mapping_kwargs=dict(),
+                          epilogue_kwargs=dict(mbstd_group_size=2)).cuda().eval().requires_grad_(False)
+    img = {'image': torch.randn(2, 3, 128, 128, device='cuda'), 'image_raw': torch.randn(2, 3, 32, 32, device='cuda')}
+    c = torch.randn(2, 25, device='cuda')
+    with torch.no_grad():
+        n0 = _lib.launch_count('conv')
+        y = D(img, c)
+        assert _lib.launch_count('conv') > n0, 'the native conv kernels did not run'
+        modconv.enabled = False
+        try:
+            ref = D(img, c)
+        finally:
+            modconv.enabled = True
+    assert y.shape == (2, 1)
+    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < (2e-2 if num_fp16_res else 1e-4)
