@@ -144,6 +144,23 @@ conv3x3 = conv2d
 _plain_weights = {}
 
 
+def _cached_weight(weight, tag, make):
+    """Derived form of an (inference-time constant) weight tensor, rebuilt when the tensor object, its storage or its version
+    changes.  The entry holds a weak reference to the tensor itself: ``id()`` and ``data_ptr()`` are both recycled once a module
+    is freed, so a key made of them alone can hand a new layer another layer's weights."""
+    import weakref
+    slot = (id(weight), tag)
+    hit = _plain_weights.get(slot)
+    if hit is not None and hit[0]() is weight and hit[1] == (weight.data_ptr(), weight._version):
+        return hit[2]
+    value = make()
+    if len(_plain_weights) > 4096:                       # dead entries of freed modules
+        for k in [k for k, v in _plain_weights.items() if v[0]() is None]:
+            del _plain_weights[k]
+    _plain_weights[slot] = (weakref.ref(weight), (weight.data_ptr(), weight._version), value)
+    return value
+
+
 def plain_layer_supported(x, weight, up, down, activation):
     """Conv2dLayer calls (networks_stylegan2.py:135-188) the native kernels cover: inference on the device, 1x1 / 3x3, down in {1, 2}."""
     if not enabled or up != 1 or down not in (1, 2) or not _dense_dev(x) or activation not in ('linear', 'lrelu'):
@@ -160,12 +177,8 @@ def _plain_small(x, weight, bias, weight_gain, resample_filter, down, padding, a
     """Low-resolution Conv2dLayer: one library GEMM with shared weights, [Co, Ci*k*k] @ [N, Ci*k*k, OH*OW] (im2col in one launch)."""
     co, ci, k, _ = weight.shape
     n, _, h, w = x.shape
-    key = (weight.data_ptr(), weight._version, 'gemm', float(weight_gain))
-    wm = _plain_weights.get((id(weight), 'gemm'))
-    if wm is None or wm[0] != key:
-        wm = (key, (weight.detach().float() * float(weight_gain)).reshape(co, ci * k * k).contiguous())
-        _plain_weights[(id(weight), 'gemm')] = wm
-    wm = wm[1]
+    wm = _cached_weight(weight, ('gemm', float(weight_gain)),
+                        lambda: (weight.detach().float() * float(weight_gain)).reshape(co, ci * k * k).contiguous())
     fw = resample_filter.shape[-1]
     p0, p1 = padding + (fw - down + 1) // 2, padding + (fw - down) // 2
     if k == 1:
@@ -192,13 +205,9 @@ def plain_layer(x, weight, bias, weight_gain, resample_filter, down, padding, ac
     co, ci, k, _ = weight.shape
     if x.shape[2] * x.shape[3] <= gemm_max_pixels:
         return _plain_small(x, weight, bias, weight_gain, resample_filter, down, padding, act, act_gain, clamp)
-    key = (weight.data_ptr(), weight._version, x.dtype, float(weight_gain))
-    wmod = _plain_weights.get(id(weight))
-    if wmod is None or wmod[0] != key:
-        ones = torch.ones([1, ci], dtype=torch.float32, device=weight.device)
-        wmod = (key, modulate_weights(weight, ones, demodulate=False, pre_scale=float(weight_gain), dtype=x.dtype))
-        _plain_weights[id(weight)] = wmod
-    wmod = wmod[1]
+    wmod = _cached_weight(weight, ('mfma', x.dtype, float(weight_gain)),
+                          lambda: modulate_weights(weight, torch.ones([1, ci], dtype=torch.float32, device=weight.device), demodulate=False,
+                                                   pre_scale=float(weight_gain), dtype=x.dtype))
     x = x.contiguous(memory_format=torch.channels_last)
     act_idx = {'linear': 0, 'lrelu': 1}[act]
     clampv = -1.0 if clamp is None else float(clamp)

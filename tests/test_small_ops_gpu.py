@@ -196,3 +196,25 @@ def test_discriminator_and_encoder_forward_on_native_convs(hip_lib, num_fp16_res
             modconv.enabled = True
     assert y.shape == (2, 1)
     assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < (2e-2 if num_fp16_res else 1e-4)
+
+
+def test_plain_layer_weight_cache_survives_recycled_tensors(hip_lib):
+    """The derived-weight cache of the native Conv2dLayer route must not serve a freed layer's weights to a new layer that happens to get
+    the same id() / data_ptr() (regression: a key made of those alone did)."""
+    import gc
+    from pix2pix3d_amd.training import networks_stylegan2 as ns2
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    x = torch.randn(1, 64, 64, 64, device='cuda')
+    for i in range(12):
+        torch.manual_seed(100 + i)
+        layer = ns2.Conv2dLayer(64, 64, kernel_size=3, activation='lrelu').cuda().eval()
+        with torch.no_grad():
+            y = layer(x)
+            modconv.enabled = False
+            try:
+                ref = layer(x)
+            finally:
+                modconv.enabled = True
+        assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < 1e-5, i
+        del layer
+        gc.collect()
