@@ -56,6 +56,8 @@ __global__ void __launch_bounds__(256) pack_decoder_bwd_kernel(PackBwdArgs p, fl
     }
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 // 16 consecutive floats of a transposed tile row -> registers (4 x ds_read_b128)
 __device__ __forceinline__ void read_row16(const float* p, float (&v)[16])
 {
@@ -67,10 +69,10 @@ __device__ __forceinline__ void read_row16(const float* p, float (&v)[16])
 }
 
 // d planes: the transpose of gather_features, with COALESCED atomics.  Scattering straight from the accumulator layout (lane = ray)
-// makes every atomic instruction touch 32 texel lines with 2 dwords each, and the L2 serialises them: 1.2 G atomics ran at 20 G/s
-// (61 of the kernel's 64 ms).  Instead the wave parks dL/dfeature as [ray][feature] in LDS together with each ray's 12 tap offsets
-// and weights, and then walks the 384 (ray, tap) pairs two at a time with lane = CHANNEL: an atomic instruction is two full
-// 128-byte texel lines, one request each.
+// makes every atomic instruction touch 32 texel lines with 2 dwords each, and the memory side serialises them: 1.2 G atomics ran at
+// 20 G/s (61 of the kernel's then 64 ms).  Instead the wave parks dL/dfeature as [ray][feature] in LDS together with each ray's 12 tap
+// offsets and weights, and then walks the rays two at a time with lane = CHANNEL: an atomic instruction is two full 128-byte texel
+// lines, one request each.
 __device__ __forceinline__ void scatter_features(const RenderArgs& a, float* __restrict__ d_planes, unsigned img_off, int lane, bool live,
                                                  float px, float py, float pz, const f32x16& df, float* Tdf, unsigned* Toff, float* Tw)
 {
@@ -99,18 +101,31 @@ __device__ __forceinline__ void scatter_features(const RenderArgs& a, float* __r
                 const int x = x0 + (t & 1), y = y0 + (t >> 1);
                 const bool ok = live & (x >= 0) & (x < W) & (y >= 0) & (y < H);     // zero padding: such a tap never contributed
                 const float w = ((t & 1) ? wx1 : wx0) * ((t >> 1) ? wy1 : wy0) * (1.f / 3.f);
-                Tw[(p * 4 + t) * 32 + j] = ok ? w : 0.f;
-                Toff[(p * 4 + t) * 32 + j] = ok ? img_off + (unsigned)((p * H + y) * W + x) * 32u : 0u;
+                Tw[j * 12 + p * 4 + t] = ok ? w : 0.f;
+                Toff[j * 12 + p * 4 + t] = ok ? img_off + (unsigned)((p * H + y) * W + x) * 32u : 0u;
             }
         }
     }
     wave_sync();
-    const int c = lane & 31;
-#pragma unroll 4
-    for (int it = 0; it < 192; ++it) {                              // 12 taps x 16 ray pairs; each half-wave serves one (ray, tap)
-        const int slot = (it >> 4) * 32 + ((it & 15) << 1) + (lane >> 5);
-        const float w = Tw[slot];
-        if (w != 0.f) unsafeAtomicAdd(d_planes + Toff[slot] + c, w * Tdf[(slot & 31) * TP + c]);
+    // ray-major walk: per (ray pair) one read of the lane's channel value and six 16-byte reads of the ray's 12 weights / offsets, all
+    // independent, then up to 12 atomics.  (A tap-major walk with three dependent LDS reads per atomic spent more time in LDS latency
+    // than in the atomics themselves: at one wave per SIMD nothing hides it.)
+    const int c = lane & 31, half = lane >> 5;
+#pragma unroll 2
+    for (int pr = 0; pr < 16; ++pr) {
+        const int ray = 2 * pr + half;
+        const float v = Tdf[ray * TP + c];
+        float w[12]; unsigned off[12];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const f32x4 wv = *(const f32x4*)(Tw + ray * 12 + 4 * q);
+            const u32x4 ov = *(const u32x4*)(Toff + ray * 12 + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { w[4 * q + e] = wv[e]; off[4 * q + e] = ov[e]; }
+        }
+#pragma unroll
+        for (int t = 0; t < 12; ++t)
+            if (w[t] != 0.f) unsafeAtomicAdd(d_planes + off[t] + c, w[t] * v);
     }
 }
 
