@@ -157,3 +157,35 @@ def test_synthesis_layer_native_vs_generic(hip_lib):
         y0 = rgb(x, wl).float()
         modconv.enabled = True
     assert rel_err(y1.cpu().numpy(), y0.cpu().numpy()) < 6e-3
+
+
+@pytest.mark.parametrize('dtype,ci,co,h,w', [
+    (torch.float16, 128, 128, 64, 64),      # conv3x3_q256_f16_kernel: the big SR layers (16 x 16 patches, Ci, Co multiples of 128)
+    (torch.float16, 256, 256, 80, 72),      # ... with partial patches on both axes and four channel chunks
+    (torch.float16, 128, 256, 64, 200),
+    (torch.float16, 64, 128, 40, 24),       # conv3x3_halo_kernel<half>: 8 x 16 patches (Ci not a multiple of 128)
+    (torch.float32, 64, 128, 24, 40),       # conv3x3_halo_kernel<float>: the fp32 backbone layers
+    (torch.float32, 96, 72, 19, 33),
+])
+@pytest.mark.parametrize('with_noise', [False, True])
+def test_halo_and_q256_kernels_at_their_own_sizes(hip_lib, dtype, ci, co, h, w, with_noise):
+    """The two halo-reuse 3x3 kernels only engage from 8 x 16 / 64 x 64 pixels on: checked here directly (bias, noise, lrelu, gain,
+    clamp in the epilogue) against torch's fp32 convolution of the same (fp16-rounded) operands, with per-sample weights."""
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    torch.manual_seed(ci + co + h)
+    n = 2
+    x = _nhwc(torch.randn(n, ci, h, w, device='cuda').to(dtype))
+    weight = torch.randn(co, ci, 3, 3, device='cuda')
+    styles = torch.randn(n, ci, device='cuda') + 1
+    bias = torch.randn(co, device='cuda')
+    noise = torch.randn(h, w, device='cuda') if with_noise else None
+    ns = torch.tensor(0.25, device='cuda') if with_noise else None
+    wmod = modconv.modulate_weights(weight, styles, dtype=dtype)
+    y = modconv.conv2d(x, wmod, bias=bias, noise=noise, noise_strength=ns, act=1, gain=1.3, clamp=3.0)
+    wq = wmod.float().reshape(n, co, 3, 3, ci).permute(0, 1, 4, 2, 3)
+    ref = torch.stack([F.conv2d(x[i:i + 1].float(), wq[i], padding=1)[0] for i in range(n)])
+    if with_noise:
+        ref = ref + noise * ns
+    ref = (F.leaky_relu(ref + bias.reshape(1, -1, 1, 1), 0.2) * 1.3).clamp(-3.0, 3.0)
+    assert y.shape == ref.shape and y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
+    assert rel_err(y.float().cpu().numpy(), ref.cpu().numpy()) < (2e-3 if dtype == torch.float16 else 1e-5)
