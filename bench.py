@@ -166,9 +166,19 @@ def main():
             torch.cuda.synchronize()
 
     run = graph.replay if graph is not None else step
-    for _ in range(2):
-        run()
-    torch.cuda.synchronize()
+    # untimed settling: a box that has just booted (or idled) needs a moment of sustained load before its clocks / power state level
+    # out.  Replay in chunks of 10 until at least 1.5 s have passed and three consecutive chunks agree within 1.5 % (at most 8 s).
+    # (Run-to-run spread on one box stays about +-3 % either way: 359-379 img/s over six back-to-back runs.)
+    chunks, t_start = [], time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        for _ in range(10):
+            run()
+        torch.cuda.synchronize()
+        chunks.append(time.perf_counter() - t0)
+        spent = time.perf_counter() - t_start
+        if spent > 8.0 or (spent > 1.5 and len(chunks) >= 3 and max(chunks[-3:]) < 1.015 * min(chunks[-3:])):
+            break
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
