@@ -229,13 +229,13 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         line = {
-            'metric': 'rendered img/s (512^2, 128 depth)' if args.depth == 128 else f'rendered img/s (512^2, {args.depth} depth)',
+            'metric': f'rendered img/s ({info["res"]}^2, {args.depth} depth)',
             'value': round(imgs / elapsed, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if args.force_fp32 else 'f32 (backbone, ray-marcher) + f16/f32-acc (super-resolution), as the reference GPU config',
             'data': 'synthetic',
             'config': {'workload': f'{args.dataset} G.synthesis: batch {args.batch}/GPU, 256^2x96 tri-planes, {nrr}^2 rays x {args.depth // 2}+{args.depth // 2} samples, '
-                                   f'two 8XDC SR heads -> {info["res"]}^2 image + label map', 'launch': launch, 'parallelism': f'replicas x{world} (images sharded, no collective)'},
+                                   f'two {info["sr"]} SR heads -> {info["res"]}^2 image + label map', 'launch': launch, 'parallelism': f'replicas x{world} (images sharded, no collective)'},
             'ray_samples_per_s': round(samples_per_launch / render_s, 1) if render_s > 0 else None,
             'stage_ms': {k: round(v, 3) for k, v in stage_ms.items()},
             'conv_tflops': round(FLOP_PER_IMG * args.batch / ((stage_ms['backbone'] + stage_ms['sr']) * 1e-3) / 1e12, 2) if stage_ms['backbone'] + stage_ms['sr'] > 0 else None,
