@@ -249,17 +249,20 @@ extern "C" int p3d_render_forward(const float* planes_cl, const float* decoder, 
     a.total_rays = (int)total; a.rays_per_img = d->rays_per_img;
     { int r = 1; while (r * r < d->rays_per_img) ++r; a.res = (r * r == d->rays_per_img && d->raster_order) ? r : 0; }
     hipStream_t s = (hipStream_t)stream;
+    // a block is one-per-CU (LDS): small launches take fewer waves per block so that every CU still gets one
+    int wpb = kWavesPerBlock;
+    while (wpb > 2 && (total + wpb * 32 - 1) / (wpb * 32) < kNumCU) wpb >>= 1;
     const size_t lds_bytes = (size_t)(kDecoderFloats + kWavesPerBlock * kWaveTile) * sizeof(float);
-    const int blocks = (int)((total + kWavesPerBlock * 32 - 1) / (kWavesPerBlock * 32));
+    const int blocks = (int)((total + wpb * 32 - 1) / (wpb * 32));
     hipLaunchKernelGGL(render_init_minmax_kernel, dim3(1), dim3(1), 0, s, minmax_ws);
     if (d->n_nets == 1) {
         static hipError_t once1 = hipFuncSetAttribute((const void*)render_forward_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (once1 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_forward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(once1));
-        hipLaunchKernelGGL((render_forward_kernel<1, false>), dim3(blocks), dim3(kWavesPerBlock * 64), lds_bytes, s, a);
+        hipLaunchKernelGGL((render_forward_kernel<1, false>), dim3(blocks), dim3(wpb * 64), lds_bytes, s, a);
     } else {
         static hipError_t once2 = hipFuncSetAttribute((const void*)render_forward_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (once2 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_forward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(once2));
-        hipLaunchKernelGGL((render_forward_kernel<2, false>), dim3(blocks), dim3(kWavesPerBlock * 64), lds_bytes, s, a);
+        hipLaunchKernelGGL((render_forward_kernel<2, false>), dim3(blocks), dim3(wpb * 64), lds_bytes, s, a);
     }
     rc = check_launch("render_forward");
     if (rc != P3D_OK) return rc;

@@ -402,16 +402,19 @@ extern "C" int p3d_render_backward(const float* planes_cl, const float* decoder,
 
     // 1. the forward sweep with tape
     {
+        // a block is one-per-CU (LDS): small launches take fewer waves per block so that every CU still gets one
+        int wpb = kWavesPerBlock;
+        while (wpb > 2 && (total + wpb * 32 - 1) / (wpb * 32) < kNumCU) wpb >>= 1;
         const size_t lds_bytes = (size_t)(kDecoderFloats + kWavesPerBlock * kWaveTile) * sizeof(float);
-        const int blocks = (int)((total + kWavesPerBlock * 32 - 1) / (kWavesPerBlock * 32));
+        const int blocks = (int)((total + wpb * 32 - 1) / (wpb * 32));
         if (d->n_nets == 1) {
             static hipError_t once1 = hipFuncSetAttribute((const void*)render_forward_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (once1 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_backward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(once1));
-            hipLaunchKernelGGL((render_forward_kernel<1, true>), dim3(blocks), dim3(kWavesPerBlock * 64), lds_bytes, s, a);
+            hipLaunchKernelGGL((render_forward_kernel<1, true>), dim3(blocks), dim3(wpb * 64), lds_bytes, s, a);
         } else {
             static hipError_t once2 = hipFuncSetAttribute((const void*)render_forward_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (once2 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_backward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(once2));
-            hipLaunchKernelGGL((render_forward_kernel<2, true>), dim3(blocks), dim3(kWavesPerBlock * 64), lds_bytes, s, a);
+            hipLaunchKernelGGL((render_forward_kernel<2, true>), dim3(blocks), dim3(wpb * 64), lds_bytes, s, a);
         }
         int rc = check_launch("render_backward (tape sweep)");
         if (rc != P3D_OK) return rc;

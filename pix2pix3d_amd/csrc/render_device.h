@@ -305,17 +305,19 @@ render_forward_kernel(RenderArgs a)
     // strip needs (~1 MB per image) stay in that XCD's L2 for all its rows instead of being re-fetched by 8 L2s.
     // A workgroup is a 16 x 16 pixel block, a wave two 16-pixel rows of it (same row => same (z,y) texels: one fetch
     // serves 16 lanes).  Any other shape falls back to consecutive rays.
-    int ray0 = (blockIdx.x * kWavesPerBlock + wave) * 32;        // linear assignment (and the bound for 'live')
+    const int wpb = (int)blockDim.x >> 6;                        // waves per block: 8, or fewer for small launches (host: p3d_render_forward)
+    int ray0 = (blockIdx.x * wpb + wave) * 32;                   // linear assignment (and the bound for 'live')
     int g_lane = ray0 + j;
     {
         const int R = a.res;
-        const int ns = R >> 4;
-        if (R > 0 && (R & 15) == 0 && ns <= 8 && (8 % ns) == 0 && a.rays_per_img == R * R && ((a.total_rays / 256) & 7) == 0) {
+        const int ns = R >> 4, rpb = 2 * wpb;                     // 16-pixel column strips; pixel rows per block
+        if (R > 0 && (R & 15) == 0 && (R % rpb) == 0 && ns <= 8 && (8 % ns) == 0 && a.rays_per_img == R * R && ((a.total_rays / (wpb * 32)) & 7) == 0) {
             const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
             const int strip = xcd % ns, sub = xcd / ns, per = 8 / ns;         // `per` XCDs share a strip
             const int blk = slot * per + sub;                                 // (image, row block) index within the strip
-            const int n_i = blk / ns, rb = blk - n_i * ns;                    // ns row blocks of 16 rows per image
-            const int row = rb * 16 + wave * 2 + (j >> 4), col = strip * 16 + (j & 15);
+            const int nrb = R / rpb;                                          // row blocks per image
+            const int n_i = blk / nrb, rb = blk - n_i * nrb;
+            const int row = rb * rpb + wave * 2 + (j >> 4), col = strip * 16 + (j & 15);
             g_lane = n_i * a.rays_per_img + row * R + col;
             ray0 = 0;                                                         // every lane is a real ray in this mode
         }
