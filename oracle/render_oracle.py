@@ -153,6 +153,47 @@ def ray_march(colors, sigmas, depths, white_back=False, clamp_range=None):
     return (rgb * 2 - 1).astype(F32), d.astype(F32), weights
 
 
+def ray_march_backward(colors, sigmas, depths, g_rgb, g_wsum=None, white_back=False):
+    """Gradient of ``ray_march`` with respect to the per-sample colours and densities, for upstream gradients ``g_rgb`` [R,C] on the
+    returned rgb (= rgb_raw * 2 - 1) and ``g_wsum`` [R] on sum(weights) — what autograd derives for ray_marcher.py:25-57 — written
+    as the two explicit sweeps csrc/render_bwd.hip runs (fp64 here).  Depths are constants (renderer.py:198, 211).
+
+    Forward:  w_i = a_i T_i,  T_i = prod_{j<i} (1 - a_j + 1e-10),  a_i = 1 - exp(-softplus(sm_i - 1) d_i),  sm_i = (s_i + s_{i+1}) / 2,
+              rgb = 2 (sum_i w_i (c_i + c_{i+1}) / 2 [+ 1 - sum_i w_i]) - 1.
+    Returns (d_colors [R,S,C], d_sigmas [R,S], colour_weight [R,S]) with d_colors = 2 g_rgb * colour_weight."""
+    colors, sigmas, depths = np.asarray(colors, np.float64), np.asarray(sigmas, np.float64), np.asarray(depths, np.float64)
+    g_rgb = np.asarray(g_rgb, np.float64)
+    r, s, c = colors.shape
+    dC = 2.0 * g_rgb                                                    # dL/d(composited colour)
+    base = (0.0 if g_wsum is None else np.asarray(g_wsum, np.float64)) - (dC.sum(1) if white_back else 0.0)
+    alpha, T, w, sm = (np.zeros([r, s - 1]) for _ in range(4))
+    t = np.ones([r])
+    for i in range(s - 1):                                              # forward sweep: what the tape records
+        sm[:, i] = (sigmas[:, i] + sigmas[:, i + 1]) / 2
+        x = sm[:, i] - 1
+        dens = np.where(x > 20, x, np.log1p(np.exp(np.minimum(x, 20))))
+        alpha[:, i] = 1 - np.exp(-dens * (depths[:, i + 1] - depths[:, i]))
+        T[:, i] = t
+        w[:, i] = alpha[:, i] * t
+        t = t * (1 - alpha[:, i] + 1e-10)
+    dw = np.einsum('rc,rsc->rs', dC, (colors[:, :-1] + colors[:, 1:]) / 2) + np.reshape(base, [-1, 1] if np.ndim(base) else [])
+    dsm = np.zeros([r, s - 1])
+    suffix = np.zeros([r])
+    for i in range(s - 2, -1, -1):                                      # back to front: sum_{j>i} dw_j w_j
+        dalpha = dw[:, i] * T[:, i] - suffix / (1 - alpha[:, i] + 1e-10)
+        suffix = suffix + dw[:, i] * w[:, i]
+        x = sm[:, i] - 1
+        sg = np.where(x > 20, 1.0, 1 / (1 + np.exp(-x)))
+        dsm[:, i] = dalpha * (depths[:, i + 1] - depths[:, i]) * (1 - alpha[:, i]) * sg
+    d_sig = np.zeros([r, s])
+    d_sig[:, :-1] += dsm / 2
+    d_sig[:, 1:] += dsm / 2
+    cw = np.zeros([r, s])
+    cw[:, :-1] += w / 2
+    cw[:, 1:] += w / 2
+    return dC[:, None, :] * cw[:, :, None], d_sig, cw
+
+
 def importance_bins(z, weights):
     """First half of sample_importance (renderer.py:194-212): smoothed weights and bin positions.
     z [R,S], weights [R,S-1] -> bins [R,S-1], w_pdf [R,S-3]."""
@@ -232,7 +273,7 @@ def render(planes, dec, ray_o, ray_d, opts, u_coarse, u_fine, t_start=None, t_en
         rgb, depth, w = ray_march(c_c, s_c, zc, opts.get('white_back', False))
     out = rgb.reshape(n, m, -1), depth.reshape(n, m), w.sum(1).reshape(n, m)
     if details:
-        return out + (dict(z_coarse=zc, w_coarse=w_c, z_fine=z_f, z_all=z_s),)
+        return out + (dict(z_coarse=zc, w_coarse=w_c, z_fine=z_f, z_all=z_s, colors=(c_s if sf > 0 else c_c), sigmas=(s_s if sf > 0 else s_c)),)
     return out
 
 

@@ -398,9 +398,9 @@ class _FusedRenderFn(torch.autograd.Function):
         return (None,) * 7 + tuple(res)
 
 
-def fused_render_backward(planes, decoder, ray_origins, ray_directions, opt, u_coarse, u_fine, t_start, t_end, g_feat, g_wsum=None):
+def fused_render_backward(planes, decoder, ray_origins, ray_directions, opt, u_coarse, u_fine, t_start, t_end, g_feat, g_wsum=None, debug=False):
     """dL/dplanes (same shape and layout class as ``planes``) and dL/d(decoder parameters) (in ``decoder.parameters()`` order) of the
-    fused render, by the two recomputing launches of csrc/render_bwd.hip."""
+    fused render, by the two recomputing launches of csrc/render_bwd.hip.  Decoder parameters must require grad to get an entry."""
     info = _decoder_nets(decoder)
     nets, lr_mul, _ = info
     lib = _lib.lib()
@@ -441,6 +441,8 @@ def fused_render_backward(planes, decoder, ray_origins, ray_directions, opt, u_c
         by_param[id(fc2.weight)] = g[2112:4224].reshape(33, 64) * fc2.weight_gain
         by_param[id(fc2.bias)] = g[4224:4257] * fc2.bias_gain
     g_params = [by_param.get(id(p)) if p.requires_grad else None for p in decoder.parameters()]
+    if debug:                                                     # the per-sample tape: z, colour weight, dL/dsigma (tests)
+        return g_planes, g_params, tape_s
     return g_planes, g_params
 
 

@@ -131,3 +131,32 @@ def test_bench_sized_backward_properties(hip_lib):
         feat, _, _ = renderer._forward_tensor_ops(pl, dec, o, d, op)
         ref, = torch.autograd.grad((feat * g1).sum(), [pl])
     assert rel_err(gp1.cpu().numpy(), ref.cpu().numpy()) < 2e-3
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_tape_matches_the_compositing_backward_oracle(hip_lib, name):
+    """What the tape sweep hands each sample (depth, colour weight, dL/dsigma) against oracle.render_oracle: the oracle renders the same
+    rays, keeps its sorted per-sample colours / densities, and ray_march_backward (pinned to autograd on the CPU) differentiates them."""
+    from oracle import render_oracle as RO
+    R, dec, opts, planes, ro, rd = _setup(name)
+    g, _, dec_np = load_case(name)
+    n, m = ro.shape[0], ro.shape[1]
+    nch = 32 * len(R._decoder_nets(dec)[0])
+    sc, sf = int(opts['depth_resolution']), int(opts['depth_resolution_importance'])
+    u_c, u_f = torch.tensor(g['u_coarse'], device='cuda'), torch.tensor(g['u_fine'], device='cuda')
+    torch.manual_seed(9)
+    g_feat = torch.randn(n, m, nch, device='cuda')
+    g_w = torch.randn(n, m, 1, device='cuda')
+    t0 = t1 = None
+    if opts['ray_start'] == 'auto':
+        t0, t1 = R.ImportanceRenderer()._ray_limits(ro, rd, opts)
+    _, _, tape = R.fused_render_backward(planes, dec, ro, rd, opts, u_c, u_f, t0, t1, g_feat, g_w, debug=True)
+    tape = tape.cpu().numpy()
+    _, _, _, det = RO.render(g['planes'], dec_np, g['ray_o'], g['ray_d'], opts, g['u_coarse'], g['u_fine'],
+                             t_start=None if t0 is None else t0.cpu().numpy(), t_end=None if t1 is None else t1.cpu().numpy(), details=True)
+    _, d_sig, cw = RO.ray_march_backward(det['colors'], det['sigmas'], det['z_all'], g_feat.reshape(n * m, nch).cpu().numpy(),
+                                         g_w.reshape(-1).cpu().numpy(), white_back=bool(opts.get('white_back', False)))
+    assert tape.shape == (n * m, sc + sf, 4)
+    assert np.abs(tape[..., 0] - det['z_all']).max() < 2e-6
+    assert rel_err(tape[..., 1], cw) < 2e-4
+    assert rel_err(tape[..., 2], d_sig) < 2e-3

@@ -48,3 +48,27 @@ def test_importance_sampling_oracle_indices_and_values():
     # empty rays (first 8): pdf is uniform over the S-3 bins, so the index is floor(u * (S-3)) + 1 up to cdf rounding
     exp = np.floor(g['u'][:8] * w.shape[1]).astype(np.int64) + 1
     assert (np.abs(inds[:8] - exp) <= 1).all() and (inds[:8] == exp).mean() > 0.98
+
+
+@pytest.mark.parametrize('white_back', [False, True])
+def test_compositing_backward_oracle_is_autograd_of_the_ray_marcher(white_back):
+    """oracle.render_oracle.ray_march_backward (the two sweeps the fused backward runs on the device) against autograd through this
+    package's MipRayMarcher2 (itself pinned to the reference's records): d colours, d densities, with and without a wsum gradient."""
+    import torch
+    from oracle import render_oracle as RO
+    from pix2pix3d_amd.training.volumetric_rendering.ray_marcher import MipRayMarcher2
+    rng = np.random.RandomState(3)
+    r, s, c = 7, 13, 5
+    colors = torch.tensor(rng.rand(1, r, s, c), dtype=torch.float64, requires_grad=True)
+    sigmas = torch.tensor(rng.randn(1, r, s, 1) * 2 + 1, dtype=torch.float64, requires_grad=True)
+    depths = torch.tensor(np.sort(rng.rand(1, r, s, 1) * 1.0 + 2.25, axis=2), dtype=torch.float64)
+    rgb, depth, weights = MipRayMarcher2()(colors, sigmas, depths, {'clamp_mode': 'softplus', 'white_back': white_back})
+    g_rgb = torch.tensor(rng.randn(1, r, c), dtype=torch.float64)
+    g_w = torch.tensor(rng.randn(1, r), dtype=torch.float64)
+    loss = (rgb * g_rgb).sum() + (weights.sum(2)[..., 0] * g_w).sum()
+    gc, gs = torch.autograd.grad(loss, [colors, sigmas])
+    dcol, dsig, cw = RO.ray_march_backward(colors.detach()[0].numpy(), sigmas.detach()[0, ..., 0].numpy(), depths[0, ..., 0].numpy(),
+                                           g_rgb[0].numpy(), g_w[0].numpy(), white_back=white_back)
+    assert rel_err(dcol, gc[0].numpy()) < 1e-10
+    assert rel_err(dsig, gs[0, ..., 0].numpy()) < 1e-9
+    assert np.allclose(cw[:, 1:-1], ((weights[0, :, :-1, 0] + weights[0, :, 1:, 0]) / 2).detach().numpy())
