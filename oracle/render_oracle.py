@@ -236,10 +236,11 @@ def sample_importance(z, weights, u):
     return sample_pdf(bins, w, u)
 
 
-def render(planes, dec, ray_o, ray_d, opts, u_coarse, u_fine, t_start=None, t_end=None, details=False):
+def render(planes, dec, ray_o, ray_d, opts, u_coarse, u_fine, t_start=None, t_end=None, details=False, point_fn=None):
     """ImportanceRenderer.forward (renderer.py:88-140).  planes [N,3,32,H,W]; ray_o, ray_d [N,M,3];
-    u_coarse [N,M,Sc]; u_fine [N*M,Sf] -> feat [N,M,C], depth [N,M], wsum [N,M]."""
-    planes = np.asarray(planes, F32)
+    u_coarse [N,M,Sc]; u_fine [N*M,Sf] -> feat [N,M,C], depth [N,M], wsum [N,M].  ``point_fn(pts [N,P,3]) -> (colours [N,P,C], sigma
+    [N,P])`` replaces the plane lookup + decoder (render_semantic)."""
+    planes = None if planes is None else np.asarray(planes, F32)
     o, d = np.asarray(ray_o, F32), np.asarray(ray_d, F32)
     n, m, _ = o.shape
     if t_start is not None:
@@ -251,7 +252,7 @@ def render(planes, dec, ray_o, ray_d, opts, u_coarse, u_fine, t_start=None, t_en
     def run(z):
         s = z.shape[-1]
         pts = (o[:, :, None, :] + z[..., None] * d[:, :, None, :]).reshape(n, m * s, 3)
-        col, sig = decode(sample_from_planes(planes, pts, opts['box_warp']), dec)
+        col, sig = point_fn(pts) if point_fn is not None else decode(sample_from_planes(planes, pts, opts['box_warp']), dec)
         return col.reshape(n * m, s, -1), sig.reshape(n * m, s)
 
     c_c, s_c = run(z_c)
@@ -280,3 +281,27 @@ def render(planes, dec, ray_o, ray_d, opts, u_coarse, u_fine, t_start=None, t_en
 def run_model(planes, dec, coords, box_warp):
     """ImportanceRenderer.run_model (renderer.py:142-148): coords [N,P,3] -> rgb [N,P,C], sigma [N,P]."""
     return decode(sample_from_planes(np.asarray(planes, F32), coords, box_warp), dec)
+
+
+def run_model_semantic(planes_t, planes_s, dec_t, dec_s, coords, box_warp):
+    """ImportanceSemanticRenderer.run_model (renderer.py:324-333): the label decoder (OSGDecoder_semantic, triplane_cond.py:859-887) sees
+    the semantic planes and gives density + labels; the colour decoder (OSGDecoder on 64 features, triplane.py:112-135) sees
+    cat(texture, semantic).  dec_t / dec_s: dicts 'w1','b1','w2','b2','lr_mul'; dec_s['sigmoid'] squashes the labels.
+    -> rgb [N,P,32], sigma [N,P], semantic [N,P,32]."""
+    ft = sample_from_planes(planes_t, coords, box_warp)
+    fs = sample_from_planes(planes_s, coords, box_warp)
+    xs = fs.mean(1)
+    ys = _fc(_softplus(_fc(xs, dec_s['w1'], dec_s['b1'], dec_s['lr_mul'])), dec_s['w2'], dec_s['b2'], dec_s['lr_mul'])
+    sem = _squash(ys[..., 1:]) if dec_s.get('sigmoid', False) else ys[..., 1:].astype(F32)
+    xt = np.concatenate([ft, fs], -1).mean(1)
+    yt = _fc(_softplus(_fc(xt, dec_t['w1'], dec_t['b1'], dec_t['lr_mul'])), dec_t['w2'], dec_t['b2'], dec_t['lr_mul'])
+    return _squash(yt[..., 1:]), ys[..., 0], sem
+
+
+def render_semantic(planes_t, planes_s, dec_t, dec_s, ray_o, ray_d, opts, u_coarse, u_fine):
+    """ImportanceSemanticRenderer.forward (renderer.py:262-322): same sampling and compositing as ``render`` over the feature vector
+    cat(colour, label) -> feat [N,M,64], depth [N,M], wsum [N,M]."""
+    def point_fn(pts):
+        rgb, sig, sem = run_model_semantic(planes_t, planes_s, dec_t, dec_s, pts, opts['box_warp'])
+        return np.concatenate([rgb, sem], -1).astype(F32), sig
+    return render(None, None, ray_o, ray_d, opts, u_coarse, u_fine, point_fn=point_fn)

@@ -217,6 +217,26 @@ class Generator_cond(torch.nn.Module):
         return self.synthesis(ws, update_emas=update_emas, **synthesis_kwargs)
 
 
+class OSGDecoder_semantic(torch.nn.Module):
+    """Label decoder of the two-backbone generator (:859-887): one 32-64-33 MLP on the plane-averaged semantic features; channel 0 is
+    the density, the rest the labels — raw logits, or clamped-sigmoid when ``options['sigmoid']`` (single-channel edge maps)."""
+
+    def __init__(self, n_features, options):
+        super().__init__()
+        self.hidden_dim = 64
+        self.net = _osg_mlp(n_features, self.hidden_dim, 1 + options['decoder_output_dim'], options['decoder_lr_mul'])
+        self.final_sigmoid = options['sigmoid']
+
+    def forward(self, sampled_features, ray_directions):
+        x = sampled_features.mean(1)
+        n, m, c = x.shape
+        y = self.net(x.reshape(n * m, c)).reshape(n, m, -1)
+        labels = y[..., 1:]
+        if self.final_sigmoid:
+            labels = torch.sigmoid(labels) * (1 + 2 * 0.001) - 0.001
+        return {'rgb': labels, 'sigma': y[..., 0:1]}
+
+
 class OSGDecoder_semantic_lateSeparate(torch.nn.Module):
     """Two independent 32-64-33 MLPs on the plane-averaged feature: a colour net and a label net; the density is
     channel 0 of the LABEL net (:926-970).  Output 'rgb' = cat(32 colour channels, 32 label channels)."""

@@ -213,7 +213,9 @@ class ImportanceRenderer(torch.nn.Module):
         return fused_render(planes, decoder, ray_origins, ray_directions, opt, u_c, u_f, t0, t1)
 
     # ------------------------------------------------------------------------------------------------
-    def _forward_tensor_ops(self, planes, decoder, ray_origins, ray_directions, opt):
+    def _forward_tensor_ops(self, planes, decoder, ray_origins, ray_directions, opt, point_fn=None):
+        """The differentiable tensor-op restatement of forward().  ``point_fn(points, directions) -> {'rgb', 'sigma'}`` replaces the
+        plane lookup + decoder (ImportanceSemanticRenderer)."""
         if opt['ray_start'] == opt['ray_end'] == 'auto':
             t0, t1 = self._ray_limits(ray_origins, ray_directions, opt)
             z_c = self.sample_stratified(ray_origins, t0, t1, opt['depth_resolution'], opt['disparity_space_sampling'])
@@ -225,7 +227,7 @@ class ImportanceRenderer(torch.nn.Module):
             s = z.shape[2]
             pts = (ray_origins.unsqueeze(-2) + z * ray_directions.unsqueeze(-2)).reshape(n, -1, 3)
             dirs = ray_directions.unsqueeze(-2).expand(-1, -1, s, -1).reshape(n, -1, 3)
-            out = self.run_model(planes, decoder, pts, dirs, opt)
+            out = point_fn(pts, dirs) if point_fn is not None else self.run_model(planes, decoder, pts, dirs, opt)
             return out['rgb'].reshape(n, m, s, -1), out['sigma'].reshape(n, m, s, 1)
 
         c_c, s_c = decode(z_c)
@@ -324,6 +326,35 @@ class ImportanceRenderer(torch.nn.Module):
         span = c1 - c0
         span = torch.where(span < eps, torch.ones_like(span), span)
         return b0 + (u - c0) / span * (b1 - b0)
+
+
+class ImportanceSemanticRenderer(ImportanceRenderer):
+    """Renderer of the two-backbone generator (reference: renderer.py:256-438): a texture plane set and a semantic plane set; the label
+    decoder reads the semantic features and provides density + labels, the colour decoder reads cat(texture, semantic).  Sampling
+    and compositing are ImportanceRenderer's, over the feature vector cat(colour, label).  train.py no longer selects the generator
+    that uses it (:375), so this is the plain tensor-op formulation on every device — no fused kernel, and ``fused_policy ==
+    'require'`` refuses device tensors here like everywhere else."""
+
+    def forward(self, planes_texture, planes_semantic, decoder_texture, decoder_semantic, ray_origins, ray_directions, rendering_options):
+        self.plane_axes = self.plane_axes.to(ray_origins.device)
+        self._tensor_op_guard(planes_texture, 'two plane sets (ImportanceSemanticRenderer) have no fused kernel')
+
+        def point_fn(pts, dirs):
+            out = self.run_model(planes_texture, planes_semantic, decoder_texture, decoder_semantic, pts, dirs, rendering_options)
+            return {'rgb': torch.cat([out['rgb'], out['semantic']], dim=-1), 'sigma': out['sigma']}
+        return self._forward_tensor_ops(None, None, ray_origins, ray_directions, rendering_options, point_fn=point_fn)
+
+    def run_model(self, planes_texture, planes_semantic, decoder_texture, decoder_semantic, sample_coordinates, sample_directions, options):
+        """-> {'rgb': [N,P,32], 'sigma': [N,P,1], 'semantic': [N,P,32]}  (renderer.py:324-333)."""
+        self.plane_axes = self.plane_axes.to(sample_coordinates.device)
+        tex = sample_from_planes(self.plane_axes, planes_texture, sample_coordinates, padding_mode='zeros', box_warp=options['box_warp'])
+        sem = sample_from_planes(self.plane_axes, planes_semantic, sample_coordinates, padding_mode='zeros', box_warp=options['box_warp'])
+        label = decoder_semantic(sem, sample_directions)
+        colour = decoder_texture(torch.cat([tex, sem], dim=-1), sample_directions)
+        out = {'sigma': label['sigma'], 'rgb': colour['rgb'], 'semantic': label['rgb']}
+        if options.get('density_noise', 0) > 0:
+            out['sigma'] = out['sigma'] + torch.randn_like(out['sigma']) * options['density_noise']
+        return out
 
 
 def importance_sample_native(z_coarse, w_coarse, u_fine, sort=False):

@@ -3,7 +3,7 @@
 Run in the authoring container only (it needs the read-only checkout at /root/reference, which does
 not exist on the GPU box):
 
-    python tests/golden/make_golden.py [group ...]      # groups: ops renderer model
+    python tests/golden/make_golden.py [group ...]      # groups: ops renderer semrenderer model flrelu train
 
 The reference and this repo own the same top-level module names, so this script must never import
 ``pix2pix3d_amd``; it puts /root/reference first on sys.path and imports the reference's modules
@@ -234,6 +234,53 @@ def group_renderer():
 
 
 GROUPS['renderer'] = group_renderer
+
+
+def group_semrenderer():
+    """ImportanceSemanticRenderer (renderer.py:256-438): two plane sets, OSGDecoder on cat(texture, semantic) features for colour and
+    OSGDecoder_semantic on the semantic planes for density + labels.  Not selected by train.py any more; recorded for parity of the
+    host-side mirror."""
+    from training.volumetric_rendering.renderer import ImportanceSemanticRenderer
+    from training.volumetric_rendering.ray_sampler import RaySampler
+    from training.triplane import OSGDecoder
+    from training.triplane_cond import OSGDecoder_semantic
+    cases = [
+        dict(name='a', sem_sigmoid=False, n=2, hw=(12, 14), res=5, focal=4.2647, radius=2.7, lr_mul=1.0,
+             opts=dict(depth_resolution=10, depth_resolution_importance=8, ray_start=2.25, ray_end=3.3, box_warp=1, disparity_space_sampling=False, clamp_mode='softplus')),
+        dict(name='b', sem_sigmoid=True, n=1, hw=(16, 16), res=6, focal=1.2, radius=1.7, lr_mul=0.5,
+             opts=dict(depth_resolution=12, depth_resolution_importance=0, ray_start=0.1, ray_end=2.6, box_warp=1.6, disparity_space_sampling=False, clamp_mode='softplus', white_back=True)),
+    ]
+    for ci, cs in enumerate(cases):
+        torch.manual_seed(300 + ci)
+        n, (h, w), res = cs['n'], cs['hw'], cs['res']
+        planes_t, planes_s = torch.randn(n, 3, 32, h, w), torch.randn(n, 3, 32, h, w)
+        dec_t = OSGDecoder(64, {'decoder_lr_mul': cs['lr_mul'], 'decoder_output_dim': 32})
+        dec_s = OSGDecoder_semantic(32, {'decoder_lr_mul': cs['lr_mul'], 'decoder_output_dim': 32, 'sigmoid': cs['sem_sigmoid']})
+        with torch.no_grad():
+            for d_ in (dec_t, dec_s):
+                for p_ in d_.parameters():
+                    if p_.ndim == 1:
+                        p_.copy_(torch.randn_like(p_) * 0.3 / cs['lr_mul'])
+        c2w = torch.tensor(np.stack([_look_at(cs['radius'], 0.2 + 0.8 * i, 1.45 - 0.2 * i) for i in range(n)]))
+        K = torch.tensor([[cs['focal'], 0.0, 0.5], [0, cs['focal'], 0.5], [0, 0, 1]], dtype=torch.float32).repeat(n, 1, 1)
+        ray_o, ray_d = RaySampler()(c2w, K, res)
+        rend = ImportanceSemanticRenderer()
+        with _RandTape() as tape, torch.no_grad():
+            feat, depth, wsum = rend(planes_t, planes_s, dec_t, dec_s, ray_o, ray_d, cs['opts'])
+        pts = (torch.rand(n, 30, 3) - 0.5) * 1.3 * cs['opts']['box_warp']
+        with torch.no_grad():
+            pm = rend.run_model(planes_t, planes_s, dec_t, dec_s, pts, None, cs['opts'])
+        arrays = dict(planes_t=planes_t, planes_s=planes_s, ray_o=ray_o, ray_d=ray_d, u_coarse=tape.draws[0],
+                      u_fine=tape.draws[1] if len(tape.draws) > 1 else np.zeros([0], np.float32), feat=feat, depth=depth, wsum=wsum,
+                      pts=pts, pts_rgb=pm['rgb'], pts_sigma=pm['sigma'], pts_semantic=pm['semantic'],
+                      sem_sigmoid=np.int64(cs['sem_sigmoid']), lr_mul=np.float64(cs['lr_mul']),
+                      opt_keys=np.array(list(cs['opts'].keys())), opt_vals=np.array([str(v) for v in cs['opts'].values()]))
+        arrays.update({'dect_' + k: v for k, v in _decoder_arrays(dec_t).items()})
+        arrays.update({'decs_' + k: v for k, v in _decoder_arrays(dec_s).items()})
+        save('semrenderer_' + cs['name'], **arrays)
+
+
+GROUPS['semrenderer'] = group_semrenderer
 
 
 # ---------------------------------------------------------------------------------------------------------

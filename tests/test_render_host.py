@@ -52,3 +52,34 @@ def test_decoder_recognition_for_fused_path():
     info = renderer._decoder_nets(make_decoder(g))
     assert info is not None and len(info[0]) == 1 and info[1] == 0.5
     assert renderer._decoder_nets(torch.nn.Linear(3, 3)) is None
+
+
+@pytest.mark.parametrize('name', ['a', 'b'])
+def test_semantic_renderer_mirror_matches_reference_records(name):
+    """ImportanceSemanticRenderer + OSGDecoder_semantic (the two-backbone generator's renderer, not selected by train.py any more) on the
+    CPU against the reference's records: run_model on free points and the full render with the recorded draws replayed."""
+    import torch
+    from conftest import load_golden
+    from render_cases import _parse
+    from pix2pix3d_amd.training.volumetric_rendering import renderer as R
+    from pix2pix3d_amd.training.triplane import OSGDecoder
+    from pix2pix3d_amd.training.triplane_cond import OSGDecoder_semantic
+    g = load_golden('semrenderer_' + name)
+    opts = {k: _parse(v) for k, v in zip(g['opt_keys'].tolist(), g['opt_vals'].tolist())}
+    lr = float(g['lr_mul'])
+    dec_t = OSGDecoder(64, {'decoder_lr_mul': lr, 'decoder_output_dim': 32})
+    dec_s = OSGDecoder_semantic(32, {'decoder_lr_mul': lr, 'decoder_output_dim': 32, 'sigmoid': bool(g['sem_sigmoid'])})
+    with torch.no_grad():
+        for dec, pre in ((dec_t, 'dect_'), (dec_s, 'decs_')):
+            dec.net[0].weight.copy_(torch.tensor(g[pre + 'w1'])); dec.net[0].bias.copy_(torch.tensor(g[pre + 'b1']))
+            dec.net[2].weight.copy_(torch.tensor(g[pre + 'w2'])); dec.net[2].bias.copy_(torch.tensor(g[pre + 'b2']))
+    rend = R.ImportanceSemanticRenderer()
+    pt, ps = torch.tensor(g['planes_t']), torch.tensor(g['planes_s'])
+    with torch.no_grad():
+        pm = rend.run_model(pt, ps, dec_t, dec_s, torch.tensor(g['pts']), None, opts)
+        draws = [torch.tensor(g['u_coarse'])] + ([torch.tensor(g['u_fine'])] if g['u_fine'].size else [])
+        with R._replay_draws(*draws):
+            feat, depth, wsum = rend(pt, ps, dec_t, dec_s, torch.tensor(g['ray_o']), torch.tensor(g['ray_d']), opts)
+    for key in ('rgb', 'sigma', 'semantic'):
+        assert rel_err(pm[key].numpy(), g['pts_' + key]) < 1e-5, key
+    assert rel_err(feat.numpy(), g['feat']) < 1e-5 and rel_err(depth.numpy(), g['depth']) < 1e-5 and rel_err(wsum.numpy(), g['wsum']) < 1e-5

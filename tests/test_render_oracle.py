@@ -72,3 +72,24 @@ def test_compositing_backward_oracle_is_autograd_of_the_ray_marcher(white_back):
     assert rel_err(dcol, gc[0].numpy()) < 1e-10
     assert rel_err(dsig, gs[0, ..., 0].numpy()) < 1e-9
     assert np.allclose(cw[:, 1:-1], ((weights[0, :, :-1, 0] + weights[0, :, 1:, 0]) / 2).detach().numpy())
+
+
+def _sem_case(name):
+    g = load_golden('semrenderer_' + name)
+    from render_cases import _parse
+    opts = {k: _parse(v) for k, v in zip(g['opt_keys'].tolist(), g['opt_vals'].tolist())}
+    lr = float(g['lr_mul'])
+    dec_t = {k[5:]: g[k] for k in g.files if k.startswith('dect_')}
+    dec_s = {k[5:]: g[k] for k in g.files if k.startswith('decs_')}
+    dec_t['lr_mul'], dec_s['lr_mul'], dec_s['sigmoid'] = lr, lr, bool(g['sem_sigmoid'])
+    return g, opts, dec_t, dec_s
+
+
+@pytest.mark.parametrize('name', ['a', 'b'])
+def test_semantic_renderer_oracle_matches_reference_records(name):
+    """oracle.render_oracle.render_semantic / run_model_semantic against what the reference's ImportanceSemanticRenderer produced."""
+    g, opts, dec_t, dec_s = _sem_case(name)
+    rgb, sig, sem = R.run_model_semantic(g['planes_t'], g['planes_s'], dec_t, dec_s, g['pts'], opts['box_warp'])
+    assert rel_err(rgb, g['pts_rgb']) < 2e-5 and rel_err(sig, g['pts_sigma'][..., 0]) < 2e-5 and rel_err(sem, g['pts_semantic']) < 2e-5
+    feat, depth, wsum = R.render_semantic(g['planes_t'], g['planes_s'], dec_t, dec_s, g['ray_o'], g['ray_d'], opts, g['u_coarse'][..., 0], g['u_fine'])
+    assert rel_err(feat, g['feat']) < 1e-4 and rel_err(depth, g['depth'][..., 0]) < 1e-4 and rel_err(wsum, g['wsum'][..., 0]) < 1e-4
