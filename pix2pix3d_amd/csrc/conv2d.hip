@@ -245,14 +245,19 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
         }
     } else {
         int opix[2][16];                                                        // output pixel offset of each accumulator row (or -1)
+        // one division for the wave's first row, then every row by carry (its 32 rows span 64 consecutive m): the 32 runtime
+        // divisions this replaces were a fifth of a short-K (1x1) block's life
+        const int mb = m0 + wm * 64;
+        const int sib = mb / kc.SW, sjb = mb - sib * kc.SW;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                const int si = m / kc.SW, sj = m - si * kc.SW;
+                const int d = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                int si = sib, sj = sjb + d;
+                while (sj >= kc.SW) { sj -= kc.SW; ++si; }
                 const int oy = si * a.osy + kc.ooy, ox = sj * a.osx + kc.oox;
-                opix[i][r] = (m < M && oy < a.OH && ox < a.OW) ? oy * a.OW + ox : -1;
+                opix[i][r] = (mb + d < M && oy < a.OH && ox < a.OW) ? oy * a.OW + ox : -1;
             }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
