@@ -37,3 +37,12 @@ for name, c, r, dt in [('sr.b1 fir 512^2x128 f16', 128, 512, torch.float16), ('s
     es = y.element_size()
     gb = N * c * ((r + 1) ** 2 + r * r) * es / 1e9
     print(f'p3d {name}: {t * 1e3:.3f} ms, {gb / t / 1e3:.2f} TB/s (algorithmic read+write)', flush=True)
+
+for name, ci, r in [('bb.b256.torgb 1x1 128->96', 128, 256), ('bb.b128.torgb 1x1 256->96', 256, 128), ('bb.b64.torgb 1x1 512->96', 512, 64)]:
+    x = torch.randn(N, ci, r, r, device='cuda').to(memory_format=torch.channels_last)
+    weight = torch.randn(96, ci, 1, 1, device='cuda'); styles = torch.randn(N, ci, device='cuda') + 1
+    wmod = modconv.modulate_weights(weight, styles, demodulate=False, dtype=torch.float32)
+    bias = torch.randn(96, device='cuda')
+    t = timeit(lambda: modconv.conv2d(x, wmod, bias=bias))
+    gb = N * r * r * (ci + 96) * 4 / 1e9
+    print(f'p3d fp32 {name}: {t * 1e3:.3f} ms, {2 * N * ci * 96 * r * r / t / 1e12:.1f} TF, {gb / t / 1e3:.2f} TB/s (x read + y write)', flush=True)
