@@ -414,17 +414,15 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(ConvArgs a)
     }
 }
 
-// ---- 3x3 conv, 256-pixel tile, three-stage weight pipeline (fp16) ---------------------------------------------------------
+// ---- 3x3 conv, 256-pixel tile, three-slot weight ring (fp16) ---------------------------------------------------------------
 // The two-stage kernels above wait for the whole prefetch at every barrier, so a K step costs one L2 round trip however
-// little compute it holds.  This variant (what the big fp16 super-resolution layers run) keeps the halo slab idea but
+// little compute it holds.  This variant keeps the halo slab idea but
 //   * doubles the pixel tile to 16 x 16 (512 threads, 8 waves as 4 x 2; weight traffic per FLOP halves),
-//   * rings the weight tiles through THREE LDS buffers: at step k the tile of step k+2 is issued, and the barrier at the
-//     end of step k only waits for the tile of step k+1 — a counted `s_waitcnt vmcnt(n)` with n = the LDS-DMA instructions
-//     this wave issued during step k (they are the youngest), followed by a bare `s_barrier` (a `__syncthreads()` would
-//     drain the queue to zero),
-//   * keeps two slab buffers; the next channel chunk's slab is issued at tap 0 and is forced to land by the next counted
-//     wait, eight steps before its first use.
-// LDS: 2 x 41.5 KB slabs + 3 x 16 KB weights = 131 KB -> one block (2 waves per SIMD) per CU.
+//   * rings the weight tiles through THREE LDS buffers with ONE barrier per step (details at the loop),
+//   * keeps two slab buffers; the next channel chunk's slab is issued at tap 0, eight steps before its first use.
+// LDS: 2 x 41.5 KB slabs + 3 x 16 KB weights = 131 KB -> one block (2 waves per SIMD) per CU.  Superseded as the default by
+// conv3x3_h2_f16_kernel below (same pipeline, 70 KB, two blocks per CU: +5 % on the SR layers); kept selectable
+// (P3D_CONV_NO_H2) as the measured comparison point.
 constexpr int QH = 16, QW = 16;                     // pixel patch (QH * QW = 256)
 constexpr int QSLAB_W = QW + 2, QSLAB_ROWS = (QH + 2) * (QW + 2);        // 18, 324
 constexpr int QSLAB_GROUPS = (QSLAB_ROWS + 7) / 8;                       // 41 DMA groups of 8 slab pixels
@@ -627,6 +625,186 @@ __global__ void __launch_bounds__(512, 2) conv3x3_q256_f16_kernel(ConvArgs a)
     }
 }
 
+// ---- 3x3 conv, 16 x 16 patch, 64-byte K rows: TWO blocks per CU (fp16) ----------------------------------------------------
+// Same halo / ring / lane-constant / counted-wait structure as the 256-pixel kernel above, re-cut so that a block needs 70 KB of
+// LDS instead of 131 KB: K rows are 32 channels (64 bytes), the slab of a chunk is 23 KB, a weight tile 8 KB.  Two blocks then
+// share a CU and one's prologue (slab from HBM) and epilogue hide under the other's main loop — with one block per CU they are
+// exposed and cap that structure near 1.5 PFLOP/s.  4 waves per block, each 64 pixels x all 128 output channels (8 accumulator
+// tiles: 12 fragment reads per 16 MFMAs instead of 16).  64-byte rows put FOUR rows in a 256-byte bank row, so the slab pitch is 20
+// pixels (a multiple of 4) and the XOR key of a row is (column >> 2) & 3: the 16 rows one ds_read_b128 cycle serves (8 pixels
+// of a patch row, 8 of the next) then cover all 16 bank quads.
+constexpr int H2_PITCH = 20;
+constexpr int H2_SLAB_ROWS = 18 * H2_PITCH;                     // 360 rows of 64 bytes
+constexpr int H2_SLAB_PIECES = (H2_SLAB_ROWS * 64 + 1023) / 1024;   // 23 DMA pieces (16 rows each)
+constexpr int H2_SLAB_BUF = H2_SLAB_PIECES * 1024;              // 23552
+constexpr int H2_WT_BYTES = BN * 64;                            // 8192
+constexpr int H2_WT_BASE = 2 * H2_SLAB_BUF;                     // 47104
+constexpr int H2_LDS = H2_WT_BASE + 3 * H2_WT_BYTES;            // 71680 (>= the 69632-byte epilogue stage)
+
+__global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
+{
+    __shared__ __attribute__((aligned(16))) char lds_b[H2_LDS];     // ONE object (see conv3x3_q256_f16_kernel)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.z;
+    const int tiles_x = (a.W + QW - 1) / QW;
+    int mt = blockIdx.x, cb = blockIdx.y;
+    {
+        const int nmt = gridDim.x, ncb = gridDim.y, L = blockIdx.x + blockIdx.y * nmt;
+        if ((nmt & 7) == 0) { const int q = L >> 3, r = L & 7; cb = q % ncb; mt = (q / ncb) * 8 + r; }
+    }
+    const int ty0 = mt / tiles_x, tx0 = mt - ty0 * tiles_x;
+    const int oy0 = ty0 * QH, ox0 = tx0 * QW, co0 = cb * BN;
+    const char* const xin_b = (const char*)((const __half*)a.x + (int64_t)n * a.H * a.W * a.Ci);
+    const char* const wgt_b = (const char*)((const __half*)a.w + (int64_t)n * a.w_img_stride);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const int pos = lane & 3, prow = lane >> 2;                                // DMA lane: 16-byte position / row within its 16-row piece
+    const int kpairs = a.Ci / 64;                                              // the loop body covers TWO 32-channel chunks (18 taps)
+
+    unsigned woff[2];                                                          // weight pieces 2 * wave, 2 * wave + 1 (16 rows each)
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) {
+        const int row = (wave * 2 + p2) * 16 + prow;
+        woff[p2] = (unsigned)(((co0 + row) * 9 * a.Ci + (pos ^ ((row >> 2) & 3)) * 8) * 2);
+    }
+    unsigned soff[6]; bool sok[6];                                             // slab pieces wave, wave + 4, ...  (6, or 5 for wave 3)
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+        const int q = (wave + 4 * g) * 16 + prow;
+        const int sy = q / H2_PITCH, sx = q - sy * H2_PITCH;
+        const int iy = oy0 - 1 + sy, ix = ox0 - 1 + sx;
+        sok[g] = (q < H2_SLAB_ROWS) & (sx < 18) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
+        soff[g] = (unsigned)(((iy * a.W + ix) * a.Ci + (pos ^ ((sx >> 2) & 3)) * 8) * 2);
+    }
+    const int nslab = (wave == 3) ? 5 : 6;
+    auto stage_slab = [&](int cc, int buf) {
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            if (g < nslab) {
+                const char* src = sok[g] ? xin_b + soff[g] + cc * 64 : (const char*)a.zeros;
+                __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(lds_b + buf * H2_SLAB_BUF + (wave + 4 * g) * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto stage_w = [&](int cc, int t, int slot) {
+        const char* base = wgt_b + (t * a.Ci + cc * 32) * 2;
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2)
+            __builtin_amdgcn_global_load_lds((glb_ptr)(base + woff[p2]), (lds_ptr)(lds_b + H2_WT_BASE + slot * H2_WT_BYTES + (wave * 2 + p2) * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int frow = lane & 31, fk = lane >> 5;
+    const int acol = frow & 15;
+    int preA[3][2], preB[2];
+#pragma unroll
+    for (int tx2 = 0; tx2 < 3; ++tx2)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+            preA[tx2][kk] = ((wave * 4 + (frow >> 4)) * H2_PITCH + acol + tx2) * 64 + (((kk * 2 + fk) ^ (((acol + tx2) >> 2) & 3)) << 4);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) preB[kk] = H2_WT_BASE + frow * 64 + (((kk * 2 + fk) ^ ((frow >> 2) & 3)) << 4);
+
+    f32x4 fa[2][2], fb[2][4];
+    auto load_frags = [&](int buf, int t, int kk, f32x4* pa, f32x4* pb) {      // buf, t, kk are compile-time after unrolling
+        const int ty2 = t / 3, tx2 = t - ty2 * 3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pa[i]) : "v"(preA[tx2][kk]), "n"(buf * H2_SLAB_BUF + (i * 2 + ty2) * H2_PITCH * 64) : "memory");
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pb[j]) : "v"(preB[kk]), "n"((t % 3) * H2_WT_BYTES + j * 32 * 64) : "memory");
+    };
+
+    stage_slab(0, 0);
+    stage_w(0, 0, 0);
+    stage_w(0, 1, 1);
+    stage_w(0, 2, 2);
+    wait_vmcnt<2>();                                                            // slab 0, tiles 0 and 1 (tile 2 stays in flight)
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, 0, 0, fa[0], fb[0]);
+    for (int cp = 0; cp < kpairs; ++cp) {
+        const bool more = cp + 1 < kpairs;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int cc = cp * 2 + h;
+            const bool next_chunk = (h == 0) || more;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int cur = kk & 1, nxt = cur ^ 1;
+                    if (kk == 0) { load_frags(h, t, 1, fa[nxt], fb[nxt]); asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); }
+                    else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        const bool t2 = (t < 7) || next_chunk;                  // tile ks+2 exists
+                        if (t == 1 && next_chunk) { if (nslab == 6) wait_vmcnt<8>(); else wait_vmcnt<7>(); }
+                        else if (t2) wait_vmcnt<2>();
+                        else wait_vmcnt<0>();
+                        __builtin_amdgcn_s_barrier();
+                        if (t < 6) stage_w(cc, t + 3, t % 3);
+                        else if (next_chunk) stage_w(cc + 1, t - 6, t % 3);
+                        if (t == 0 && next_chunk) stage_slab(cc + 1, h ^ 1);
+                        if (t < 8) load_frags(h, t + 1, 0, fa[nxt], fb[nxt]);
+                        else if (next_chunk) load_frags(h ^ 1, 0, 0, fa[nxt], fb[nxt]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, fa[cur][i]), __builtin_bit_cast(h8, fb[cur][j]), acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    __syncthreads();                                                            // every wave is done with the slabs and tiles
+
+    constexpr int OP = 136;
+    __half* const ot = (__half*)lds_b;
+    float* const nz = (float*)(ot + 256 * OP);                                   // 69632 .. 70656 < H2_LDS
+    const float ns = a.noise ? a.noise_strength[0] : 0.f;
+    if (a.noise) {
+        const int oy = oy0 + (tid >> 4), ox = ox0 + (tid & 15);
+        nz[tid] = (oy < a.H && ox < a.W) ? a.noise[(int64_t)oy * a.W + ox] * ns : 0.f;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cl = j * 32 + frow, co = co0 + cl;
+        const float b = (a.bias && co < a.Co) ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                float v = acc[i][j][r];
+                if (a.noise) v += nz[p];
+                v += b;
+                if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
+                v *= a.gain;
+                if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
+                ot[p * OP + cl] = __float2half(v);
+            }
+    }
+    __syncthreads();
+    __half* const yout = (__half*)a.y + (int64_t)n * a.H * a.W * a.Co;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int idx = it * 256 + tid, p = idx >> 4, ch = idx & 15;
+        const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15), co = co0 + ch * 8;
+        if (oy < a.H && ox < a.W && co < a.Co)
+            *(f32x4*)(yout + ((int64_t)oy * a.W + ox) * a.Co + co) = *(const f32x4*)(ot + p * OP + ch * 8);
+    }
+}
+
 // ---- per-sample weight modulation + demodulation -> fp16, tap-major -------------------------------------------------
 // one block per (co, n): wm[i, t] = w[co, i, t] * s[n, i]; d = rsqrt(sum wm^2 + 1e-8) (if demodulate); out[n][co][t][i]
 template <class T>
@@ -779,6 +957,13 @@ extern "C" int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype,
         for (int t = 0; t < a.KT; ++t) a.cls[0].taps[t] = ConvTap{t / kernel_size - kernel_size / 2, t % kernel_size - kernel_size / 2, t};
         static const bool no_halo = getenv("P3D_CONV_NO_HALO") != nullptr;
         static const bool no_q256 = getenv("P3D_CONV_NO_Q256") != nullptr;
+        static const bool no_h2 = getenv("P3D_CONV_NO_H2") != nullptr;
+        if (!no_h2 && !no_halo && kernel_size == 3 && dtype == P3D_F16 && h >= 32 && wdt >= 32 && ci % 64 == 0 && co % BN == 0 && (((uintptr_t)y) & 15u) == 0) {
+            dim3 grid(((h + QH - 1) / QH) * ((wdt + QW - 1) / QW), co / BN, n_img);
+            hipLaunchKernelGGL(conv3x3_h2_f16_kernel, grid, dim3(256), 0, s, a);
+            count_launch(FAM_CONV);
+            return check_launch("conv3x3_h2_f16");
+        }
         if (kernel_size == 3 && dtype == P3D_F16 && h >= 64 && wdt >= 64 && ci % 128 == 0 && co % BN == 0 && (((uintptr_t)y) & 15u) == 0 && !no_halo && !no_q256) {     // big fp16 layers: 256-pixel tiles, 3-stage weights
             static hipError_t attr = hipFuncSetAttribute((const void*)conv3x3_q256_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 0);
             (void)attr;
