@@ -805,6 +805,186 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
     }
 }
 
+// ---- stride-2 transposed 3x3 conv on the two-blocks-per-CU structure (fp16) ------------------------------------------------
+// The x2 layers' conv_transpose2d (conv2d_resample.py:114-127) is four dense sub-problems, one per output parity (4 / 2 / 2 / 1
+// taps, offsets in {-1, 0}).  Each block takes one 16 x 16 patch of ONE parity class and runs conv3x3_h2_f16_kernel's pipeline over
+// that class's tap list: the slab is shared by the class's taps (the generic kernel re-fetched a 16 KB activation tile per tap and
+// had 4..16-step K loops), 70 KB of LDS, two blocks per CU.  Tap list and ring slot are run-time values here (1..4 taps do not
+// divide the three slots), so a step pays two extra adds for its fragment bases; everything else is as above.
+__global__ void __launch_bounds__(256, 2) convT_h2_f16_kernel(ConvArgs a)
+{
+    __shared__ __attribute__((aligned(16))) char lds_b[H2_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.z / a.ncls;
+    const ConvArgs::Cls& kc = a.cls[blockIdx.z - n * a.ncls];
+    const int tiles_x = (kc.SW + QW - 1) / QW, tiles_y = (kc.SH + QH - 1) / QH;
+    const int mt = blockIdx.x, cb = blockIdx.y;
+    if (mt >= tiles_x * tiles_y) return;                                       // classes differ by one row / column of positions
+    const int ty0 = mt / tiles_x, tx0 = mt - ty0 * tiles_x;
+    const int oy0 = ty0 * QH, ox0 = tx0 * QW, co0 = cb * BN;                   // class-grid position of the patch = input pixel of tap (0, 0)
+    const char* const xin_b = (const char*)((const __half*)a.x + (int64_t)n * a.H * a.W * a.Ci);
+    const char* const wgt_b = (const char*)((const __half*)a.w + (int64_t)n * a.w_img_stride);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const int pos = lane & 3, prow = lane >> 2;
+    const int kchunks = a.Ci / 32, ntaps = kc.ntaps, ksteps = kchunks * ntaps;
+
+    unsigned woff[2];
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) {
+        const int row = (wave * 2 + p2) * 16 + prow;
+        woff[p2] = (unsigned)(((co0 + row) * 9 * a.Ci + (pos ^ ((row >> 2) & 3)) * 8) * 2);
+    }
+    unsigned soff[6]; bool sok[6];
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+        const int q = (wave + 4 * g) * 16 + prow;
+        const int sy = q / H2_PITCH, sx = q - sy * H2_PITCH;
+        const int iy = oy0 - 1 + sy, ix = ox0 - 1 + sx;
+        sok[g] = (q < H2_SLAB_ROWS) & (sx < 18) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
+        soff[g] = (unsigned)(((iy * a.W + ix) * a.Ci + (pos ^ ((sx >> 2) & 3)) * 8) * 2);
+    }
+    const int nslab = (wave == 3) ? 5 : 6;
+    auto stage_slab = [&](int cc, int buf) {
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            if (g < nslab) {
+                const char* src = sok[g] ? xin_b + soff[g] + cc * 64 : (const char*)a.zeros;
+                __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(lds_b + buf * H2_SLAB_BUF + (wave + 4 * g) * 1024), 16, 0, 0);
+            }
+        }
+    };
+    // the class's tap table goes into registers once: a scalar load per step would sit on lgkmcnt and drain the fragment pipeline
+    int tap_w[4], tap_a[4], tap_x[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int tt = t < ntaps ? t : 0;
+        tap_w[t] = kc.taps[tt].widx * a.Ci * 2;                                // byte offset of the tap inside a weight row
+        tap_a[t] = (1 + kc.taps[tt].dy) * (H2_PITCH * 64);                     // slab row offset (dy in {-1, 0})
+        tap_x[t] = 1 + kc.taps[tt].dx;                                         // slab column offset in {0, 1}
+    }
+    auto sel4 = [](const int (&v)[4], int t) { return t == 0 ? v[0] : (t == 1 ? v[1] : (t == 2 ? v[2] : v[3])); };
+    auto stage_w = [&](int cc, int t, int slot) {                              // weight tile of (chunk cc, tap t of the class)
+        const char* base = wgt_b + sel4(tap_w, t) + cc * 64;
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2)
+            __builtin_amdgcn_global_load_lds((glb_ptr)(base + woff[p2]), (lds_ptr)(lds_b + H2_WT_BASE + slot * H2_WT_BYTES + (wave * 2 + p2) * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int frow = lane & 31, fk = lane >> 5;
+    const int acol = frow & 15;
+    int preA[2][2], preB[2];                                                   // slab column offset 1 + dx in {0, 1}
+#pragma unroll
+    for (int tx2 = 0; tx2 < 2; ++tx2)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+            preA[tx2][kk] = ((wave * 4 + (frow >> 4)) * H2_PITCH + acol + tx2) * 64 + (((kk * 2 + fk) ^ (((acol + tx2) >> 2) & 3)) << 4);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) preB[kk] = H2_WT_BASE + frow * 64 + (((kk * 2 + fk) ^ ((frow >> 2) & 3)) << 4);
+
+    f32x4 fa[2][2], fb[2][4];
+    auto load_frags = [&](int cc, int t, int slot, int kk, f32x4* pa, f32x4* pb) {   // kk is compile-time; the rest is not
+        const int abase = (sel4(tap_x, t) ? preA[1][kk] : preA[0][kk]) + (cc & 1) * H2_SLAB_BUF + sel4(tap_a, t);
+        const int bbase = preB[kk] + slot * H2_WT_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pa[i]) : "v"(abase), "n"(i * 2 * H2_PITCH * 64) : "memory");
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pb[j]) : "v"(bbase), "n"(j * 32 * 64) : "memory");
+    };
+    auto wait_group = [&](int nloads) {                                        // counted wait: let the newest `nloads` DMA instructions fly
+        if (nloads >= 8) wait_vmcnt<8>(); else if (nloads == 7) wait_vmcnt<7>(); else if (nloads == 6) wait_vmcnt<6>();
+        else if (nloads == 5) wait_vmcnt<5>(); else if (nloads >= 2) wait_vmcnt<2>(); else wait_vmcnt<0>();
+    };
+
+    // Slabs: chunk c lives in buffer c & 1.  Buffer c & 1 is free once the last step of chunk c-2 has its fragments in registers, so
+    // slab c is issued right there — `ntaps` steps before its first read (the prefetch at the end of chunk c-1).  For ntaps >= 2
+    // the counted waits in between force it to land; a one-tap class has only one step of lead and waits for everything.
+    stage_slab(0, 0);
+    if (kchunks > 1) stage_slab(1, 1);
+    int issued = 0;                                                            // DMA instructions of the newest issue group
+    {
+        int c1 = 0, t1 = 0;
+        for (int k = 0; k < 3 && k < ksteps; ++k) {
+            stage_w(c1, t1, k);
+            if (k == 2) issued = 2;
+            if (++t1 == ntaps) { t1 = 0; ++c1; }
+        }
+    }
+    wait_group(issued);                                                        // both slabs, tiles 0 and 1 (tile 2 may stay in flight)
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, 0, 0, 0, fa[0], fb[0]);
+    int slot = 0;                                                              // ring slot of the current step's weight tile (= s % 3)
+    int c3 = 0, t3 = 0;                                                        // (chunk, tap) of step s + 3
+    for (int k = 0; k < 3; ++k) if (++t3 == ntaps) { t3 = 0; ++c3; }
+    int s = 0;
+    for (int cc = 0; cc < kchunks; ++cc)
+        for (int t = 0; t < ntaps; ++t, ++s) {
+            int cn = cc, tn = t + 1;                                           // (chunk, tap) of step s + 1
+            if (tn == ntaps) { tn = 0; ++cn; }
+            const int slot_n = slot == 2 ? 0 : slot + 1;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int cur = kk, nxt = kk ^ 1;
+                if (kk == 0) { load_frags(cc, t, slot, 1, fa[nxt], fb[nxt]); asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); }
+                else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    wait_group(ntaps == 1 ? 0 : issued);                       // tile s+1 (and the next chunk's slab) have landed
+                    __builtin_amdgcn_s_barrier();
+                    issued = 0;
+                    if (s + 3 < ksteps) { stage_w(c3, t3, slot); issued = 2; }   // tile s+3 -> the slot tile s just left
+                    if (t == ntaps - 1 && cc + 2 < kchunks) { stage_slab(cc + 2, cc & 1); issued += nslab; }
+                    {   // unconditional (the last step re-reads its own tile): a conditional asm read makes every fragment register a phi
+                        const bool last = s + 1 >= ksteps;
+                        load_frags(last ? cc : cn, last ? t : tn, last ? slot : slot_n, 0, fa[nxt], fb[nxt]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, fa[cur][i]), __builtin_bit_cast(h8, fb[cur][j]), acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            slot = slot_n;
+            if (++t3 == ntaps) { t3 = 0; ++c3; }
+        }
+    __syncthreads();
+
+    constexpr int OP = 136;
+    __half* const ot = (__half*)lds_b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cl = j * 32 + frow;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                ot[p * OP + cl] = __float2half(acc[i][j][r] * a.gain);
+            }
+    }
+    __syncthreads();
+    __half* const yout = (__half*)a.y + (int64_t)n * a.OH * a.OW * a.Co;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int idx = it * 256 + tid, p = idx >> 4, ch = idx & 15;
+        const int si = oy0 + (p >> 4), sj = ox0 + (p & 15), co = co0 + ch * 8;
+        const int oy = si * a.osy + kc.ooy, ox = sj * a.osx + kc.oox;
+        if (si < kc.SH && sj < kc.SW && oy < a.OH && ox < a.OW && co < a.Co)
+            *(f32x4*)(yout + ((int64_t)oy * a.OW + ox) * a.Co + co) = *(const f32x4*)(ot + p * OP + ch * 8);
+    }
+}
+
 // ---- per-sample weight modulation + demodulation -> fp16, tap-major -------------------------------------------------
 // one block per (co, n): wm[i, t] = w[co, i, t] * s[n, i]; d = rsqrt(sum wm^2 + 1e-8) (if demodulate); out[n][co][t][i]
 template <class T>
@@ -936,8 +1116,10 @@ extern "C" int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype,
     P3D_REQUIRE(n_img >= 1 && h >= 1 && wdt >= 1 && co >= 1, "conv2d_nhwc: bad sizes");
     P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32, "conv2d_nhwc: dtype must be fp16 or fp32");
     P3D_REQUIRE(kernel_size == 3 || (kernel_size == 1 && !transposed_stride2), "conv2d_nhwc: kernel 3x3, or 1x1 without upsampling");
+    static const bool no_h2t = getenv("P3D_CONV_NO_H2") != nullptr;
+    const bool h2t = !no_h2t && resample == 1 && dtype == P3D_F16 && h >= 32 && wdt >= 32 && ci % 32 == 0 && co % BN == 0 && (((uintptr_t)y) & 15u) == 0;   // convT_h2_f16_kernel: 64-byte K rows
     const int bk = dtype == P3D_F16 ? 64 : 32;
-    if (ci % bk != 0) return fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc: Ci=%d must be a multiple of %d", ci, bk);
+    if (ci % bk != 0 && !h2t) return fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc: Ci=%d must be a multiple of %d", ci, bk);
     P3D_REQUIRE((((uintptr_t)x) & 15u) == 0 && (((uintptr_t)w) & 15u) == 0 && (((uintptr_t)zeros128) & 15u) == 0, "conv2d_nhwc: x, w and zeros128 must be 16-byte aligned");
     ConvArgs a{};
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.noise = noise; a.noise_strength = noise_strength; a.zeros = zeros128;
@@ -995,6 +1177,14 @@ extern "C" int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype,
                 for (int kx = px; kx < 3; kx += 2)
                     c.taps[c.ntaps++] = ConvTap{-(ky - py) / 2, -(kx - px) / 2, ky * 3 + kx};
         }
+    {
+        if (h2t) {
+            const int tiles = ((h + 1 + QH - 1) / QH) * ((wdt + 1 + QW - 1) / QW);          // class (0, 0) is the largest: (H + 1) x (W + 1) positions
+            hipLaunchKernelGGL(convT_h2_f16_kernel, dim3(tiles, co / BN, n_img * 4), dim3(256), 0, s, a);
+            count_launch(FAM_CONV);
+            return check_launch("convT_h2_f16");
+        }
+    }
     return launch_conv(a, dtype, s);
 }
 

@@ -97,11 +97,14 @@ def modulate_weights(weight, styles, demodulate=True, pre_scale=1.0, dtype=torch
     return out
 
 
-def _pad_channels(x, wmod):
-    """Zero-pad Ci to a whole 128-byte K row (only the 32-channel fp16 SR input needs it; that tensor is tiny)."""
+def _pad_channels(x, wmod, transposed=False):
+    """Zero-pad Ci to a whole 128-byte K row where the kernel needs one (the x2 fp16 kernel works on 64-byte rows: the 32-channel
+    SR input goes in as it is)."""
     mult = 64 if x.dtype == torch.float16 else 32
     ci = x.shape[1]
     if ci % mult == 0:
+        return x, wmod
+    if transposed and x.dtype == torch.float16 and ci % 32 == 0 and wmod.shape[1] % 128 == 0 and x.shape[2] >= 32 and x.shape[3] >= 32:
         return x, wmod
     pad = mult - ci % mult
     xp = torch.empty([x.shape[0], ci + pad, x.shape[2], x.shape[3]], dtype=x.dtype, device=x.device, memory_format=torch.channels_last).zero_()
@@ -117,7 +120,7 @@ def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None
     stride-2 correlation [N,Co,(H-3)//2+1,(W-3)//2+1]; k*k = 1: 1x1."""
     assert _is_nhwc(x) and wmod.dtype == x.dtype and wmod.is_contiguous() and wmod.shape[2] in (1, 9)
     assert down in (1, 2) and not (transposed and down == 2)
-    x, wmod = _pad_channels(x, wmod)
+    x, wmod = _pad_channels(x, wmod, transposed)
     n, ci, h, w = x.shape
     co, k = wmod.shape[1], (3 if wmod.shape[2] == 9 else 1)
     oh, ow = (2 * h + 1, 2 * w + 1) if transposed else (((h - k) // 2 + 1, (w - k) // 2 + 1) if down == 2 else (h, w))

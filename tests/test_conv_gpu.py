@@ -78,7 +78,8 @@ def test_modulate_and_conv3x3(hip_lib, ci, co, h, w):
     assert rel_err(y3.float().cpu().numpy(), yr3.cpu().numpy()) < 2e-3
 
 
-@pytest.mark.parametrize('ci,co,h,w', [(64, 128, 8, 8), (128, 64, 17, 9), (32, 256, 16, 16)])
+@pytest.mark.parametrize('ci,co,h,w', [(64, 128, 8, 8), (128, 64, 17, 9), (32, 256, 16, 16),
+                                      (64, 128, 32, 32), (32, 256, 40, 33), (256, 128, 48, 70), (96, 128, 64, 32)])   # >= 32 x 32 with Co % 128 == 0: convT_h2_f16_kernel
 def test_transposed_stride2_conv(hip_lib, ci, co, h, w):
     from pix2pix3d_amd.torch_utils.ops import modconv
     torch.manual_seed(ci * co)
