@@ -15,6 +15,26 @@ from ... import _lib
 from . import upfirdn2d, bias_act
 
 enabled = True
+prefetch_styles = True       # run every layer's style affine + weight modulation ahead of the convolutions on a second stream
+_plan = {}                   # id(layer) -> (styles, (wmod, route tag) or None, event), filled by SynthesisNetwork.forward
+_side = {}
+
+
+def side_stream(device):
+    st = _side.get(device)
+    if st is None:
+        st = _side[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def take_plan(layer):
+    """Pop this layer's prefetched (styles, premodulated weights) and make the current stream wait for them."""
+    hit = _plan.pop(id(layer), None)
+    if hit is None:
+        return None
+    torch.cuda.current_stream().wait_event(hit[2])
+    return hit[0], hit[1]
+
 
 _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 _lib.register('p3d_modulate_weights', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp])
@@ -271,25 +291,41 @@ def noise_bias_act(y, bias, noise, noise_strength, act, act_gain, clamp):
     return y
 
 
-def _small_layer(x, weight, styles, up):
+def _small_layer(x, weight, styles, up, wm=None):
     """Per-sample modulated 3x3 conv (or its stride-2 transposed form) for images too small for the MFMA tiles: the
     classic lowering to ONE batched GEMM per layer.  up == 1: im2col then W[n] @ cols[n]; up == 2: (W[n]^T arranged
     [Co*9, Ci]) @ x[n] then col2im (F.fold, stride 2) -> [N, Co, 2H+1, 2W+1].  Any dense layout in, NCHW out."""
     n, ci, h, w = x.shape
     co = weight.shape[0]
     if up == 1:
-        wm = modulate_weights(weight, styles, demodulate=True, dtype=x.dtype, oihw=True).reshape(n, co, ci * 9)
+        if wm is None:
+            wm = modulate_weights(weight, styles, demodulate=True, dtype=x.dtype, oihw=True)
+        wm = wm.reshape(n, co, ci * 9)
         cols = im2col3x3(x) if x.dtype == torch.float32 else torch.nn.functional.unfold(x.contiguous(), kernel_size=3, padding=1)   # [N, Ci*9, H*W]
         return torch.bmm(wm, cols).reshape(n, co, h, w)
-    wm = modulate_weights(weight, styles, demodulate=True, dtype=x.dtype, oihw=False)       # [N, Co, 9, Ci]
+    if wm is None:
+        wm = modulate_weights(weight, styles, demodulate=True, dtype=x.dtype, oihw=False)   # [N, Co, 9, Ci]
     cols = torch.bmm(wm.reshape(n, co * 9, ci), x.contiguous().reshape(n, ci, h * w))      # [N, Co*9, H*W]
     return torch.nn.functional.fold(cols, output_size=(2 * h + 1, 2 * w + 1), kernel_size=3, stride=2)
 
 
-def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=None, noise_strength=None, act='lrelu', act_gain=1.0, clamp=None):
-    """Whole SynthesisLayer body after the style affine: modulated 3x3 conv (x2 up when ``up == 2``) + noise + bias + act."""
-    if is_small(x, up):
-        y = _small_layer(x, weight, styles, up)
+def premodulate(weight, styles, up, in_pixels, dtype):
+    """The modulated weights synthesis_layer will want for a layer whose input has ``in_pixels`` pixels per image, in the layout of
+    the route it will take; returns (tensor, route tag).  Used to run every layer's modulation ahead of the convolutions on a
+    second stream (SynthesisNetwork.forward)."""
+    small = in_pixels <= (gemm_max_pixels if up == 1 else gemm_max_pixels_up)
+    if small:
+        return modulate_weights(weight, styles, demodulate=True, dtype=dtype, oihw=(up == 1)), ('gemm', up, dtype)
+    return modulate_weights(weight, styles, demodulate=True, dtype=dtype), ('mfma', up, dtype)
+
+
+def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=None, noise_strength=None, act='lrelu', act_gain=1.0, clamp=None, pre=None):
+    """Whole SynthesisLayer body after the style affine: modulated 3x3 conv (x2 up when ``up == 2``) + noise + bias + act.
+    ``pre`` = (modulated weights, route tag) from ``premodulate`` — used when the tag matches the route taken here."""
+    small = is_small(x, up)
+    wpre = pre[0] if pre is not None and pre[1] == ('gemm' if small else 'mfma', up, x.dtype) else None
+    if small:
+        y = _small_layer(x, weight, styles, up, wpre)
         if up == 2:
             y = upfirdn2d.upfirdn2d(y, resample_filter, padding=[1, 1, 1, 1], gain=4)
         if y.dtype == torch.float32 and act in ('linear', 'lrelu') and (y.shape[2] * y.shape[3]) % 4 == 0 and y.is_contiguous():
@@ -297,7 +333,7 @@ def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=No
         if noise_const is not None:
             y = y.add_((noise_const * noise_strength).to(y.dtype))
         return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
-    wmod = modulate_weights(weight, styles, demodulate=True, dtype=x.dtype)
+    wmod = wpre if wpre is not None else modulate_weights(weight, styles, demodulate=True, dtype=x.dtype)
     act_idx = {'linear': 0, 'lrelu': 1}.get(act)
     clampv = -1.0 if clamp is None else float(clamp)
     if up == 1 and act_idx is not None:

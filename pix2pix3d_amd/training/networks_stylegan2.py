@@ -220,7 +220,8 @@ class SynthesisLayer(torch.nn.Module):
         assert noise_mode in ['random', 'const', 'none']
         in_res = self.resolution // self.up
         misc.assert_shape(x, [None, self.in_channels, in_res, in_res])
-        styles = self.affine(w)
+        planned = modconv.take_plan(self) if modconv._plan else None
+        styles, pre = planned if planned is not None else (self.affine(w), None)
         noise = None
         if self.use_noise and noise_mode == 'random':
             noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
@@ -234,7 +235,7 @@ class SynthesisLayer(torch.nn.Module):
             return modconv.synthesis_layer(x, self.weight, styles, self.bias, self.up, self.resample_filter,
                                            noise_const=self.noise_const if const_noise else None,
                                            noise_strength=self.noise_strength if const_noise else None,
-                                           act=self.activation, act_gain=self.act_gain * gain, clamp=clamp)
+                                           act=self.activation, act_gain=self.act_gain * gain, clamp=clamp, pre=pre)
         if self.use_noise and noise_mode == 'const':
             noise = self.noise_const * self.noise_strength
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
@@ -260,7 +261,8 @@ class ToRGBLayer(torch.nn.Module):
         self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
 
     def forward(self, x, w, fused_modconv=True):
-        styles = self.affine(w, out_scale=self.weight_gain)
+        planned = modconv.take_plan(self) if modconv._plan else None
+        styles = planned[0] if planned is not None else self.affine(w, out_scale=self.weight_gain)
         if modconv.torgb_supported(x, self.weight, styles, fused_modconv):
             return modconv.torgb(x, self.weight, styles, self.bias, clamp=self.conv_clamp)      # fp32 NCHW, bias + clamp fused
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
@@ -399,10 +401,48 @@ class SynthesisNetwork(torch.nn.Module):
                 block = getattr(self, f'b{res}')
                 block_ws.append(ws.narrow(1, idx, block.num_conv + block.num_torgb))     # ToRGB shares the next block's first w
                 idx += block.num_conv
+        planned = self._prefetch(block_ws, block_kwargs)
         x = img = None
         for res, cur in zip(self.block_resolutions, block_ws):
             x, img = getattr(self, f'b{res}')(x, img, cur, **block_kwargs)
+        if planned:
+            torch.cuda.current_stream().wait_stream(modconv.side_stream(ws.device))
+            modconv._plan.clear()
         return img
+
+    def _prefetch(self, block_ws, block_kwargs):
+        """Device inference: every layer's style affine and weight modulation depend on ``ws`` alone, so they are issued up front on a
+        second stream and run under the convolutions of the layers before them (they are memory-bound, the convolutions are not);
+        each layer waits on its own event.  Anything the plan gets wrong (a layer that ends up on another route) is simply recomputed."""
+        ws0 = block_ws[0]
+        fused = block_kwargs.get('fused_modconv')
+        if not (modconv.prefetch_styles and modconv.enabled and native_channels_last and ws0.is_cuda and not torch.is_grad_enabled()
+                and block_kwargs.get('noise_mode', 'random') != 'random' and (fused is None or fused is True)):
+            return False
+        force_fp32 = bool(block_kwargs.get('force_fp32', False))
+        main, side = torch.cuda.current_stream(), modconv.side_stream(ws0.device)
+        side.wait_stream(main)
+        modconv._plan.clear()
+        with torch.cuda.stream(side):
+            for res, cur in zip(self.block_resolutions, block_ws):
+                block = getattr(self, f'b{res}')
+                if block.fused_modconv_default is not True and fused is None and block.training:
+                    continue
+                dtype = torch.float16 if block.use_fp16 and not force_fp32 else torch.float32
+                ws_iter = iter(cur.unbind(dim=1))
+                layers = [(block.conv1, res)] if block.in_channels == 0 else [(block.conv0, res // 2), (block.conv1, res)]
+                for layer, in_res in layers:
+                    styles = layer.affine(next(ws_iter))
+                    pre = modconv.premodulate(layer.weight, styles, layer.up, in_res * in_res, dtype)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    modconv._plan[id(layer)] = (styles, pre, ev)
+                if block.is_last or block.architecture == 'skip':
+                    styles = block.torgb.affine(next(ws_iter), out_scale=block.torgb.weight_gain)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    modconv._plan[id(block.torgb)] = (styles, None, ev)
+        return True
 
     def extra_repr(self):
         return (f'w_dim={self.w_dim:d}, num_ws={self.num_ws:d}, img_resolution={self.img_resolution:d}, '
