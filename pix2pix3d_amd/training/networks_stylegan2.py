@@ -371,6 +371,47 @@ class SynthesisBlock(torch.nn.Module):
         return f'resolution={self.resolution:d}, architecture={self.architecture:s}'
 
 
+def prefetch_styles(blocks, block_ws, block_kwargs):
+    """Device inference: every layer's style affine and weight modulation depend on ``ws`` alone, so they are issued up front on a
+    second stream and run under the convolutions of the layers before them (they are memory-bound, the convolutions are not);
+    each layer waits on its own event (modconv.take_plan).  Anything the plan gets wrong (a layer that ends up on another route) is
+    simply recomputed.  Returns True when a plan was made: the caller joins the side stream and clears the plan afterwards."""
+    ws0 = block_ws[0]
+    fused = block_kwargs.get('fused_modconv')
+    if not (modconv.prefetch_styles and modconv.enabled and native_channels_last and ws0.is_cuda and not torch.is_grad_enabled()
+            and block_kwargs.get('noise_mode', 'random') != 'random' and (fused is None or fused is True)):
+        return False
+    force_fp32 = bool(block_kwargs.get('force_fp32', False))
+    main, side = torch.cuda.current_stream(), modconv.side_stream(ws0.device)
+    side.wait_stream(main)
+    modconv._plan.clear()
+    with torch.cuda.stream(side):
+        for block, cur in zip(blocks, block_ws):
+            if block.fused_modconv_default is not True and fused is None and block.training:
+                continue
+            res = block.resolution
+            dtype = torch.float16 if block.use_fp16 and not force_fp32 else torch.float32
+            ws_iter = iter(cur.unbind(dim=1))
+            layers = [(block.conv1, res)] if block.in_channels == 0 else [(block.conv0, res // block._in_div), (block.conv1, res)]
+            for layer, in_res in layers:
+                styles = layer.affine(next(ws_iter))
+                pre = modconv.premodulate(layer.weight, styles, layer.up, in_res * in_res, dtype)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                modconv._plan[id(layer)] = (styles, pre, ev)
+            if block.is_last or block.architecture == 'skip':
+                styles = block.torgb.affine(next(ws_iter), out_scale=block.torgb.weight_gain)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                modconv._plan[id(block.torgb)] = (styles, None, ev)
+    return True
+
+
+def finish_prefetch(device):
+    torch.cuda.current_stream().wait_stream(modconv.side_stream(device))
+    modconv._plan.clear()
+
+
 @persistence.persistent_class
 class SynthesisNetwork(torch.nn.Module):
     """Stack of SynthesisBlocks b4..b{img_resolution}; ws are dealt out block by block (:471-526)."""
@@ -406,43 +447,11 @@ class SynthesisNetwork(torch.nn.Module):
         for res, cur in zip(self.block_resolutions, block_ws):
             x, img = getattr(self, f'b{res}')(x, img, cur, **block_kwargs)
         if planned:
-            torch.cuda.current_stream().wait_stream(modconv.side_stream(ws.device))
-            modconv._plan.clear()
+            finish_prefetch(ws.device)
         return img
 
     def _prefetch(self, block_ws, block_kwargs):
-        """Device inference: every layer's style affine and weight modulation depend on ``ws`` alone, so they are issued up front on a
-        second stream and run under the convolutions of the layers before them (they are memory-bound, the convolutions are not);
-        each layer waits on its own event.  Anything the plan gets wrong (a layer that ends up on another route) is simply recomputed."""
-        ws0 = block_ws[0]
-        fused = block_kwargs.get('fused_modconv')
-        if not (modconv.prefetch_styles and modconv.enabled and native_channels_last and ws0.is_cuda and not torch.is_grad_enabled()
-                and block_kwargs.get('noise_mode', 'random') != 'random' and (fused is None or fused is True)):
-            return False
-        force_fp32 = bool(block_kwargs.get('force_fp32', False))
-        main, side = torch.cuda.current_stream(), modconv.side_stream(ws0.device)
-        side.wait_stream(main)
-        modconv._plan.clear()
-        with torch.cuda.stream(side):
-            for res, cur in zip(self.block_resolutions, block_ws):
-                block = getattr(self, f'b{res}')
-                if block.fused_modconv_default is not True and fused is None and block.training:
-                    continue
-                dtype = torch.float16 if block.use_fp16 and not force_fp32 else torch.float32
-                ws_iter = iter(cur.unbind(dim=1))
-                layers = [(block.conv1, res)] if block.in_channels == 0 else [(block.conv0, res // 2), (block.conv1, res)]
-                for layer, in_res in layers:
-                    styles = layer.affine(next(ws_iter))
-                    pre = modconv.premodulate(layer.weight, styles, layer.up, in_res * in_res, dtype)
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    modconv._plan[id(layer)] = (styles, pre, ev)
-                if block.is_last or block.architecture == 'skip':
-                    styles = block.torgb.affine(next(ws_iter), out_scale=block.torgb.weight_gain)
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    modconv._plan[id(block.torgb)] = (styles, None, ev)
-        return True
+        return prefetch_styles([getattr(self, f'b{res}') for res in self.block_resolutions], block_ws, block_kwargs)
 
     def extra_repr(self):
         return (f'w_dim={self.w_dim:d}, num_ws={self.num_ws:d}, img_resolution={self.img_resolution:d}, '

@@ -4,7 +4,7 @@ parameter names."""
 import torch
 
 from ..torch_utils import persistence
-from .networks_stylegan2 import SynthesisBlock
+from .networks_stylegan2 import SynthesisBlock, prefetch_styles, finish_prefetch
 
 
 @persistence.persistent_class
@@ -32,8 +32,11 @@ class _SuperresolutionBase(torch.nn.Module):
     def forward(self, rgb, x, ws, **block_kwargs):
         ws = ws[:, -1:, :].repeat(1, 3, 1)
         rgb, x = self._prep(rgb, x)
+        planned = prefetch_styles([self.block0, self.block1], [ws, ws], block_kwargs)
         x, rgb = self.block0(x, rgb, ws, **block_kwargs)
         x, rgb = self.block1(x, rgb, ws, **block_kwargs)
+        if planned:
+            finish_prefetch(ws.device)
         return rgb
 
 
