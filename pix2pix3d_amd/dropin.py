@@ -4,7 +4,7 @@ The reference (and every released checkpoint, whose pickles re-import module sou
 absolute imports such as ``from torch_utils.ops import bias_act`` and ``training.triplane_cond.TriPlane...``.
 ``install()`` registers this package's mirrors under those names in ``sys.modules`` so that
 ``training_loop.py`` / ``applications/*.py`` of the reference run unchanged on top of the HIP kernels.
-Modules this package does not mirror (loss, dataset, legacy, camera_utils, metrics, ...) keep resolving to the
+Modules this package does not mirror (loss, dataset, camera_utils, metrics, ...) keep resolving to the
 reference checkout if it is on ``sys.path``: for that, ``training`` / ``torch_utils`` get the reference's
 directories appended to their ``__path__``.
 """
@@ -13,7 +13,7 @@ import os
 import sys
 
 _MIRRORED = [
-    'dnnlib', 'dnnlib.util',
+    'dnnlib', 'dnnlib.util', 'legacy',
     'torch_utils', 'torch_utils.misc', 'torch_utils.persistence', 'torch_utils.custom_ops',
     'torch_utils.ops', 'torch_utils.ops.bias_act', 'torch_utils.ops.upfirdn2d', 'torch_utils.ops.fma',
     'torch_utils.ops.conv2d_gradfix', 'torch_utils.ops.conv2d_resample', 'torch_utils.ops.grid_sample_gradfix',

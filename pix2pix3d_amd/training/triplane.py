@@ -1,9 +1,14 @@
-"""EG3D tri-plane decoder (mirror of training/triplane.py:112-135).  The unconditional ``TriPlaneGenerator``
-of that file is not on the pix2pix3D path (train.py:374-380 selects the conditional generators of
-``triplane_cond``); the decoder is, via ``triplane_cond.TriPlaneGenerator``."""
+"""EG3D tri-plane generator and decoder (mirror of training/triplane.py; line refs are to that file), plus the core that the
+conditional generators of ``triplane_cond`` share with it: camera split, backbone with the one-slot plane cache, fused
+ray-marcher, point queries.  pix2pix3D's train.py selects the conditional generators (train.py:374-380); the unconditional
+``TriPlaneGenerator`` is what EG3D checkpoints (``afhqcats512-128.pkl``) hold, so ``legacy.load_network_pkl`` resolves to it."""
 import torch
 
-from .networks_stylegan2 import FullyConnectedLayer
+from .. import dnnlib
+from ..torch_utils import persistence
+from .networks_stylegan2 import FullyConnectedLayer, Generator as StyleGAN2Backbone
+from .volumetric_rendering.renderer import ImportanceRenderer
+from .volumetric_rendering.ray_sampler import RaySampler
 
 
 def _osg_mlp(n_features, hidden, out_dim, lr_mul):
@@ -12,7 +17,7 @@ def _osg_mlp(n_features, hidden, out_dim, lr_mul):
 
 
 class OSGDecoder(torch.nn.Module):
-    """mean over planes -> FC(32,64) -> softplus -> FC(64, 1+C): density = channel 0, colour = clamped sigmoid of the rest."""
+    """mean over planes -> FC(32,64) -> softplus -> FC(64, 1+C): density = channel 0, colour = clamped sigmoid of the rest (:112-135)."""
 
     def __init__(self, n_features, options):
         super().__init__()
@@ -25,3 +30,92 @@ class OSGDecoder(torch.nn.Module):
         y = self.net(x.reshape(n * m, c)).reshape(n, m, -1)
         rgb = torch.sigmoid(y[..., 1:]) * (1 + 2 * 0.001) - 0.001      # MipNeRF-style sigmoid clamping
         return {'rgb': rgb, 'sigma': y[..., 0:1]}
+
+
+class _TriPlaneCore(torch.nn.Module):
+    """What every tri-plane generator shares.  Subclasses set ``_backbone_class`` (the StyleGAN2 generator that makes the planes),
+    build ``self.decoder`` / the SR head(s) and define ``mapping`` / ``synthesis`` / ``sample`` / ``forward``."""
+    _backbone_class = None
+
+    def _init_common(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs, rendering_kwargs, synthesis_kwargs):
+        self.z_dim, self.c_dim, self.w_dim, self.img_resolution, self.img_channels = z_dim, c_dim, w_dim, img_resolution, img_channels
+        self.renderer = ImportanceRenderer()
+        self.ray_sampler = RaySampler()
+        self.backbone = self._backbone_class(z_dim, c_dim, w_dim, img_resolution=256, img_channels=32 * 3, mapping_kwargs=mapping_kwargs, **synthesis_kwargs)
+
+    def _finish_init(self, rendering_kwargs):
+        self.neural_rendering_resolution = 64
+        self.rendering_kwargs = rendering_kwargs
+        self._last_planes = None
+
+    def _planes(self, ws, update_emas, synthesis_kwargs, cache_backbone=False, use_cached_backbone=False):
+        if use_cached_backbone and self._last_planes is not None:
+            planes = self._last_planes
+        else:
+            planes = self.backbone.synthesis(ws, update_emas=update_emas, **synthesis_kwargs)
+        if cache_backbone:
+            self._last_planes = planes
+        return planes.view(len(planes), 3, 32, planes.shape[-2], planes.shape[-1])
+
+    def _render(self, ws, c, neural_rendering_resolution, update_emas, cache_backbone, use_cached_backbone, synthesis_kwargs):
+        cam2world = c[:, :16].view(-1, 4, 4)
+        intrinsics = c[:, 16:25].view(-1, 3, 3)
+        if neural_rendering_resolution is None:
+            neural_rendering_resolution = self.neural_rendering_resolution
+        else:
+            self.neural_rendering_resolution = neural_rendering_resolution
+        ray_o, ray_d = self.ray_sampler(cam2world, intrinsics, neural_rendering_resolution)
+        n = ray_o.shape[0]
+        planes = self._planes(ws, update_emas, synthesis_kwargs, cache_backbone, use_cached_backbone)
+        feat, depth, _ = self.renderer(planes, self.decoder, ray_o, ray_d, self.rendering_kwargs)
+        r = self.neural_rendering_resolution
+        feature_image = feat.permute(0, 2, 1).reshape(n, feat.shape[-1], r, r).contiguous()
+        depth_image = depth.permute(0, 2, 1).reshape(n, 1, r, r)
+        return feature_image, depth_image
+
+    def _sr_kwargs(self, synthesis_kwargs):
+        kw = {k: v for k, v in synthesis_kwargs.items() if k != 'noise_mode'}
+        return dict(noise_mode=self.rendering_kwargs['superresolution_noise_mode'], **kw)
+
+    def sample_mixed(self, coordinates, directions, ws, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
+        """Colour features + density at arbitrary 3-D points for given latents (shape extraction, density regularisation)."""
+        planes = self._planes(ws, update_emas, synthesis_kwargs)
+        return self.renderer.run_model(planes, self.decoder, coordinates, directions, self.rendering_kwargs)
+
+
+@persistence.persistent_class
+class TriPlaneGenerator(_TriPlaneCore):
+    """EG3D's unconditional generator (:18-107): StyleGAN2 mapping on (z, camera label), one OSG decoder, one SR head."""
+    _backbone_class = StyleGAN2Backbone
+
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, sr_num_fp16_res=0, mapping_kwargs={}, rendering_kwargs={},
+                 sr_kwargs={}, **synthesis_kwargs):
+        super().__init__()
+        self._init_common(z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs, rendering_kwargs, synthesis_kwargs)
+        self.superresolution = dnnlib.util.construct_class_by_name(class_name=rendering_kwargs['superresolution_module'], channels=32,
+                                                                   img_resolution=img_resolution, sr_num_fp16_res=sr_num_fp16_res,
+                                                                   sr_antialias=rendering_kwargs['sr_antialias'], **sr_kwargs)
+        self.decoder = OSGDecoder(32, {'decoder_lr_mul': rendering_kwargs.get('decoder_lr_mul', 1), 'decoder_output_dim': 32})
+        self._finish_init(rendering_kwargs)
+
+    def mapping(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False):
+        if self.rendering_kwargs['c_gen_conditioning_zero']:
+            c = torch.zeros_like(c)
+        return self.backbone.mapping(z, c * self.rendering_kwargs.get('c_scale', 0), truncation_psi=truncation_psi,
+                                     truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+
+    def synthesis(self, ws, c, neural_rendering_resolution=None, update_emas=False, cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
+        feature_image, depth_image = self._render(ws, c, neural_rendering_resolution, update_emas, cache_backbone, use_cached_backbone, synthesis_kwargs)
+        rgb_image = feature_image[:, :3]
+        sr_image = self.superresolution(rgb_image, feature_image, ws, **self._sr_kwargs(synthesis_kwargs))
+        return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image}
+
+    def sample(self, coordinates, directions, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        return self.sample_mixed(coordinates, directions, ws, update_emas=update_emas, **synthesis_kwargs)
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, neural_rendering_resolution=None, update_emas=False,
+                cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        return self.synthesis(ws, c, update_emas=update_emas, neural_rendering_resolution=neural_rendering_resolution,
+                              cache_backbone=cache_backbone, use_cached_backbone=use_cached_backbone, **synthesis_kwargs)

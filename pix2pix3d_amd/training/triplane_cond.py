@@ -16,9 +16,7 @@ from .. import dnnlib
 from ..torch_utils import misc
 from ..torch_utils import persistence
 from .networks_stylegan2 import SynthesisNetwork, FullyConnectedLayer, normalize_2nd_moment, DiscriminatorBlock
-from .triplane import OSGDecoder, _osg_mlp
-from .volumetric_rendering.renderer import ImportanceRenderer
-from .volumetric_rendering.ray_sampler import RaySampler
+from .triplane import OSGDecoder, _osg_mlp, _TriPlaneCore
 
 
 @persistence.persistent_class
@@ -260,20 +258,9 @@ class OSGDecoder_semantic_lateSeparate(torch.nn.Module):
         return {'rgb': torch.cat((rgb, sem), dim=-1), 'sigma': label[..., 0:1]}
 
 
-class _TriPlaneBase(torch.nn.Module):
-    """What the conditional tri-plane generators share: camera split, backbone (with the one-slot plane cache),
-    rendering, point queries."""
-
-    def _init_common(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs, rendering_kwargs, synthesis_kwargs):
-        self.z_dim, self.c_dim, self.w_dim, self.img_resolution, self.img_channels = z_dim, c_dim, w_dim, img_resolution, img_channels
-        self.renderer = ImportanceRenderer()
-        self.ray_sampler = RaySampler()
-        self.backbone = Generator_cond(z_dim, c_dim, w_dim, img_resolution=256, img_channels=32 * 3, mapping_kwargs=mapping_kwargs, **synthesis_kwargs)
-
-    def _finish_init(self, rendering_kwargs):
-        self.neural_rendering_resolution = 64
-        self.rendering_kwargs = rendering_kwargs
-        self._last_planes = None
+class _TriPlaneBase(_TriPlaneCore):
+    """The conditional generators' entry points: ``mapping`` / ``sample`` / ``forward`` take the data batch (label map + pose)."""
+    _backbone_class = None      # Generator_cond, set below the class
 
     def mapping(self, z, c, batch, truncation_psi=1, truncation_cutoff=None, update_emas=False):
         if self.rendering_kwargs['c_gen_conditioning_zero']:
@@ -281,49 +268,19 @@ class _TriPlaneBase(torch.nn.Module):
         return self.backbone.mapping(z, c * self.rendering_kwargs.get('c_scale', 0), batch, truncation_psi=truncation_psi,
                                      truncation_cutoff=truncation_cutoff, update_emas=update_emas)
 
-    def _planes(self, ws, update_emas, synthesis_kwargs, cache_backbone=False, use_cached_backbone=False):
-        if use_cached_backbone and self._last_planes is not None:
-            planes = self._last_planes
-        else:
-            planes = self.backbone.synthesis(ws, update_emas=update_emas, **synthesis_kwargs)
-        if cache_backbone:
-            self._last_planes = planes
-        return planes.view(len(planes), 3, 32, planes.shape[-2], planes.shape[-1])
-
-    def _render(self, ws, c, neural_rendering_resolution, update_emas, cache_backbone, use_cached_backbone, synthesis_kwargs):
-        cam2world = c[:, :16].view(-1, 4, 4)
-        intrinsics = c[:, 16:25].view(-1, 3, 3)
-        if neural_rendering_resolution is None:
-            neural_rendering_resolution = self.neural_rendering_resolution
-        else:
-            self.neural_rendering_resolution = neural_rendering_resolution
-        ray_o, ray_d = self.ray_sampler(cam2world, intrinsics, neural_rendering_resolution)
-        n = ray_o.shape[0]
-        planes = self._planes(ws, update_emas, synthesis_kwargs, cache_backbone, use_cached_backbone)
-        feat, depth, _ = self.renderer(planes, self.decoder, ray_o, ray_d, self.rendering_kwargs)
-        r = self.neural_rendering_resolution
-        feature_image = feat.permute(0, 2, 1).reshape(n, feat.shape[-1], r, r).contiguous()
-        depth_image = depth.permute(0, 2, 1).reshape(n, 1, r, r)
-        return feature_image, depth_image
-
-    def _sr_kwargs(self, synthesis_kwargs):
-        kw = {k: v for k, v in synthesis_kwargs.items() if k != 'noise_mode'}
-        return dict(noise_mode=self.rendering_kwargs['superresolution_noise_mode'], **kw)
-
     def sample(self, coordinates, directions, z, c, batch, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
         """Colour features + density at arbitrary 3-D points (shape extraction)."""
         ws = self.mapping(z, batch['pose'], batch, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
         return self.sample_mixed(coordinates, directions, ws, update_emas=update_emas, **synthesis_kwargs)
-
-    def sample_mixed(self, coordinates, directions, ws, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
-        planes = self._planes(ws, update_emas, synthesis_kwargs)
-        return self.renderer.run_model(planes, self.decoder, coordinates, directions, self.rendering_kwargs)
 
     def forward(self, z, c, batch, truncation_psi=1, truncation_cutoff=None, neural_rendering_resolution=None, update_emas=False,
                 cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
         ws = self.mapping(z, batch['pose'], batch, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
         return self.synthesis(ws, c, update_emas=update_emas, neural_rendering_resolution=neural_rendering_resolution,
                               cache_backbone=cache_backbone, use_cached_backbone=use_cached_backbone, **synthesis_kwargs)
+
+
+_TriPlaneBase._backbone_class = Generator_cond
 
 
 @persistence.persistent_class

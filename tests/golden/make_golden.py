@@ -3,7 +3,7 @@
 Run in the authoring container only (it needs the read-only checkout at /root/reference, which does
 not exist on the GPU box):
 
-    python tests/golden/make_golden.py [group ...]      # groups: ops renderer semrenderer model flrelu train
+    python tests/golden/make_golden.py [group ...]      # groups: ops renderer semrenderer model flrelu train checkpoint
 
 The reference and this repo own the same top-level module names, so this script must never import
 ``pix2pix3d_amd``; it puts /root/reference first on sys.path and imports the reference's modules
@@ -402,6 +402,84 @@ def group_train():
 
 
 GROUPS['train'] = group_train
+
+
+def _tile_large(module, period=512, limit=1024):
+    """Replace every tensor above ``limit`` elements by a tiling of its first ``period`` values: the checkpoint then xz-compresses
+    to a few hundred KiB (the label-map Encoder alone is 204 MB of fixed 512-channel layers) while every value stays name-seeded."""
+    with torch.no_grad():
+        for _, t in list(module.named_parameters()) + list(module.named_buffers()):
+            if t.numel() > limit and t.is_floating_point():
+                flat = t.reshape(-1)
+                reps = -(-flat.numel() // period)
+                flat.copy_(flat[:period].clone().repeat(reps)[:flat.numel()])
+
+
+def group_checkpoint():
+    """A checkpoint in the reference's wire format (training_loop.py:455-470: pickle of dict(G, D, G_ema, D_semantic, augment_pipe,
+    training_set_kwargs) with persistence-decorated networks), written AND read back by the reference (legacy.load_network_pkl), plus
+    what the reloaded networks compute on fixed inputs.  tests/test_checkpoint*.py load the same file through pix2pix3d_amd.legacy."""
+    import lzma
+    import pickle
+    import dnnlib
+    import legacy
+    from training.augment import AugmentPipe
+    configs = _load_by_path('p3d_configs', os.path.join(os.path.dirname(os.path.dirname(HERE)), 'pix2pix3d_amd', 'configs.py'))
+    weights = _load_by_path('p3d_weights', os.path.join(HERE, 'weights.py'))
+    torch.manual_seed(0)
+    kw = configs.generator_kwargs('edge2car', cbase=1024, cmax=16)
+    G = dnnlib.util.construct_class_by_name(**kw).train().requires_grad_(True)
+    weights.seed_module(G, seed=3); _tile_large(G)
+    G_ema = G                                                   # one copy on the wire (pickle memo); both keys must come back
+    G.neural_rendering_resolution = 24                          # assigned after construction by the training loop (loss.py)
+    dkw = dict(class_name='training.dual_discriminator.DualDiscriminator', c_dim=25, img_resolution=128, img_channels=3,
+               channel_base=1024, channel_max=16, num_fp16_res=4, conv_clamp=256, disc_c_noise=0, block_kwargs={}, mapping_kwargs={}, epilogue_kwargs=dict(mbstd_group_size=2))
+    D = dnnlib.util.construct_class_by_name(**dkw).train().requires_grad_(True)
+    weights.seed_module(D, seed=4); _tile_large(D)
+    ekw = dict(class_name='training.triplane.TriPlaneGenerator', z_dim=512, w_dim=512, c_dim=25, img_resolution=128, img_channels=3,
+               mapping_kwargs=dict(num_layers=2), rendering_kwargs=kw['rendering_kwargs'], channel_base=1024, channel_max=16,
+               fused_modconv_default='inference_only', num_fp16_res=0, conv_clamp=None, sr_num_fp16_res=4,
+               sr_kwargs=dict(channel_base=1024, channel_max=16, fused_modconv_default='inference_only'))
+    E = dnnlib.util.construct_class_by_name(**ekw).eval().requires_grad_(False)
+    weights.seed_module(E, seed=5); _tile_large(E)
+    aug = AugmentPipe(xflip=1, rotate90=1, xint=1).train().requires_grad_(False)
+    snapshot = dict(G=G, D=D, G_ema=G_ema, eg3d=E, augment_pipe=aug, training_set_kwargs=dnnlib.EasyDict(class_name='training.dataset.ImageSegFolderDataset', resolution=128, use_labels=True))
+    blob = pickle.dumps(snapshot)
+    path = os.path.join(HERE, 'checkpoint_small.pkl.xz')
+    with lzma.open(path, 'wb', preset=6) as f:
+        f.write(blob)
+    print(f'wrote {path}: {len(blob) / 2**20:.1f} MiB pickled, {os.path.getsize(path) / 1024:.1f} KiB compressed')
+
+    with lzma.open(path, 'rb') as f:
+        data = legacy.load_network_pkl(f)
+    G2, D2, E2 = data['G_ema'].eval().requires_grad_(False), data['D'].eval().requires_grad_(False), data['eg3d']
+    assert data['G'] is data['G_ema'] and G2.neural_rendering_resolution == 24
+    gz = torch.Generator().manual_seed(11)
+    n = 2
+    c = torch.tensor(np.stack([configs.orbit_camera(k, radius=1.7, focal=1.7074) for k in (5, 70)]))
+    z = torch.randn(n, 512, generator=gz)
+    mask = torch.rand([n, 1, 128, 128], generator=gz) * 2 - 1
+    arrays = dict(c=c, z=z, mask=mask, render_seed=np.int64(99))
+    with torch.no_grad():
+        ws = G2.mapping(z, c, {'mask': mask, 'pose': c})
+        torch.manual_seed(99)
+        out = G2.synthesis(ws, c, neural_rendering_resolution=16, noise_mode='const')
+        logits = D2({'image': out['image'], 'image_raw': out['image_raw']}, c)
+        ws_e = E2.mapping(z, c)
+        torch.manual_seed(99)
+        out_e = E2.synthesis(ws_e, c, neural_rendering_resolution=16, noise_mode='const')
+    arrays.update(ws=ws, image=out['image'], image_raw=out['image_raw'], image_depth=out['image_depth'], semantic=out['semantic'],
+                  semantic_raw=out['semantic_raw'], logits=logits, eg3d_ws=ws_e, eg3d_image=out_e['image'], eg3d_image_raw=out_e['image_raw'],
+                  eg3d_image_depth=out_e['image_depth'])
+    sd = G2.state_dict()
+    arrays['param_names'] = np.array(sorted(sd))
+    arrays['param_sums'] = np.array([float(sd[k].double().sum()) for k in sorted(sd)])
+    arrays['d_param_sums'] = np.array([float(v.double().sum()) for k, v in sorted(D2.state_dict().items())])
+    arrays['aug_buffers'] = np.array(sorted(k for k, _ in aug.named_buffers()))
+    save('checkpoint_small', **arrays)
+
+
+GROUPS['checkpoint'] = group_checkpoint
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GROUPS)

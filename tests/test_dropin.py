@@ -26,6 +26,8 @@ conv2d_gradfix.enabled = True                       # training_loop.py:281
 grid_sample_gradfix.enabled = False                 # training_loop.py:282
 cls = dnnlib.util.get_obj_by_name('training.superresolution.SuperresolutionHybrid8XDC')
 assert cls.__module__.startswith('pix2pix3d_amd.')
+import legacy                                       # applications/generate_samples.py:16
+assert legacy.load_network_pkl.__module__ == 'pix2pix3d_amd.legacy'
 print('ok')
 ''' % ROOT
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
