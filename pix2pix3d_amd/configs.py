@@ -74,3 +74,32 @@ def orbit_camera(k, radius=2.7, focal=4.2647, n_frames=120, pivot=(0.0, 0.0, 0.0
     c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, up2, fwd, pos
     K = np.array([[focal, 0, 0.5], [0, focal, 0.5], [0, 0, 1]], np.float64)
     return np.concatenate([c2w.reshape(-1), K.reshape(-1)]).astype(np.float32)
+
+
+def variant_kwargs(which):
+    """Small instances (16-channel backbone, 128^2 output) of the generator classes train.py does not select any more: the two-backbone
+    ``TriPlaneSemanticGenerator``, ``..._withBG``, and the image-only ``TriPlaneGenerator`` over the entangled mapping networks.
+    Used by the golden generator and the tests of those classes."""
+    kw = generator_kwargs('edge2car', cbase=1024, cmax=16)
+    seg = dict(class_name='training.triplane_cond.MaskMappingNetwork_disentangle', in_resolution=128, in_channels=6, num_layers=2)
+    if which == 'two_backbone':          # label maps, texture + semantic plane sets
+        kw.update(class_name='training.triplane_cond.TriPlaneSemanticGenerator', semantic_channels=6, data_type='seg',
+                  mapping_kwargs=dict(seg, class_name='training.triplane_cond.MaskMappingNetwork'))   # z_dim = 0 needs the entangled network
+    elif which == 'with_bg':             # label maps, background panorama
+        kw.update(class_name='training.triplane_cond.TriPlaneSemanticEntangleGenerator_withBG', semantic_channels=6, data_type='seg', mapping_kwargs=seg)
+    elif which == 'with_bg_edge':        # edge maps: the background's label half is not pinned to class 0
+        kw.update(class_name='training.triplane_cond.TriPlaneSemanticEntangleGenerator_withBG')
+    elif which in ('mask_entangled', 'edge_entangled'):
+        for k in ('semantic_channels', 'data_type'):
+            kw.pop(k)
+        kw['class_name'] = 'training.triplane_cond.TriPlaneGenerator'
+        if which == 'mask_entangled':
+            kw['mapping_kwargs'] = dict(seg, class_name='training.triplane_cond.MaskMappingNetwork')
+        else:
+            kw['mapping_kwargs'] = dict(kw['mapping_kwargs'], class_name='training.triplane_cond.EdgeMappingNetwork')
+    else:
+        raise KeyError(which)
+    return kw
+
+
+VARIANTS = ('two_backbone', 'with_bg', 'with_bg_edge', 'mask_entangled', 'edge_entangled')

@@ -148,7 +148,7 @@ class MappingNetwork(torch.nn.Module):
     """z (and optional label c) -> ws [N, num_ws, w_dim], with w_avg tracking and truncation (:193-272)."""
 
     def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=8, embed_features=None, layer_features=None,
-                 activation='lrelu', lr_multiplier=0.01, w_avg_beta=0.998):
+                 activation='lrelu', lr_multiplier=0.01, w_avg_beta=0.998, **unused_kwargs):
         super().__init__()
         self.z_dim, self.c_dim, self.w_dim, self.num_ws, self.num_layers, self.w_avg_beta = z_dim, c_dim, w_dim, num_ws, num_layers, w_avg_beta
         if embed_features is None:

@@ -16,7 +16,10 @@ from .. import dnnlib
 from ..torch_utils import misc
 from ..torch_utils import persistence
 from .networks_stylegan2 import SynthesisNetwork, FullyConnectedLayer, normalize_2nd_moment, DiscriminatorBlock
+from .networks_stylegan2 import Generator as StyleGAN2Backbone
 from .triplane import OSGDecoder, _osg_mlp, _TriPlaneCore
+from .volumetric_rendering.renderer import ImportanceSemanticRenderer
+from .volumetric_rendering.ray_sampler import RaySampler
 
 
 @persistence.persistent_class
@@ -108,6 +111,94 @@ class Encoder(torch.nn.Module):
         else:
             out = None
         return {'ws': out}
+
+
+class _EntangledMapping(torch.nn.Module):
+    """Shared body of the two earlier conditional mapping networks (:201-296, :403-494): the conditioning image becomes ONE embedding
+    (Encoder in 'W' mode) that is concatenated with z (and the embedded camera label) in front of the MLP; every w is the same."""
+    _encoder_name = None
+
+    def _setup(self, z_dim, c_dim, in_resolution, in_channels, w_dim, num_ws, num_layers, embed_features, layer_features,
+               activation, lr_multiplier, w_avg_beta):
+        self.z_dim, self.c_dim, self.in_resolution, self.in_channels = z_dim, c_dim, in_resolution, in_channels
+        self.w_dim, self.num_ws, self.num_layers, self.w_avg_beta = w_dim, num_ws, num_layers, w_avg_beta
+        embed_features = w_dim if embed_features is None else embed_features
+        layer_features = w_dim if layer_features is None else layer_features
+        sizes = [z_dim + embed_features * (2 if c_dim > 0 else 1)] + [layer_features] * (num_layers - 1) + [w_dim]
+        if c_dim > 0:
+            self.embed = FullyConnectedLayer(c_dim, embed_features)
+        setattr(self, self._encoder_name, Encoder(img_resolution=in_resolution, img_channels=in_channels,
+                                                  model_kwargs={'num_ws': 1, 'w_dim': embed_features, 'output_mode': 'W'}))
+        for idx in range(num_layers):
+            setattr(self, f'fc{idx}', FullyConnectedLayer(sizes[idx], sizes[idx + 1], activation=activation, lr_multiplier=lr_multiplier))
+        if num_ws is not None and w_avg_beta is not None:
+            self.register_buffer('w_avg', torch.zeros([w_dim]))
+
+    def _condition_image(self, batch):
+        raise NotImplementedError
+
+    def forward(self, z=None, c=None, batch=None, truncation_psi=1, truncation_cutoff=None, update_emas=False, **unused_kwargs):
+        x = None
+        with torch.autograd.profiler.record_function('input'):
+            if self.z_dim > 0:
+                misc.assert_shape(z, [None, self.z_dim])
+                x = normalize_2nd_moment(z.to(torch.float32))
+            cond = self._condition_image(batch)
+            misc.assert_shape(cond, [None, self.in_channels, self.in_resolution, self.in_resolution])
+            y = normalize_2nd_moment(getattr(self, self._encoder_name)(cond.to(torch.float32))['ws'].squeeze(1))
+            misc.assert_shape(y, [None, self.w_dim])
+            x = torch.cat([x.contiguous(), y.contiguous()], dim=1) if x is not None else y
+            if self.c_dim > 0:
+                misc.assert_shape(c, [None, self.c_dim])
+                e = normalize_2nd_moment(self.embed(c.to(torch.float32)))
+                x = torch.cat([x, e], dim=1) if x is not None else e
+        for idx in range(self.num_layers):
+            x = getattr(self, f'fc{idx}')(x)
+        if self.w_avg_beta is not None and update_emas:
+            with torch.autograd.profiler.record_function('update_w_avg'):
+                self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+        if self.num_ws is not None:
+            with torch.autograd.profiler.record_function('broadcast'):
+                x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if truncation_psi != 1:
+            with torch.autograd.profiler.record_function('truncate'):
+                assert self.w_avg_beta is not None
+                if self.num_ws is None or truncation_cutoff is None:
+                    x = self.w_avg.lerp(x, truncation_psi)
+                else:
+                    x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
+        return x
+
+
+@persistence.persistent_class
+class MaskMappingNetwork(_EntangledMapping):
+    """Label map -> one-hot -> a single embedding mixed into every w (:201-296)."""
+    _encoder_name = 'embed_mask'
+
+    def __init__(self, z_dim, c_dim, in_resolution, in_channels, w_dim, num_ws, num_layers=8, embed_features=None, layer_features=None,
+                 activation='lrelu', lr_multiplier=0.01, w_avg_beta=0.995, one_hot=True, **unused):
+        super().__init__()
+        self.one_hot = one_hot
+        self._setup(z_dim, c_dim, in_resolution, in_channels, w_dim, num_ws, num_layers, embed_features, layer_features, activation, lr_multiplier, w_avg_beta)
+
+    def _condition_image(self, batch):
+        if self.one_hot:
+            return torch.nn.functional.one_hot(batch['mask'].squeeze(1).long(), self.in_channels).permute(0, 3, 1, 2)
+        return batch['mask']
+
+
+@persistence.persistent_class
+class EdgeMappingNetwork(_EntangledMapping):
+    """Edge image -> a single embedding mixed into every w (:403-494)."""
+    _encoder_name = 'embed_edge'
+
+    def __init__(self, z_dim, c_dim, in_resolution, in_channels, w_dim, num_ws, num_layers=8, embed_features=None, layer_features=None,
+                 activation='lrelu', lr_multiplier=0.01, w_avg_beta=0.995, **unused):
+        super().__init__()
+        self._setup(z_dim, c_dim, in_resolution, in_channels, w_dim, num_ws, num_layers, embed_features, layer_features, activation, lr_multiplier, w_avg_beta)
+
+    def _condition_image(self, batch):
+        return batch['mask'].to(torch.float32)
 
 
 class _DisentangledMapping(torch.nn.Module):
@@ -331,3 +422,139 @@ class TriPlaneSemanticEntangleGenerator(_TriPlaneBase):
         semantic_image = sem_feat[:, :self.semantic_channels]
         sr_semantic = self.superresolution_semantic(semantic_image, sem_feat, ws, **sr_kw)
         return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image, 'semantic': sr_semantic, 'semantic_raw': semantic_image}
+
+
+def _split_planes(planes, n_planes, channels):
+    return planes.view(len(planes), n_planes, channels, planes.shape[-2], planes.shape[-1])
+
+
+@persistence.persistent_class
+class TriPlaneSemanticGenerator(_TriPlaneBase):
+    """The two-backbone generator (:722-853): texture planes from an unconditional StyleGAN2 generator on z, semantic planes from a
+    conditional one on the label map alone (z_dim = 0); ``ws`` carries both latents side by side ([N, num_ws, 2*w_dim]).  Rendering is
+    ``ImportanceSemanticRenderer``'s tensor-op formulation (train.py no longer selects this class); backbones and SR heads run on the
+    native layers."""
+
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, semantic_channels, sr_num_fp16_res=0, mapping_kwargs={},
+                 rendering_kwargs={}, sr_kwargs={}, data_type=None, **synthesis_kwargs):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim, self.img_resolution, self.img_channels = z_dim, c_dim, w_dim, img_resolution, img_channels
+        self.semantic_channels, self.data_type = semantic_channels, data_type
+        self.renderer = ImportanceSemanticRenderer()
+        self.ray_sampler = RaySampler()
+        self.backbone = StyleGAN2Backbone(z_dim, c_dim, w_dim, img_resolution=256, img_channels=32 * 3, mapping_kwargs=mapping_kwargs, **synthesis_kwargs)
+        self.backbone_semantic = Generator_cond(0, c_dim, w_dim, img_resolution=256, img_channels=32 * 3, mapping_kwargs=mapping_kwargs, **synthesis_kwargs)
+        sr_common = dict(channels=32, img_resolution=img_resolution, sr_num_fp16_res=sr_num_fp16_res, sr_antialias=rendering_kwargs['sr_antialias'])
+        self.superresolution = dnnlib.util.construct_class_by_name(class_name=rendering_kwargs['superresolution_module'], **sr_common, **sr_kwargs)
+        self.superresolution_semantic = dnnlib.util.construct_class_by_name(class_name=rendering_kwargs['superresolution_module_semantic'],
+                                                                            semantic_channels=semantic_channels, **sr_common, **sr_kwargs)
+        lr_mul = rendering_kwargs.get('decoder_lr_mul', 1)
+        self.decoder = OSGDecoder(64, {'decoder_lr_mul': lr_mul, 'decoder_output_dim': 32, 'sigmoid': True})
+        self.decoder_semantic = OSGDecoder_semantic(32, {'decoder_lr_mul': lr_mul, 'decoder_output_dim': 32, 'sigmoid': semantic_channels == 1})
+        self._finish_init(rendering_kwargs)
+
+    def mapping(self, z, c, batch, truncation_psi=1, truncation_cutoff=None, update_emas=False):
+        if self.rendering_kwargs['c_gen_conditioning_zero']:
+            c = torch.zeros_like(c)
+        c = c * self.rendering_kwargs.get('c_scale', 0)
+        kw = dict(truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        return torch.cat([self.backbone.mapping(z, c, **kw), self.backbone_semantic.mapping(None, c, batch, **kw)], dim=-1)
+
+    def _both_planes(self, ws, update_emas, synthesis_kwargs):
+        assert ws.shape[-1] == self.w_dim * 2
+        ws_texture, ws_semantic = ws[..., :self.w_dim], ws[..., self.w_dim:]
+        tex = self.backbone.synthesis(ws_texture, update_emas=update_emas, **synthesis_kwargs)
+        sem = self.backbone_semantic.synthesis(ws_semantic, update_emas=update_emas, **synthesis_kwargs)
+        return _split_planes(tex, 3, 32), _split_planes(sem, 3, 32), ws_texture, ws_semantic
+
+    def synthesis(self, ws, c, neural_rendering_resolution=None, update_emas=False, cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
+        cam2world, intrinsics = c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3)
+        if neural_rendering_resolution is None:
+            neural_rendering_resolution = self.neural_rendering_resolution
+        else:
+            self.neural_rendering_resolution = neural_rendering_resolution
+        ray_o, ray_d = self.ray_sampler(cam2world, intrinsics, neural_rendering_resolution)
+        n = ray_o.shape[0]
+        tex, sem, ws_texture, ws_semantic = self._both_planes(ws, update_emas, synthesis_kwargs)
+        feat, depth, _ = self.renderer(tex, sem, self.decoder, self.decoder_semantic, ray_o, ray_d, self.rendering_kwargs)
+        r = self.neural_rendering_resolution
+        feature_image = feat.permute(0, 2, 1).reshape(n, feat.shape[-1], r, r).contiguous()
+        depth_image = depth.permute(0, 2, 1).reshape(n, 1, r, r)
+        half = feature_image.shape[1] // 2
+        rgb_feat, sem_feat = feature_image[:, :half], feature_image[:, half:]
+        sr_kw = self._sr_kwargs(synthesis_kwargs)
+        rgb_image = rgb_feat[:, :3]
+        sr_image = self.superresolution(rgb_image, rgb_feat, ws_texture, **sr_kw)
+        semantic_image = sem_feat[:, :self.semantic_channels]
+        sr_semantic = self.superresolution_semantic(semantic_image, sem_feat, ws_semantic, **sr_kw)
+        return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image, 'semantic': sr_semantic, 'semantic_raw': semantic_image}
+
+    def sample_mixed(self, coordinates, directions, ws, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
+        tex, sem, _, _ = self._both_planes(ws, update_emas, synthesis_kwargs)
+        return self.renderer.run_model(tex, sem, self.decoder, self.decoder_semantic, coordinates, directions, self.rendering_kwargs)
+
+
+@persistence.persistent_class
+class TriPlaneSemanticEntangleGenerator_withBG(TriPlaneSemanticEntangleGenerator):
+    """``TriPlaneSemanticEntangleGenerator`` plus a background: a second, unconditional StyleGAN2 synthesis network driven by the last w
+    paints a 64-channel panorama that is looked up by ray direction and composited behind the rendered foreground with the rays'
+    leftover transmittance (:1084-1246).  The foreground is the fused ray-marcher; the panorama lookup is per ray (M per image) and
+    stays a tensor op."""
+
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, semantic_channels, sr_num_fp16_res=0, mapping_kwargs={},
+                 rendering_kwargs={}, sr_kwargs={}, data_type=None, **synthesis_kwargs):
+        super().__init__(z_dim, c_dim, w_dim, img_resolution, img_channels, semantic_channels, sr_num_fp16_res=sr_num_fp16_res,
+                         mapping_kwargs=mapping_kwargs, rendering_kwargs=rendering_kwargs, sr_kwargs=sr_kwargs, data_type=data_type, **synthesis_kwargs)
+        mapping_bg_kwargs = dict(mapping_kwargs)
+        mapping_bg_kwargs['class_name'] = None
+        self.backbone_bg = StyleGAN2Backbone(z_dim, 0, w_dim, img_resolution=256, img_channels=32 * 2, mapping_kwargs=mapping_bg_kwargs, **synthesis_kwargs)
+
+    def synthesis(self, ws, c, neural_rendering_resolution=None, update_emas=False, cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
+        cam2world, intrinsics = c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3)
+        if neural_rendering_resolution is None:
+            neural_rendering_resolution = self.neural_rendering_resolution
+        else:
+            self.neural_rendering_resolution = neural_rendering_resolution
+        ray_o, ray_d = self.ray_sampler(cam2world, intrinsics, neural_rendering_resolution)
+        n = ray_o.shape[0]
+        planes = self._planes(ws, update_emas, synthesis_kwargs, cache_backbone, use_cached_backbone)
+        feat, depth, wsum = self.renderer(planes, self.decoder, ray_o, ray_d, self.rendering_kwargs)
+        ws_bg = ws[:, -1, :].unsqueeze(1).repeat([1, ws.shape[1], 1])
+        planes_bg = self.backbone_bg.synthesis(ws_bg, update_emas=update_emas, **synthesis_kwargs)
+        planes_bg = planes_bg.view(len(planes_bg), 64, planes_bg.shape[-2], planes_bg.shape[-1])
+        feat, depth = self.combine_fg_bg(feat, depth, wsum, planes_bg, ray_o, ray_d, self.rendering_kwargs)
+        r = self.neural_rendering_resolution
+        feature_image = feat.permute(0, 2, 1).reshape(n, feat.shape[-1], r, r).contiguous()
+        depth_image = depth.permute(0, 2, 1).reshape(n, 1, r, r)
+        weight_image = wsum.permute(0, 2, 1).reshape(n, 1, r, r)
+        half = feature_image.shape[1] // 2
+        rgb_feat, sem_feat = feature_image[:, :half], feature_image[:, half:]
+        sr_kw = self._sr_kwargs(synthesis_kwargs)
+        rgb_image = rgb_feat[:, :3]
+        sr_image = self.superresolution(rgb_image, rgb_feat, ws, **sr_kw)
+        semantic_image = sem_feat[:, :self.semantic_channels]
+        sr_semantic = self.superresolution_semantic(semantic_image, sem_feat, ws, **sr_kw)
+        return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image, 'semantic': sr_semantic, 'semantic_raw': semantic_image,
+                'weight': weight_image}
+
+    def combine_fg_bg(self, feature_samples, depth_samples, weights_samples, planes_bg, ray_origins, ray_directions, rendering_kwargs):
+        """[N,M,64] foreground + (1 - accumulated weight) x panorama(direction) (:1202-1246): the direction's azimuth / polar angle index
+        the panorama; its colour half is squashed to [-1, 1], its label half to [-10, 10], and for label maps the background is pinned to
+        class 0 (logit 20, the others 0); depth gets ``ray_end`` behind the foreground."""
+        d = ray_directions / torch.norm(ray_directions, dim=-1, keepdim=True)
+        theta = torch.atan2(d[:, :, 1], d[:, :, 0])
+        phi = torch.acos(d[:, :, 2])
+        grid = torch.stack([theta * 2 / np.pi, phi * 2 / np.pi - 1], dim=-1).unsqueeze(1)
+        bg = F.grid_sample(planes_bg.float(), grid, mode='bilinear', padding_mode='border', align_corners=False).squeeze(2).permute(0, 2, 1)
+        assert bg.shape == feature_samples.shape
+        bg = (torch.sigmoid(bg) * (1 + 2 * 0.001) - 0.001) * 2 - 1
+        scale = torch.ones(bg.shape[-1], device=bg.device)
+        scale[32:] = 10
+        bg = bg * scale
+        if self.semantic_channels > 1:
+            bg = bg.clone()
+            bg[:, :, 32 + 1:32 + self.semantic_channels] = 0
+            bg[:, :, 32] = 20
+        feature_samples = feature_samples + bg * (1 - weights_samples)
+        depth_samples = depth_samples + rendering_kwargs['ray_end'] * (1 - weights_samples)
+        return feature_samples, depth_samples

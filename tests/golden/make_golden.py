@@ -3,7 +3,7 @@
 Run in the authoring container only (it needs the read-only checkout at /root/reference, which does
 not exist on the GPU box):
 
-    python tests/golden/make_golden.py [group ...]      # groups: ops renderer semrenderer model flrelu train checkpoint
+    python tests/golden/make_golden.py [group ...]      # groups: ops renderer semrenderer model flrelu train checkpoint variants
 
 The reference and this repo own the same top-level module names, so this script must never import
 ``pix2pix3d_amd``; it puts /root/reference first on sys.path and imports the reference's modules
@@ -480,6 +480,49 @@ def group_checkpoint():
 
 
 GROUPS['checkpoint'] = group_checkpoint
+
+
+def group_variants():
+    """The generator classes outside train.py's current selection (configs.variant_kwargs): mapping + synthesis + point queries of small
+    name-seeded instances."""
+    import dnnlib
+    configs = _load_by_path('p3d_configs', os.path.join(os.path.dirname(os.path.dirname(HERE)), 'pix2pix3d_amd', 'configs.py'))
+    weights = _load_by_path('p3d_weights', os.path.join(HERE, 'weights.py'))
+    arrays = {}
+    for which in configs.VARIANTS:
+        kw = configs.variant_kwargs(which)
+        torch.manual_seed(0)
+        G = dnnlib.util.construct_class_by_name(**kw).eval().requires_grad_(False)
+        weights.seed_module(G, seed=7)
+        gz = torch.Generator().manual_seed(21)
+        n = 1
+        c = torch.tensor(np.stack([configs.orbit_camera(33, radius=1.7, focal=1.7074)]))
+        z = torch.randn(n, 512, generator=gz)
+        if kw['mapping_kwargs']['in_channels'] > 1:
+            mask = torch.randint(0, 6, [n, 1, 128, 128], generator=gz)
+        else:
+            mask = torch.rand([n, 1, 128, 128], generator=gz) * 2 - 1
+        pts = (torch.rand(n, 32, 3, generator=gz) - 0.5) * kw['rendering_kwargs']['box_warp']
+        with torch.no_grad():
+            ws = G.mapping(z, c, {'mask': mask, 'pose': c})
+            torch.manual_seed(77)
+            out = G.synthesis(ws, c, neural_rendering_resolution=16, noise_mode='const')
+            sm = G.sample_mixed(pts, None, ws, noise_mode='const')
+        a = dict(c=c, z=z, mask=mask.to(torch.int16) if mask.dtype == torch.int64 else mask, pts=pts, ws=ws, pts_sigma=sm['sigma'], pts_rgb=sm['rgb'])
+        if 'semantic' in sm:
+            a['pts_semantic'] = sm['semantic']
+        for k, v in out.items():
+            if v.shape[-1] > 32:
+                a[k + '_thumb'], a[k + '_crop'] = _thumb(v, 4)
+            else:
+                a[k] = v
+        arrays.update({f'{which}.{k}': v for k, v in a.items()})
+        print(which, {k: tuple(v.shape) for k, v in out.items()})
+    arrays['render_seed'] = np.int64(77)
+    save('model_variants', **arrays)
+
+
+GROUPS['variants'] = group_variants
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GROUPS)
