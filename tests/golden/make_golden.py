@@ -3,7 +3,7 @@
 Run in the authoring container only (it needs the read-only checkout at /root/reference, which does
 not exist on the GPU box):
 
-    python tests/golden/make_golden.py [group ...]      # groups: ops renderer semrenderer model flrelu train checkpoint variants
+    python tests/golden/make_golden.py [group ...]      # groups: ops renderer semrenderer model flrelu train checkpoint variants discriminator
 
 The reference and this repo own the same top-level module names, so this script must never import
 ``pix2pix3d_amd``; it puts /root/reference first on sys.path and imports the reference's modules
@@ -523,6 +523,63 @@ def group_variants():
 
 
 GROUPS['variants'] = group_variants
+
+
+def discriminator_case(D, conv2d_gradfix, g_in):
+    """The 'Dboth' phase on real images (loss.py:327-367): logits, softplus(-logits), R1 gradients w.r.t. both input images under
+    ``no_weight_gradients`` with create_graph, (loss_Dreal + r1_penalty * gamma/2).mean().backward().  Shared by the golden run (reference
+    modules) and nothing else — the tests restate it against this package's modules."""
+    img = {'image': g_in['image'].clone().requires_grad_(True), 'image_raw': g_in['image_raw'].clone().requires_grad_(True)}
+    logits = D(img, g_in['c'])
+    loss_real = torch.nn.functional.softplus(-logits)
+    with conv2d_gradfix.no_weight_gradients():
+        g_img, g_raw = torch.autograd.grad(outputs=[logits.sum()], inputs=[img['image'], img['image_raw']], create_graph=True, only_inputs=True)
+    r1 = g_img.square().sum([1, 2, 3]) + g_raw.square().sum([1, 2, 3])
+    (loss_real + r1 * (10 / 2)).mean().backward()
+    return logits, g_img, g_raw, r1
+
+
+def group_discriminator():
+    import dnnlib
+    from torch_utils.ops import conv2d_gradfix
+    weights = _load_by_path('p3d_weights', os.path.join(HERE, 'weights.py'))
+    arrays = {}
+    cases = dict(dual=dict(class_name='training.dual_discriminator.DualDiscriminator', c_dim=25, img_resolution=64, img_channels=3, channel_base=1024,
+                           channel_max=32, num_fp16_res=0, conv_clamp=None, disc_c_noise=0, block_kwargs=dict(freeze_layers=0), mapping_kwargs={},
+                           epilogue_kwargs=dict(mbstd_group_size=2)),
+                 dual_clamp=dict(class_name='training.dual_discriminator.DualDiscriminator', c_dim=25, img_resolution=32, img_channels=1, channel_base=512,
+                                 channel_max=16, num_fp16_res=0, conv_clamp=0.5, architecture='resnet', epilogue_kwargs=dict(mbstd_group_size=4, mbstd_num_channels=2)),
+                 single=dict(class_name='training.dual_discriminator.SingleDiscriminator', c_dim=0, img_resolution=32, img_channels=3, channel_base=512,
+                             channel_max=16, num_fp16_res=0, conv_clamp=None))
+    for name, kw in cases.items():
+        torch.manual_seed(0)
+        D = dnnlib.util.construct_class_by_name(**kw).train().requires_grad_(True)
+        weights.seed_module(D, seed=9)
+        gz = torch.Generator().manual_seed(31)
+        res, ch = kw['img_resolution'], kw['img_channels']
+        g_in = dict(image=torch.randn(4, ch, res, res, generator=gz), image_raw=torch.randn(4, ch, res // 4, res // 4, generator=gz), c=torch.randn(4, 25, generator=gz))
+        if name == 'single':
+            img = {'image': g_in['image'].clone().requires_grad_(True)}
+            logits = D(img, None)
+            with conv2d_gradfix.no_weight_gradients():
+                g_img, = torch.autograd.grad(outputs=[logits.sum()], inputs=[img['image']], create_graph=True, only_inputs=True)
+            r1 = g_img.square().sum([1, 2, 3])
+            (torch.nn.functional.softplus(-logits) + r1 * 5).mean().backward()
+            g_raw = torch.zeros(1)
+        else:
+            logits, g_img, g_raw, r1 = discriminator_case(D, conv2d_gradfix, g_in)
+        a = dict(image=g_in['image'], image_raw=g_in['image_raw'], c=g_in['c'], logits=logits.detach(), g_img=g_img.detach(), g_raw=g_raw.detach(), r1=r1.detach())
+        names = [n for n, p in D.named_parameters() if p.grad is not None]
+        a['grad_names'] = np.array(names)
+        a['grad_norms'] = np.array([float(dict(D.named_parameters())[n].grad.double().norm()) for n in names])
+        first = names[0]
+        a['grad_head'] = dict(D.named_parameters())[first].grad.reshape(-1)[:64].clone()
+        arrays.update({f'{name}.{k}': v for k, v in a.items()})
+        print(name, tuple(logits.shape), len(names), 'grads')
+    save('discriminator', **arrays)
+
+
+GROUPS['discriminator'] = group_discriminator
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GROUPS)

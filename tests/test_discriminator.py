@@ -1,0 +1,59 @@
+"""DualDiscriminator / SingleDiscriminator in the 'Dboth' training phase on real images (loss.py:327-367) against the reference:
+logits, the R1 gradients w.r.t. both input images (double-backward through conv2d_gradfix under no_weight_gradients) and the
+parameter gradients of softplus(-logits) + 5 * r1.  Goldens: tests/golden/make_golden.py group ``discriminator``."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from model_cases import weights
+
+CASES = dict(dual=dict(class_name='training.dual_discriminator.DualDiscriminator', c_dim=25, img_resolution=64, img_channels=3, channel_base=1024,
+                       channel_max=32, num_fp16_res=0, conv_clamp=None, disc_c_noise=0, block_kwargs=dict(freeze_layers=0), mapping_kwargs={},
+                       epilogue_kwargs=dict(mbstd_group_size=2)),
+             dual_clamp=dict(class_name='training.dual_discriminator.DualDiscriminator', c_dim=25, img_resolution=32, img_channels=1, channel_base=512,
+                             channel_max=16, num_fp16_res=0, conv_clamp=0.5, architecture='resnet', epilogue_kwargs=dict(mbstd_group_size=4, mbstd_num_channels=2)),
+             single=dict(class_name='training.dual_discriminator.SingleDiscriminator', c_dim=0, img_resolution=32, img_channels=3, channel_base=512,
+                         channel_max=16, num_fp16_res=0, conv_clamp=None))
+
+
+def _dboth(name, device, tol):
+    from pix2pix3d_amd import dnnlib
+    from pix2pix3d_amd.torch_utils.ops import conv2d_gradfix
+    g = {k.split('.', 1)[1]: v for k, v in load_golden('discriminator').items() if k.startswith(name + '.')}
+    torch.manual_seed(0)
+    D = dnnlib.util.construct_class_by_name(**CASES[name]).train().requires_grad_(True)
+    weights.seed_module(D, seed=9)
+    D = D.to(device)
+    img = {'image': torch.tensor(g['image']).to(device).requires_grad_(True)}
+    if name != 'single':
+        img['image_raw'] = torch.tensor(g['image_raw']).to(device).requires_grad_(True)
+    c = torch.tensor(g['c']).to(device) if name != 'single' else None
+    logits = D(img, c)
+    assert rel_err(logits.detach().cpu().numpy(), g['logits']) < tol
+    with conv2d_gradfix.no_weight_gradients():
+        grads = torch.autograd.grad(outputs=[logits.sum()], inputs=list(img.values()), create_graph=True, only_inputs=True)
+    r1 = sum(gr.square().sum([1, 2, 3]) for gr in grads)
+    (torch.nn.functional.softplus(-logits) + r1 * 5).mean().backward()
+    assert rel_err(grads[0].detach().cpu().numpy(), g['g_img']) < tol
+    if name != 'single':
+        assert rel_err(grads[1].detach().cpu().numpy(), g['g_raw']) < tol
+    assert rel_err(r1.detach().cpu().numpy(), g['r1']) < tol
+    params = dict(D.named_parameters())
+    names = [n for n, p in params.items() if p.grad is not None]
+    assert names == list(g['grad_names'])
+    norms = np.array([float(params[n].grad.double().norm()) for n in names])
+    assert np.abs(norms - g['grad_norms']).max() / g['grad_norms'].max() < tol
+    assert np.all(np.abs(norms - g['grad_norms']) <= tol * 10 * np.maximum(g['grad_norms'], 1e-3 * g['grad_norms'].max()))
+    assert rel_err(params[names[0]].grad.reshape(-1)[:64].cpu().numpy(), g['grad_head']) < tol
+
+
+@pytest.mark.parametrize('name', list(CASES))
+def test_discriminator_dboth_phase_matches_reference_cpu(name):
+    _dboth(name, 'cpu', 2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', list(CASES))
+def test_discriminator_dboth_phase_matches_reference_device(name):
+    _dboth(name, 'cuda', 2e-3)
