@@ -414,225 +414,25 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(ConvArgs a)
     }
 }
 
-// ---- 3x3 conv, 256-pixel tile, three-slot weight ring (fp16) ---------------------------------------------------------------
-// The two-stage kernels above wait for the whole prefetch at every barrier, so a K step costs one L2 round trip however
-// little compute it holds.  This variant keeps the halo slab idea but
-//   * doubles the pixel tile to 16 x 16 (512 threads, 8 waves as 4 x 2; weight traffic per FLOP halves),
+// ---- 3x3 conv, 16 x 16 patch, three-slot weight ring, 64-byte K rows: TWO blocks per CU (fp16) -----------------------------------
+// The two-stage kernels above wait for the whole prefetch at every barrier, so a K step costs one L2 round trip however little
+// compute it holds.  This kernel keeps the halo-slab idea and
+//   * takes a 16 x 16 pixel patch per block (weight traffic per FLOP is half the 8 x 16 kernel's); 4 waves, each 64 pixels x all
+//     128 output channels (8 accumulator tiles: 12 fragment reads per 16 MFMAs),
 //   * rings the weight tiles through THREE LDS buffers with ONE barrier per step (details at the loop),
-//   * keeps two slab buffers; the next channel chunk's slab is issued at tap 0, eight steps before its first use.
-// LDS: 2 x 41.5 KB slabs + 3 x 16 KB weights = 131 KB -> one block (2 waves per SIMD) per CU.  Superseded as the default by
-// conv3x3_h2_f16_kernel below (same pipeline, 70 KB, two blocks per CU: +5 % on the SR layers); kept selectable
-// (P3D_CONV_NO_H2) as the measured comparison point.
+//   * keeps two slab buffers; the next channel chunk's slab is issued at tap 0, eight steps before its first use,
+//   * computes everything lane-dependent ONCE (DMA source offsets, fragment addresses): a K step then costs a handful of scalar
+//     adds — the first version spent ~110 VALU + ~90 SALU instructions per 16 MFMAs on addresses and was issue-bound,
+//   * uses 64-byte K rows (32 channels): a chunk's slab is 23 KB, a weight tile 8 KB, 70 KB per block, so TWO blocks share a CU and
+//     one's prologue (slab from HBM) and epilogue hide under the other's main loop.  The first cut of this pipeline (512 threads,
+//     128-byte rows, 131 KB, one block per CU) exposed both — 25 % of a block's life — and measured 840-926 TFLOP/s on the SR layers
+//     where this one gives 906-938.
+// 64-byte rows put FOUR rows in a 256-byte bank row, so the slab pitch is 20 pixels (a multiple of 4) and the XOR key of a row is
+// (column >> 2) & 3: the 16 rows one ds_read_b128 cycle serves (8 pixels of a patch row, 8 of the next) then cover all 16 bank quads.
 constexpr int QH = 16, QW = 16;                     // pixel patch (QH * QW = 256)
-constexpr int QSLAB_W = QW + 2, QSLAB_ROWS = (QH + 2) * (QW + 2);        // 18, 324
-constexpr int QSLAB_GROUPS = (QSLAB_ROWS + 7) / 8;                       // 41 DMA groups of 8 slab pixels
-constexpr int QSLAB_SLOTS = QSLAB_GROUPS * 64;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-__global__ void __launch_bounds__(512, 2) conv3x3_q256_f16_kernel(ConvArgs a)
-{
-    // ONE __shared__ object on purpose: with two, hipcc drains vmcnt to 0 before the first ds_read of every step and the
-    // counted waits below are moot (cdna_hip_programming.md, 'three .s-level traps' (a))
-    __shared__ __attribute__((aligned(16))) f32x4 lds[2 * QSLAB_SLOTS + 3 * BN * 8];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;                                   // 4 x 2 waves, 64 x 64 outputs each
-    const int n = blockIdx.z;
-    const int tiles_x = (a.W + QW - 1) / QW;
-    int mt = blockIdx.x, cb = blockIdx.y;
-    {
-        const int nmt = gridDim.x, ncb = gridDim.y, L = blockIdx.x + blockIdx.y * nmt;
-        if ((nmt & 7) == 0) { const int q = L >> 3, r = L & 7; cb = q % ncb; mt = (q / ncb) * 8 + r; }
-    }
-    const int ty = mt / tiles_x, tx = mt - ty * tiles_x;
-    const int oy0 = ty * QH, ox0 = tx * QW, co0 = cb * BN;
-    const __half* xin = (const __half*)a.x + (int64_t)n * a.H * a.W * a.Ci;
-    const __half* wgt = (const __half*)a.w + (int64_t)n * a.w_img_stride;
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    typedef const __attribute__((address_space(1))) void* glb_ptr;
-    const int pos = lane & 7, lrow = lane >> 3;                                // DMA lane within its 8-row group
-    const int kpairs = a.Ci / 128;                                             // the loop body covers TWO 64-channel chunks (18 taps)
-    char* const lds_b = (char*)lds;
-    constexpr int SLAB_BYTES = QSLAB_SLOTS * 16, WT_BYTES = BN * 8 * 16, WT_BASE = 2 * SLAB_BYTES;
-
-    // ---- everything lane-dependent is computed ONCE; a K step then costs a handful of scalar adds (the first version spent
-    //      ~110 VALU + ~90 SALU instructions per 16 MFMAs on addresses and was issue-bound, not MFMA-bound)
-    // weight DMA: piece p of this wave fills tile rows (wave*2+p)*8 .. +7; byte offset of the lane's 16 bytes inside tap 0 / chunk 0
-    unsigned woff[2];
-#pragma unroll
-    for (int p2 = 0; p2 < 2; ++p2) {
-        const int row = (wave * 2 + p2) * 8 + lrow;
-        woff[p2] = (unsigned)(((co0 + row) * 9 * a.Ci + (pos ^ ((row >> 1) & 7)) * 8) * 2);
-    }
-    const char* const wgt_b = (const char*)wgt;
-    // slab DMA: groups wave, wave+8, ... (6 for wave 0, else 5); out-of-image pixels read the zero line
-    unsigned soff[6]; bool sok[6];
-#pragma unroll
-    for (int g = 0; g < 6; ++g) {
-        const int row = (wave + 8 * g) * 8 + lrow;
-        const int sr = row / QSLAB_W, sc = row - sr * QSLAB_W;
-        const int iy = oy0 - 1 + sr, ix = ox0 - 1 + sc;
-        sok[g] = (row < QSLAB_ROWS) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
-        soff[g] = (unsigned)(((iy * a.W + ix) * a.Ci + (pos ^ ((sc >> 1) & 7)) * 8) * 2);     // keyed on the slab COLUMN (see below)
-    }
-    const char* const xin_b = (const char*)xin;
-    const int nslab = (wave == 0) ? 6 : 5;
-    auto stage_slab = [&](int cc, int buf) {
-#pragma unroll
-        for (int g = 0; g < 6; ++g) {
-            if (g < nslab) {
-                const char* src = sok[g] ? xin_b + soff[g] + cc * 128 : (const char*)a.zeros;
-                __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(lds_b + buf * SLAB_BYTES + (wave + 8 * g) * 1024), 16, 0, 0);
-            }
-        }
-    };
-    auto stage_w = [&](int cc, int t, int slot) {
-        const char* base = wgt_b + (t * a.Ci + cc * 64) * 2;
-#pragma unroll
-        for (int p2 = 0; p2 < 2; ++p2)
-            __builtin_amdgcn_global_load_lds((glb_ptr)(base + woff[p2]), (lds_ptr)(lds_b + WT_BASE + slot * WT_BYTES + (wave * 2 + p2) * 1024), 16, 0, 0);
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int frow = lane & 31, fk = lane >> 5;
-    // fragment addresses (LDS byte offsets).  A: pixel (wm*4 + 2i + frow/16, frow%16) of the patch, tap (ty, tx) -> slab row
-    // arowm + i*36 + ty*18 + tx; its 16-byte chunk c sits at slot position c ^ key with key from the slab COLUMN, so the 16
-    // lanes one ds_read_b128 cycle serves (8 pixels of a patch row + 8 of the next) hit 16 distinct bank quads although the
-    // slab pitch is 18.  Only tx changes the key: 3 x 4 lane constants; i, ty and the slab buffer are immediates.
-    const int acol = frow & 15;
-    const int arowm = (wm * 4 + (frow >> 4)) * QSLAB_W + acol;
-    int preA[3][4], preB[4];
-#pragma unroll
-    for (int tx2 = 0; tx2 < 3; ++tx2)
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-            preA[tx2][kk] = (arowm + tx2) * 128 + (((kk * 2 + fk) ^ (((acol + tx2) >> 1) & 7)) << 4);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) preB[kk] = WT_BASE + swz(wn * 64 + frow, kk * 2 + fk) * 16;
-
-    f32x4 fa[2][2], fb[2][2];
-    auto load_frags = [&](int buf, int t, int kk, f32x4* pa, f32x4* pb) {      // buf, t, kk are compile-time after unrolling
-        const int ty2 = t / 3, tx2 = t - ty2 * 3;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            // issued as opaque asm so that the compiler's own s_waitcnt (always lgkmcnt(0) here) stays out of the way: the
-            // waits are the counted ones written next to the MFMAs below
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pa[i]) : "v"(preA[tx2][kk]), "n"(buf * SLAB_BYTES + (i * 2 * QSLAB_W + ty2 * QSLAB_W) * 128) : "memory");
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pb[i]) : "v"(preB[kk]), "n"((t % 3) * WT_BYTES + i * 32 * 128) : "memory");
-        }
-    };
-
-    // Software pipeline.  Fragments are double-buffered in registers (the reads of sub-step kk+1 fly under the MFMAs of kk).
-    // ONE block-wide rendezvous per step, at kk = 3, after the step's last fragment reads have landed (lgkmcnt(0)): everyone is
-    // then done with tile ks, so its ring slot takes the DMA of tile ks+3 at once, and the same point waits for tile ks+1 — issued
-    // TWO steps earlier, while the group issued one step earlier (tile ks+2, plus a slab after tap 0) stays in flight under a
-    // counted vmcnt.  Two full steps of flight out of three 16 KB slots; PMC on the previous one-step version: 46 % of the wave
-    // cycles waiting at vmcnt(0) + barrier.  Nine taps and three slots: the slot index is t % 3, a compile-time constant of the
-    // unrolled body.  The slab of the next channel chunk rides along at tap 0.
-    stage_slab(0, 0);
-    stage_w(0, 0, 0);
-    stage_w(0, 1, 1);
-    stage_w(0, 2, 2);
-    wait_vmcnt<2>();                                                            // slab 0, tiles 0 and 1 (tile 2 stays in flight)
-    __builtin_amdgcn_s_barrier();
-    load_frags(0, 0, 0, fa[0], fb[0]);
-    for (int cp = 0; cp < kpairs; ++cp) {
-        const bool more = cp + 1 < kpairs;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int cc = cp * 2 + h;
-            const bool next_chunk = (h == 0) || more;                           // chunk cc + 1 exists
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int cur = kk & 1, nxt = cur ^ 1;
-                    if (kk < 3) { load_frags(h, t, kk + 1, fa[nxt], fb[nxt]); asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); }
-                    else {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this step's last fragments are in registers
-                        // what may stay in flight: the group issued one step ago = tile ks+2 (if any) + the slab issued at tap 0
-                        const bool t2 = (t < 7) || next_chunk;                  // tile ks+2 exists
-                        if (t == 1 && next_chunk) { if (nslab == 6) wait_vmcnt<8>(); else wait_vmcnt<7>(); }
-                        else if (t2) wait_vmcnt<2>();
-                        else wait_vmcnt<0>();
-                        __builtin_amdgcn_s_barrier();
-                        if (t < 6) stage_w(cc, t + 3, t % 3);                   // tile ks+3 -> the slot tile ks just left
-                        else if (next_chunk) stage_w(cc + 1, t - 6, t % 3);
-                        if (t == 0 && next_chunk) stage_slab(cc + 1, h ^ 1);
-                        if (t < 8) load_frags(h, t + 1, 0, fa[nxt], fb[nxt]);
-                        else if (next_chunk) load_frags(h ^ 1, 0, 0, fa[nxt], fb[nxt]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, fa[cur][i]), __builtin_bit_cast(h8, fb[cur][j]), acc[i][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-    }
-    __syncthreads();                                                            // every wave is done with the slabs and tiles
-
-    // Epilogue through LDS (the loop's last barrier has retired every fragment read, so the slabs are free): each lane holds
-    // ONE channel of 64 pixels, which as direct stores is 64 two-byte writes per lane.  Instead the finished tile is laid out
-    // [256 pixels][128 channels] (pitch 136 halfs: the fk = 1 half-wave lands 16 banks away) and leaves as 16-byte stores,
-    // 16 lanes per pixel = the pixel's whole 256-byte channel run.
-    constexpr int OP = 136;
-    __half* const ot = (__half*)lds;
-    float* const nz = (float*)(ot + 256 * OP);                                   // the tile's noise (256 floats), if any
-    const float ns = a.noise ? a.noise_strength[0] : 0.f;
-    if (a.noise) {
-        if (tid < 256) {
-            const int oy = oy0 + (tid >> 4), ox = ox0 + (tid & 15);
-            nz[tid] = (oy < a.H && ox < a.W) ? a.noise[(int64_t)oy * a.W + ox] * ns : 0.f;
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int cl = wn * 64 + j * 32 + frow, co = co0 + cl;
-        const float b = (a.bias && co < a.Co) ? a.bias[co] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int p = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;   // pixel within the 16 x 16 tile, row-major
-                float v = acc[i][j][r];
-                if (a.noise) v += nz[p];
-                v += b;
-                if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
-                v *= a.gain;
-                if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
-                ot[p * OP + cl] = __float2half(v);
-            }
-    }
-    __syncthreads();
-    __half* const yout = (__half*)a.y + (int64_t)n * a.H * a.W * a.Co;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int idx = it * 512 + tid, p = idx >> 4, ch = idx & 15;
-        const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15), co = co0 + ch * 8;
-        if (oy < a.H && ox < a.W && co < a.Co)
-            *(f32x4*)(yout + ((int64_t)oy * a.W + ox) * a.Co + co) = *(const f32x4*)(ot + p * OP + ch * 8);
-    }
-}
-
-// ---- 3x3 conv, 16 x 16 patch, 64-byte K rows: TWO blocks per CU (fp16) ----------------------------------------------------
-// Same halo / ring / lane-constant / counted-wait structure as the 256-pixel kernel above, re-cut so that a block needs 70 KB of
-// LDS instead of 131 KB: K rows are 32 channels (64 bytes), the slab of a chunk is 23 KB, a weight tile 8 KB.  Two blocks then
-// share a CU and one's prologue (slab from HBM) and epilogue hide under the other's main loop — with one block per CU they are
-// exposed and cap that structure near 1.5 PFLOP/s.  4 waves per block, each 64 pixels x all 128 output channels (8 accumulator
-// tiles: 12 fragment reads per 16 MFMAs instead of 16).  64-byte rows put FOUR rows in a 256-byte bank row, so the slab pitch is 20
-// pixels (a multiple of 4) and the XOR key of a row is (column >> 2) & 3: the 16 rows one ds_read_b128 cycle serves (8 pixels
-// of a patch row, 8 of the next) then cover all 16 bank quads.
 constexpr int H2_PITCH = 20;
 constexpr int H2_SLAB_ROWS = 18 * H2_PITCH;                     // 360 rows of 64 bytes
 constexpr int H2_SLAB_PIECES = (H2_SLAB_ROWS * 64 + 1023) / 1024;   // 23 DMA pieces (16 rows each)
@@ -643,7 +443,9 @@ constexpr int H2_LDS = H2_WT_BASE + 3 * H2_WT_BYTES;            // 71680 (>= the
 
 __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
 {
-    __shared__ __attribute__((aligned(16))) char lds_b[H2_LDS];     // ONE object (see conv3x3_q256_f16_kernel)
+    // ONE __shared__ object on purpose: with two, hipcc drains vmcnt to 0 before the first ds_read of every step and the counted
+    // waits below are moot (cdna_hip_programming.md, 'three .s-level traps' (a))
+    __shared__ __attribute__((aligned(16))) char lds_b[H2_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = blockIdx.z;
     const int tiles_x = (a.W + QW - 1) / QW;
@@ -700,6 +502,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // fragment addresses (LDS byte offsets).  A: pixel (wave*4 + 2i + frow/16, frow%16) of the patch at tap (ty, tx) is slab row
+    // (that pixel row + ty) * PITCH + column + tx; its 16-byte piece c sits at position c ^ key with the key taken from the slab
+    // COLUMN.  Only tx changes the key: 3 x 2 lane constants; i, ty, the slab buffer and the ring slot are instruction immediates.
     const int frow = lane & 31, fk = lane >> 5;
     const int acol = frow & 15;
     int preA[3][2], preB[2];
@@ -713,6 +518,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
 
     f32x4 fa[2][2], fb[2][4];
     auto load_frags = [&](int buf, int t, int kk, f32x4* pa, f32x4* pb) {      // buf, t, kk are compile-time after unrolling
+        // issued as opaque asm so that the compiler's own s_waitcnt (always lgkmcnt(0) here) stays out of the way: the waits are
+        // the counted ones written next to the MFMAs below
         const int ty2 = t / 3, tx2 = t - ty2 * 3;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -722,6 +529,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pb[j]) : "v"(preB[kk]), "n"((t % 3) * H2_WT_BYTES + j * 32 * 64) : "memory");
     };
 
+    // Software pipeline.  Fragments are double-buffered in registers (the reads of sub-step kk+1 fly under the MFMAs of kk).  ONE
+    // block-wide rendezvous per step, at its last sub-step, after the step's last fragment reads have landed (lgkmcnt(0)): everyone
+    // is then done with tile ks, so its ring slot takes the DMA of tile ks+3 at once, and the same point waits for tile ks+1 — issued
+    // TWO steps earlier, while the group issued one step earlier (tile ks+2, plus a slab after tap 0) stays in flight under a counted
+    // vmcnt.  Two full steps of flight out of three slots (PMC on a one-step version: 46 % of the wave cycles waiting at vmcnt(0) +
+    // barrier).  Nine taps and three slots: the slot index is t % 3, a compile-time constant of the unrolled body.
     stage_slab(0, 0);
     stage_w(0, 0, 0);
     stage_w(0, 1, 1);
@@ -743,12 +556,13 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
                     if (kk == 0) { load_frags(h, t, 1, fa[nxt], fb[nxt]); asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); }
                     else {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        // what may stay in flight: the group issued one step ago = tile ks+2 (if any) + the slab issued at tap 0
                         const bool t2 = (t < 7) || next_chunk;                  // tile ks+2 exists
                         if (t == 1 && next_chunk) { if (nslab == 6) wait_vmcnt<8>(); else wait_vmcnt<7>(); }
                         else if (t2) wait_vmcnt<2>();
                         else wait_vmcnt<0>();
                         __builtin_amdgcn_s_barrier();
-                        if (t < 6) stage_w(cc, t + 3, t % 3);
+                        if (t < 6) stage_w(cc, t + 3, t % 3);                   // tile ks+3 -> the slot tile ks just left
                         else if (next_chunk) stage_w(cc + 1, t - 6, t % 3);
                         if (t == 0 && next_chunk) stage_slab(cc + 1, h ^ 1);
                         if (t < 8) load_frags(h, t + 1, 0, fa[nxt], fb[nxt]);
@@ -767,9 +581,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
     }
     __syncthreads();                                                            // every wave is done with the slabs and tiles
 
+    // Epilogue through LDS (the slabs are free now): each lane holds ONE channel of 64 pixels, which as direct stores is 64 two-byte
+    // writes per lane.  Instead the finished tile is laid out [256 pixels][128 channels] (pitch 136 halfs: the fk = 1 half-wave lands
+    // 16 banks away) and leaves as 16-byte stores, 16 lanes per pixel = the pixel's whole 256-byte channel run.
     constexpr int OP = 136;
     __half* const ot = (__half*)lds_b;
-    float* const nz = (float*)(ot + 256 * OP);                                   // 69632 .. 70656 < H2_LDS
+    float* const nz = (float*)(ot + 256 * OP);                                   // the tile's noise: bytes 69632 .. 70656 < H2_LDS
     const float ns = a.noise ? a.noise_strength[0] : 0.f;
     if (a.noise) {
         const int oy = oy0 + (tid >> 4), ox = ox0 + (tid & 15);
@@ -1138,21 +955,12 @@ extern "C" int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype,
         a.cls[0].SH = h; a.cls[0].SW = wdt; a.cls[0].ooy = a.cls[0].oox = 0; a.cls[0].ntaps = a.KT;
         for (int t = 0; t < a.KT; ++t) a.cls[0].taps[t] = ConvTap{t / kernel_size - kernel_size / 2, t % kernel_size - kernel_size / 2, t};
         static const bool no_halo = getenv("P3D_CONV_NO_HALO") != nullptr;
-        static const bool no_q256 = getenv("P3D_CONV_NO_Q256") != nullptr;
         static const bool no_h2 = getenv("P3D_CONV_NO_H2") != nullptr;
         if (!no_h2 && !no_halo && kernel_size == 3 && dtype == P3D_F16 && h >= 32 && wdt >= 32 && ci % 64 == 0 && co % BN == 0 && (((uintptr_t)y) & 15u) == 0) {
             dim3 grid(((h + QH - 1) / QH) * ((wdt + QW - 1) / QW), co / BN, n_img);
             hipLaunchKernelGGL(conv3x3_h2_f16_kernel, grid, dim3(256), 0, s, a);
             count_launch(FAM_CONV);
             return check_launch("conv3x3_h2_f16");
-        }
-        if (kernel_size == 3 && dtype == P3D_F16 && h >= 64 && wdt >= 64 && ci % 128 == 0 && co % BN == 0 && (((uintptr_t)y) & 15u) == 0 && !no_halo && !no_q256) {     // big fp16 layers: 256-pixel tiles, 3-stage weights
-            static hipError_t attr = hipFuncSetAttribute((const void*)conv3x3_q256_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 0);
-            (void)attr;
-            dim3 grid(((h + QH - 1) / QH) * ((wdt + QW - 1) / QW), (co + BN - 1) / BN, n_img);
-            hipLaunchKernelGGL(conv3x3_q256_f16_kernel, grid, dim3(512), 0, s, a);
-            count_launch(FAM_CONV);
-            return check_launch("conv3x3_q256_f16");
         }
         if (kernel_size == 3 && h >= PH && wdt >= PW && !no_halo) {       // halo-reuse kernel for the plain 3x3 layers
             dim3 grid(((h + PH - 1) / PH) * ((wdt + PW - 1) / PW), (co + BN - 1) / BN, n_img);

@@ -161,7 +161,7 @@ def test_synthesis_layer_native_vs_generic(hip_lib):
 
 
 @pytest.mark.parametrize('dtype,ci,co,h,w', [
-    (torch.float16, 128, 128, 64, 64),      # conv3x3_q256_f16_kernel: the big SR layers (16 x 16 patches, Ci, Co multiples of 128)
+    (torch.float16, 128, 128, 64, 64),      # conv3x3_h2_f16_kernel: the fp16 SR layers (16 x 16 patches, Ci multiple of 64, Co of 128)
     (torch.float16, 256, 256, 80, 72),      # ... with partial patches on both axes and four channel chunks
     (torch.float16, 128, 256, 64, 200),
     (torch.float16, 64, 128, 40, 24),       # conv3x3_halo_kernel<half>: 8 x 16 patches (Ci not a multiple of 128)
@@ -169,8 +169,8 @@ def test_synthesis_layer_native_vs_generic(hip_lib):
     (torch.float32, 96, 72, 19, 33),
 ])
 @pytest.mark.parametrize('with_noise', [False, True])
-def test_halo_and_q256_kernels_at_their_own_sizes(hip_lib, dtype, ci, co, h, w, with_noise):
-    """The two halo-reuse 3x3 kernels only engage from 8 x 16 / 64 x 64 pixels on: checked here directly (bias, noise, lrelu, gain,
+def test_halo_kernels_at_their_own_sizes(hip_lib, dtype, ci, co, h, w, with_noise):
+    """The halo-reuse 3x3 kernels only engage from 8 x 16 (fp32 / narrow fp16) and 32 x 32 (fp16, 16 x 16 patches) pixels on: checked here directly (bias, noise, lrelu, gain,
     clamp in the epilogue) against torch's fp32 convolution of the same (fp16-rounded) operands, with per-sample weights."""
     from pix2pix3d_amd.torch_utils.ops import modconv
     torch.manual_seed(ci + co + h)
