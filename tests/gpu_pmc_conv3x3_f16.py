@@ -8,5 +8,5 @@ weight = torch.randn(co, ci, 3, 3, device='cuda'); styles = torch.randn(N, ci, d
 wmod = modconv.modulate_weights(weight, styles)
 bias = torch.randn(co, device='cuda')
 for _ in range(5):
-    y = modconv.conv3x3(x, wmod, bias=bias, act=1, gain=1.414, clamp=256)
+    y = modconv.conv2d(x, wmod, bias=bias, act=1, gain=1.414, clamp=256.0)
 torch.cuda.synchronize()
