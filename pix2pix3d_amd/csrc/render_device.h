@@ -66,6 +66,12 @@ __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_log
 __device__ __forceinline__ float softplus20(float x) {      // torch.nn.Softplus(beta=1, threshold=20)
     return x > 20.f ? x : fast_log(1.f + fast_exp(x));
 }
+// The same in the log2 domain: with layer 1's weights and biases pre-scaled by log2(e) (see the LDS copy in render_forward_kernel) the
+// accumulator holds xs = x log2(e) and softplus(x) / ln 2 = log2(1 + 2^xs) — v_exp, v_add, v_log with no scaling multiplies; the 1 / ln 2 is
+// folded into layer 2.  x > 20 <=> xs > 20 log2(e) keeps torch's threshold semantics.
+__device__ __forceinline__ float softplus20_log2(float xs) {
+    return xs > 28.853900817779268f ? xs : __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(xs));
+}
 __device__ __forceinline__ float sigmoid_clamped(float x) {  // sigmoid(x) * (1 + 2*0.001) - 0.001
     return fmaf(__builtin_amdgcn_rcpf(1.f + fast_exp(-x)), 1.002f, -0.001f);
 }
@@ -140,12 +146,11 @@ __device__ __forceinline__ void gather_features(const RenderArgs& a, rsrc_t rsrc
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float s = v00[q][e] * w00;
+            for (int e = 0; e < 4; ++e) {                  // four FMAs per channel, straight into the three-plane sum
+                float s = fmaf(v00[q][e], w00, acc[q * 4 + e]);
                 s = fmaf(v10[q][e], w10, s);
                 s = fmaf(v01[q][e], w01, s);
-                s = fmaf(v11[q][e], w11, s);
-                acc[q * 4 + e] += s;
+                acc[q * 4 + e] = fmaf(v11[q][e], w11, s);
             }
     }
 #pragma unroll
@@ -155,6 +160,7 @@ __device__ __forceinline__ void gather_features(const RenderArgs& a, rsrc_t rsrc
 // ---- decoder pieces -------------------------------------------------------------------------------
 // Layer 1 of net `n` for this wave's 32 samples: returns the 64 hidden units (post-softplus) as two
 // accumulator tiles; lane (j,h) holds hidden unit 32t + (r&3) + 8(r>>2) + 4h of sample j in tile[t][r].
+template <bool LOG2 = false>
 __device__ __forceinline__ void mlp_layer1(const float* lds, int n, int lane, int h, const float (&feat)[16],
                                            f32x16& h0, f32x16& h1)
 {
@@ -176,7 +182,10 @@ __device__ __forceinline__ void mlp_layer1(const float* lds, int n, int lane, in
         }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { h0[r] = softplus20(h0[r]); h1[r] = softplus20(h1[r]); }
+    for (int r = 0; r < 16; ++r) {
+        h0[r] = LOG2 ? softplus20_log2(h0[r]) : softplus20(h0[r]);
+        h1[r] = LOG2 ? softplus20_log2(h1[r]) : softplus20(h1[r]);
+    }
 }
 
 // Layer 2 colour rows (decoder outputs 1..32) of net `n`: lane (j,h) gets channel (r&3)+8(r>>2)+4h in out[r].
@@ -285,10 +294,24 @@ render_forward_kernel(RenderArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
 
-    {   // decoder stream -> LDS (straight copy, 16 B per lane)
+    // Inference works in the log2 domain (softplus20_log2): its LDS copy of the decoder has layer 1 (weights, biases) scaled by log2(e) and
+    // everything that consumes the hidden units (layer-2 colour rows, the density row) by ln 2.  The packed stream in global memory is
+    // the same for every consumer; the tape sweep (TAPE) and the backward kernel keep natural units, their gradients use the hidden values.
+    constexpr bool LOG2 = !TAPE;
+    {   // decoder stream -> LDS (16 B per lane)
         const f32x4* src = (const f32x4*)a.decoder;
         f32x4* dst = (f32x4*)lds;
-        for (int i = tid; i < kDecoderFloats / 4; i += blockDim.x) dst[i] = src[i];
+        for (int i = tid; i < kDecoderFloats / 4; i += blockDim.x) {
+            f32x4 v = src[i];
+            if (LOG2) {
+                const int f = i * 4;
+                const bool first  = f < OFF_B1 ? (f & (kNetStride - 1)) < kNetStride / 2 : f < OFF_B2;      // layer-1 weights / biases
+                const bool second = f < OFF_B1 ? !first : (f >= OFF_W2S && f < OFF_B2S);                    // layer-2 colour rows / density row
+                const float sc = first ? 1.4426950408889634f : (second ? 0.6931471805599453f : 1.f);
+                v = v * sc;
+            }
+            dst[i] = v;
+        }
     }
     __syncthreads();
 
@@ -341,7 +364,7 @@ render_forward_kernel(RenderArgs a)
             float feat[16];
             gather_features(a, rsrc, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
             f32x16 h0, h1;
-            mlp_layer1(lds, SN, lane, h, feat, h0, h1);
+            mlp_layer1<LOG2>(lds, SN, lane, h, feat, h0, h1);
             const float sigma = mlp_sigma(lds, h, h0, h1);
             if (i > 0) {
                 const float dens = softplus20(0.5f * (s_prev + sigma) - 1.f);
@@ -404,7 +427,7 @@ render_forward_kernel(RenderArgs a)
         for (int idx = 0; idx < NNETS; ++idx) {
             const int n = (idx == 0) ? SN : idx - 1;
             f32x16 h0, h1, o;
-            mlp_layer1(lds, n, lane, h, feat, h0, h1);
+            mlp_layer1<LOG2>(lds, n, lane, h, feat, h0, h1);
             if (idx == 0) {
                 sigma = mlp_sigma(lds, h, h0, h1);
                 if (k == 0) z_first = z;
