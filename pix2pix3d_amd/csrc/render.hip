@@ -63,7 +63,7 @@ sample_points_kernel(RenderArgs a, const float* coords, int pts_per_img, int tot
         const unsigned img = (unsigned)(p / pts_per_img) * a.img_bytes;
         const float cs = a.coord_scale;
         float feat[16];
-        gather_features(a, rsrc, img, h, cs * coords[(size_t)p * 3], cs * coords[(size_t)p * 3 + 1], cs * coords[(size_t)p * 3 + 2], feat);
+        gather_features<true>(a, rsrc, img, h, cs * coords[(size_t)p * 3], cs * coords[(size_t)p * 3 + 1], cs * coords[(size_t)p * 3 + 2], feat);
 #pragma unroll
         for (int n = 0; n < NNETS; ++n) {
             f32x16 h0, h1, o;

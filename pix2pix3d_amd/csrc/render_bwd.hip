@@ -190,7 +190,7 @@ render_backward_kernel(RenderArgs a, const float* __restrict__ bwd_stream, float
         const float z = rec.x, wgt = live ? rec.y : 0.f, dsig = live ? rec.z : 0.f;
         const float px = cs * fmaf(z, dx, ox), py = cs * fmaf(z, dy, oy), pz = cs * fmaf(z, dz, oz);
         float feat[16];
-        gather_features(a, rsrc, img, h, px, py, pz, feat);
+        gather_features<false>(a, rsrc, img, h, px, py, pz, feat);
         wave_sync();                                              // the previous sample's readers of T_f are done
 #pragma unroll
         for (int c = 0; c < 16; ++c) Tf[(16 * h + c) * TP + j] = feat[c];

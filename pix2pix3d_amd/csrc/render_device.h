@@ -100,58 +100,104 @@ __device__ __forceinline__ float coarse_depth(const RenderArgs& a, int g, int i,
 
 // ---- tri-plane gather: mean over planes of the bilinear sample, channels [16h, 16h+16) ------------
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
+struct PlaneTaps { unsigned o00, o10, o01, o11; float w00, w10, w01, w11; };
+
+// Byte offsets and weights of the four bilinear taps of plane p (grid_sample, align_corners=False, zero padding).
+__device__ __forceinline__ PlaneTaps plane_taps(const RenderArgs& a, unsigned img_off, int h, int p, float px, float py, float pz)
+{
+    const int W = a.W, H = a.H;
+    // inverse plane bases (renderer.py:23-53): plane 0 -> (x, y), plane 1 -> (x, z), plane 2 -> (z, x)
+    const float gx = (p == 2) ? pz : px;
+    const float gy = (p == 0) ? py : (p == 1 ? pz : px);
+    // pixel = ((g + 1) * size - 1) / 2
+    float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+    float iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+    ix = fminf(fmaxf(ix, -2.f), (float)W + 1.f);       // keeps the int conversion sane; all taps of a
+    iy = fminf(fmaxf(iy, -2.f), (float)H + 1.f);       // clamped coordinate are out of range anyway
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx1 = ix - fx, wx0 = (fx + 1.f) - ix;
+    const float wy1 = iy - fy, wy0 = (fy + 1.f) - iy;
+    const bool vx0 = (x0 >= 0) & (x0 < W), vx1 = (x0 + 1 >= 0) & (x0 + 1 < W);
+    const bool vy0 = (y0 >= 0) & (y0 < H), vy1 = (y0 + 1 >= 0) & (y0 + 1 < H);
+    const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x0 + 1, 0), W - 1);
+    const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y0 + 1, 0), H - 1);
+    PlaneTaps t;
+    t.w00 = (vx0 & vy0) ? wx0 * wy0 : 0.f;    // nw
+    t.w10 = (vx1 & vy0) ? wx1 * wy0 : 0.f;    // ne
+    t.w01 = (vx0 & vy1) ? wx0 * wy1 : 0.f;    // sw
+    t.w11 = (vx1 & vy1) ? wx1 * wy1 : 0.f;    // se
+    // 32-bit byte offsets into one buffer resource (wave-uniform descriptor): no 64-bit address arithmetic per tap
+    const unsigned pbase = img_off + (unsigned)p * a.plane_bytes + (unsigned)h * 64u;
+    t.o00 = pbase + __umul24(__umul24(cy0, W) + cx0, a.pix_bytes);
+    t.o10 = pbase + __umul24(__umul24(cy0, W) + cx1, a.pix_bytes);
+    t.o01 = pbase + __umul24(__umul24(cy1, W) + cx0, a.pix_bytes);
+    t.o11 = pbase + __umul24(__umul24(cy1, W) + cx1, a.pix_bytes);
+    return t;
+}
+// One ROW of a plane's 2 x 2 footprint (two taps x 64 bytes per lane): 8 buffer_load_b128 into v, and its share of the blend.
+__device__ __forceinline__ void issue_row(rsrc_t rsrc, unsigned o_left, unsigned o_right, f32x4 (&v)[8])
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        v[q]     = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o_left + 16 * q, 0, 0));
+        v[4 + q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o_right + 16 * q, 0, 0));
+    }
+}
+__device__ __forceinline__ void blend_row(const f32x4 (&v)[8], float w_left, float w_right, float (&acc)[16])
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)                    // FMAs straight into the three-plane sum
+            acc[q * 4 + e] = fmaf(v[4 + q][e], w_right, fmaf(v[q][e], w_left, acc[q * 4 + e]));
+}
+
+// PIPE = false: one plane at a time (16 loads in flight per lane, then its blend) — three exposed memory latencies per sample, 64 staging
+// registers; what the training kernels use, their register budget is spent on gradients.  PIPE = true (inference): the six footprint rows
+// of a sample go through THREE 8-load buffers, the next row's loads being issued as soon as a buffer has been blended, so roughly one
+// latency is exposed per sample for 96 staging registers (two whole planes in flight need 128 and spill).
+template <bool PIPE>
 __device__ __forceinline__ void gather_features(const RenderArgs& a, rsrc_t rsrc, unsigned img_off, int h,
                                                 float px, float py, float pz, float (&feat)[16])
 {
-    const int W = a.W, H = a.H;
     float acc[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+    if (!PIPE) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        // inverse plane bases (renderer.py:23-53): plane 0 -> (x, y), plane 1 -> (x, z), plane 2 -> (z, x)
-        const float gx = (p == 2) ? pz : px;
-        const float gy = (p == 0) ? py : (p == 1 ? pz : px);
-        // grid_sample(align_corners=False): pixel = ((g + 1) * size - 1) / 2, zero padding
-        float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
-        float iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
-        ix = fminf(fmaxf(ix, -2.f), (float)W + 1.f);       // keeps the int conversion sane; all taps of a
-        iy = fminf(fmaxf(iy, -2.f), (float)H + 1.f);       // clamped coordinate are out of range anyway
-        const float fx = floorf(ix), fy = floorf(iy);
-        const int x0 = (int)fx, y0 = (int)fy;
-        const float wx1 = ix - fx, wx0 = (fx + 1.f) - ix;
-        const float wy1 = iy - fy, wy0 = (fy + 1.f) - iy;
-        const bool vx0 = (x0 >= 0) & (x0 < W), vx1 = (x0 + 1 >= 0) & (x0 + 1 < W);
-        const bool vy0 = (y0 >= 0) & (y0 < H), vy1 = (y0 + 1 >= 0) & (y0 + 1 < H);
-        const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x0 + 1, 0), W - 1);
-        const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y0 + 1, 0), H - 1);
-        const float w00 = (vx0 & vy0) ? wx0 * wy0 : 0.f;    // nw
-        const float w10 = (vx1 & vy0) ? wx1 * wy0 : 0.f;    // ne
-        const float w01 = (vx0 & vy1) ? wx0 * wy1 : 0.f;    // sw
-        const float w11 = (vx1 & vy1) ? wx1 * wy1 : 0.f;    // se
-        // 32-bit byte offsets into one buffer resource (wave-uniform descriptor): no 64-bit address arithmetic per tap
-        const unsigned pbase = img_off + (unsigned)p * a.plane_bytes + (unsigned)h * 64u;
-        const unsigned o00 = pbase + __umul24(__umul24(cy0, W) + cx0, a.pix_bytes);
-        const unsigned o10 = pbase + __umul24(__umul24(cy0, W) + cx1, a.pix_bytes);
-        const unsigned o01 = pbase + __umul24(__umul24(cy1, W) + cx0, a.pix_bytes);
-        const unsigned o11 = pbase + __umul24(__umul24(cy1, W) + cx1, a.pix_bytes);
-        f32x4 v00[4], v10[4], v01[4], v11[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            v00[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o00 + 16 * q, 0, 0));
-            v10[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o10 + 16 * q, 0, 0));
-            v01[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o01 + 16 * q, 0, 0));
-            v11[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o11 + 16 * q, 0, 0));
+        for (int p = 0; p < 3; ++p) {
+            const PlaneTaps t = plane_taps(a, img_off, h, p, px, py, pz);
+            f32x4 top[8], bot[8];
+            issue_row(rsrc, t.o00, t.o10, top);
+            issue_row(rsrc, t.o01, t.o11, bot);
+            blend_row(top, t.w00, t.w10, acc);
+            blend_row(bot, t.w01, t.w11, acc);
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {                  // four FMAs per channel, straight into the three-plane sum
-                float s = fmaf(v00[q][e], w00, acc[q * 4 + e]);
-                s = fmaf(v10[q][e], w10, s);
-                s = fmaf(v01[q][e], w01, s);
-                acc[q * 4 + e] = fmaf(v11[q][e], w11, s);
-            }
+    } else {
+        const PlaneTaps t0 = plane_taps(a, img_off, h, 0, px, py, pz);
+        const PlaneTaps t1 = plane_taps(a, img_off, h, 1, px, py, pz);
+        f32x4 b0[8], b1[8], b2[8];
+        issue_row(rsrc, t0.o00, t0.o10, b0);
+        issue_row(rsrc, t0.o01, t0.o11, b1);
+        issue_row(rsrc, t1.o00, t1.o10, b2);
+        __builtin_amdgcn_sched_barrier(0);
+        blend_row(b0, t0.w00, t0.w10, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_row(rsrc, t1.o01, t1.o11, b0);
+        const PlaneTaps t2 = plane_taps(a, img_off, h, 2, px, py, pz);       // under the loads in flight; keeps 8 registers free until here
+        __builtin_amdgcn_sched_barrier(0);
+        blend_row(b1, t0.w01, t0.w11, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_row(rsrc, t2.o00, t2.o10, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        blend_row(b2, t1.w00, t1.w10, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_row(rsrc, t2.o01, t2.o11, b2);
+        __builtin_amdgcn_sched_barrier(0);
+        blend_row(b0, t1.w01, t1.w11, acc);
+        blend_row(b1, t2.w00, t2.w10, acc);
+        blend_row(b2, t2.w01, t2.w11, acc);
     }
 #pragma unroll
     for (int c = 0; c < 16; ++c) feat[c] = acc[c] * (1.f / 3.f);
@@ -362,7 +408,7 @@ render_forward_kernel(RenderArgs a)
         for (int i = 0; i < Sc; ++i) {
             const float z = coarse_depth(a, g, i, uc[i]);
             float feat[16];
-            gather_features(a, rsrc, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
+            gather_features<!TAPE>(a, rsrc, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
             f32x16 h0, h1;
             mlp_layer1<LOG2>(lds, SN, lane, h, feat, h0, h1);
             const float sigma = mlp_sigma(lds, h, h0, h1);
@@ -417,7 +463,7 @@ render_forward_kernel(RenderArgs a)
         else        { ++jf; zf = (jf < Sf) ? tile[jf * kPitch + j] : INFINITY; }
 
         float feat[16];
-        gather_features(a, rsrc, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
+        gather_features<!TAPE>(a, rsrc, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
         // The density net goes first: its sigma closes interval k-1 (weight w), after which every net's
         // colours are folded into the accumulators as soon as its layer 2 retires — only `prev` (the
         // other end of the midpoint rule) stays live across samples.
