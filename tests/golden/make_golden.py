@@ -3,7 +3,7 @@
 Run in the authoring container only (it needs the read-only checkout at /root/reference, which does
 not exist on the GPU box):
 
-    python tests/golden/make_golden.py [group ...]      # groups: ops renderer semrenderer model flrelu train checkpoint variants discriminator
+    python tests/golden/make_golden.py [group ...]      # groups: ops renderer semrenderer model flrelu train checkpoint variants discriminator api
 
 The reference and this repo own the same top-level module names, so this script must never import
 ``pix2pix3d_amd``; it puts /root/reference first on sys.path and imports the reference's modules
@@ -580,6 +580,76 @@ def group_discriminator():
 
 
 GROUPS['discriminator'] = group_discriminator
+
+
+def group_api():
+    """Entry points and switches around the hot path that the other groups leave at their defaults: truncation, w_avg tracking, the plane cache,
+    random noise, zeroed / scaled camera conditioning, density noise, G.forward / G.sample, the discriminator's camera noise.  Small
+    name-seeded edge2car-style generator (configs.variant_kwargs base), everything seeded so that the draws can be replayed."""
+    import dnnlib
+    configs = _load_by_path('p3d_configs', os.path.join(os.path.dirname(os.path.dirname(HERE)), 'pix2pix3d_amd', 'configs.py'))
+    weights = _load_by_path('p3d_weights', os.path.join(HERE, 'weights.py'))
+    kw = configs.generator_kwargs('edge2car', cbase=1024, cmax=16)
+    torch.manual_seed(0)
+    G = dnnlib.util.construct_class_by_name(**kw).eval().requires_grad_(False)
+    weights.seed_module(G, seed=13)
+    gz = torch.Generator().manual_seed(41)
+    n = 2
+    c = torch.tensor(np.stack([configs.orbit_camera(k, radius=1.7, focal=1.7074) for k in (9, 50)]))
+    z = torch.randn(n, 512, generator=gz)
+    mask = torch.rand([n, 1, 128, 128], generator=gz) * 2 - 1
+    batch = {'mask': mask, 'pose': c}
+    pts = (torch.rand(n, 48, 3, generator=gz) - 0.5) * kw['rendering_kwargs']['box_warp']
+    a = dict(c=c, z=z, mask=mask, pts=pts)
+    with torch.no_grad():
+        # (truncation_cutoff cannot be used with the per-layer w_avg of the disentangled mapping networks: triplane_cond.py:591 raises — tested as such)
+        a['ws_trunc_all'] = G.mapping(z, c, batch, truncation_psi=0.4)
+        # w_avg tracking (training_loop calls mapping with update_emas=True on G_ema copies): one update from the seeded state
+        before = G.backbone.mapping.w_avg.clone()
+        G.mapping(z, c, batch, update_emas=True)
+        a['w_avg_after'] = G.backbone.mapping.w_avg.clone()
+        G.backbone.mapping.w_avg.copy_(before)
+        ws = G.mapping(z, c, batch)
+        a['ws'] = ws
+        # G.forward = mapping(z, batch['pose']) + synthesis(ws, c)
+        torch.manual_seed(5)
+        out = G(z, c, batch, neural_rendering_resolution=16, noise_mode='const')
+        a['fwd_image_raw'], a['fwd_semantic_raw'] = out['image_raw'], out['semantic_raw']
+        # plane cache: the second call must ignore its ws for the planes (but not for the SR heads)
+        torch.manual_seed(5)
+        G.synthesis(ws, c, neural_rendering_resolution=16, noise_mode='const', cache_backbone=True)
+        torch.manual_seed(5)
+        out2 = G.synthesis(ws.flip(0), c, neural_rendering_resolution=16, noise_mode='const', use_cached_backbone=True)
+        a['cached_image_raw'], a['cached_image_thumb'] = out2['image_raw'], out2['image'][..., ::4, ::4]
+        G._last_planes = None
+        # random noise: per-layer torch.randn draws, replayable from the seed on CPU
+        torch.manual_seed(6)
+        out3 = G.synthesis(ws, c, neural_rendering_resolution=16, noise_mode='random')
+        a['rand_image_raw'], a['rand_image_thumb'] = out3['image_raw'], out3['image'][..., ::4, ::4]
+        # point queries through z, with density noise
+        G.rendering_kwargs['density_noise'] = 0.5
+        torch.manual_seed(7)
+        sm = G.sample(pts, None, z, c, batch, noise_mode='const')
+        a['sample_sigma'], a['sample_rgb'] = sm['sigma'], sm['rgb']
+        G.rendering_kwargs['density_noise'] = 0
+        # camera conditioning switches
+        G.rendering_kwargs['c_gen_conditioning_zero'] = True
+        a['ws_czero'] = G.mapping(z, c, batch)
+        G.rendering_kwargs['c_gen_conditioning_zero'] = False
+        G.rendering_kwargs['c_scale'] = 0.25
+        a['ws_cscale'] = G.mapping(z, c, batch)
+        G.rendering_kwargs['c_scale'] = 1.0
+        # discriminator with camera noise
+        D = dnnlib.util.construct_class_by_name(class_name='training.dual_discriminator.DualDiscriminator', c_dim=25, img_resolution=128, img_channels=3,
+                                                channel_base=1024, channel_max=16, num_fp16_res=0, conv_clamp=None, disc_c_noise=0.5).eval().requires_grad_(False)
+        weights.seed_module(D, seed=14)
+        torch.manual_seed(8)
+        a['d_logits_cnoise'] = D({'image': out['image'], 'image_raw': out['image_raw']}, c.clone())
+        a['d_image'], a['d_image_raw'] = out['image'], out['image_raw']
+    save('model_api', **a)
+
+
+GROUPS['api'] = group_api
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GROUPS)
