@@ -21,9 +21,10 @@ class SynthesisBlockNoUp(SynthesisBlock):
 class _SuperresolutionBase(torch.nn.Module):
     """ws[:, -1] feeds all three layers of both blocks; inputs are resized to ``input_resolution`` first (:312-323)."""
     input_resolution = 128
+    _resize_only_up = False          # SuperresolutionHybrid4X resizes only inputs SMALLER than its input resolution (:80); the others any mismatch
 
     def _prep(self, rgb, x):
-        if x.shape[-1] != self.input_resolution:
+        if (x.shape[-1] < self.input_resolution) if self._resize_only_up else (x.shape[-1] != self.input_resolution):
             size = (self.input_resolution, self.input_resolution)
             x = torch.nn.functional.interpolate(x, size=size, mode='bilinear', align_corners=False, antialias=self.sr_antialias)
             rgb = torch.nn.functional.interpolate(rgb, size=size, mode='bilinear', align_corners=False, antialias=self.sr_antialias)
@@ -92,6 +93,7 @@ class SuperresolutionHybrid8X(_SuperresolutionBase):
 @persistence.persistent_class
 class SuperresolutionHybrid4X(_SuperresolutionBase):
     """128^2 -> 256^2: a no-upsampling block then a x2 block (:62-88)."""
+    _resize_only_up = True
 
     def __init__(self, channels, img_resolution, sr_num_fp16_res, sr_antialias, num_fp16_res=4, conv_clamp=None, channel_base=None,
                  channel_max=None, **block_kwargs):

@@ -3,7 +3,7 @@
 Run in the authoring container only (it needs the read-only checkout at /root/reference, which does
 not exist on the GPU box):
 
-    python tests/golden/make_golden.py [group ...]      # groups: ops renderer semrenderer model flrelu train checkpoint variants discriminator api
+    python tests/golden/make_golden.py [group ...]      # groups: ops renderer semrenderer model flrelu train checkpoint variants discriminator api srheads
 
 The reference and this repo own the same top-level module names, so this script must never import
 ``pix2pix3d_amd``; it puts /root/reference first on sys.path and imports the reference's modules
@@ -650,6 +650,47 @@ def group_api():
 
 
 GROUPS['api'] = group_api
+
+
+SR_CASES = [  # (class, img_resolution, input side fed, sr_antialias, extra kwargs)
+    ('SuperresolutionHybrid8X', 512, 128, True, {}),
+    ('SuperresolutionHybrid8X', 512, 64, True, {}),            # resized up to 128 first (antialias has no effect when enlarging)
+    ('SuperresolutionHybrid4X', 256, 128, True, {}),
+    ('SuperresolutionHybrid4X', 256, 96, True, {}),            # 4X resizes only smaller inputs (:80); a larger one trips block0's shape assert
+    ('SuperresolutionHybrid8X', 512, 160, True, {}),           # resized DOWN to 128 with the antialiased kernel
+    ('SuperresolutionHybrid8X', 512, 160, False, {}),          # ... and with plain bilinear
+    ('SuperresolutionHybrid2X', 128, 64, True, {}),
+    ('SuperresolutionHybrid2X_semantic', 128, 48, True, dict(semantic_channels=5)),
+    ('SuperresolutionHybrid8XDC', 512, 128, True, {}),
+    ('SuperresolutionHybrid8XDC_semantic', 512, 96, False, dict(semantic_channels=6)),
+]
+
+
+def group_srheads():
+    """Every super-resolution head class on its own (the model groups only reach 8XDC and 2X), including the input resize in front of it."""
+    import dnnlib
+    weights = _load_by_path('p3d_weights', os.path.join(HERE, 'weights.py'))
+    arrays = {}
+    for i, (cls, res, side, aa, extra) in enumerate(SR_CASES):
+        torch.manual_seed(0)
+        sr = dnnlib.util.construct_class_by_name(class_name='training.superresolution.' + cls, channels=32, img_resolution=res, sr_num_fp16_res=4,
+                                                 sr_antialias=aa, channel_base=32768, channel_max=512, fused_modconv_default='inference_only', **extra).eval().requires_grad_(False)
+        weights.seed_module(sr, seed=20 + i)
+        gz = torch.Generator().manual_seed(60 + i)
+        ch = extra.get('semantic_channels', 3)
+        x = torch.randn(1, 32, side, side, generator=gz)
+        rgb = x[:, :ch].clone()
+        ws = torch.randn(1, 14, 512, generator=gz)
+        with torch.no_grad():
+            y = sr(rgb, x, ws, noise_mode='const')
+        assert y.shape == (1, ch, res, res)
+        arrays[f'{i}.x_head'], arrays[f'{i}.ws_head'] = x.reshape(-1)[:16].clone(), ws.reshape(-1)[:16].clone()     # inputs are re-drawn from the seed by the tests
+        arrays[f'{i}.thumb'], arrays[f'{i}.crop'] = _thumb(y, res // 32)
+        print(cls, side, aa, tuple(y.shape))
+    save('srheads', **arrays)
+
+
+GROUPS['srheads'] = group_srheads
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GROUPS)
