@@ -3,7 +3,7 @@
 Run in the authoring container only (it needs the read-only checkout at /root/reference, which does
 not exist on the GPU box):
 
-    python tests/golden/make_golden.py [group ...]      # groups: ops renderer semrenderer model flrelu train checkpoint variants discriminator api srheads
+    python tests/golden/make_golden.py [group ...]      # groups: ops renderer semrenderer model flrelu train checkpoint variants discriminator api srheads architectures
 
 The reference and this repo own the same top-level module names, so this script must never import
 ``pix2pix3d_amd``; it puts /root/reference first on sys.path and imports the reference's modules
@@ -691,6 +691,54 @@ def group_srheads():
 
 
 GROUPS['srheads'] = group_srheads
+
+
+ARCH_CASES = dict(
+    g_orig=dict(class_name='training.networks_stylegan2.Generator', z_dim=64, c_dim=0, w_dim=64, img_resolution=32, img_channels=3, channel_base=512, channel_max=32,
+                architecture='orig', mapping_kwargs=dict(num_layers=2)),
+    g_skip=dict(class_name='training.networks_stylegan2.Generator', z_dim=64, c_dim=5, w_dim=64, img_resolution=32, img_channels=3, channel_base=512, channel_max=32,
+                architecture='skip', mapping_kwargs=dict(num_layers=3, embed_features=16, layer_features=48)),
+    g_resnet=dict(class_name='training.networks_stylegan2.Generator', z_dim=64, c_dim=0, w_dim=64, img_resolution=64, img_channels=2, channel_base=512, channel_max=24,
+                  architecture='resnet', mapping_kwargs=dict(num_layers=2), conv_clamp=1.5, use_noise=False),
+    d_orig=dict(class_name='training.networks_stylegan2.Discriminator', c_dim=0, img_resolution=32, img_channels=3, architecture='orig', channel_base=512, channel_max=32,
+                num_fp16_res=0, conv_clamp=None),
+    d_skip=dict(class_name='training.networks_stylegan2.Discriminator', c_dim=5, img_resolution=32, img_channels=3, architecture='skip', channel_base=512, channel_max=32,
+                num_fp16_res=0, conv_clamp=None, cmap_dim=12, epilogue_kwargs=dict(mbstd_group_size=None)),
+    d_resnet=dict(class_name='training.networks_stylegan2.Discriminator', c_dim=0, img_resolution=64, img_channels=1, architecture='resnet', channel_base=512, channel_max=24,
+                  num_fp16_res=0, conv_clamp=0.8, block_kwargs=dict(activation='relu'), epilogue_kwargs=dict(mbstd_num_channels=0)),
+)
+
+
+def group_architectures():
+    """The StyleGAN2 generator / discriminator in the three block architectures ('orig', 'skip', 'resnet') and the constructor options pix2pix3D's
+    own configurations never flip (conditional mapping with its own feature widths, truncation cutoff, no noise, clamps, relu, no minibatch-std)."""
+    import dnnlib
+    weights = _load_by_path('p3d_weights', os.path.join(HERE, 'weights.py'))
+    arrays = {}
+    for name, kw in ARCH_CASES.items():
+        torch.manual_seed(0)
+        net = dnnlib.util.construct_class_by_name(**kw).eval().requires_grad_(False)
+        weights.seed_module(net, seed=33)
+        gz = torch.Generator().manual_seed(71)
+        n = 3
+        c = torch.randn(n, kw['c_dim'], generator=gz) if kw['c_dim'] > 0 else None
+        with torch.no_grad():
+            if name.startswith('g_'):
+                z = torch.randn(n, kw['z_dim'], generator=gz)
+                ws = net.mapping(z, c, truncation_psi=0.7, truncation_cutoff=4)
+                img = net.synthesis(ws, noise_mode='const')
+                img_none = net.synthesis(ws, noise_mode='none', force_fp32=True)
+                arrays.update({f'{name}.z': z, f'{name}.ws': ws, f'{name}.img': img, f'{name}.img_none': img_none})
+            else:
+                img = torch.randn(n, kw['img_channels'], kw['img_resolution'], kw['img_resolution'], generator=gz)
+                arrays.update({f'{name}.img': img, f'{name}.logits': net(img, c)})
+        if c is not None:
+            arrays[f'{name}.c'] = c
+        print(name, 'ok')
+    save('architectures', **arrays)
+
+
+GROUPS['architectures'] = group_architectures
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GROUPS)
