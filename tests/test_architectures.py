@@ -22,7 +22,7 @@ def _cases():
 ARCH_CASES = _cases()
 
 
-def _run(name, device, tol):
+def _run(name, device, tol, tol_fp16=None):
     from pix2pix3d_amd import dnnlib
     kw = ARCH_CASES[name]
     g = {k.split('.', 1)[1]: v for k, v in load_golden('architectures').items() if k.startswith(name + '.')}
@@ -36,7 +36,9 @@ def _run(name, device, tol):
             ws = net.mapping(torch.tensor(g['z']).to(device), c, truncation_psi=0.7, truncation_cutoff=4)
             assert rel_err(ws.cpu().numpy(), g['ws']) < tol
             ws = torch.tensor(g['ws']).to(device)
-            assert rel_err(net.synthesis(ws, noise_mode='const').float().cpu().numpy(), g['img']) < tol
+            # on a device the top num_fp16_res (default 4) resolutions run in fp16 unless forced (networks_stylegan2.py:423-425)
+            assert rel_err(net.synthesis(ws, noise_mode='const').float().cpu().numpy(), g['img']) < (tol_fp16 or tol)
+            assert rel_err(net.synthesis(ws, noise_mode='const', force_fp32=True).float().cpu().numpy(), g['img']) < tol
             assert rel_err(net.synthesis(ws, noise_mode='none', force_fp32=True).float().cpu().numpy(), g['img_none']) < tol
         else:
             assert rel_err(net(torch.tensor(g['img']).to(device), c).cpu().numpy(), g['logits']) < tol
@@ -50,4 +52,4 @@ def test_architecture_cpu_path_matches_reference(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', list(ARCH_CASES))
 def test_architecture_device_path_matches_reference(name):
-    _run(name, 'cuda', 1e-3)
+    _run(name, 'cuda', 1e-3, tol_fp16=3e-2)
