@@ -66,3 +66,9 @@ def call_func_by_name(*args, func_name: str = None, **kwargs) -> Any:
 
 def construct_class_by_name(*args, class_name: str = None, **kwargs) -> Any:
     return call_func_by_name(*args, func_name=class_name, **kwargs)
+
+
+def __getattr__(name):
+    """Host-side helpers that are not restated here resolve to the reference checkout's own ``dnnlib.util`` (see dropin.reference_attr)."""
+    from .. import dropin
+    return dropin.reference_attr('dnnlib.util', name)

@@ -9,8 +9,12 @@ reference checkout if it is on ``sys.path``: for that, ``training`` / ``torch_ut
 directories appended to their ``__path__``.
 """
 import importlib
+import importlib.util
 import os
 import sys
+
+_reference_root = None          # set by install(reference_root=...)
+_reference_modules = {}
 
 _MIRRORED = [
     'dnnlib', 'dnnlib.util', 'legacy',
@@ -39,6 +43,8 @@ def install(reference_root=None, strict=False):
         sys.modules[name] = mod
         done.append(name)
     if reference_root:
+        global _reference_root
+        _reference_root = reference_root
         for pkg in ('training', 'torch_utils', 'dnnlib'):
             extra = os.path.join(reference_root, pkg)
             if pkg in sys.modules and os.path.isdir(extra) and extra not in sys.modules[pkg].__path__:
@@ -46,3 +52,31 @@ def install(reference_root=None, strict=False):
         if reference_root not in sys.path:
             sys.path.append(reference_root)
     return done
+
+
+def reference_attr(module, name):
+    """``module.name`` served by the reference checkout's own file — for the host-side helpers the mirrors deliberately do not restate
+    (``dnnlib.util.open_url`` / ``Logger`` / ``format_time``, ``misc.print_module_summary`` / ``ddp_sync``, ...): the mirrored modules
+    forward unknown attributes here (PEP 562), so ``training_loop.py`` and ``applications/*.py`` find them where they expect them.  The
+    file is executed under a private module name; its own ``import dnnlib`` / ``from torch_utils import misc`` resolve to the mirrors."""
+    if name.startswith('__'):
+        raise AttributeError(name)
+    if _reference_root is None:
+        raise AttributeError(f'{module}.{name} is a host-side helper pix2pix3d_amd does not mirror; call '
+                             f'pix2pix3d_amd.dropin.install(reference_root=<pix2pix3D checkout>) and the reference\'s own {module} will serve it')
+    mod = _reference_modules.get(module)
+    if mod is None:
+        base = os.path.join(_reference_root, *module.split('.'))
+        path = base + '.py' if os.path.isfile(base + '.py') else os.path.join(base, '__init__.py')
+        spec = importlib.util.spec_from_file_location('_p3d_reference.' + module, path)
+        mod = importlib.util.module_from_spec(spec)
+        _reference_modules[module] = mod
+        try:
+            spec.loader.exec_module(mod)
+        except BaseException:
+            del _reference_modules[module]
+            raise
+    try:
+        return getattr(mod, name)
+    except AttributeError:
+        raise AttributeError(f'neither pix2pix3d_amd nor the reference checkout defines {module}.{name}') from None

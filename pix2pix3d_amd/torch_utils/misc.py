@@ -131,3 +131,9 @@ def check_ddp_consistency(module, ignore_regex=None):
         other = tensor.clone()
         torch.distributed.broadcast(tensor=other, src=0)
         assert (tensor == other).all(), fullname
+
+
+def __getattr__(name):
+    """Host-side helpers that are not restated here resolve to the reference checkout's own ``torch_utils.misc`` (see dropin.reference_attr)."""
+    from .. import dropin
+    return dropin.reference_attr('torch_utils.misc', name)

@@ -32,3 +32,54 @@ print('ok')
 ''' % ROOT
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-2000:]
+
+
+def test_unmirrored_host_helpers_come_from_the_reference_checkout(tmp_path):
+    """dnnlib.util.open_url / format_time / Logger, misc.print_module_summary, dnnlib.make_cache_dir_path are not restated by this package:
+    with a reference checkout registered they resolve to its own files (and run on top of the mirrors); without one the error says what to do."""
+    import os
+    import pytest
+    ref = os.environ.get('P3D_REFERENCE', '/root/reference')
+    code_no_root = r'''
+import sys
+sys.path.insert(0, %r)
+import pix2pix3d_amd
+pix2pix3d_amd.install_dropin()
+import dnnlib
+try:
+    dnnlib.util.open_url
+except AttributeError as e:
+    assert 'reference_root' in str(e), e
+    print('ok')
+''' % ROOT
+    r = subprocess.run([sys.executable, '-c', code_no_root], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-2000:]
+    if not os.path.isdir(ref):
+        pytest.skip('no reference checkout here')
+    blob = tmp_path / 'blob.bin'
+    blob.write_bytes(b'checkpoint bytes')
+    code = r'''
+import sys, io, contextlib
+sys.path.insert(0, %r)
+from pix2pix3d_amd import dropin
+dropin.install(reference_root=%r)
+import torch, dnnlib
+from torch_utils import misc
+assert dnnlib.util.format_time(3725) == '1h 02m 05s' and dnnlib.util.format_time_brief(90061) == '1d 01h'
+with dnnlib.util.open_url(%r) as f:                       # applications/generate_samples.py:76
+    assert f.read() == b'checkpoint bytes'
+assert dnnlib.make_cache_dir_path('x').endswith('x')
+from training.networks_stylegan2 import Generator
+assert Generator.__module__.startswith('pix2pix3d_amd.')
+G = Generator(z_dim=16, c_dim=0, w_dim=16, img_resolution=16, img_channels=3, channel_base=128, channel_max=8, mapping_kwargs=dict(num_layers=2))
+buf = io.StringIO()
+with contextlib.redirect_stdout(buf):
+    img = misc.print_module_summary(G, [torch.randn(2, 16), None])        # training_loop.py:172-176
+table = buf.getvalue()
+assert img.shape == (2, 3, 16, 16) and 'synthesis.b16.torgb' in table and 'Total' in table, table
+with misc.ddp_sync(G, True):
+    pass
+print('ok')
+''' % (ROOT, ref, str(blob))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-3000:]
