@@ -72,6 +72,16 @@ def sample_from_planes(plane_axes, plane_features, coordinates, mode='bilinear',
     return out.permute(0, 3, 2, 1).reshape(n, k, m, c)
 
 
+def sample_from_3dgrid(grid, coordinates):
+    """Trilinear lookup in a dense feature volume (renderer.py:67-80; not called by any generator, kept for the module's surface):
+    grid [1 or N, C, H, W, D], coordinates [N, P, 3] in [-1, 1] -> [N, P, C]."""
+    n, _, dims = coordinates.shape
+    out = torch.nn.functional.grid_sample(grid.expand(n, -1, -1, -1, -1), coordinates.reshape(n, 1, 1, -1, dims),
+                                          mode='bilinear', padding_mode='zeros', align_corners=False)
+    n, c, h, w, d = out.shape
+    return out.permute(0, 4, 3, 2, 1).reshape(n, h * w * d, c)
+
+
 def _decoder_nets(decoder):
     """Recognise the OSG decoders the fused kernel implements; returns (nets, lr_mul-free raw params, sigmoid flag) or None.
 

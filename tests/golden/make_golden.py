@@ -3,7 +3,7 @@
 Run in the authoring container only (it needs the read-only checkout at /root/reference, which does
 not exist on the GPU box):
 
-    python tests/golden/make_golden.py [group ...]      # groups: ops renderer semrenderer model flrelu train checkpoint variants discriminator api srheads architectures
+    python tests/golden/make_golden.py [group ...]      # groups: ops renderer semrenderer model flrelu train checkpoint variants discriminator api srheads architectures helpers
 
 The reference and this repo own the same top-level module names, so this script must never import
 ``pix2pix3d_amd``; it puts /root/reference first on sys.path and imports the reference's modules
@@ -739,6 +739,47 @@ def group_architectures():
 
 
 GROUPS['architectures'] = group_architectures
+
+
+def group_helpers():
+    """Small host-side pieces next to the hot path: filtered_resizing (all four modes; loss.py feeds its result to D), sample_from_3dgrid,
+    InfiniteSampler's index streams (the rank sharding of the training loop), math_utils."""
+    from training.dual_discriminator import filtered_resizing
+    from training.volumetric_rendering.renderer import sample_from_3dgrid
+    from training.volumetric_rendering import math_utils
+    from torch_utils import misc
+    from torch_utils.ops import upfirdn2d
+    gz = torch.Generator().manual_seed(91)
+    a = {}
+    img = torch.randn(2, 3, 24, 24, generator=gz)
+    f = upfirdn2d.setup_filter([1, 3, 3, 1])
+    a['fr.img'] = img
+    for mode in ('antialiased', 'classic', 'none', 0.3):
+        a[f'fr.{mode}.up'] = filtered_resizing(img, size=64, f=f, filter_mode=mode)
+        if mode != 'classic':               # 'classic' = x2 upsample, resize, /2 decimate: only meaningful upwards
+            a[f'fr.{mode}.down'] = filtered_resizing(img, size=10, f=f, filter_mode=mode)
+    grid = torch.randn(1, 5, 6, 7, 8, generator=gz)
+    coords = torch.rand(3, 40, 3, generator=gz) * 2.4 - 1.2
+    a['g3.grid'], a['g3.coords'], a['g3.out'] = grid, coords, sample_from_3dgrid(grid, coords)
+    for i, kw in enumerate([dict(rank=0, num_replicas=1, shuffle=True, seed=0, window_size=0.5), dict(rank=1, num_replicas=3, shuffle=True, seed=7, window_size=0.5),
+                            dict(rank=2, num_replicas=4, shuffle=False), dict(rank=0, num_replicas=2, shuffle=True, seed=3, window_size=0)]):
+        smp = misc.InfiniteSampler.__new__(misc.InfiniteSampler)     # its __init__ passes the dataset to Sampler.__init__, which torch 2.x no longer takes
+        smp.dataset, smp.seed, smp.window_size = list(range(37)), kw.get('seed', 0), kw.get('window_size', 0.5)
+        smp.rank, smp.num_replicas, smp.shuffle = kw['rank'], kw['num_replicas'], kw['shuffle']
+        it = iter(smp)
+        a[f'sampler.{i}'] = np.array([int(next(it)) for _ in range(120)])
+    o = torch.randn(2, 50, 3, generator=gz) * 0.3 + torch.tensor([0., 0., 2.5])
+    d = torch.nn.functional.normalize(torch.randn(2, 50, 3, generator=gz) * 0.2 - torch.tensor([0., 0., 1.]), dim=-1)
+    near, far = math_utils.get_ray_limits_box(o, d, box_side_length=1.3)
+    a['mu.o'], a['mu.d'], a['mu.near'], a['mu.far'] = o, d, near, far
+    a['mu.linspace'] = math_utils.linspace(near.clamp(-5, 5).nan_to_num(0), far.clamp(-5, 5).nan_to_num(1), 7)
+    m = torch.randn(4, 4, generator=gz)
+    a['mu.m'], a['mu.tv'] = m, math_utils.transform_vectors(m, torch.randn(50, 4, generator=torch.Generator().manual_seed(92)))
+    a['mu.nv'], a['mu.dot'] = math_utils.normalize_vecs(o), math_utils.torch_dot(o, d)
+    save('helpers', **a)
+
+
+GROUPS['helpers'] = group_helpers
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GROUPS)

@@ -1,0 +1,47 @@
+"""Small host-side pieces next to the hot path against records from the reference (tests/golden/make_golden.py group ``helpers``):
+filtered_resizing in its four modes, sample_from_3dgrid, InfiniteSampler's rank-sharded index streams, math_utils."""
+import numpy as np
+import torch
+
+from conftest import load_golden, rel_err
+
+
+def test_filtered_resizing_modes():
+    from pix2pix3d_amd.training.dual_discriminator import filtered_resizing
+    from pix2pix3d_amd.torch_utils.ops import upfirdn2d
+    g = load_golden('helpers')
+    img, f = torch.tensor(g['fr.img']), upfirdn2d.setup_filter([1, 3, 3, 1])
+    for mode in ('antialiased', 'classic', 'none', 0.3):
+        assert rel_err(filtered_resizing(img, size=64, f=f, filter_mode=mode).numpy(), g[f'fr.{mode}.up']) < 1e-6, mode
+        if mode != 'classic':
+            assert rel_err(filtered_resizing(img, size=10, f=f, filter_mode=mode).numpy(), g[f'fr.{mode}.down']) < 1e-6, mode
+
+
+def test_sample_from_3dgrid():
+    from pix2pix3d_amd.training.volumetric_rendering.renderer import sample_from_3dgrid
+    g = load_golden('helpers')
+    out = sample_from_3dgrid(torch.tensor(g['g3.grid']), torch.tensor(g['g3.coords']))
+    assert out.shape == g['g3.out'].shape and rel_err(out.numpy(), g['g3.out']) < 1e-6
+
+
+def test_infinite_sampler_streams():
+    from pix2pix3d_amd.torch_utils import misc
+    g = load_golden('helpers')
+    cases = [dict(rank=0, num_replicas=1, shuffle=True, seed=0, window_size=0.5), dict(rank=1, num_replicas=3, shuffle=True, seed=7, window_size=0.5),
+             dict(rank=2, num_replicas=4, shuffle=False), dict(rank=0, num_replicas=2, shuffle=True, seed=3, window_size=0)]
+    for i, kw in enumerate(cases):
+        it = iter(misc.InfiniteSampler(list(range(37)), **kw))
+        assert np.array_equal(np.array([int(next(it)) for _ in range(120)]), g[f'sampler.{i}']), kw
+
+
+def test_math_utils():
+    from pix2pix3d_amd.training.volumetric_rendering import math_utils
+    g = load_golden('helpers')
+    o, d = torch.tensor(g['mu.o']), torch.tensor(g['mu.d'])
+    near, far = math_utils.get_ray_limits_box(o, d, box_side_length=1.3)
+    assert np.array_equal(near.numpy(), g['mu.near'], equal_nan=True) and np.array_equal(far.numpy(), g['mu.far'], equal_nan=True)
+    lin = math_utils.linspace(near.clamp(-5, 5).nan_to_num(0), far.clamp(-5, 5).nan_to_num(1), 7)
+    assert rel_err(lin.numpy(), g['mu.linspace']) < 1e-6
+    tv = math_utils.transform_vectors(torch.tensor(g['mu.m']), torch.randn(50, 4, generator=torch.Generator().manual_seed(92)))
+    assert rel_err(tv.numpy(), g['mu.tv']) < 1e-6
+    assert rel_err(math_utils.normalize_vecs(o).numpy(), g['mu.nv']) < 1e-6 and rel_err(math_utils.torch_dot(o, d).numpy(), g['mu.dot']) < 1e-6
