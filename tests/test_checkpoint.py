@@ -163,3 +163,35 @@ def test_reference_checkpoint_runs_on_the_hip_path(ckpt):
                 out_e = E.synthesis(torch.tensor(g['eg3d_ws']).cuda(), c, neural_rendering_resolution=16, noise_mode='const', force_fp32=force_fp32)
             for k in ('image_raw', 'image_depth', 'image'):
                 assert rel_err(out_e[k].float().cpu().numpy(), g['eg3d_' + k]) < tol, (k, force_fp32)
+
+
+def test_import_hook_and_cli_resave(tmp_path):
+    """persistence.import_hook (persistence.py:151-185) sees every record before its class is resolved; the ``legacy`` CLI re-saves a checkpoint."""
+    from pix2pix3d_amd import legacy
+    from pix2pix3d_amd.torch_utils import persistence
+    from pix2pix3d_amd.training.networks_stylegan2 import FullyConnectedLayer, Conv2dLayer
+    seen = []
+
+    def hook(meta):
+        seen.append(meta.class_name)
+        if meta.class_name == 'FullyConnectedLayer':
+            meta.state['activation'] = 'relu'                 # patch the pickled state, the documented use of the hook
+        return meta
+    persistence.import_hook(hook)
+    try:
+        fc, conv = FullyConnectedLayer(5, 4, activation='lrelu'), Conv2dLayer(3, 4, kernel_size=3)
+        assert persistence.is_persistent(fc) and persistence.is_persistent(FullyConnectedLayer) and not persistence.is_persistent(torch.nn.Identity())
+        src = tmp_path / 'in.pkl'
+        with open(src, 'wb') as f:
+            legacy.save_network_pkl(dict(G=fc, D=conv, G_ema=fc), f)
+        with open(src, 'rb') as f:
+            data = legacy.load_network_pkl(f)
+        assert seen.count('FullyConnectedLayer') == 1 and 'Conv2dLayer' in seen          # G and G_ema are one object on the wire
+        assert data['G'].activation == 'relu' and torch.equal(data['G'].weight, fc.weight) and torch.equal(data['D'].weight, conv.weight)
+    finally:
+        persistence._import_hooks.remove(hook)
+    dst = tmp_path / 'out.pkl'
+    legacy.main(['--source', str(src), '--dest', str(dst)])
+    with open(dst, 'rb') as f:
+        again = legacy.load_network_pkl(f)
+    assert again['G'].activation == 'lrelu' and torch.equal(again['G'].weight, fc.weight)
