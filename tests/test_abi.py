@@ -4,6 +4,8 @@ import glob
 import os
 import re
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -47,3 +49,27 @@ def test_argument_errors_are_reported_not_thrown():
     code = h.p3d_bias_act(None, None, None, None, None, None, 0, 0, 1, 0.0, 1.0, -1.0, 16, 0, 1, None)
     assert code == -2
     assert b'non-null' in h.p3d_last_error()
+
+
+def test_header_is_plain_c_and_a_c_client_links(tmp_path):
+    """include/p3d_hip.h is the boundary a maintainer binds from C / cgo / JNI: it must compile as C99 (and C++) on its own, and a C
+    translation unit that only includes it must link against libp3d_hip.so and be able to call the entry points that need no GPU."""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    hdr = os.path.join(ROOT, 'include', 'p3d_hip.h')
+    for lang, std in (('c', 'c99'), ('c++', 'c++11')):
+        r = subprocess.run([gcc, f'-std={std}', '-Wall', '-Wextra', '-pedantic', '-Werror', '-fsyntax-only', '-x', lang, hdr], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    src = tmp_path / 'client.c'
+    src.write_text('#include "p3d_hip.h"\n#include <stdio.h>\n'
+                   'int main(void) { printf("%d %d\\n", p3d_abi_version(), p3d_render_decoder_floats()); return p3d_abi_version() > 0 ? 0 : 1; }\n')
+    exe = tmp_path / 'client'
+    libdir = os.path.join(ROOT, 'pix2pix3d_amd')
+    r = subprocess.run([gcc, '-std=c99', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe), '-L', libdir, '-lp3d_hip',
+                        f'-Wl,-rpath,{libdir}', '-Wl,-rpath,/opt/rocm/lib'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=dict(os.environ, LD_LIBRARY_PATH=libdir + ':/opt/rocm/lib:' + os.environ.get('LD_LIBRARY_PATH', '')))
+    assert r.returncode == 0 and r.stdout.split()[0] == '2', (r.stdout, r.stderr)
