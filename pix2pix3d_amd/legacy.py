@@ -111,9 +111,11 @@ class _LegacyUnpickler(pickle.Unpickler):
                 return obj
         if module == 'collections' and name in ('OrderedDict', 'defaultdict', 'deque'):
             return super().find_class(module, name)
-        if module == 'copyreg' and name in ('_reconstructor', '__newobj__'):
+        if module in ('copyreg', 'copy_reg') and name in ('_reconstructor', '__newobj__'):       # protocol <= 2 writes the Python-2 module names
             return super().find_class(module, name)
-        if module == 'builtins' and name in _BUILTINS:
+        if module in ('builtins', '__builtin__') and name in _BUILTINS:
+            return super().find_class(module, name)
+        if module == '_codecs' and name == 'encode':                 # how protocol <= 2 spells a bytes object
             return super().find_class(module, name)
         if root == 'numpy':
             if (module in ('numpy.core.multiarray', 'numpy._core.multiarray') and name in ('_reconstruct', 'scalar')) or \

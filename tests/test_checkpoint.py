@@ -195,3 +195,21 @@ def test_import_hook_and_cli_resave(tmp_path):
     with open(dst, 'rb') as f:
         again = legacy.load_network_pkl(f)
     assert again['G'].activation == 'lrelu' and torch.equal(again['G'].weight, fc.weight)
+
+
+@pytest.mark.parametrize('protocol', [2, 3, 4, 5])
+def test_everything_a_snapshot_legitimately_holds_loads_in_every_pickle_protocol(protocol):
+    """numpy arrays / scalars, EasyDict, tuples, sets, OrderedDict, dtypes, sizes, slices, devices, fp16 / integer tensors, bare Parameters,
+    stock torch.nn modules (protocol 2 spells builtins / copyreg / bytes the Python-2 way)."""
+    import collections
+    from pix2pix3d_amd import legacy, dnnlib
+    d = dict(G=torch.nn.Identity(), D=torch.nn.Identity(), G_ema=torch.nn.Sequential(torch.nn.Linear(2, 2), torch.nn.Softplus()),
+             training_set_kwargs=dnnlib.EasyDict(a=np.arange(3), b=np.float32(2.5), c=(1, 2), d={1, 2}, e=collections.OrderedDict(x=1), f=torch.float16,
+                                                 g=torch.Size([1, 2]), h=slice(1, 2), i=torch.device('cpu')),
+             extra=torch.nn.Parameter(torch.ones(2)), t16=torch.ones(2, dtype=torch.float16), ti=torch.arange(3))
+    out = legacy.load_network_pkl(io.BytesIO(pickle.dumps(d, protocol=protocol)))
+    k = out['training_set_kwargs']
+    assert isinstance(k, dnnlib.EasyDict) and np.array_equal(k.a, np.arange(3)) and k.b == np.float32(2.5) and k.c == (1, 2) and k.d == {1, 2}
+    assert k.f is torch.float16 and k.g == torch.Size([1, 2]) and k.h == slice(1, 2) and k.i == torch.device('cpu') and list(k.e.items()) == [('x', 1)]
+    assert out['t16'].dtype == torch.float16 and torch.equal(out['ti'], torch.arange(3)) and isinstance(out['extra'], torch.nn.Parameter)
+    assert isinstance(out['G_ema'][1], torch.nn.Softplus) and out['G_ema'][0].weight.shape == (2, 2)
