@@ -79,6 +79,14 @@ table = buf.getvalue()
 assert img.shape == (2, 3, 16, 16) and 'synthesis.b16.torgb' in table and 'Total' in table, table
 with misc.ddp_sync(G, True):
     pass
+# un-mirrored MODULES of the checkout import on top of the mirrors: generate_video.py:58-61 builds its orbit with camera_utils
+import camera_utils
+from training.utils import color_mask
+from training.volumetric_rendering import math_utils
+assert math_utils.__name__.startswith('pix2pix3d_amd.') and camera_utils.math_utils is math_utils
+pose = camera_utils.LookAtPoseSampler.sample(3.14 / 2, 3.14 / 2, torch.tensor([0., 0., 0.2]), radius=2.7)
+K = camera_utils.FOV_to_intrinsics(18.837)
+assert pose.shape == (1, 4, 4) and K.shape == (3, 3) and color_mask is not None
 print('ok')
 ''' % (ROOT, ref, str(blob))
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
