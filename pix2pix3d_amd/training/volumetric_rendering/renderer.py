@@ -393,6 +393,9 @@ class _replay_draws:
         torch.rand_like, torch.rand = self._rl, self._r
 
 
+backward_calls = {'fused': 0, 'replay': 0}      # which backward _FusedRenderFn took (tests: the training step must take 'fused')
+
+
 class _FusedRenderFn(torch.autograd.Function):
     """Training-mode rendering: the FORWARD is the fused kernel and keeps nothing per-sample (the reference holds ~1.2 GB of
     sampled features per image for autograd); the BACKWARD recomputes on the device — ``p3d_render_backward``: the forward
@@ -417,9 +420,11 @@ class _FusedRenderFn(torch.autograd.Function):
         params = [p for p in ctx.decoder.parameters()]
         rays_need_grad = ctx.needs_input_grad[8] or ctx.needs_input_grad[9]
         if fused_backward and g_depth is None and not rays_need_grad and g_feat is not None:
+            backward_calls['fused'] += 1
             g_planes, g_params = fused_render_backward(planes, ctx.decoder, ray_o, ray_d, ctx.opt, u_c, u_f, ctx.limits[0], ctx.limits[1], g_feat, g_wsum)
             return (None,) * 7 + (g_planes if ctx.needs_input_grad[7] else None, None, None) + tuple(g_params)
         # depth gradients / ray gradients: the differentiable tensor-op renderer, replayed on the same draws
+        backward_calls['replay'] += 1
         n, m = ray_o.shape[0], ray_o.shape[1]
         dev = planes.device
         nch = 32 * len(_decoder_nets(ctx.decoder)[0])

@@ -347,6 +347,46 @@ def group_model():
 GROUPS['model'] = group_model
 
 
+def group_model_full():
+    """The BASELINE configurations at their real size (SURVEY §8 shape table): seg2cat batch 4 at 128^2 rays with 48+48 (cfg 2/3)
+    and 64+64 samples (the metric), seg2face (19 label channels, cfg 5) batch 2 at 48+48.  Kept small: strided thumbnails + exact
+    central crops of every output (a flipped importance bin or a wrong ray anywhere in the crop / on the thumbnail lattice shows up
+    at the 1e-3 level), plus per-image means of every output, which see all 16 384 rays."""
+    import dnnlib
+    configs = _load_by_path('p3d_configs', os.path.join(os.path.dirname(os.path.dirname(HERE)), 'pix2pix3d_amd', 'configs.py'))
+    weights = _load_by_path('p3d_weights', os.path.join(HERE, 'weights.py'))
+    runs = [dict(tag='seg2cat_96', name='seg2cat', n=4, depth=(48, 48), frames=[3, 10, 17, 24]),
+            dict(tag='seg2cat_128', name='seg2cat', n=4, depth=(64, 64), frames=[3, 10, 17, 24]),
+            dict(tag='seg2face_96', name='seg2face', n=2, depth=(48, 48), frames=[5, 70])]
+    for run in runs:
+        kw = configs.generator_kwargs(run['name'], depth=run['depth'])
+        torch.manual_seed(0)
+        G = dnnlib.util.construct_class_by_name(**kw).eval().requires_grad_(False)
+        weights.seed_module(G, seed=1)
+        n, nrr = run['n'], 128
+        gz = torch.Generator().manual_seed(5)
+        ws = torch.randn(n, G.backbone.num_ws, 512, generator=gz)
+        rk = kw['rendering_kwargs']
+        c = torch.tensor(np.stack([configs.orbit_camera(k, radius=rk['avg_camera_radius'], pivot=rk['avg_camera_pivot']) for k in run['frames']]))
+        torch.manual_seed(4321)
+        with _RandTape() as tape, torch.no_grad():
+            out = G.synthesis(ws, c, neural_rendering_resolution=nrr, noise_mode='const')
+        assert len(tape.draws) == 2
+        arrays = dict(ws=ws, c=c, nrr=np.int64(nrr), depth=np.array(run['depth']), render_seed=np.int64(4321),
+                      u_coarse_head=tape.draws[0].reshape(-1)[:16], u_fine_head=tape.draws[1].reshape(-1)[:16])
+        for k in ('image_raw', 'semantic_raw', 'image_depth', 'image', 'semantic'):
+            t = out[k]
+            step = max(t.shape[-1] // 32, 1)
+            arrays[k + '_thumb'], arrays[k + '_crop'] = _thumb(t, step)
+            arrays[k + '_step'] = np.int64(step)
+            arrays[k + '_mean'] = t.double().mean(dim=[2, 3])
+            arrays[k + '_absmax'] = t.abs().max()
+        save('model_full_' + run['tag'], **arrays)
+
+
+GROUPS['model_full'] = group_model_full
+
+
 def group_flrelu():
     from torch_utils.ops import filtered_lrelu, upfirdn2d
     g = torch.Generator().manual_seed(77)
@@ -373,32 +413,37 @@ GROUPS['flrelu'] = group_flrelu
 
 def group_train():
     """Training-mode forward + backward of the reference generator (unfused modconv, tensor-op renderer): gradients of a
-    scalar loss w.r.t. a few parameters, with the renderer's uniforms seeded as in group_model."""
+    scalar loss w.r.t. a few parameters, with the renderer's uniforms seeded as in group_model.  Two losses: one that also
+    differentiates the depth map, and one over images only (what the training losses use) — the second lets the product's
+    fused renderer backward, which produces no depth gradient, be checked at model level."""
     import dnnlib
     configs = _load_by_path('p3d_configs', os.path.join(os.path.dirname(os.path.dirname(HERE)), 'pix2pix3d_amd', 'configs.py'))
     weights = _load_by_path('p3d_weights', os.path.join(HERE, 'weights.py'))
-    kw = configs.generator_kwargs('seg2cat')
-    kw['rendering_kwargs'] = dict(kw['rendering_kwargs'], depth_resolution=8, depth_resolution_importance=8)
-    torch.manual_seed(0)
-    G = dnnlib.util.construct_class_by_name(**kw).train().requires_grad_(True)
-    weights.seed_module(G, seed=1)
-    gz = torch.Generator().manual_seed(5)
-    ws = torch.randn(1, G.backbone.num_ws, 512, generator=gz)
-    c = torch.tensor(np.stack([configs.orbit_camera(11, radius=2.7, pivot=[0, 0, -0.06])]))
-    torch.manual_seed(4321)
-    out = G.synthesis(ws, c, neural_rendering_resolution=16, noise_mode='const')
-    loss = out['image'].mean() + out['image_raw'].square().mean() + out['semantic'].square().mean() * 0.1 + out['image_depth'].mean()
-    loss.backward()
-    names = ['backbone.synthesis.b4.const', 'backbone.synthesis.b256.conv1.weight', 'backbone.synthesis.b64.conv0.affine.bias',
-             'backbone.synthesis.b256.torgb.weight', 'decoder.net.0.weight', 'decoder.net_semantic.2.bias',
-             'superresolution.block1.conv1.weight', 'superresolution.block0.conv0.bias', 'superresolution_semantic.block1.torgb.bias']
-    params = dict(G.named_parameters())
-    arrays = dict(ws=ws, c=c, loss=loss.detach(), names=np.array(names), render_seed=np.int64(4321))
-    for i, nme in enumerate(names):
-        g = params[nme].grad
-        arrays[f'g{i}.norm'] = g.norm()
-        arrays[f'g{i}.head'] = g.reshape(-1)[:64].clone()
-    save('train_seg2cat', **arrays)
+    for fname, with_depth in (('train_seg2cat', True), ('train_seg2cat_nodepth', False)):
+        kw = configs.generator_kwargs('seg2cat')
+        kw['rendering_kwargs'] = dict(kw['rendering_kwargs'], depth_resolution=8, depth_resolution_importance=8)
+        torch.manual_seed(0)
+        G = dnnlib.util.construct_class_by_name(**kw).train().requires_grad_(True)
+        weights.seed_module(G, seed=1)
+        gz = torch.Generator().manual_seed(5)
+        ws = torch.randn(1, G.backbone.num_ws, 512, generator=gz)
+        c = torch.tensor(np.stack([configs.orbit_camera(11, radius=2.7, pivot=[0, 0, -0.06])]))
+        torch.manual_seed(4321)
+        out = G.synthesis(ws, c, neural_rendering_resolution=16, noise_mode='const')
+        loss = out['image'].mean() + out['image_raw'].square().mean() + out['semantic'].square().mean() * 0.1
+        if with_depth:
+            loss = loss + out['image_depth'].mean()
+        loss.backward()
+        names = ['backbone.synthesis.b4.const', 'backbone.synthesis.b256.conv1.weight', 'backbone.synthesis.b64.conv0.affine.bias',
+                 'backbone.synthesis.b256.torgb.weight', 'decoder.net.0.weight', 'decoder.net_semantic.2.bias',
+                 'superresolution.block1.conv1.weight', 'superresolution.block0.conv0.bias', 'superresolution_semantic.block1.torgb.bias']
+        params = dict(G.named_parameters())
+        arrays = dict(ws=ws, c=c, loss=loss.detach(), names=np.array(names), render_seed=np.int64(4321), with_depth=np.int64(with_depth))
+        for i, nme in enumerate(names):
+            g = params[nme].grad
+            arrays[f'g{i}.norm'] = g.norm()
+            arrays[f'g{i}.head'] = g.reshape(-1)[:64].clone()
+        save(fname, **arrays)
 
 
 GROUPS['train'] = group_train

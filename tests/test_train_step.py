@@ -8,10 +8,11 @@ from conftest import load_golden, rel_err
 from model_cases import weights
 
 
-def _run(device):
+def _run(device, golden='train_seg2cat'):
     from pix2pix3d_amd import configs, dnnlib
     from pix2pix3d_amd.torch_utils.ops import conv2d_gradfix
-    g = load_golden('train_seg2cat')
+    g = load_golden(golden)
+    with_depth = golden == 'train_seg2cat'
     kw = configs.generator_kwargs('seg2cat')
     kw['rendering_kwargs'] = dict(kw['rendering_kwargs'], depth_resolution=8, depth_resolution_importance=8)
     torch.manual_seed(0)
@@ -27,7 +28,9 @@ def _run(device):
     try:
         with replay_uniforms(u_c, u_f):
             out = G.synthesis(ws, c, neural_rendering_resolution=16, noise_mode='const', force_fp32=True)
-        loss = out['image'].mean() + out['image_raw'].square().mean() + out['semantic'].square().mean() * 0.1 + out['image_depth'].mean()
+        loss = out['image'].mean() + out['image_raw'].square().mean() + out['semantic'].square().mean() * 0.1
+        if with_depth:
+            loss = loss + out['image_depth'].mean()
         loss.backward()
     finally:
         conv2d_gradfix.enabled = prev
@@ -45,8 +48,9 @@ def _check(g, G, loss, tol):
         assert np.abs(head - g[f'g{i}.head']).max() < tol * max(np.abs(g[f'g{i}.head']).max(), float(g[f'g{i}.norm']) * 1e-3, 1e-12), name
 
 
-def test_training_gradients_match_reference_on_cpu():
-    g, G, loss = _run('cpu')
+@pytest.mark.parametrize('golden', ['train_seg2cat', 'train_seg2cat_nodepth'])
+def test_training_gradients_match_reference_on_cpu(golden):
+    g, G, loss = _run('cpu', golden)
     _check(g, G, loss, 2e-4)
 
 
@@ -68,3 +72,16 @@ def test_training_gradients_match_reference_on_gpu(hip_lib):
     finally:
         rmod.fused_training = True
     _check(g2, G2, loss2, 2e-3)
+
+
+@pytest.mark.gpu
+def test_training_step_goes_through_the_fused_renderer_backward(hip_lib):
+    """A loss over images only (what training/loss.py differentiates): forward AND backward of the renderer are the fused
+    kernels (p3d_render_forward, p3d_render_backward), gradients as the reference's autograd gives them."""
+    from pix2pix3d_amd import _lib
+    from pix2pix3d_amd.training.volumetric_rendering import renderer as rmod
+    n0, b0 = _lib.launch_count('render'), dict(rmod.backward_calls)
+    g, G, loss = _run('cuda', 'train_seg2cat_nodepth')
+    assert rmod.backward_calls['fused'] == b0['fused'] + 1 and rmod.backward_calls['replay'] == b0['replay'], rmod.backward_calls
+    assert _lib.launch_count('render') >= n0 + 3          # forward + tape sweep + point-wise backward
+    _check(g, G, loss, 2e-3)
