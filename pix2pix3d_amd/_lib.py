@@ -7,6 +7,7 @@ then shared between torch and the kernels.
 """
 import ctypes
 import os
+import threading
 
 import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
@@ -60,15 +61,48 @@ def available():
     return _lib is not None
 
 
+_tls = threading.local()       # .device: ordinal of the tensor the pending call's stream was taken from (set by stream_of)
+
+
+class _Guarded:
+    """The library handle with a device guard around every entry point: a kernel must be enqueued with ITS tensors' device
+    current (the reference plugins wrap each op in ``OptionalCUDAGuard(device_of(x))``, bias_act.cpp:57), not whatever device the
+    caller last selected.  ``stream_of(t)`` — evaluated while the call's arguments are built — notes t's device; the call then
+    switches to it for its duration when it is not the current one."""
+
+    def __init__(self, handle):
+        self._handle, self._fns = handle, {}
+
+    def __getattr__(self, name):
+        fn = self._fns.get(name)
+        if fn is None:
+            raw = getattr(self._handle, name)
+
+            def fn(*args, _raw=raw):
+                dev, _tls.device = getattr(_tls, 'device', None), None
+                if dev is None or dev == torch.cuda.current_device():
+                    return _raw(*args)
+                with torch.cuda.device(dev):
+                    return _raw(*args)
+            self._fns[name] = fn
+        return fn
+
+
+_guarded = None
+
+
 def lib():
-    """Return the loaded library or raise: there is no fallback for device tensors."""
+    """Return the loaded library (device-guarded) or raise: there is no fallback for device tensors."""
+    global _guarded
     _load()
     if _lib is None:
         raise RuntimeError(
             f'pix2pix3d_amd: the gfx950 kernel library {LIB_PATH} could not be loaded ({_load_error}). '
             'Build it with `python -m pix2pix3d_amd.build` (or __graft_entry__.build()); '
             'CUDA/HIP tensors have no fallback path in this package.')
-    return _lib
+    if _guarded is None:
+        _guarded = _Guarded(_lib)
+    return _guarded
 
 
 def register(name, restype, argtypes):
@@ -86,6 +120,8 @@ def check(code, what):
 
 
 def stream_of(t):
+    """Current stream of t's device (what the reference plugins launch on) — and tell the device guard which device that is."""
+    _tls.device = t.device.index
     return _c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 

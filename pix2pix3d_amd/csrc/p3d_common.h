@@ -27,6 +27,19 @@ template <>        __device__ __forceinline__ float ld<__half>(const __half* p) 
 template <class T> __device__ __forceinline__ void st(T* p, typename Acc<T>::type v)          { *p = (T)v; }
 template <>        __device__ __forceinline__ void st<__half>(__half* p, float v)               { *p = __float2half(v); }
 
+// One-time opt-in to more than 64 KB of dynamic LDS for kernel `fn`, once PER DEVICE (the attribute belongs to the device's
+// code object: a process that drives several GPUs must set it on each); `done` holds one bit per device ordinal.
+inline hipError_t reserve_lds_once(const void* fn, int bytes, std::atomic<uint64_t>& done)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 } // namespace p3d

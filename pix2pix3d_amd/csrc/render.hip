@@ -256,11 +256,11 @@ extern "C" int p3d_render_forward(const float* planes_cl, const float* decoder, 
     const int blocks = (int)((total + wpb * 32 - 1) / (wpb * 32));
     hipLaunchKernelGGL(render_init_minmax_kernel, dim3(1), dim3(1), 0, s, minmax_ws);
     if (d->n_nets == 1) {
-        static hipError_t once1 = hipFuncSetAttribute((const void*)render_forward_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        static std::atomic<uint64_t> once1_devs{0}; const hipError_t once1 = reserve_lds_once((const void*)render_forward_kernel<1, false>, (int)lds_bytes, once1_devs);
         if (once1 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_forward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(once1));
         hipLaunchKernelGGL((render_forward_kernel<1, false>), dim3(blocks), dim3(wpb * 64), lds_bytes, s, a);
     } else {
-        static hipError_t once2 = hipFuncSetAttribute((const void*)render_forward_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        static std::atomic<uint64_t> once2_devs{0}; const hipError_t once2 = reserve_lds_once((const void*)render_forward_kernel<2, false>, (int)lds_bytes, once2_devs);
         if (once2 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_forward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(once2));
         hipLaunchKernelGGL((render_forward_kernel<2, false>), dim3(blocks), dim3(wpb * 64), lds_bytes, s, a);
     }

@@ -408,11 +408,11 @@ extern "C" int p3d_render_backward(const float* planes_cl, const float* decoder,
         const size_t lds_bytes = (size_t)(kDecoderFloats + kWavesPerBlock * kWaveTile) * sizeof(float);
         const int blocks = (int)((total + wpb * 32 - 1) / (wpb * 32));
         if (d->n_nets == 1) {
-            static hipError_t once1 = hipFuncSetAttribute((const void*)render_forward_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            static std::atomic<uint64_t> once1_devs{0}; const hipError_t once1 = reserve_lds_once((const void*)render_forward_kernel<1, true>, (int)lds_bytes, once1_devs);
             if (once1 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_backward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(once1));
             hipLaunchKernelGGL((render_forward_kernel<1, true>), dim3(blocks), dim3(wpb * 64), lds_bytes, s, a);
         } else {
-            static hipError_t once2 = hipFuncSetAttribute((const void*)render_forward_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            static std::atomic<uint64_t> once2_devs{0}; const hipError_t once2 = reserve_lds_once((const void*)render_forward_kernel<2, true>, (int)lds_bytes, once2_devs);
             if (once2 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_backward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(once2));
             hipLaunchKernelGGL((render_forward_kernel<2, true>), dim3(blocks), dim3(wpb * 64), lds_bytes, s, a);
         }
@@ -426,11 +426,11 @@ extern "C" int p3d_render_backward(const float* planes_cl, const float* decoder,
         int splits = 1;                                                  // one block per CU at a time: aim for >= 2 rounds of blocks
         while (blocks * splits < 2 * kNumCU && splits < 8) splits *= 2;
         if (d->n_nets == 1) {
-            static hipError_t once1 = hipFuncSetAttribute((const void*)render_backward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            static std::atomic<uint64_t> once1_devs{0}; const hipError_t once1 = reserve_lds_once((const void*)render_backward_kernel<1>, (int)lds_bytes, once1_devs);
             if (once1 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_backward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(once1));
             hipLaunchKernelGGL(render_backward_kernel<1>, dim3(blocks, splits), dim3(kBwdWaves * 64), lds_bytes, s, a, decoder_bwd, d_planes_cl, d_decoder);
         } else {
-            static hipError_t once2 = hipFuncSetAttribute((const void*)render_backward_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            static std::atomic<uint64_t> once2_devs{0}; const hipError_t once2 = reserve_lds_once((const void*)render_backward_kernel<2>, (int)lds_bytes, once2_devs);
             if (once2 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_backward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(once2));
             hipLaunchKernelGGL(render_backward_kernel<2>, dim3(blocks, splits), dim3(kBwdWaves * 64), lds_bytes, s, a, decoder_bwd, d_planes_cl, d_decoder);
         }

@@ -106,10 +106,10 @@ def copy_params_and_buffers(src_module, dst_module, require_all=False, allow_mis
     """Copy same-named tensors src -> dst (reference: misc.py:157-175, incl. the '_semantic' name fallback)."""
     src = dict(named_params_and_buffers(src_module))
     for name, tensor in named_params_and_buffers(dst_module):
+        assert (name in src) or (not require_all), f'{name} missing in source module'      # before the fallback, as misc.py:163
         src_name = name
         if src_name not in src and '_semantic' in src_name:
             src_name = src_name.replace('_semantic', '')
-        assert (src_name in src) or (not require_all), f'{name} missing in source module'
         if src_name in src:
             s = src[src_name].detach()
             if s.shape == tensor.shape:

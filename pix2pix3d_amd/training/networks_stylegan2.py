@@ -380,6 +380,7 @@ def prefetch_styles(blocks, block_ws, block_kwargs):
     fused = block_kwargs.get('fused_modconv')
     if not (modconv.prefetch_styles and modconv.enabled and native_channels_last and ws0.is_cuda and not torch.is_grad_enabled()
             and block_kwargs.get('noise_mode', 'random') != 'random' and (fused is None or fused is True)):
+        modconv._plan.clear()         # entries an interrupted forward left behind must never reach a layer of this one
         return False
     force_fp32 = bool(block_kwargs.get('force_fp32', False))
     main, side = torch.cuda.current_stream(), modconv.side_stream(ws0.device)
@@ -444,10 +445,12 @@ class SynthesisNetwork(torch.nn.Module):
                 idx += block.num_conv
         planned = self._prefetch(block_ws, block_kwargs)
         x = img = None
-        for res, cur in zip(self.block_resolutions, block_ws):
-            x, img = getattr(self, f'b{res}')(x, img, cur, **block_kwargs)
-        if planned:
-            finish_prefetch(ws.device)
+        try:
+            for res, cur in zip(self.block_resolutions, block_ws):
+                x, img = getattr(self, f'b{res}')(x, img, cur, **block_kwargs)
+        finally:
+            if planned:
+                finish_prefetch(ws.device)
         return img
 
     def _prefetch(self, block_ws, block_kwargs):

@@ -34,10 +34,12 @@ class _SuperresolutionBase(torch.nn.Module):
         ws = ws[:, -1:, :].repeat(1, 3, 1)
         rgb, x = self._prep(rgb, x)
         planned = prefetch_styles([self.block0, self.block1], [ws, ws], block_kwargs)
-        x, rgb = self.block0(x, rgb, ws, **block_kwargs)
-        x, rgb = self.block1(x, rgb, ws, **block_kwargs)
-        if planned:
-            finish_prefetch(ws.device)
+        try:
+            x, rgb = self.block0(x, rgb, ws, **block_kwargs)
+            x, rgb = self.block1(x, rgb, ws, **block_kwargs)
+        finally:
+            if planned:
+                finish_prefetch(ws.device)
         return rgb
 
 

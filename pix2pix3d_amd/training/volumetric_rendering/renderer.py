@@ -171,6 +171,8 @@ class ImportanceRenderer(torch.nn.Module):
             return f'planes shape {tuple(planes.shape)} is not [N,3,32,H,W]'
         if options.get('density_noise', 0) > 0:
             return 'density_noise > 0'
+        if options.get('clamp_mode', 'softplus') != 'softplus':
+            return "clamp_mode != 'softplus' (the tensor-op route raises the reference's assertion, ray_marcher.py:35)"
         if _decoder_nets(decoder) is None:
             return f'decoder {type(decoder).__name__} is not an OSG 32-64-33 decoder'
         return None
