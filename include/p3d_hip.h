@@ -182,6 +182,36 @@ int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype, const floa
                     const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
                     int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, p3d_stream_t stream);
 
+/* ---- conv2d_gradfix: training-mode convolution, its data gradient and its weight gradient ---------------------------------------
+ * Stand in for the vendor-library calls behind torch_utils/ops/conv2d_gradfix.py (cuDNN there, MIOpen on ROCm):
+ *   forward            conv2d_gradfix.py:37-45, 107-131   F.conv2d / F.conv_transpose2d
+ *   p3d_conv2d_bwd_data    :139-143   "grad_input = the transposed op" with output_padding from the shapes (:95-104)
+ *   p3d_conv2d_bwd_weight  :155-194   Conv2dGradWeight (aten::convolution_backward with mask [F,T,F]; a matmul for 1x1)
+ * All tensors channels-last ([N][H][W][C]), fp16 or fp32 with fp32 accumulation, groups = 1, dilation = 1, weights SHARED across the
+ * batch and passed in torch's own layout and in the activation dtype.  The family (what conv2d_resample.py:96-136 ever asks for):
+ *   transposed = 0: conv2d,            weight [Co][Ci][k][k]:  k in {1, 3} at stride 1 / padding k/2,  k = 3 at stride 2 / padding 0
+ *   transposed = 1: conv_transpose2d,  weight [Ci][Co][k][k]:  the same two geometries; at stride 2 the output is [2H+1 | 2H+2]
+ *                   (out_h / out_w; 0 = 2H+1: output_padding 0)
+ * ci = channels of x, co = channels of y in every call.  w_scratch: co*ci*k*k elements of the activation dtype, 16-byte aligned (the
+ * tap-major re-layout the matrix-core kernels read; unused by the skinny 1x1 route, may then be null).  zeros128 as p3d_conv2d_nhwc.
+ * Returns P3D_ERR_UNSUPPORTED when ci is not a multiple of 64 (fp16) / 32 (fp32) on the 3x3 routes: pad the channels.               */
+int p3d_conv2d_forward(const void* x, const void* weight, void* y, void* w_scratch, const void* zeros128, int dtype,
+                       int32_t n_img, int32_t h, int32_t w, int32_t ci, int32_t co, int32_t kernel_size, int32_t stride,
+                       int32_t transposed, int32_t out_h, int32_t out_w, p3d_stream_t stream);
+/* gy [N][gy_h][gy_w][co] -> gx [N][x_h][x_w][ci], for the FORWARD op (ci -> co, weight, kernel_size, stride, transposed) described above */
+int p3d_conv2d_bwd_data(const void* gy, const void* weight, void* gx, void* w_scratch, const void* zeros128, int dtype,
+                        int32_t n_img, int32_t gy_h, int32_t gy_w, int32_t ci, int32_t co, int32_t kernel_size, int32_t stride,
+                        int32_t transposed, int32_t x_h, int32_t x_w, p3d_stream_t stream);
+/* gw[cs][cb][ky][kx] = sum_{n,i,j} small[n,i,j,cs] * big[n, i*stride + ky - pad, j*stride + kx - pad, cb]   (out-of-image = 0)
+ * conv2d:           small = gy (cs = Co), big = x  (cb = Ci)  ->  gw [Co][Ci][k][k]
+ * conv_transpose2d: small = x  (cs = Ci), big = gy (cb = Co)  ->  gw [Ci][Co][k][k]        (the roles swap, conv2d_gradfix.py:173)
+ * gw in the activation dtype.  workspace: p3d_conv2d_bwd_weight_workspace(...) bytes of device scratch, 16-byte aligned (fp32
+ * partial sums of the split-K work-groups; deterministic: no atomics).                                                             */
+int64_t p3d_conv2d_bwd_weight_workspace(int dtype, int32_t n_img, int32_t small_h, int32_t small_w, int32_t c_small, int32_t c_big, int32_t kernel_size);
+int p3d_conv2d_bwd_weight(const void* small_img, const void* big_img, void* gw, void* workspace, int64_t workspace_bytes, int dtype,
+                          int32_t n_img, int32_t small_h, int32_t small_w, int32_t c_small, int32_t big_h, int32_t big_w, int32_t c_big,
+                          int32_t kernel_size, int32_t stride, int32_t pad, p3d_stream_t stream);
+
 /* x [N][HW][Ci] fp16 channels-last, weight [Co][Ci] fp32, styles [N][Ci] fp32 (weight gain already applied),
  * bias [Co] or null -> y [N][Co][HW] fp32 (NCHW); accumulate != 0 adds into y (the skip-image sum).
  * Ci in {64, 128, 256}, Co <= 32, HW a multiple of 4, else P3D_ERR_UNSUPPORTED (wide outputs: p3d_conv2d_nhwc, k = 1). */

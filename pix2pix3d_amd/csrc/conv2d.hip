@@ -51,6 +51,8 @@ struct ConvArgs {
     struct Cls { int SH, SW, ooy, oox, ntaps; ConvTap taps[9]; } cls[4];     // plain conv uses cls[0] with up to 9 taps; transposed classes have <= 4
     int act;               // 0: none (linear), 1: lrelu(0.2)
     float gain, clamp;     // clamp < 0: off
+    int fold;              // != 0 (generic kernel, one class, shared weights): GEMM rows run over ALL images' pixels, m = n * SH * SW + pixel,
+                           // so a batch of small images fills the 128-row tiles that one image cannot
 };
 
 // 16-B slot of (row, chunk).  Two 128-byte tile rows share one 256-byte LDS bank row, so the XOR key is (row >> 1) & 7:
@@ -69,8 +71,8 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
     __shared__ __attribute__((aligned(16))) f32x4 lds[2][2][BM * 8];          // [buffer][A|B][row*8 + chunk], 16-byte slots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;                                   // wave's 64x64 quadrant
-    const int n = blockIdx.z / a.ncls;
-    const ConvArgs::Cls& kc = a.cls[blockIdx.z - n * a.ncls];
+    const int n = a.fold ? 0 : blockIdx.z / a.ncls;
+    const ConvArgs::Cls& kc = a.cls[a.fold ? 0 : blockIdx.z - n * a.ncls];
     // XCD-aware tile order: workgroup L of a launch lands on XCD L % 8, each XCD with its own L2.  Consecutive slots
     // of one XCD get the output-channel blocks of the SAME pixel tile (they share the A operand), and pixel tiles
     // stride over XCDs, so an A neighbourhood is fetched into one L2 only.  Falls back to the plain order when the
@@ -81,8 +83,9 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
         if ((nmt & 7) == 0) { const int q = L >> 3, r = L & 7; cb = q % ncb; mt = (q / ncb) * 8 + r; }
     }
     const int m0 = mt * BM, co0 = cb * BN;
-    if (m0 >= kc.SH * kc.SW) return;                                           // classes of one launch differ slightly in size
-    const int M = kc.SH * kc.SW;
+    const int MI = kc.SH * kc.SW;                                              // GEMM rows of one image
+    const int M = a.fold ? MI * a.N : MI;
+    if (m0 >= M) return;                                                       // classes of one launch differ slightly in size
     const T* xin = (const T*)a.x + (int64_t)n * a.H * a.W * a.Ci;
     const T* wgt = (const T*)a.w + (int64_t)n * a.w_img_stride;
 
@@ -96,10 +99,12 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
     for (int p = 0; p < 4; ++p) {
         const int m = m0 + srow + 32 * p;
         pok[p] = m < M;
-        const int mm = pok[p] ? m : 0;
+        int mm = pok[p] ? m : 0;
+        const int img = a.fold ? mm / MI : 0;                                               // folded: the row's own image
+        mm -= img * MI;
         pi[p] = mm / kc.SW; pj[p] = mm - pi[p] * kc.SW;
         pi[p] *= a.isy; pj[p] *= a.isx;                                                     // from here on: the tap-(0,0) input pixel
-        poff[p] = ((pi[p] * a.W + pj[p]) * a.Ci + src_chunk * EPC) * (int)sizeof(T);      // < 2^31: one image's activations
+        poff[p] = (((img * a.H + pi[p]) * a.W + pj[p]) * a.Ci + src_chunk * EPC) * (int)sizeof(T);   // < 2^31: one image's activations (the folded batch is small by construction)
         const int co = co0 + srow + 32 * p;
         wok[p] = co < a.Co;
         woff[p] = (co * a.KT * a.Ci + src_chunk * EPC) * (int)sizeof(T);
@@ -216,14 +221,17 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int idx = it * 256 + tid, ml = idx >> 4, ch = idx & 15;
-            const int m = m0 + ml, co = co0 + ch * 8;
+            int m = m0 + ml;
+            const int co = co0 + ch * 8;
             if (m >= M || co >= a.Co) continue;
+            const int img = a.fold ? m / MI : 0;
+            m -= img * MI;
             const int si = m / kc.SW, sj = m - si * kc.SW;
-            const int oy = si * a.osy + kc.ooy, ox = sj * a.osx + kc.oox;
-            if (oy >= a.OH || ox >= a.OW) continue;
+            const int oy = si * a.osy + kc.ooy + img * a.OH, ox = sj * a.osx + kc.oox;      // folded: images are stacked along y in the output
+            if (oy >= a.OH * (img + 1) || ox >= a.OW) continue;
             f32x4 pk = *(const f32x4*)(ot + ml * OP + ch * 8);
             if (a.noise) {                                                      // rare here (the big noisy layers take the halo kernels)
-                const float nz = a.noise[(int64_t)oy * a.OW + ox] * ns;
+                const float nz = a.noise[(int64_t)(oy - img * a.OH) * a.OW + ox] * ns;
                 h8 hv = __builtin_bit_cast(h8, pk);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -248,16 +256,18 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
         // one division for the wave's first row, then every row by carry (its 32 rows span 64 consecutive m): the 32 runtime
         // divisions this replaces were a fifth of a short-K (1x1) block's life
         const int mb = m0 + wm * 64;
-        const int sib = mb / kc.SW, sjb = mb - sib * kc.SW;
+        const int imgb = a.fold ? mb / MI : 0;
+        const int sib = (mb - imgb * MI) / kc.SW, sjb = (mb - imgb * MI) - sib * kc.SW;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int d = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                int si = sib, sj = sjb + d;
+                int si = sib, sj = sjb + d, img = imgb;
                 while (sj >= kc.SW) { sj -= kc.SW; ++si; }
+                while (a.fold && si >= kc.SH) { si -= kc.SH; ++img; }
                 const int oy = si * a.osy + kc.ooy, ox = sj * a.osx + kc.oox;
-                opix[i][r] = (mb + d < M && oy < a.OH && ox < a.OW) ? oy * a.OW + ox : -1;
+                opix[i][r] = (mb + d < M && oy < a.OH && ox < a.OW) ? (img * a.OH + oy) * a.OW + ox : -1;    // folded: + the row's image
             }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -270,7 +280,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
                 for (int r = 0; r < 16; ++r) {
                     if (opix[i][r] < 0) continue;
                     float v = acc[i][j][r];
-                    if (a.noise) v = fmaf(a.noise[opix[i][r]], ns, v);
+                    if (a.noise) v = fmaf(a.noise[a.fold ? opix[i][r] % (a.OH * a.OW) : opix[i][r]], ns, v);
                     v += b;
                     if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
                     v *= a.gain;
@@ -911,12 +921,22 @@ extern "C" int p3d_modulate_weights(const float* weight, const float* styles, vo
     return check_launch("modulate_weights");
 }
 
+// Fold the batch into the GEMM rows when the weights are shared and one image cannot fill a 128-row tile (training-mode and
+// plain Conv2dLayer calls on the low-resolution blocks): N x H x W rows instead of N launches' worth of mostly empty tiles.
+static int fold_batch(const ConvArgs& a, int dtype)
+{
+    const int64_t mi = (int64_t)a.cls[0].SH * a.cls[0].SW;
+    const int64_t in_bytes = (int64_t)a.N * a.H * a.W * a.Ci * (dtype == P3D_F16 ? 2 : 4);
+    return a.ncls == 1 && a.w_img_stride == 0 && a.N > 1 && mi < 4 * BM && in_bytes < (1ll << 31) && mi * a.N < (1ll << 24);
+}
+
 static int launch_conv(ConvArgs& a, int dtype, hipStream_t s)
 {
     int M = 0;
     for (int c = 0; c < a.ncls; ++c) M = a.cls[c].SH * a.cls[c].SW > M ? a.cls[c].SH * a.cls[c].SW : M;
     if (M <= 0) return P3D_OK;
-    dim3 grid((M + BM - 1) / BM, (a.Co + BN - 1) / BN, a.N * a.ncls);
+    if (a.fold) M *= a.N;
+    dim3 grid((M + BM - 1) / BM, (a.Co + BN - 1) / BN, a.fold ? 1 : a.N * a.ncls);
     if (dtype == P3D_F16) hipLaunchKernelGGL(conv2d_nhwc_kernel<__half>, grid, dim3(256), 0, s, a);
     else                  hipLaunchKernelGGL(conv2d_nhwc_kernel<float>, grid, dim3(256), 0, s, a);
     count_launch(FAM_CONV);
@@ -926,6 +946,16 @@ static int launch_conv(ConvArgs& a, int dtype, hipStream_t s)
 extern "C" int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype, const float* bias, const float* noise, const float* noise_strength,
                                const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
                                int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, p3d_stream_t stream)
+{
+    return p3d::conv2d_nhwc_run(x, w, y, dtype, bias, noise, noise_strength, zeros128, n_img, h, wdt, ci, co, w_img_stride, kernel_size, resample, act, gain, clamp,
+                                0, 0, stream);
+}
+
+// out_h / out_w (transposed form only, 0 = 2h+1 / 2w+1): the output size conv_transpose2d's output_padding asks for (2h+1 or 2h+2);
+// the extra row / column only sees taps that fall outside the input, i.e. comes out as zeros, as in the reference's op.
+int p3d::conv2d_nhwc_run(const void* x, const void* w, void* y, int dtype, const float* bias, const float* noise, const float* noise_strength,
+                         const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
+                         int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, int32_t out_h, int32_t out_w, p3d_stream_t stream)
 {
     const bool transposed_stride2 = (resample == 1), down2 = (resample == 2);
     P3D_REQUIRE(resample >= 0 && resample <= 2, "conv2d_nhwc: resample must be 0 (same), 1 (transposed x2) or 2 (valid, stride 2)");
@@ -948,6 +978,7 @@ extern "C" int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype,
         a.OH = (h - kernel_size) / 2 + 1; a.OW = (wdt - kernel_size) / 2 + 1; a.osy = a.osx = 1; a.isy = a.isx = 2; a.ncls = 1;
         a.cls[0].SH = a.OH; a.cls[0].SW = a.OW; a.cls[0].ooy = a.cls[0].oox = 0; a.cls[0].ntaps = a.KT;
         for (int t = 0; t < a.KT; ++t) a.cls[0].taps[t] = ConvTap{t / kernel_size, t % kernel_size, t};
+        a.fold = fold_batch(a, dtype);
         return launch_conv(a, dtype, s);
     }
     if (!transposed_stride2) {                                       // correlation, "same" padding: input offset = tap - k/2
@@ -969,17 +1000,19 @@ extern "C" int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype,
             count_launch(FAM_CONV);
             return check_launch("conv3x3_halo");
         }
+        a.fold = fold_batch(a, dtype);
         return launch_conv(a, dtype, s);
     }
     // conv_transpose2d(stride 2, no padding): out[(2i+py), (2j+px)] = sum_{ky = py (mod 2), kx = px (mod 2)} x[i - (ky-py)/2, j - (kx-px)/2] w[ky, kx]
     // -> four dense sub-problems (4 / 2 / 2 / 1 taps), all in ONE launch so the grid fills the chip
     P3D_REQUIRE(!noise && !bias && act == 0, "conv2d_nhwc: the transposed form has no epilogue (the FIR runs next)");
-    a.OH = 2 * h + 1; a.OW = 2 * wdt + 1; a.osy = a.osx = 2; a.ncls = 4;
+    a.OH = out_h > 0 ? out_h : 2 * h + 1; a.OW = out_w > 0 ? out_w : 2 * wdt + 1; a.osy = a.osx = 2; a.ncls = 4;
+    P3D_REQUIRE(a.OH >= 2 * h + 1 && a.OH <= 2 * h + 2 && a.OW >= 2 * wdt + 1 && a.OW <= 2 * wdt + 2, "conv2d_nhwc: transposed output must be 2h+1 or 2h+2");
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
             ConvArgs::Cls& c = a.cls[py * 2 + px];
             c.ooy = py; c.oox = px;
-            c.SH = py ? h : h + 1; c.SW = px ? wdt : wdt + 1;
+            c.SH = (a.OH - py + 1) / 2; c.SW = (a.OW - px + 1) / 2;                // output rows py, py + 2, ... < OH
             c.ntaps = 0;
             for (int ky = py; ky < 3; ky += 2)
                 for (int kx = px; kx < 3; kx += 2)

@@ -1,0 +1,451 @@
+// Training-mode convolutions of conv2d_gradfix on the gfx950 matrix cores: the forward op with shared weights, its data gradient
+// and its weight gradient (torch_utils/ops/conv2d_gradfix.py:37-45, 107-194), channels-last, fp16 / fp32 with fp32 accumulation.
+//
+// Every derivative of a convolution is another member of the same family (conv2d_gradfix.py:95-104, 139-143), so two primitives and
+// their weight gradient cover all orders:
+//   conv2d(x, w[O][I][k][k])            stride 1 / padding k/2  ("same", k in {1, 3})   or   stride 2 / padding 0 (k = 3)
+//   conv_transpose2d(x, w[I][O][k][k])  stride 1 / padding k/2                          or   stride 2 / padding 0 (+ output_padding)
+// The dense arithmetic of both runs on the implicit-GEMM kernels of conv2d.hip (p3d_conv2d_nhwc) after a one-launch weight re-layout
+// to tap-major [O][k*k][I] — the transposed stride-1 form is the plain correlation with the weights mirrored and their channel axes
+// swapped, the transposed stride-2 form the polyphase kernel.  The weight gradient is its own kernel (below): a GEMM whose
+// contraction runs over PIXELS, so both operands are needed pixel-major while channels-last memory is channel-major.
+//
+// Skinny 1x1 layers (ToRGB: hundreds of channels -> 3; fromrgb: 6 -> 64) have no GEMM worth the name: they are memory-bound and run
+// on a strided VALU kernel.
+#include "p3d_common.h"
+
+namespace p3d {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---- weight re-layout: torch [A][B][taps] -> tap-major [O][taps][I] in the same dtype ------------------------------------------------
+// swap == 0: O = A, I = B (conv2d weights).  swap != 0: O = B, I = A (conv_transpose2d weights [in][out]).  flip mirrors the taps.
+template <class T>
+__global__ void __launch_bounds__(256) weight_relayout_kernel(const T* __restrict__ src, T* __restrict__ dst, int A, int B, int taps, int swap, int flip)
+{
+    const int O = swap ? B : A, I = swap ? A : B;
+    const int64_t total = (int64_t)O * taps * I;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e % I);
+        const int t = (int)((e / I) % taps);
+        const int o = (int)(e / ((int64_t)I * taps));
+        const int ts = flip ? taps - 1 - t : t;
+        const int64_t s = swap ? ((int64_t)i * B + o) * taps + ts : ((int64_t)o * B + i) * taps + ts;
+        dst[e] = src[s];
+    }
+}
+
+// ---- weight gradient --------------------------------------------------------------------------------------------------------------
+// G[cs][cb][ky][kx] = sum over (n, i, j) of S[n, i, j, cs] * B[n, i*stride + ky - pad, j*stride + kx - pad, cb]
+// with S the SMALL image of the pair (gy for conv2d, x for conv_transpose2d) and B the big one: for conv2d that is gw[O][I], for
+// conv_transpose2d gw[I][O] — each in torch's own layout for that op.
+//
+// One block = one 128 x 128 tile of (cs, cb) for ONE tap over a contiguous range of pixel chunks (split-K); its fp32 partial tile
+// goes to the workspace with plain coalesced stores and a second launch sums the splits and casts (two short launches cost less
+// than 16 K atomics per block).  Work-groups of the nine taps of one (tile, split) are neighbours on one XCD: they read the same S
+// rows and B rows that differ by a pixel, so the second to ninth read hit that XCD's L2.
+//
+// Staging is through registers (global -> VGPR -> LDS, double-buffered, one barrier per chunk) because the operands must be
+// re-shaped on the way:
+//   fp16: v_mfma_f32_32x32x16_f16 wants 8 consecutive K (= pixels) per lane; memory has 8 consecutive CHANNELS per 16 bytes.  A
+//         thread loads the same 8 channels of 4 consecutive pixels, transposes the 4 x 8 block in registers (one byte-permute per word) and stores
+//         eight 8-byte runs into an LDS image [channel][pixel] (pitch 72 halfs: conflict-free ds_write_b64 and ds_read_b128);
+//   fp32: v_mfma_f32_32x32x2_f32 takes ONE float per lane, so the channel-major image [pixel][channel] is already what the
+//         fragment reads want (ds_read_b32, lanes = consecutive channels): no transposition, 16-byte stores.
+struct WgradArgs {
+    const void* s;          // [N][HS][WS][Cs]
+    const void* b;          // [N][HB][WB][Cb]
+    float* ws;              // partial tiles [ksplit][taps][CsP][CbP]
+    int N, HS, WS, Cs, HB, WB, Cb;
+    int k, stride, pad;
+    int ksplit, chunks, chunks_per_split;
+    int tiles_s, tiles_b, CsP, CbP;
+};
+
+template <class T> struct WgradTraits;
+template <> struct WgradTraits<__half> { static constexpr int KP = 64, EPC = 8, PITCH = 72;  };   // pixels per chunk, elements per 16 B, LDS row pitch (elements)
+template <> struct WgradTraits<float>  { static constexpr int KP = 16, EPC = 4, PITCH = 128; };
+
+struct PixPos { int n, i, j; };
+__device__ __forceinline__ void pix_advance(PixPos& p, int d, int HS, int WS)
+{
+    p.j += d;
+    if (p.j >= WS) {
+        const int q = p.j / WS;
+        p.j -= q * WS; p.i += q;
+        if (p.i >= HS) { const int q2 = p.i / HS; p.i -= q2 * HS; p.n += q2; }
+    }
+}
+
+template <class T>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
+{
+    typedef WgradTraits<T> TR;
+    constexpr int KP = TR::KP, EPC = TR::EPC, PITCH = TR::PITCH;
+    constexpr int OPER = sizeof(T) == 2 ? 128 * PITCH : KP * PITCH;            // elements of one operand image
+    __shared__ __attribute__((aligned(16))) T lds[2][2][OPER];                  // [buffer][S | B][...]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int taps = a.k * a.k;
+    // work item: (group = (split, tile), tap); the taps of a group sit on one XCD (work-group L runs on XCD L % 8)
+    const int groups = a.ksplit * a.tiles_s * a.tiles_b;
+    int L = blockIdx.x, g, tap;
+    if ((groups & 7) == 0) { g = (L & 7) + 8 * ((L >> 3) / taps); tap = (L >> 3) % taps; }
+    else                   { g = L / taps; tap = L - g * taps; }
+    const int tile = g % (a.tiles_s * a.tiles_b), split = g / (a.tiles_s * a.tiles_b);
+    const int cs0 = (tile / a.tiles_b) * 128, cb0 = (tile % a.tiles_b) * 128;
+    const int ky = tap / a.k, kx = tap - ky * a.k;
+    const int dy = ky - a.pad, dx = kx - a.pad;
+    const int c_begin = split * a.chunks_per_split;
+    int c_end = c_begin + a.chunks_per_split;
+    if (c_end > a.chunks) c_end = a.chunks;
+    const int64_t Mtot = (int64_t)a.N * a.HS * a.WS;
+    const T* const S = (const T*)a.s;
+    const T* const B = (const T*)a.b;
+    const bool vec_s = (a.Cs % EPC) == 0 && ((uintptr_t)a.s & 15u) == 0;        // 16-byte loads need whole, aligned channel groups
+    const bool vec_b = (a.Cb % EPC) == 0 && ((uintptr_t)a.b & 15u) == 0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int frow = lane & 31, fk = lane >> 5;
+
+    // ---- loader role of this thread -------------------------------------------------------------------------------------
+    // fp16: pixel quad pq = lane & 15 (pixels 4pq .. 4pq+3 of the chunk), channel group cg = (lane >> 4) + 4 * wave (8 channels)
+    // fp32: two 16-byte pieces r = 0, 1: pixel (tid >> 5) + 8 r of the chunk, channels 4 * (tid & 31) ..
+    constexpr int NLD = sizeof(T) == 2 ? 4 : 2;                                // 16-byte loads per operand per chunk
+    int lp[NLD];                                                               // chunk-local pixel of each load
+    int lc;                                                                    // first tile-local channel of this thread's loads
+    if constexpr (sizeof(T) == 2) {
+        const int pq = lane & 15;
+        lc = ((lane >> 4) + 4 * wave) * 8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lp[q] = pq * 4 + q;
+    } else {
+        lc = (tid & 31) * 4;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) lp[q] = (tid >> 5) + 8 * q;
+    }
+    PixPos pos[NLD];                                                           // (n, i, j) of each load's pixel in the current chunk
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int64_t m = (int64_t)c_begin * KP + lp[q];
+        const int64_t per = (int64_t)a.HS * a.WS;
+        pos[q].n = (int)(m / per);
+        const int rem = (int)(m - (int64_t)pos[q].n * per);
+        pos[q].i = rem / a.WS; pos[q].j = rem - pos[q].i * a.WS;
+    }
+    f32x4 rs[NLD], rb[NLD];                                                    // staged operands of the NEXT chunk
+
+    auto load16 = [&](const T* base, int64_t elem_off, int c_first, int C, bool vec) -> f32x4 {
+        // 16 bytes = EPC channels starting at channel c_first of one pixel (elem_off = the pixel's first element); channels >= C read 0
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c_first >= C) return v;
+        if (vec) return *(const f32x4*)(base + elem_off + c_first);
+        T tmp[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) tmp[e] = (c_first + e < C) ? base[elem_off + c_first + e] : (T)0.f;
+        return *(const f32x4*)tmp;
+    };
+    auto fetch = [&](int chunk) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int64_t m = (int64_t)chunk * KP + lp[q];
+            const bool live = m < Mtot;
+            f32x4 vs = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            if (live) {
+                vs = load16(S, m * a.Cs, cs0 + lc, a.Cs, vec_s);
+                const int bi = pos[q].i * a.stride + dy, bj = pos[q].j * a.stride + dx;
+                if (bi >= 0 && bi < a.HB && bj >= 0 && bj < a.WB)
+                    vb = load16(B, (((int64_t)pos[q].n * a.HB + bi) * a.WB + bj) * a.Cb, cb0 + lc, a.Cb, vec_b);
+            }
+            rs[q] = vs; rb[q] = vb;
+            pix_advance(pos[q], KP, a.HS, a.WS);
+        }
+    };
+    auto deposit = [&](int buf) {
+        if constexpr (sizeof(T) == 2) {
+            // registers hold [pixel q][8 channels]; LDS wants [channel][4 pixels] as one 8-byte run per channel
+            const int pq = lane & 15;
+#pragma unroll
+            for (int op = 0; op < 2; ++op) {
+                const f32x4* r = op ? rb : rs;
+                T* img = lds[buf][op];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {                                   // register e of each pixel = channels 2e, 2e+1
+                    const unsigned v0 = __builtin_bit_cast(unsigned, r[0][e]), v1 = __builtin_bit_cast(unsigned, r[1][e]);
+                    const unsigned v2 = __builtin_bit_cast(unsigned, r[2][e]), v3 = __builtin_bit_cast(unsigned, r[3][e]);
+                    // (the compiler turns these into one v_perm_b32 / v_pack each)
+                    const unsigned lo01 = (v0 & 0xffffu) | (v1 << 16), lo23 = (v2 & 0xffffu) | (v3 << 16);
+                    const unsigned hi01 = (v0 >> 16) | (v1 & 0xffff0000u), hi23 = (v2 >> 16) | (v3 & 0xffff0000u);
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    *(u32x2*)(img + (lc + 2 * e) * PITCH + pq * 4) = u32x2{lo01, lo23};
+                    *(u32x2*)(img + (lc + 2 * e + 1) * PITCH + pq * 4) = u32x2{hi01, hi23};
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NLD; ++q) {
+                *(f32x4*)(lds[buf][0] + lp[q] * PITCH + lc) = rs[q];
+                *(f32x4*)(lds[buf][1] + lp[q] * PITCH + lc) = rb[q];
+            }
+        }
+    };
+
+    if (c_begin < c_end) fetch(c_begin);
+    int buf = 0;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        deposit(buf);
+        __syncthreads();
+        if (chunk + 1 < c_end) fetch(chunk + 1);                               // flies under this chunk's MFMAs
+        const T* ls = lds[buf][0];
+        const T* lb = lds[buf][1];
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int kk = 0; kk < KP / 16; ++kk) {
+                h8 fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fa[i] = *(const h8*)(ls + (wm * 64 + i * 32 + frow) * PITCH + kk * 16 + fk * 8);
+                    fb[i] = *(const h8*)(lb + (wn * 64 + i * 32 + frow) * PITCH + kk * 16 + fk * 8);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KP / 2; ++kk) {
+                float fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fa[i] = ls[(kk * 2 + fk) * PITCH + wm * 64 + i * 32 + frow];
+                    fb[i] = lb[(kk * 2 + fk) * PITCH + wn * 64 + i * 32 + frow];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        buf ^= 1;
+    }
+
+    // partial tile -> workspace [split][tap][CsP][CbP]: accumulator element r of tile (i, j) is row (r&3) + 8(r>>2) + 4 fk, column frow
+    float* out = a.ws + ((int64_t)split * taps + tap) * a.CsP * a.CbP;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = cb0 + wn * 64 + j * 32 + frow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = cs0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                out[(int64_t)row * a.CbP + col] = acc[i][j][r];
+            }
+        }
+}
+
+// sum the splits, cast, and write torch's layout gw[cs][cb][taps]
+template <class T>
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, T* __restrict__ gw, int Cs, int Cb, int taps, int ksplit, int CsP, int CbP)
+{
+    const int64_t total = (int64_t)Cs * Cb;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int cb = (int)(e % Cb), cs = (int)(e / Cb);
+        for (int t = 0; t < taps; ++t) {
+            float sum = 0.f;
+            for (int k = 0; k < ksplit; ++k) sum += ws[(((int64_t)k * taps + t) * CsP + cs) * CbP + cb];
+            st(gw + e * taps + t, sum);
+        }
+    }
+}
+
+// ---- skinny 1x1: y[n, p, o] = sum_i x[n, p, i] * w[o, i] with a handful of channels on one side -------------------------------------
+// Any dense layout by element strides; w is addressed by (w_so, w_si) so the data gradient passes the same tensor transposed.
+// One thread = one pixel x up to 8 consecutive outputs; the channel loop reads 16-byte vectors when the input channels are
+// contiguous.  Memory-bound by construction (ToRGB reads Ci * sizeof(T) per pixel for 3 outputs).
+template <class T>
+__global__ void __launch_bounds__(256) conv1x1_skinny_kernel(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ y, int N, int HW, int Ci, int Co,
+                                                             int64_t xs_n, int64_t xs_c, int64_t xs_p, int64_t ys_n, int64_t ys_c, int64_t ys_p,
+                                                             int64_t w_so, int64_t w_si)
+{
+    constexpr int EPC = 16 / sizeof(T);
+    const int ogroups = (Co + 7) / 8;
+    const int64_t total = (int64_t)N * HW * ogroups;
+    const bool vec = xs_c == 1 && (Ci % EPC) == 0 && (xs_p % EPC) == 0 && (xs_n % EPC) == 0 && ((uintptr_t)x & 15u) == 0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int og = (int)(e % ogroups);
+        const int64_t np = e / ogroups;
+        const int p = (int)(np % HW), n = (int)(np / HW);
+        const int o0 = og * 8;
+        const T* xp = x + n * xs_n + p * xs_p;
+        float acc[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+        if (vec) {
+            for (int i0 = 0; i0 < Ci; i0 += EPC) {
+                const f32x4 raw = *(const f32x4*)(xp + i0);
+                T xv[EPC];
+                *(f32x4*)xv = raw;
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    if (o0 + o < Co) {
+                        const T* wr = w + (o0 + o) * w_so + i0 * w_si;
+#pragma unroll
+                        for (int q = 0; q < EPC; ++q) acc[o] = fmaf(ld(xv + q), ld(wr + q * w_si), acc[o]);
+                    }
+                }
+            }
+        } else {
+            for (int i = 0; i < Ci; ++i) {
+                const float xv = ld(xp + i * xs_c);
+#pragma unroll
+                for (int o = 0; o < 8; ++o)
+                    if (o0 + o < Co) acc[o] = fmaf(xv, ld(w + (o0 + o) * w_so + i * w_si), acc[o]);
+            }
+        }
+        T* yp = y + n * ys_n + p * ys_p;
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+            if (o0 + o < Co) st(yp + (o0 + o) * ys_c, acc[o]);
+    }
+}
+
+static int wgrad_plan(int dtype, int64_t pixels, int cs, int cb, int k, int* ksplit, int* chunks, int* cps)
+{
+    const int KP = dtype == P3D_F16 ? 64 : 16;
+    const int taps = k * k;
+    const int tiles = ceil_div(cs, 128) * ceil_div(cb, 128);
+    const int64_t nchunks = (pixels + KP - 1) / KP;
+    int64_t want = (3 * kNumCU + tiles * taps - 1) / (tiles * taps);            // ~3 work-groups per CU
+    if (want < 1) want = 1;
+    if (want > nchunks) want = nchunks;
+    if (want > 1024) want = 1024;
+    int64_t per = (nchunks + want - 1) / want;
+    int64_t split = (nchunks + per - 1) / per;
+    if (tiles * split >= 8) {                                                   // a multiple of 8 groups keeps a group's taps on one XCD
+        const int64_t up = ((tiles * split + 7) / 8) * 8;
+        if (up % tiles == 0 && up / tiles <= nchunks) { split = up / tiles; per = (nchunks + split - 1) / split; }
+    }
+    *ksplit = (int)split; *chunks = (int)nchunks; *cps = (int)per;
+    return taps;
+}
+
+} // namespace p3d
+
+using namespace p3d;
+
+enum { MODE_SAME = 0, MODE_STRIDE2 = 1 };
+
+static int relayout(const void* w, void* dst, int dtype, int A, int B, int taps, int swap, int flip, hipStream_t s)
+{
+    const int64_t total = (int64_t)A * B * taps;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    if (dtype == P3D_F16) hipLaunchKernelGGL(weight_relayout_kernel<__half>, dim3(blocks), dim3(256), 0, s, (const __half*)w, (__half*)dst, A, B, taps, swap, flip);
+    else                  hipLaunchKernelGGL(weight_relayout_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)w, (float*)dst, A, B, taps, swap, flip);
+    count_launch(FAM_CONV);
+    return check_launch("conv weight relayout");
+}
+
+static bool mfma_channels_ok(int dtype, int ci) { return ci % (dtype == P3D_F16 ? 64 : 32) == 0; }
+
+extern "C" int p3d_conv2d_forward(const void* x, const void* weight, void* y, void* w_scratch, const void* zeros128, int dtype,
+                                  int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int32_t kernel_size, int32_t stride,
+                                  int32_t transposed, int32_t out_h, int32_t out_w, p3d_stream_t stream)
+{
+    P3D_REQUIRE(x && weight && y, "conv2d_forward: null pointer");
+    P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32, "conv2d_forward: dtype must be fp16 or fp32");
+    P3D_REQUIRE(n_img >= 1 && h >= 1 && wdt >= 1 && ci >= 1 && co >= 1, "conv2d_forward: bad sizes");
+    P3D_REQUIRE((kernel_size == 3 && (stride == 1 || stride == 2)) || (kernel_size == 1 && stride == 1), "conv2d_forward: 3x3 at stride 1 / 2 or 1x1 at stride 1");
+    hipStream_t s = (hipStream_t)stream;
+    const int taps = kernel_size * kernel_size;
+    if (kernel_size == 1 && (!mfma_channels_ok(dtype, ci) || co < 32)) {
+        // skinny 1x1 (either direction: a transposed 1x1 is the same product with the weight read transposed), channels-last
+        const int64_t hw = (int64_t)h * wdt;
+        const int64_t total = (int64_t)n_img * hw * ((co + 7) / 8);
+        const int blocks = (int)((total + 255) / 256 < 16 * kNumCU ? (total + 255) / 256 : 16 * kNumCU);
+        const int64_t w_so = transposed ? 1 : ci, w_si = transposed ? co : 1;   // conv2d: w[o][i]; conv_transpose2d: w[i][o]
+        if (dtype == P3D_F16) hipLaunchKernelGGL(conv1x1_skinny_kernel<__half>, dim3(blocks), dim3(256), 0, s, (const __half*)x, (const __half*)weight, (__half*)y, n_img, (int)hw, ci, co,
+                                                 hw * ci, (int64_t)1, (int64_t)ci, hw * co, (int64_t)1, (int64_t)co, w_so, w_si);
+        else                  hipLaunchKernelGGL(conv1x1_skinny_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, (const float*)weight, (float*)y, n_img, (int)hw, ci, co,
+                                                 hw * ci, (int64_t)1, (int64_t)ci, hw * co, (int64_t)1, (int64_t)co, w_so, w_si);
+        count_launch(FAM_CONV);
+        return check_launch("conv1x1_skinny");
+    }
+    P3D_REQUIRE(w_scratch && zeros128, "conv2d_forward: the MFMA route needs w_scratch (Co*Ci*k*k elements) and zeros128");
+    if (!mfma_channels_ok(dtype, ci) && !(dtype == P3D_F16 && transposed && stride == 2 && ci % 32 == 0 && co % 128 == 0 && h >= 32 && wdt >= 32))
+        return fail(P3D_ERR_UNSUPPORTED, "conv2d_forward: Ci=%d must be a multiple of %d (pad the channels)", ci, dtype == P3D_F16 ? 64 : 32);
+    int rc;
+    if (!transposed) {
+        rc = relayout(weight, w_scratch, dtype, co, ci, taps, 0, 0, s);                          // wm[o][t][i] = w[o][i][t]
+        if (rc != P3D_OK) return rc;
+        return conv2d_nhwc_run(x, w_scratch, y, dtype, nullptr, nullptr, nullptr, zeros128, n_img, h, wdt, ci, co, 0, kernel_size, stride == 2 ? 2 : 0, 0, 1.f, -1.f, 0, 0, stream);
+    }
+    if (stride == 1) {                                                                            // = correlation with mirrored taps and swapped channel axes
+        rc = relayout(weight, w_scratch, dtype, ci, co, taps, 1, 1, s);                          // wm[o][t][i] = w[i][o][taps-1-t]
+        if (rc != P3D_OK) return rc;
+        return conv2d_nhwc_run(x, w_scratch, y, dtype, nullptr, nullptr, nullptr, zeros128, n_img, h, wdt, ci, co, 0, kernel_size, 0, 0, 1.f, -1.f, 0, 0, stream);
+    }
+    rc = relayout(weight, w_scratch, dtype, ci, co, taps, 1, 0, s);                              // wm[o][t][i] = w[i][o][t]
+    if (rc != P3D_OK) return rc;
+    return conv2d_nhwc_run(x, w_scratch, y, dtype, nullptr, nullptr, nullptr, zeros128, n_img, h, wdt, ci, co, 0, kernel_size, 1, 0, 1.f, -1.f, out_h, out_w, stream);
+}
+
+extern "C" int p3d_conv2d_bwd_data(const void* gy, const void* weight, void* gx, void* w_scratch, const void* zeros128, int dtype,
+                                   int32_t n_img, int32_t gy_h, int32_t gy_w, int32_t ci, int32_t co, int32_t kernel_size, int32_t stride,
+                                   int32_t transposed, int32_t x_h, int32_t x_w, p3d_stream_t stream)
+{
+    // d(input) of op(transposed) is op(!transposed) over the same weight tensor with input / output channels trading places
+    // (conv2d_gradfix.py:139-143); x_h / x_w fix the output_padding when that op is the transposed one
+    return p3d_conv2d_forward(gy, weight, gx, w_scratch, zeros128, dtype, n_img, gy_h, gy_w, co, ci, kernel_size, stride, !transposed, x_h, x_w, stream);
+}
+
+extern "C" int64_t p3d_conv2d_bwd_weight_workspace(int dtype, int32_t n_img, int32_t small_h, int32_t small_w, int32_t c_small, int32_t c_big, int32_t kernel_size)
+{
+    int ksplit, chunks, cps;
+    const int taps = wgrad_plan(dtype, (int64_t)n_img * small_h * small_w, c_small, c_big, kernel_size, &ksplit, &chunks, &cps);
+    return (int64_t)ksplit * taps * (ceil_div(c_small, 128) * 128) * (ceil_div(c_big, 128) * 128) * 4;
+}
+
+extern "C" int p3d_conv2d_bwd_weight(const void* small_img, const void* big_img, void* gw, void* workspace, int64_t workspace_bytes, int dtype,
+                                     int32_t n_img, int32_t small_h, int32_t small_w, int32_t c_small, int32_t big_h, int32_t big_w, int32_t c_big,
+                                     int32_t kernel_size, int32_t stride, int32_t pad, p3d_stream_t stream)
+{
+    P3D_REQUIRE(small_img && big_img && gw && workspace, "conv2d_bwd_weight: null pointer");
+    P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32, "conv2d_bwd_weight: dtype must be fp16 or fp32");
+    P3D_REQUIRE(n_img >= 1 && small_h >= 1 && small_w >= 1 && big_h >= 1 && big_w >= 1 && c_small >= 1 && c_big >= 1, "conv2d_bwd_weight: bad sizes");
+    P3D_REQUIRE((kernel_size == 1 || kernel_size == 3) && (stride == 1 || stride == 2) && pad >= 0 && pad <= 1, "conv2d_bwd_weight: k in {1,3}, stride in {1,2}, pad in {0,1}");
+    P3D_REQUIRE(workspace_bytes >= p3d_conv2d_bwd_weight_workspace(dtype, n_img, small_h, small_w, c_small, c_big, kernel_size), "conv2d_bwd_weight: workspace too small");
+    P3D_REQUIRE((((uintptr_t)workspace) & 15u) == 0, "conv2d_bwd_weight: workspace must be 16-byte aligned");
+    WgradArgs a{};
+    a.s = small_img; a.b = big_img; a.ws = (float*)workspace;
+    a.N = n_img; a.HS = small_h; a.WS = small_w; a.Cs = c_small; a.HB = big_h; a.WB = big_w; a.Cb = c_big;
+    a.k = kernel_size; a.stride = stride; a.pad = pad;
+    const int taps = wgrad_plan(dtype, (int64_t)n_img * small_h * small_w, c_small, c_big, kernel_size, &a.ksplit, &a.chunks, &a.chunks_per_split);
+    a.tiles_s = ceil_div(c_small, 128); a.tiles_b = ceil_div(c_big, 128);
+    a.CsP = a.tiles_s * 128; a.CbP = a.tiles_b * 128;
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = a.ksplit * a.tiles_s * a.tiles_b * taps;
+    if (dtype == P3D_F16) hipLaunchKernelGGL(conv_wgrad_kernel<__half>, dim3(blocks), dim3(256), 0, s, a);
+    else                  hipLaunchKernelGGL(conv_wgrad_kernel<float>, dim3(blocks), dim3(256), 0, s, a);
+    count_launch(FAM_CONV);
+    int rc = check_launch("conv_wgrad");
+    if (rc != P3D_OK) return rc;
+    const int64_t total = (int64_t)c_small * c_big;
+    const int rblocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (dtype == P3D_F16) hipLaunchKernelGGL(wgrad_reduce_kernel<__half>, dim3(rblocks), dim3(256), 0, s, a.ws, (__half*)gw, c_small, c_big, taps, a.ksplit, a.CsP, a.CbP);
+    else                  hipLaunchKernelGGL(wgrad_reduce_kernel<float>, dim3(rblocks), dim3(256), 0, s, a.ws, (float*)gw, c_small, c_big, taps, a.ksplit, a.CsP, a.CbP);
+    count_launch(FAM_CONV);
+    return check_launch("conv_wgrad reduce");
+}

@@ -22,7 +22,7 @@ int check_launch(const char* what) {
 
 extern "C" {
 const char* p3d_last_error(void) { return p3d::g_err; }
-int p3d_abi_version(void) { return 2; }
+int p3d_abi_version(void) { return 3; }
 uint64_t p3d_launch_count(void) {
     uint64_t s = 0; for (int i = 0; i < p3d::FAM_COUNT; ++i) s += p3d::g_launches[i].load(); return s;
 }

@@ -4,12 +4,19 @@ weight gradients (used for R1, loss.py:873).  Mirror of torch_utils/ops/conv2d_g
 Every derivative of a convolution is again a convolution of the same family, so one autograd
 Function (``_Conv``) expresses data gradients as the transposed op and a second one
 (``_ConvWeightGrad``) the weight gradient; both route their dense arithmetic through
-``_conv_impl`` / ``_weight_grad_impl`` — the single place where the MFMA implicit-GEMM kernels of
-libp3d_hip.so (csrc/conv2d.hip) take over from the vendor library for the shapes they cover.
+``_conv_impl`` / ``_weight_grad_impl``.  For device tensors those two call libp3d_hip.so
+(``p3d_conv2d_forward`` / ``p3d_conv2d_bwd_weight``, csrc/conv2d_grad.hip: MFMA implicit GEMM,
+channels-last, fp16 / fp32) for every geometry conv2d_resample ever asks for — 1x1 and 3x3 at
+stride 1 with "same" padding, 3x3 at stride 2 without padding, plain and transposed — so neither
+the forward nor any gradient order of a training step enters the vendor convolution library.
+Anything else (groups, dilation, other strides; CPU tensors) takes torch's own operators.
 """
 import contextlib
+import ctypes
 
 import torch
+
+from ... import _lib
 
 enabled = False                     # set True by training_loop.py:281
 weight_gradients_disabled = False   # toggled by no_weight_gradients()
@@ -77,8 +84,82 @@ class _Cfg:
         return _Cfg(not self.transpose, self.wshape, self.stride, self.padding, op, self.dilation, self.groups)
 
 
+native = True              # device tensors of the covered family go to libp3d_hip.so; False = torch's operators everywhere
+native_calls = {'forward': 0, 'weight_grad': 0, 'aten': 0}      # which route the dense arithmetic took (tests)
+
+_vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+_lib.register('p3d_conv2d_forward', ctypes.c_int, [_vp] * 5 + [ctypes.c_int] + [_i32] * 10 + [_vp])
+_lib.register('p3d_conv2d_bwd_data', ctypes.c_int, [_vp] * 5 + [ctypes.c_int] + [_i32] * 10 + [_vp])
+_lib.register('p3d_conv2d_bwd_weight_workspace', _i64, [ctypes.c_int] + [_i32] * 6)
+_lib.register('p3d_conv2d_bwd_weight', ctypes.c_int, [_vp] * 4 + [_i64, ctypes.c_int] + [_i32] * 10 + [_vp])
+
+_zero_pages = {}
+
+
+def _zeros_page(device):
+    z = _zero_pages.get(device)
+    if z is None:
+        z = _zero_pages[device] = torch.zeros(256, dtype=torch.float32, device=device)
+    return z
+
+
+def _native_geometry(x, w, cfg):
+    """(k, stride) when libp3d_hip.so covers this op for these tensors, else None."""
+    if not native or not x.is_cuda or x.dtype not in (torch.float16, torch.float32) or w.dtype != x.dtype or x.ndim != 4:
+        return None
+    kh, kw = cfg.wshape[2:]
+    if cfg.groups != 1 or cfg.dilation != (1, 1) or kh != kw or kh not in (1, 3) or cfg.stride[0] != cfg.stride[1] or cfg.padding[0] != cfg.padding[1]:
+        return None
+    if cfg.stride == (1, 1) and cfg.padding == (kh // 2, kh // 2) and cfg.output_padding == (0, 0):
+        return kh, 1
+    if kh == 3 and cfg.stride == (2, 2) and cfg.padding == (0, 0) and all(o in (0, 1) for o in cfg.output_padding):
+        return 3, 2
+    return None
+
+
+def _channels_last(t):
+    return t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
+
+
+def _native_conv(x, w, cfg, k, stride):
+    """One launch of p3d_conv2d_forward (+ the weight re-layout it does): x any dense layout -> y channels-last."""
+    n, ci, h, wd = x.shape
+    tr = cfg.transpose
+    co = w.shape[1] if tr else w.shape[0]
+    assert w.shape[0 if tr else 1] == ci, 'conv2d_gradfix: weight / input channel mismatch'
+    if not tr:
+        oh, ow = (h, wd) if stride == 1 else ((h - 3) // 2 + 1, (wd - 3) // 2 + 1)
+    else:
+        oh, ow = (h, wd) if stride == 1 else (2 * h + 1 + cfg.output_padding[0], 2 * wd + 1 + cfg.output_padding[1])
+    mult = 64 if x.dtype == torch.float16 else 32
+    skinny = k == 1 and (ci % mult != 0 or co < 32)
+    x = _channels_last(x)
+    w = w.contiguous()
+    if not skinny and ci % mult != 0 and not (tr and stride == 2 and x.dtype == torch.float16 and ci % 32 == 0 and co % 128 == 0 and h >= 32 and wd >= 32):
+        cip = (ci + mult - 1) // mult * mult            # whole K rows for the matrix-core kernel: zero channels change nothing
+        xp = torch.empty([n, cip, h, wd], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        xp[:, :ci] = x
+        xp[:, ci:] = 0
+        wshape = list(w.shape)
+        wshape[0 if tr else 1] = cip - ci
+        w = torch.cat([w, w.new_zeros(wshape)], dim=0 if tr else 1).contiguous()
+        x, ci = xp, cip
+    y = torch.empty([n, co, oh, ow], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    scratch = None if skinny else torch.empty([co * ci * k * k], dtype=x.dtype, device=x.device)
+    code = _lib.lib().p3d_conv2d_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), _lib.ptr(scratch), _lib.ptr(_zeros_page(x.device)), _lib.DTYPE_CODE[x.dtype],
+                                         n, h, wd, ci, co, k, stride, int(tr), oh if tr and stride == 2 else 0, ow if tr and stride == 2 else 0, _lib.stream_of(x))
+    _lib.check(code, 'conv2d_forward')
+    native_calls['forward'] += 1
+    return y
+
+
 def _conv_impl(x, w, b, cfg):
     """Dense arithmetic of one (possibly transposed) convolution."""
+    geo = _native_geometry(x, w, cfg)
+    if geo is not None:
+        y = _native_conv(x, w, cfg, *geo)
+        return y if b is None else y + b.to(y.dtype).reshape(1, -1, 1, 1)
+    native_calls['aten'] += 1
     if not cfg.transpose:
         return torch.nn.functional.conv2d(x, w, b, stride=cfg.stride, padding=cfg.padding, dilation=cfg.dilation, groups=cfg.groups)
     return torch.nn.functional.conv_transpose2d(x, w, b, stride=cfg.stride, padding=cfg.padding, output_padding=cfg.output_padding,
@@ -89,8 +170,30 @@ def _is_pointwise(cfg):
     return cfg.wshape[2:] == (1, 1) and cfg.stride == (1, 1) and cfg.dilation == (1, 1) and cfg.padding == (0, 0)
 
 
+def _native_weight_grad(grad_output, x, cfg, k, stride):
+    """p3d_conv2d_bwd_weight: the SMALL image of (x, grad_output) is correlated against the big one, pixels are the contraction."""
+    small, big = (x, grad_output) if cfg.transpose else (grad_output, x)
+    small, big = _channels_last(small), _channels_last(big)
+    n, cs, hs, ws_ = small.shape
+    _, cb, hb, wb = big.shape
+    assert (cs, cb) == tuple(cfg.wshape[:2]) and big.shape[0] == n
+    gw = torch.empty(cfg.wshape, dtype=x.dtype, device=x.device)
+    code_dtype = _lib.DTYPE_CODE[x.dtype]
+    nbytes = int(_lib.lib().p3d_conv2d_bwd_weight_workspace(code_dtype, n, hs, ws_, cs, cb, k))
+    work = torch.empty([nbytes // 4], dtype=torch.float32, device=x.device)
+    code = _lib.lib().p3d_conv2d_bwd_weight(_lib.ptr(small), _lib.ptr(big), _lib.ptr(gw), _lib.ptr(work), nbytes, code_dtype, n, hs, ws_, cs, hb, wb, cb,
+                                            k, stride, cfg.padding[0], _lib.stream_of(gw))
+    _lib.check(code, 'conv2d_bwd_weight')
+    native_calls['weight_grad'] += 1
+    return gw
+
+
 def _weight_grad_impl(grad_output, x, cfg):
     """d(weight) for y = conv(x, w): for the transposed op the roles of x and grad_output swap."""
+    geo = None if grad_output.dtype != x.dtype else _native_geometry(x, torch.empty(0, dtype=x.dtype), cfg)
+    if geo is not None:
+        return _native_weight_grad(grad_output, x, cfg, *geo)
+    native_calls['aten'] += 1
     if _is_pointwise(cfg) and not cfg.transpose:          # 1x1: a batched matmul over pixels (conv2d_gradfix.py:165-170)
         g = cfg.groups
         a = grad_output.reshape(grad_output.shape[0], g, grad_output.shape[1] // g, -1).permute(1, 2, 0, 3).flatten(2)
@@ -109,7 +212,7 @@ class _Conv(torch.autograd.Function):
         assert w.shape == cfg.wshape
         ctx.save_for_backward(x if w.requires_grad else None, w if x.requires_grad else None)
         ctx.cfg, ctx.x_shape = cfg, x.shape
-        if _is_pointwise(cfg) and not cfg.transpose and cfg.groups == 1 and x.stride(1) != 1:
+        if _is_pointwise(cfg) and not cfg.transpose and cfg.groups == 1 and x.stride(1) != 1 and _native_geometry(x, w, cfg) is None:
             # 1x1 as a matmul keeps NCHW layout work off the conv path (conv2d_gradfix.py:117-124)
             y = (w.reshape(w.shape[0], -1) @ x.reshape(x.shape[0], x.shape[1], -1)).reshape(x.shape[0], w.shape[0], *x.shape[2:])
             return y if b is None else y + b.reshape(1, -1, 1, 1)

@@ -9,7 +9,7 @@ import torch
 
 from ..torch_utils import misc
 from ..torch_utils import persistence
-from ..torch_utils.ops import conv2d_resample, upfirdn2d, bias_act, fma, modconv
+from ..torch_utils.ops import conv2d_resample, conv2d_gradfix, upfirdn2d, bias_act, fma, modconv
 
 
 @misc.profiled_function
@@ -289,7 +289,16 @@ def _block_mode(block, ws, force_fp32, fused_modconv):
         # inference on the device: channels-last is the layout the MFMA conv kernels consume (any dtype); the low-resolution
         # blocks run as batched GEMMs on plain NCHW and are left alone (a layout round trip per layer is pure launch latency)
         fmt = torch.channels_last if block.resolution ** 2 > modconv.gemm_max_pixels else torch.contiguous_format
+    elif _native_training(ws):
+        fmt = torch.channels_last
     return dtype, fmt, fused_modconv
+
+
+def _native_training(t):
+    """Training-mode pass on the device with conv2d_gradfix's native route on: every convolution (and each of its gradients)
+    consumes and produces channels-last tensors, so the blocks keep their activations that way and no layout copy sits between
+    layers (the reference only does this for fp16 under ``fp16_channels_last``)."""
+    return native_channels_last and t.device.type == 'cuda' and conv2d_gradfix.enabled and conv2d_gradfix.native and torch.is_grad_enabled()
 
 
 @persistence.persistent_class
@@ -517,6 +526,8 @@ class DiscriminatorBlock(torch.nn.Module):
         probe = x if x is not None else img
         if native_channels_last and modconv.enabled and probe.is_cuda and not torch.is_grad_enabled() and self.resolution ** 2 > modconv.gemm_max_pixels:
             fmt = torch.channels_last      # inference on the device: the layout the MFMA conv kernels consume and produce
+        elif _native_training(probe):
+            fmt = torch.channels_last
         if x is not None:
             misc.assert_shape(x, [None, self.in_channels, self.resolution, self.resolution])
             x = x.to(dtype=dtype, memory_format=fmt)

@@ -57,3 +57,19 @@ def test_discriminator_dboth_phase_matches_reference_cpu(name):
 @pytest.mark.parametrize('name', list(CASES))
 def test_discriminator_dboth_phase_matches_reference_device(name):
     _dboth(name, 'cuda', 2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', list(CASES))
+def test_discriminator_dboth_phase_on_the_native_convolutions(hip_lib, name):
+    """The same phase as the training loop runs it (conv2d_gradfix.enabled = True, training_loop.py:281): every convolution, its
+    data gradient, the R1 double-backward and the weight gradients go through libp3d_hip.so — none through torch's operators."""
+    from pix2pix3d_amd.torch_utils.ops import conv2d_gradfix
+    prev, conv2d_gradfix.enabled = conv2d_gradfix.enabled, True
+    c0 = dict(conv2d_gradfix.native_calls)
+    try:
+        _dboth(name, 'cuda', 2e-3)
+    finally:
+        conv2d_gradfix.enabled = prev
+    assert conv2d_gradfix.native_calls['aten'] == c0['aten'], conv2d_gradfix.native_calls
+    assert conv2d_gradfix.native_calls['forward'] > c0['forward'] + 10 and conv2d_gradfix.native_calls['weight_grad'] > c0['weight_grad'] + 5
