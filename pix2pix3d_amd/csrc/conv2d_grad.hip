@@ -180,8 +180,9 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
                 T* img = lds[buf][op];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {                                   // register e of each pixel = channels 2e, 2e+1
-                    const unsigned v0 = __builtin_bit_cast(unsigned, r[0][e]), v1 = __builtin_bit_cast(unsigned, r[1][e]);
-                    const unsigned v2 = __builtin_bit_cast(unsigned, r[2][e]), v3 = __builtin_bit_cast(unsigned, r[3][e]);
+                    // (element first, THEN reinterpret: __builtin_bit_cast applied to a vector-element expression reads element 0)
+                    const float f0 = r[0][e], f1 = r[1][e], f2 = r[2][e], f3 = r[3][e];
+                    const unsigned v0 = __float_as_uint(f0), v1 = __float_as_uint(f1), v2 = __float_as_uint(f2), v3 = __float_as_uint(f3);
                     // (the compiler turns these into one v_perm_b32 / v_pack each)
                     const unsigned lo01 = (v0 & 0xffffu) | (v1 << 16), lo23 = (v2 & 0xffffu) | (v3 << 16);
                     const unsigned hi01 = (v0 >> 16) | (v1 & 0xffff0000u), hi23 = (v2 >> 16) | (v3 & 0xffff0000u);

@@ -18,53 +18,63 @@ def normalize_2nd_moment(x, dim=1, eps=1e-8):
     return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
 
 
+def _fp16_prescale(weight, styles):
+    """Keep fp16 products in range before demodulation cancels the scale again (:54-56): each output filter and each sample's style
+    vector is divided by its largest magnitude (the filters additionally by sqrt(fan_in))."""
+    cout, cin, kh, kw = weight.shape
+    peak_w = weight.abs().amax(dim=(1, 2, 3), keepdim=True)
+    peak_s = styles.abs().amax(dim=1, keepdim=True)
+    return weight / (peak_w * np.sqrt(cin * kh * kw)), styles / peak_s
+
+
+def _demod_coefficients(weight, styles):
+    """rsqrt(sum_{i,ky,kx} (w[o,i,ky,kx] * s[n,i])^2 + 1e-8) as [N, O] (:65) — the taps are summed first, so the [N,O,I,k,k] product
+    the reference forms for this is never materialised: one [N,I] x [I,O] product."""
+    energy = weight.square().sum(dim=(2, 3))                     # [O, I]
+    return torch.rsqrt(styles.square() @ energy.t() + 1e-8)
+
+
+def _per_sample_conv(x, w_each, **resample):
+    """One grouped convolution applying sample n's own filter bank w_each[n] to image n (:81-88)."""
+    n, cin = x.shape[:2]
+    cout, kh, kw = w_each.shape[1], w_each.shape[3], w_each.shape[4]
+    flat = conv2d_resample.conv2d_resample(x=x.reshape(1, n * cin, *x.shape[2:]), w=w_each.reshape(n * cout, cin, kh, kw).to(x.dtype), groups=n, **resample)
+    return flat.reshape(n, cout, *flat.shape[2:])
+
+
 @misc.profiled_function
 def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None,
                      demodulate=True, flip_weight=True, fused_modconv=True):
-    """Style-modulated convolution (:34-91).  x [N,I,H,W], weight [O,I,k,k], styles [N,I].
+    """Style-modulated convolution (:34-91).  x [N,I,H,W], weight [O,I,k,k], styles [N,I], noise broadcastable to the output.
 
-    fused: per-sample weights w*s (optionally demodulated) run as one grouped conv.
-    unfused: activations are pre-scaled by s, a shared-weight conv runs, and the demodulation
-    coefficient (and noise) is applied afterwards — algebraically the same result."""
+    fused: every sample gets its own filters w * s (times the demodulation coefficient) and the batch runs as one grouped conv.
+    unfused: the styles scale the activations, ONE shared-weight conv runs, and the demodulation coefficient (with the noise) is
+    applied to its output — the same function, and the form whose weight gradient is a plain convolution gradient."""
     n = x.shape[0]
-    o, i, kh, kw = weight.shape
-    misc.assert_shape(weight, [o, i, kh, kw])
-    misc.assert_shape(x, [n, i, None, None])
-    misc.assert_shape(styles, [n, i])
+    cout, cin, kh, kw = weight.shape
+    misc.assert_shape(x, [n, cin, None, None])
+    misc.assert_shape(styles, [n, cin])
+    if demodulate and x.dtype == torch.float16:
+        weight, styles = _fp16_prescale(weight, styles)
+    demod = _demod_coefficients(weight, styles) if demodulate else None
+    resample = dict(f=resample_filter, up=up, down=down, padding=padding, flip_weight=flip_weight)
 
-    if x.dtype == torch.float16 and demodulate:                      # keep fp16 products in range (:54-56)
-        weight = weight * (1 / np.sqrt(i * kh * kw) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
-        styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
+    if fused_modconv:
+        w_each = weight.unsqueeze(0) * styles.reshape(n, 1, cin, 1, 1)
+        if demod is not None:
+            w_each = w_each * demod.reshape(n, cout, 1, 1, 1)
+        y = _per_sample_conv(x, w_each, **resample)
+        return y if noise is None else y.add_(noise)
 
-    w_mod = dcoefs = None
-    if demodulate or fused_modconv:
-        w_mod = weight.unsqueeze(0) * styles.reshape(n, 1, -1, 1, 1)              # [N,O,I,k,k]
-    if demodulate:
-        dcoefs = (w_mod.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt()               # [N,O]
-    if demodulate and fused_modconv:
-        w_mod = w_mod * dcoefs.reshape(n, -1, 1, 1, 1)
-
-    if not fused_modconv:
-        x = x * styles.to(x.dtype).reshape(n, -1, 1, 1)
-        x = conv2d_resample.conv2d_resample(x=x, w=weight.to(x.dtype), f=resample_filter, up=up, down=down, padding=padding, flip_weight=flip_weight)
-        if demodulate and noise is not None:
-            x = fma.fma(x, dcoefs.to(x.dtype).reshape(n, -1, 1, 1), noise.to(x.dtype))
-        elif demodulate:
-            x = x * dcoefs.to(x.dtype).reshape(n, -1, 1, 1)
-        elif noise is not None:
-            x = x.add_(noise.to(x.dtype))
-        return x
-
-    with misc.suppress_tracer_warnings():
-        n = int(n)
-    misc.assert_shape(x, [n, i, None, None])
-    x = x.reshape(1, -1, *x.shape[2:])
-    x = conv2d_resample.conv2d_resample(x=x, w=w_mod.reshape(-1, i, kh, kw).to(x.dtype), f=resample_filter, up=up, down=down,
-                                        padding=padding, groups=n, flip_weight=flip_weight)
-    x = x.reshape(n, -1, *x.shape[2:])
+    y = conv2d_resample.conv2d_resample(x=x * styles.to(x.dtype).reshape(n, cin, 1, 1), w=weight.to(x.dtype), **resample)
+    scale = None if demod is None else demod.to(y.dtype).reshape(n, cout, 1, 1)
     if noise is not None:
-        x = x.add_(noise)
-    return x
+        noise = noise.to(y.dtype)
+    if scale is not None and noise is not None:
+        return fma.fma(y, scale, noise)
+    if scale is not None:
+        return y * scale
+    return y if noise is None else y.add_(noise)
 
 
 @persistence.persistent_class
@@ -87,15 +97,13 @@ class FullyConnectedLayer(torch.nn.Module):
         return y if out_scale == 1 else y * out_scale
 
     def _forward(self, x):
+        """Generic route: equalised-learning-rate gains applied at run time, the affine map as one library call, anything but the
+        identity activation through bias_act."""
         w = self.weight.to(x.dtype) * self.weight_gain
-        b = self.bias
-        if b is not None:
-            b = b.to(x.dtype)
-            if self.bias_gain != 1:
-                b = b * self.bias_gain
-        if self.activation == 'linear' and b is not None:
-            return torch.addmm(b.unsqueeze(0), x, w.t())
-        return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
+        b = None if self.bias is None else self.bias.to(x.dtype) * self.bias_gain
+        if self.activation == 'linear':
+            return torch.nn.functional.linear(x, w, b)
+        return bias_act.bias_act(torch.nn.functional.linear(x, w), b, act=self.activation)
 
     def extra_repr(self):
         return f'in_features={self.in_features:d}, out_features={self.out_features:d}, activation={self.activation:s}'
@@ -143,6 +151,27 @@ class Conv2dLayer(torch.nn.Module):
         return f'in_channels={self.in_channels:d}, out_channels={self.out_channels:d}, activation={self.activation:s}, up={self.up}, down={self.down}'
 
 
+def track_w_avg(net, w):
+    """Exponential moving average of the mapping output, ``net.w_avg`` (:258-260); no-op for networks that do not track one."""
+    if getattr(net, 'w_avg_beta', None) is None:
+        return
+    with torch.autograd.profiler.record_function('update_w_avg'):
+        net.w_avg.copy_(w.detach().mean(dim=0).lerp(net.w_avg, net.w_avg_beta))
+
+
+def truncate_ws(net, ws, psi, cutoff):
+    """Truncation trick (:267-273): pull ws towards ``net.w_avg`` by ``psi``; with a cutoff only the first ``cutoff`` layers (in place,
+    as the reference does).  psi == 1 returns ws untouched."""
+    if psi == 1:
+        return ws
+    assert net.w_avg_beta is not None
+    with torch.autograd.profiler.record_function('truncate'):
+        if net.num_ws is None or cutoff is None:
+            return net.w_avg.lerp(ws, psi)
+        ws[:, :cutoff] = net.w_avg.lerp(ws[:, :cutoff], psi)
+        return ws
+
+
 @persistence.persistent_class
 class MappingNetwork(torch.nn.Module):
     """z (and optional label c) -> ws [N, num_ws, w_dim], with w_avg tracking and truncation (:193-272)."""
@@ -166,31 +195,21 @@ class MappingNetwork(torch.nn.Module):
             self.register_buffer('w_avg', torch.zeros([w_dim]))
 
     def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False):
-        x = None
-        with torch.autograd.profiler.record_function('input'):
-            if self.z_dim > 0:
-                misc.assert_shape(z, [None, self.z_dim])
-                x = normalize_2nd_moment(z.to(torch.float32))
-            if self.c_dim > 0:
-                misc.assert_shape(c, [None, self.c_dim])
-                y = normalize_2nd_moment(self.embed(c.to(torch.float32)))
-                x = torch.cat([x, y], dim=1) if x is not None else y
+        feats = []
+        if self.z_dim > 0:
+            misc.assert_shape(z, [None, self.z_dim])
+            feats.append(normalize_2nd_moment(z.to(torch.float32)))
+        if self.c_dim > 0:
+            misc.assert_shape(c, [None, self.c_dim])
+            feats.append(normalize_2nd_moment(self.embed(c.to(torch.float32))))
+        x = feats[0] if len(feats) == 1 else torch.cat(feats, dim=1)
         for idx in range(self.num_layers):
             x = getattr(self, f'fc{idx}')(x)
-        if update_emas and self.w_avg_beta is not None:
-            with torch.autograd.profiler.record_function('update_w_avg'):
-                self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+        if update_emas:
+            track_w_avg(self, x)
         if self.num_ws is not None:
-            with torch.autograd.profiler.record_function('broadcast'):
-                x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
-        if truncation_psi != 1:
-            with torch.autograd.profiler.record_function('truncate'):
-                assert self.w_avg_beta is not None
-                if self.num_ws is None or truncation_cutoff is None:
-                    x = self.w_avg.lerp(x, truncation_psi)
-                else:
-                    x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
-        return x
+            x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+        return truncate_ws(self, x, truncation_psi, truncation_cutoff)
 
     def extra_repr(self):
         return f'z_dim={self.z_dim:d}, c_dim={self.c_dim:d}, w_dim={self.w_dim:d}, num_ws={self.num_ws:d}'
@@ -335,46 +354,52 @@ class SynthesisBlock(torch.nn.Module):
     _in_div = 2          # input resolution = resolution // _in_div (the NoUp variant in superresolution.py uses 1)
 
     def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, **layer_kwargs):
-        _ = update_emas
+        del update_emas
         misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
-        w_iter = iter(ws.unbind(dim=1))
         dtype, fmt, fused_modconv = _block_mode(self, ws, force_fp32, fused_modconv)
+        per_layer = list(ws.unbind(dim=1))                       # one w per conv layer, then one for ToRGB
+        conv_kwargs = dict(layer_kwargs, fused_modconv=fused_modconv)
 
+        x = self._entry_features(x, ws.shape[0], dtype, fmt)
         if self.in_channels == 0:
-            x = self.const.to(dtype=dtype).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1]).contiguous(memory_format=fmt)
-        else:
-            misc.assert_shape(x, [None, self.in_channels, self.resolution // self._in_div, self.resolution // self._in_div])
-            if fmt == torch.channels_last and native_channels_last and modconv.is_small(x, self._in_div) and x.is_cuda and not torch.is_grad_enabled():
-                x = x.to(dtype=dtype)     # first MFMA-sized block: its x2 layer still takes the GEMM route on NCHW; conv1 converts
-            else:
-                x = x.to(dtype=dtype, memory_format=fmt)
-
-        if self.in_channels == 0:
-            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+            x = self.conv1(x, per_layer[0], **conv_kwargs)
         elif self.architecture == 'resnet':
-            y = self.skip(x, gain=np.sqrt(0.5))
-            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
-            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, gain=np.sqrt(0.5), **layer_kwargs)
-            x = y.add_(x)
+            shortcut = self.skip(x, gain=np.sqrt(0.5))
+            x = self.conv0(x, per_layer[0], **conv_kwargs)
+            x = self.conv1(x, per_layer[1], gain=np.sqrt(0.5), **conv_kwargs)
+            x = shortcut.add_(x)
         else:
-            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
-            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+            x = self.conv1(self.conv0(x, per_layer[0], **conv_kwargs), per_layer[1], **conv_kwargs)
 
-        if img is not None and self._in_div == 2:
+        if img is not None and self._in_div == 2:                # carry the running image to this block's resolution
             misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
             img = upfirdn2d.upsample2d(img, self.resample_filter)
         if self.is_last or self.architecture == 'skip':
-            y = self.torgb(x, next(w_iter), fused_modconv=fused_modconv)
-            wide_cl = fmt == torch.channels_last and y.shape[1] > 8 and y.shape[1] % 4 == 0
-            # a wide skip image (the 96-channel tri-planes) stays channels-last end to end: the ray-marcher reads it in place
-            y = y.to(dtype=torch.float32, memory_format=torch.channels_last if wide_cl else torch.contiguous_format)
-            if img is not None and wide_cl and not img.is_contiguous(memory_format=torch.channels_last):
-                img = img.contiguous(memory_format=torch.channels_last)     # the skip image turns channels-last where the blocks do
-            img = img.add_(y) if img is not None else y
+            img = self._accumulate_image(img, self.torgb(x, per_layer[self.num_conv], fused_modconv=fused_modconv), fmt)
 
-        assert x.dtype == dtype
-        assert img is None or img.dtype == torch.float32
+        assert x.dtype == dtype and (img is None or img.dtype == torch.float32)
         return x, img
+
+    def _entry_features(self, x, batch, dtype, fmt):
+        """The block's input activations in its working dtype / layout: the learned constant for b4, else the previous block's x."""
+        if self.in_channels == 0:
+            return self.const.to(dtype=dtype).unsqueeze(0).repeat([batch, 1, 1, 1]).contiguous(memory_format=fmt)
+        in_res = self.resolution // self._in_div
+        misc.assert_shape(x, [None, self.in_channels, in_res, in_res])
+        if fmt == torch.channels_last and native_channels_last and modconv.is_small(x, self._in_div) and x.is_cuda and not torch.is_grad_enabled():
+            return x.to(dtype=dtype)      # first MFMA-sized block: its x2 layer still takes the GEMM route on NCHW; conv1 converts
+        return x.to(dtype=dtype, memory_format=fmt)
+
+    def _accumulate_image(self, img, y, fmt):
+        """Skip-connection image: fp32 sum of every block's ToRGB output.  A wide image (the 96-channel tri-planes) stays
+        channels-last where the blocks are, so the ray-marcher reads it in place."""
+        wide_cl = fmt == torch.channels_last and y.shape[1] > 8 and y.shape[1] % 4 == 0
+        y = y.to(dtype=torch.float32, memory_format=torch.channels_last if wide_cl else torch.contiguous_format)
+        if img is None:
+            return y
+        if wide_cl and not img.is_contiguous(memory_format=torch.channels_last):
+            img = img.contiguous(memory_format=torch.channels_last)
+        return img.add_(y)
 
     def extra_repr(self):
         return f'resolution={self.resolution:d}, architecture={self.architecture:s}'
@@ -519,34 +544,36 @@ class DiscriminatorBlock(torch.nn.Module):
                                     resample_filter=resample_filter, channels_last=self.channels_last)
 
     def forward(self, x, img, force_fp32=False):
-        if (x if x is not None else img).device.type != 'cuda':
-            force_fp32 = True
-        dtype = torch.float16 if self.use_fp16 and not force_fp32 else torch.float32
-        fmt = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
-        probe = x if x is not None else img
-        if native_channels_last and modconv.enabled and probe.is_cuda and not torch.is_grad_enabled() and self.resolution ** 2 > modconv.gemm_max_pixels:
-            fmt = torch.channels_last      # inference on the device: the layout the MFMA conv kernels consume and produce
-        elif _native_training(probe):
-            fmt = torch.channels_last
+        probe = img if x is None else x
+        dtype, fmt = self._working_format(probe, force_fp32)
         if x is not None:
             misc.assert_shape(x, [None, self.in_channels, self.resolution, self.resolution])
             x = x.to(dtype=dtype, memory_format=fmt)
-        if self.in_channels == 0 or self.architecture == 'skip':
+        if self.in_channels == 0 or self.architecture == 'skip':            # this block reads the image
             misc.assert_shape(img, [None, self.img_channels, self.resolution, self.resolution])
             img = img.to(dtype=dtype, memory_format=fmt)
-            y = self.fromrgb(img)
-            x = x + y if x is not None else y
+            feats = self.fromrgb(img)
+            x = feats if x is None else x + feats
             img = upfirdn2d.downsample2d(img, self.resample_filter) if self.architecture == 'skip' else None
         if self.architecture == 'resnet':
-            y = self.skip(x, gain=np.sqrt(0.5))
-            x = self.conv0(x)
-            x = self.conv1(x, gain=np.sqrt(0.5))
-            x = y.add_(x)
+            shortcut = self.skip(x, gain=np.sqrt(0.5))
+            x = shortcut.add_(self.conv1(self.conv0(x), gain=np.sqrt(0.5)))
         else:
-            x = self.conv0(x)
-            x = self.conv1(x)
+            x = self.conv1(self.conv0(x))
         assert x.dtype == dtype
         return x, img
+
+    def _working_format(self, probe, force_fp32):
+        """dtype / memory format of this block (:625-628) — fp32 NCHW off the device; channels-last wherever the native convolution
+        kernels run (inference above the GEMM-route size, and every training pass)."""
+        force_fp32 = force_fp32 or probe.device.type != 'cuda'
+        dtype = torch.float16 if self.use_fp16 and not force_fp32 else torch.float32
+        fmt = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
+        if native_channels_last and modconv.enabled and probe.is_cuda and not torch.is_grad_enabled() and self.resolution ** 2 > modconv.gemm_max_pixels:
+            fmt = torch.channels_last
+        elif _native_training(probe):
+            fmt = torch.channels_last
+        return dtype, fmt
 
     def extra_repr(self):
         return f'resolution={self.resolution:d}, architecture={self.architecture:s}'

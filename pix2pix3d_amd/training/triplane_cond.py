@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from .. import dnnlib
 from ..torch_utils import misc
 from ..torch_utils import persistence
-from .networks_stylegan2 import SynthesisNetwork, FullyConnectedLayer, normalize_2nd_moment, DiscriminatorBlock
+from .networks_stylegan2 import SynthesisNetwork, FullyConnectedLayer, normalize_2nd_moment, DiscriminatorBlock, track_w_avg, truncate_ws
 from .networks_stylegan2 import Generator as StyleGAN2Backbone
 from .triplane import OSGDecoder, _osg_mlp, _TriPlaneCore
 from .volumetric_rendering.renderer import ImportanceSemanticRenderer
@@ -138,36 +138,27 @@ class _EntangledMapping(torch.nn.Module):
         raise NotImplementedError
 
     def forward(self, z=None, c=None, batch=None, truncation_psi=1, truncation_cutoff=None, update_emas=False, **unused_kwargs):
-        x = None
-        with torch.autograd.profiler.record_function('input'):
-            if self.z_dim > 0:
-                misc.assert_shape(z, [None, self.z_dim])
-                x = normalize_2nd_moment(z.to(torch.float32))
-            cond = self._condition_image(batch)
-            misc.assert_shape(cond, [None, self.in_channels, self.in_resolution, self.in_resolution])
-            y = normalize_2nd_moment(getattr(self, self._encoder_name)(cond.to(torch.float32))['ws'].squeeze(1))
-            misc.assert_shape(y, [None, self.w_dim])
-            x = torch.cat([x.contiguous(), y.contiguous()], dim=1) if x is not None else y
-            if self.c_dim > 0:
-                misc.assert_shape(c, [None, self.c_dim])
-                e = normalize_2nd_moment(self.embed(c.to(torch.float32)))
-                x = torch.cat([x, e], dim=1) if x is not None else e
+        """MLP over cat(normalised z, normalised image embedding, normalised camera embedding); the same w for every layer."""
+        feats = []
+        if self.z_dim > 0:
+            misc.assert_shape(z, [None, self.z_dim])
+            feats.append(normalize_2nd_moment(z.to(torch.float32)).contiguous())
+        cond = self._condition_image(batch)
+        misc.assert_shape(cond, [None, self.in_channels, self.in_resolution, self.in_resolution])
+        emb = getattr(self, self._encoder_name)(cond.to(torch.float32))['ws'].squeeze(1)
+        misc.assert_shape(emb, [None, self.w_dim])
+        feats.append(normalize_2nd_moment(emb).contiguous())
+        if self.c_dim > 0:
+            misc.assert_shape(c, [None, self.c_dim])
+            feats.append(normalize_2nd_moment(self.embed(c.to(torch.float32))))
+        x = torch.cat(feats, dim=1) if len(feats) > 1 else feats[0]
         for idx in range(self.num_layers):
             x = getattr(self, f'fc{idx}')(x)
-        if self.w_avg_beta is not None and update_emas:
-            with torch.autograd.profiler.record_function('update_w_avg'):
-                self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+        if update_emas:
+            track_w_avg(self, x)
         if self.num_ws is not None:
-            with torch.autograd.profiler.record_function('broadcast'):
-                x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
-        if truncation_psi != 1:
-            with torch.autograd.profiler.record_function('truncate'):
-                assert self.w_avg_beta is not None
-                if self.num_ws is None or truncation_cutoff is None:
-                    x = self.w_avg.lerp(x, truncation_psi)
-                else:
-                    x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
-        return x
+            x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+        return truncate_ws(self, x, truncation_psi, truncation_cutoff)
 
 
 @persistence.persistent_class
@@ -227,37 +218,29 @@ class _DisentangledMapping(torch.nn.Module):
         raise NotImplementedError
 
     def forward(self, z=None, c=None, batch=None, truncation_psi=1, truncation_cutoff=None, update_emas=False, **unused_kwargs):
-        x = None
-        with torch.autograd.profiler.record_function('input'):
-            if self.z_dim > 0:
-                misc.assert_shape(z, [None, self.z_dim])
-                x = normalize_2nd_moment(z.to(torch.float32))
-            if self.c_dim > 0:
-                misc.assert_shape(c, [None, self.c_dim])
-                e = normalize_2nd_moment(self.embed(c.to(torch.float32)))
-                x = torch.cat([x, e], dim=1) if x is not None else e
+        """ws = [geometry ws from the conditioning image (Encoder, W+ mode)] ++ [the z / camera MLP's w, repeated]."""
+        feats = []
+        if self.z_dim > 0:
+            misc.assert_shape(z, [None, self.z_dim])
+            feats.append(normalize_2nd_moment(z.to(torch.float32)))
+        if self.c_dim > 0:
+            misc.assert_shape(c, [None, self.c_dim])
+            feats.append(normalize_2nd_moment(self.embed(c.to(torch.float32))))
+        x = torch.cat(feats, dim=1) if len(feats) > 1 else feats[0]
         for idx in range(self.num_layers):
             x = getattr(self, f'fc{idx}')(x)
 
-        cond = self._condition_image(batch, z.shape[0])
-        misc.assert_shape(cond, [z.shape[0], self.in_channels, self.in_resolution, self.in_resolution])
-        y = self.embed_mask(cond.to(torch.float32))['ws']                       # [N, 7, w_dim]
-        misc.assert_shape(y, [None, self.geometry_layer, self.w_dim])
-
+        batch_size = z.shape[0]
+        cond = self._condition_image(batch, batch_size)
+        misc.assert_shape(cond, [batch_size, self.in_channels, self.in_resolution, self.in_resolution])
+        geometry = self.embed_mask(cond.to(torch.float32))['ws']
+        misc.assert_shape(geometry, [None, self.geometry_layer, self.w_dim])
         if self.num_ws is not None:
-            with torch.autograd.profiler.record_function('broadcast'):
-                x = torch.cat([y, x.unsqueeze(1).repeat([1, self.num_ws - self.geometry_layer, 1])], dim=1)
-        if self.w_avg_beta is not None and update_emas:
-            with torch.autograd.profiler.record_function('update_w_avg'):
-                self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
-        if truncation_psi != 1:
-            with torch.autograd.profiler.record_function('truncate'):
-                assert self.w_avg_beta is not None
-                if self.num_ws is None or truncation_cutoff is None:
-                    x = self.w_avg.lerp(x, truncation_psi)
-                else:
-                    x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
-        return x
+            appearance = x.unsqueeze(1).repeat([1, self.num_ws - self.geometry_layer, 1])
+            x = torch.cat([geometry, appearance], dim=1)
+        if update_emas:
+            track_w_avg(self, x)
+        return truncate_ws(self, x, truncation_psi, truncation_cutoff)
 
 
 @persistence.persistent_class

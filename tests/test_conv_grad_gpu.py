@@ -90,7 +90,7 @@ def test_forward_and_first_order_gradients(hip_lib, gradfix, geom, dtype, layout
     assert gradfix.native_calls['aten'] == c0['aten']
     assert yd.shape == yr.shape and gxd.shape == xr.shape and gwd.shape == wr.shape
     tol = TOL[dtype]
-    e = dict(y=rel_err(yd.double().cpu(), yr.detach()), gx=rel_err(gxd.double().cpu(), gxr), gw=rel_err(gwd.double().cpu(), gwr))
+    e = dict(y=rel_err(yd.detach().double().cpu(), yr.detach()), gx=rel_err(gxd.double().cpu(), gxr), gw=rel_err(gwd.double().cpu(), gwr))
     print(geom[0], dtype, layout, e)
     assert e['y'] < tol and e['gx'] < tol and e['gw'] < tol, e
 

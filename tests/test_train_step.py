@@ -85,5 +85,5 @@ def test_training_step_goes_through_the_fused_renderer_backward(hip_lib):
     from pix2pix3d_amd.torch_utils.ops import conv2d_gradfix
     assert rmod.backward_calls['fused'] == b0['fused'] + 1 and rmod.backward_calls['replay'] == b0['replay'], rmod.backward_calls
     assert conv2d_gradfix.native_calls['aten'] == 0 or conv2d_gradfix.native_calls['forward'] > 0
-    assert _lib.launch_count('render') >= n0 + 3          # forward + tape sweep + point-wise backward
+    assert _lib.launch_count('render') >= n0 + 2          # the forward entry point + the backward entry point (two launches, counted once)
     _check(g, G, loss, 2e-3)
