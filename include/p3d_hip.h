@@ -195,13 +195,19 @@ int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype, const floa
  * ci = channels of x, co = channels of y in every call.  w_scratch: co*ci*k*k elements of the activation dtype, 16-byte aligned (the
  * tap-major re-layout the matrix-core kernels read; unused by the skinny 1x1 route, may then be null).  zeros128 as p3d_conv2d_nhwc.
  * Returns P3D_ERR_UNSUPPORTED when ci is not a multiple of 64 (fp16) / 32 (fp32) on the 3x3 routes: pad the channels.               */
+/* workspace: optional device scratch for the split-K schedule of low-resolution layers (a 512-channel 3x3 layer at 4^2 .. 32^2 is a
+ * handful of output tiles with a 144-step K loop: its K steps are dealt to many work-groups and a second launch sums them);
+ * p3d_conv2d_forward_workspace(...) says how many bytes a call would use (0: none), 16-byte aligned; null = never split.            */
 int p3d_conv2d_forward(const void* x, const void* weight, void* y, void* w_scratch, const void* zeros128, int dtype,
                        int32_t n_img, int32_t h, int32_t w, int32_t ci, int32_t co, int32_t kernel_size, int32_t stride,
-                       int32_t transposed, int32_t out_h, int32_t out_w, p3d_stream_t stream);
-/* gy [N][gy_h][gy_w][co] -> gx [N][x_h][x_w][ci], for the FORWARD op (ci -> co, weight, kernel_size, stride, transposed) described above */
+                       int32_t transposed, int32_t out_h, int32_t out_w, void* workspace, int64_t workspace_bytes, p3d_stream_t stream);
+int64_t p3d_conv2d_forward_workspace(int dtype, int32_t n_img, int32_t h, int32_t w, int32_t ci, int32_t co, int32_t kernel_size, int32_t stride,
+                                     int32_t transposed);
+/* gy [N][gy_h][gy_w][co] -> gx [N][x_h][x_w][ci], for the FORWARD op (ci -> co, weight, kernel_size, stride, transposed) described above;
+ * workspace as p3d_conv2d_forward_workspace(dtype, n_img, gy_h, gy_w, co, ci, kernel_size, stride, !transposed)                      */
 int p3d_conv2d_bwd_data(const void* gy, const void* weight, void* gx, void* w_scratch, const void* zeros128, int dtype,
                         int32_t n_img, int32_t gy_h, int32_t gy_w, int32_t ci, int32_t co, int32_t kernel_size, int32_t stride,
-                        int32_t transposed, int32_t x_h, int32_t x_w, p3d_stream_t stream);
+                        int32_t transposed, int32_t x_h, int32_t x_w, void* workspace, int64_t workspace_bytes, p3d_stream_t stream);
 /* gw[cs][cb][ky][kx] = sum_{n,i,j} small[n,i,j,cs] * big[n, i*stride + ky - pad, j*stride + kx - pad, cb]   (out-of-image = 0)
  * conv2d:           small = gy (cs = Co), big = x  (cb = Ci)  ->  gw [Co][Ci][k][k]
  * conv_transpose2d: small = x  (cs = Ci), big = gy (cb = Co)  ->  gw [Ci][Co][k][k]        (the roles swap, conv2d_gradfix.py:173)
@@ -211,6 +217,14 @@ int64_t p3d_conv2d_bwd_weight_workspace(int dtype, int32_t n_img, int32_t small_
 int p3d_conv2d_bwd_weight(const void* small_img, const void* big_img, void* gw, void* workspace, int64_t workspace_bytes, int dtype,
                           int32_t n_img, int32_t small_h, int32_t small_w, int32_t c_small, int32_t big_h, int32_t big_w, int32_t c_big,
                           int32_t kernel_size, int32_t stride, int32_t pad, p3d_stream_t stream);
+
+/* p3d_conv2d_nhwc with optional split-K scratch (see p3d_conv2d_forward): workspace of p3d_conv2d_nhwc_workspace(...) bytes, or null */
+int p3d_conv2d_nhwc_ws(const void* x, const void* w, void* y, int dtype, const float* bias, const float* noise, const float* noise_strength,
+                       const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
+                       int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, void* workspace, int64_t workspace_bytes,
+                       p3d_stream_t stream);
+int64_t p3d_conv2d_nhwc_workspace(int dtype, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride, int32_t kernel_size,
+                                  int32_t resample);
 
 /* x [N][HW][Ci] fp16 channels-last, weight [Co][Ci] fp32, styles [N][Ci] fp32 (weight gain already applied),
  * bias [Co] or null -> y [N][Co][HW] fp32 (NCHW); accumulate != 0 adds into y (the skip-image sum).

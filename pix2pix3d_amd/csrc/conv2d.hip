@@ -53,6 +53,9 @@ struct ConvArgs {
     float gain, clamp;     // clamp < 0: off
     int fold;              // != 0 (generic kernel, one class, shared weights): GEMM rows run over ALL images' pixels, m = n * SH * SW + pixel,
                            // so a batch of small images fills the 128-row tiles that one image cannot
+    int ksplit;            // > 1 (generic kernel): the K steps of a tile are dealt to `ksplit` work-groups (blockIdx.z % ksplit) whose fp32
+    float* partial;        // partial tiles go to partial[split][z][Mpad][CoP] and are summed + finished by splitk_epilogue_kernel — the
+                           // low-resolution layers (K = 4608, a handful of tiles) otherwise run 144 serial K steps on 8 of 256 CUs
 };
 
 // 16-B slot of (row, chunk).  Two 128-byte tile rows share one 256-byte LDS bank row, so the XOR key is (row >> 1) & 7:
@@ -71,8 +74,9 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
     __shared__ __attribute__((aligned(16))) f32x4 lds[2][2][BM * 8];          // [buffer][A|B][row*8 + chunk], 16-byte slots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;                                   // wave's 64x64 quadrant
-    const int n = a.fold ? 0 : blockIdx.z / a.ncls;
-    const ConvArgs::Cls& kc = a.cls[a.fold ? 0 : blockIdx.z - n * a.ncls];
+    const int split = blockIdx.z % a.ksplit, zz = blockIdx.z / a.ksplit;
+    const int n = a.fold ? 0 : zz / a.ncls;
+    const ConvArgs::Cls& kc = a.cls[a.fold ? 0 : zz - n * a.ncls];
     // XCD-aware tile order: workgroup L of a launch lands on XCD L % 8, each XCD with its own L2.  Consecutive slots
     // of one XCD get the output-channel blocks of the SAME pixel tile (they share the A operand), and pixel tiles
     // stride over XCDs, so an A neighbourhood is fetched into one L2 only.  Falls back to the plain order when the
@@ -144,7 +148,14 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    stage(0, 0, 0);
+    // K steps of this work-group: all of them, or its share of the split
+    const int nsteps = kchunks * ntaps;
+    const int steps_per = (nsteps + a.ksplit - 1) / a.ksplit;
+    const int s_begin = split * steps_per;
+    int s_end = s_begin + steps_per;
+    if (s_end > nsteps) s_end = nsteps;
+    int cc = s_begin / ntaps, t = s_begin - cc * ntaps;
+    if (s_begin < s_end) stage(cc, t, 0);
     __syncthreads();
     const int frow = lane & 31, fk = lane >> 5;                                 // fragment row / k-group of this lane
     int pa[2][4], pb[2][4];                                                     // fragment slots of this lane (buffer 0)
@@ -156,12 +167,10 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
             pb[i][kk] = swz(wn * 64 + i * 32 + frow, kk * 2 + fk);
         }
     int buf = 0;
-    for (int cc = 0; cc < kchunks; ++cc)
-        for (int t = 0; t < ntaps; ++t) {
+    for (int s = s_begin; s < s_end; ++s) {
             {                                                                   // next tile streams into the other buffer under the MFMAs
-                int t2 = t + 1, cc2 = cc;
-                if (t2 == ntaps) { t2 = 0; ++cc2; }
-                if (cc2 < kchunks) stage(cc2, t2, buf ^ 1);
+                if (++t == ntaps) { t = 0; ++cc; }
+                if (s + 1 < s_end) stage(cc, t, buf ^ 1);
             }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {                                    // 4 x 32 bytes of K per 128-byte row
@@ -187,6 +196,23 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
             __syncthreads();                                                    // drains the LDS-DMA (vmcnt) and fences the buffer swap
             buf ^= 1;
         }
+
+    if (a.ksplit > 1) {                                                         // split K: raw fp32 partial tile, finished by splitk_epilogue_kernel
+        const int Mpad = gridDim.x * BM, CoP = gridDim.y * BN;
+        float* out = a.partial + ((int64_t)split * (gridDim.z / a.ksplit) + zz) * Mpad * CoP;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = co0 + wn * 64 + j * 32 + frow;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    out[(int64_t)row * CoP + col] = acc[i][j][r];
+                }
+            }
+        return;
+    }
 
     // ---- epilogue: accumulator element (row = (r&3) + 8(r>>2) + 4*fk, col = frow) of each 32x32 tile -------------
     const float ns = a.noise ? a.noise_strength[0] : 0.f;
@@ -287,6 +313,46 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
                     if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
                     st((T*)a.y + ((int64_t)n * a.OH * a.OW + opix[i][r]) * a.Co + co, v);
                 }
+        }
+    }
+}
+
+// ---- finish of the split-K launches: sum the partial tiles, then the epilogue and the store of conv2d_nhwc_kernel ----------------------
+// One thread = one GEMM row (output pixel) x 4 consecutive output channels of one z-slice (image x class, or the folded batch).
+template <class T>
+__global__ void __launch_bounds__(256) splitk_epilogue_kernel(ConvArgs a, int Mpad, int CoP, int zcount)
+{
+    const int co4 = (a.Co + 3) / 4;
+    const int64_t per_z = (int64_t)Mpad * co4;
+    const float ns = a.noise ? a.noise_strength[0] : 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < per_z * zcount; e += (int64_t)gridDim.x * blockDim.x) {
+        const int zz = (int)(e / per_z);
+        const int64_t rem = e - zz * per_z;
+        int m = (int)(rem / co4);
+        const int co = (int)(rem - (int64_t)m * co4) * 4;
+        int n = a.fold ? 0 : zz / a.ncls;
+        const ConvArgs::Cls& kc = a.cls[a.fold ? 0 : zz - n * a.ncls];
+        const int MI = kc.SH * kc.SW;
+        if (m >= (a.fold ? MI * a.N : MI)) continue;
+        const float* src = a.partial + ((int64_t)zz * Mpad + m) * CoP + co;
+        const int64_t split_stride = (int64_t)zcount * Mpad * CoP;
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < a.ksplit; ++k) sum += *(const f32x4*)(src + k * split_stride);
+        if (a.fold) { n = m / MI; m -= n * MI; }
+        const int si = m / kc.SW, sj = m - si * kc.SW;
+        const int oy = si * a.osy + kc.ooy, ox = sj * a.osx + kc.oox;
+        if (oy >= a.OH || ox >= a.OW) continue;
+        const float nz = a.noise ? a.noise[(int64_t)oy * a.OW + ox] * ns : 0.f;
+        T* dst = (T*)a.y + (((int64_t)n * a.OH + oy) * a.OW + ox) * a.Co + co;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (co + c >= a.Co) break;
+            float v = sum[c] + nz;
+            if (a.bias) v += a.bias[co + c];
+            if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
+            v *= a.gain;
+            if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
+            st(dst + c, v);
         }
     }
 }
@@ -930,17 +996,54 @@ static int fold_batch(const ConvArgs& a, int dtype)
     return a.ncls == 1 && a.w_img_stride == 0 && a.N > 1 && mi < 4 * BM && in_bytes < (1ll << 31) && mi * a.N < (1ll << 24);
 }
 
-static int launch_conv(ConvArgs& a, int dtype, hipStream_t s)
+// Split-K plan of the generic kernel for a launch of `blocks` work-groups whose longest K loop has `nsteps` steps: 1 when the
+// launch already fills the chip or the loop is short; otherwise enough splits for ~2 work-groups per CU with >= 4 steps each.
+static int splitk_plan(int64_t blocks, int nsteps)
 {
-    int M = 0;
-    for (int c = 0; c < a.ncls; ++c) M = a.cls[c].SH * a.cls[c].SW > M ? a.cls[c].SH * a.cls[c].SW : M;
+    if (blocks >= kNumCU || nsteps < 8) return 1;
+    int64_t want = (2 * kNumCU + blocks - 1) / blocks;
+    if (want > nsteps / 4) want = nsteps / 4;
+    if (want < 2) return 1;
+    const int per = (int)((nsteps + want - 1) / want);
+    return (nsteps + per - 1) / per;
+}
+
+static void conv_launch_shape(const ConvArgs& a, int* M, int* z, int* nsteps)
+{
+    int m = 0, taps = 0;
+    for (int c = 0; c < a.ncls; ++c) {
+        m = a.cls[c].SH * a.cls[c].SW > m ? a.cls[c].SH * a.cls[c].SW : m;
+        taps = a.cls[c].ntaps > taps ? a.cls[c].ntaps : taps;
+    }
+    *M = a.fold ? m * a.N : m;
+    *z = a.fold ? 1 : a.N * a.ncls;
+    *nsteps = taps;
+}
+
+static int launch_conv(ConvArgs& a, int dtype, hipStream_t s, void* workspace, int64_t workspace_bytes, int64_t* query)
+{
+    int M, z, taps;
+    conv_launch_shape(a, &M, &z, &taps);
     if (M <= 0) return P3D_OK;
-    if (a.fold) M *= a.N;
-    dim3 grid((M + BM - 1) / BM, (a.Co + BN - 1) / BN, a.fold ? 1 : a.N * a.ncls);
+    const int gx = (M + BM - 1) / BM, gy = (a.Co + BN - 1) / BN;
+    const int nsteps = taps * (a.Ci / (dtype == P3D_F16 ? 64 : 32));
+    a.ksplit = 1; a.partial = nullptr;
+    const int want = splitk_plan((int64_t)gx * gy * z, nsteps);
+    const int64_t need = want > 1 ? (int64_t)want * z * gx * BM * gy * BN * 4 : 0;
+    if (query) { *query = need; return P3D_OK; }
+    if (want > 1 && workspace && workspace_bytes >= need && (((uintptr_t)workspace) & 15u) == 0) { a.ksplit = want; a.partial = (float*)workspace; }
+    dim3 grid(gx, gy, z * a.ksplit);
     if (dtype == P3D_F16) hipLaunchKernelGGL(conv2d_nhwc_kernel<__half>, grid, dim3(256), 0, s, a);
     else                  hipLaunchKernelGGL(conv2d_nhwc_kernel<float>, grid, dim3(256), 0, s, a);
     count_launch(FAM_CONV);
-    return check_launch("conv2d_nhwc");
+    int rc = check_launch("conv2d_nhwc");
+    if (rc != P3D_OK || a.ksplit == 1) return rc;
+    const int64_t total = (int64_t)z * gx * BM * ((a.Co + 3) / 4);
+    const int blocks = (int)((total + 255) / 256 < 8 * kNumCU ? (total + 255) / 256 : 8 * kNumCU);
+    if (dtype == P3D_F16) hipLaunchKernelGGL(splitk_epilogue_kernel<__half>, dim3(blocks), dim3(256), 0, s, a, gx * BM, gy * BN, z);
+    else                  hipLaunchKernelGGL(splitk_epilogue_kernel<float>, dim3(blocks), dim3(256), 0, s, a, gx * BM, gy * BN, z);
+    count_launch(FAM_CONV);
+    return check_launch("conv2d_nhwc split-K epilogue");
 }
 
 extern "C" int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype, const float* bias, const float* noise, const float* noise_strength,
@@ -948,15 +1051,37 @@ extern "C" int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype,
                                int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, p3d_stream_t stream)
 {
     return p3d::conv2d_nhwc_run(x, w, y, dtype, bias, noise, noise_strength, zeros128, n_img, h, wdt, ci, co, w_img_stride, kernel_size, resample, act, gain, clamp,
-                                0, 0, stream);
+                                0, 0, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int p3d_conv2d_nhwc_ws(const void* x, const void* w, void* y, int dtype, const float* bias, const float* noise, const float* noise_strength,
+                                  const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
+                                  int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, void* workspace, int64_t workspace_bytes,
+                                  p3d_stream_t stream)
+{
+    return p3d::conv2d_nhwc_run(x, w, y, dtype, bias, noise, noise_strength, zeros128, n_img, h, wdt, ci, co, w_img_stride, kernel_size, resample, act, gain, clamp,
+                                0, 0, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int64_t p3d_conv2d_nhwc_workspace(int dtype, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride, int32_t kernel_size,
+                                             int32_t resample)
+{
+    int64_t bytes = 0;
+    const int rc = p3d::conv2d_nhwc_run(nullptr, nullptr, nullptr, dtype, nullptr, nullptr, nullptr, nullptr, n_img, h, wdt, ci, co, w_img_stride, kernel_size, resample, 0, 1.f, -1.f,
+                                        0, 0, nullptr, 0, &bytes, nullptr);
+    return rc == P3D_OK ? bytes : 0;
 }
 
 // out_h / out_w (transposed form only, 0 = 2h+1 / 2w+1): the output size conv_transpose2d's output_padding asks for (2h+1 or 2h+2);
 // the extra row / column only sees taps that fall outside the input, i.e. comes out as zeros, as in the reference's op.
 int p3d::conv2d_nhwc_run(const void* x, const void* w, void* y, int dtype, const float* bias, const float* noise, const float* noise_strength,
                          const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
-                         int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, int32_t out_h, int32_t out_w, p3d_stream_t stream)
+                         int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, int32_t out_h, int32_t out_w,
+                         void* workspace, int64_t workspace_bytes, int64_t* query, p3d_stream_t stream)
 {
+    // query != null: dry run — *query = bytes of split-K scratch this call would like (0: none); nothing is launched
+    const bool dry = query != nullptr;
+    if (dry) { *query = 0; x = w = zeros128 = (const void*)(uintptr_t)16; y = (void*)(uintptr_t)16; }
     const bool transposed_stride2 = (resample == 1), down2 = (resample == 2);
     P3D_REQUIRE(resample >= 0 && resample <= 2, "conv2d_nhwc: resample must be 0 (same), 1 (transposed x2) or 2 (valid, stride 2)");
     P3D_REQUIRE(x && w && y && zeros128, "conv2d_nhwc: null pointer");
@@ -979,7 +1104,7 @@ int p3d::conv2d_nhwc_run(const void* x, const void* w, void* y, int dtype, const
         a.cls[0].SH = a.OH; a.cls[0].SW = a.OW; a.cls[0].ooy = a.cls[0].oox = 0; a.cls[0].ntaps = a.KT;
         for (int t = 0; t < a.KT; ++t) a.cls[0].taps[t] = ConvTap{t / kernel_size, t % kernel_size, t};
         a.fold = fold_batch(a, dtype);
-        return launch_conv(a, dtype, s);
+        return launch_conv(a, dtype, s, workspace, workspace_bytes, query);
     }
     if (!transposed_stride2) {                                       // correlation, "same" padding: input offset = tap - k/2
         a.OH = h; a.OW = wdt; a.osy = a.osx = 1; a.ncls = 1;
@@ -987,13 +1112,24 @@ int p3d::conv2d_nhwc_run(const void* x, const void* w, void* y, int dtype, const
         for (int t = 0; t < a.KT; ++t) a.cls[0].taps[t] = ConvTap{t / kernel_size - kernel_size / 2, t % kernel_size - kernel_size / 2, t};
         static const bool no_halo = getenv("P3D_CONV_NO_HALO") != nullptr;
         static const bool no_h2 = getenv("P3D_CONV_NO_H2") != nullptr;
-        if (!no_h2 && !no_halo && kernel_size == 3 && dtype == P3D_F16 && h >= 32 && wdt >= 32 && ci % 64 == 0 && co % BN == 0 && (((uintptr_t)y) & 15u) == 0) {
+        // the halo kernels have no split-K: they take the layers whose own grid fills the chip (or every layer when the caller brought
+        // no scratch); a 512-channel layer at 16^2 / 32^2 is 32 / 128 work-groups with a 144-step K loop — that goes to the generic
+        // kernel with its K steps dealt out
+        const bool h2_ok = !no_h2 && !no_halo && kernel_size == 3 && dtype == P3D_F16 && h >= 32 && wdt >= 32 && ci % 64 == 0 && co % BN == 0 && (((uintptr_t)y) & 15u) == 0;
+        const bool halo_ok = kernel_size == 3 && h >= PH && wdt >= PW && !no_halo;
+        const int64_t own_blocks = h2_ok ? (int64_t)((h + QH - 1) / QH) * ((wdt + QW - 1) / QW) * (co / BN) * n_img
+                                         : (int64_t)((h + PH - 1) / PH) * ((wdt + PW - 1) / PW) * ((co + BN - 1) / BN) * n_img;
+        const bool have_ws = dry || (workspace != nullptr && workspace_bytes > 0);
+        const bool prefer_split = have_ws && (h2_ok || halo_ok) && own_blocks < 192 && ci / bk * a.KT >= 16;
+        if (h2_ok && !prefer_split) {
+            if (dry) return P3D_OK;
             dim3 grid(((h + QH - 1) / QH) * ((wdt + QW - 1) / QW), co / BN, n_img);
             hipLaunchKernelGGL(conv3x3_h2_f16_kernel, grid, dim3(256), 0, s, a);
             count_launch(FAM_CONV);
             return check_launch("conv3x3_h2_f16");
         }
-        if (kernel_size == 3 && h >= PH && wdt >= PW && !no_halo) {       // halo-reuse kernel for the plain 3x3 layers
+        if (halo_ok && !prefer_split) {                                   // halo-reuse kernel for the plain 3x3 layers
+            if (dry) return P3D_OK;
             dim3 grid(((h + PH - 1) / PH) * ((wdt + PW - 1) / PW), (co + BN - 1) / BN, n_img);
             if (dtype == P3D_F16) hipLaunchKernelGGL(conv3x3_halo_kernel<__half>, grid, dim3(256), 0, s, a);
             else                  hipLaunchKernelGGL(conv3x3_halo_kernel<float>, grid, dim3(256), 0, s, a);
@@ -1001,7 +1137,7 @@ int p3d::conv2d_nhwc_run(const void* x, const void* w, void* y, int dtype, const
             return check_launch("conv3x3_halo");
         }
         a.fold = fold_batch(a, dtype);
-        return launch_conv(a, dtype, s);
+        return launch_conv(a, dtype, s, workspace, workspace_bytes, query);
     }
     // conv_transpose2d(stride 2, no padding): out[(2i+py), (2j+px)] = sum_{ky = py (mod 2), kx = px (mod 2)} x[i - (ky-py)/2, j - (kx-px)/2] w[ky, kx]
     // -> four dense sub-problems (4 / 2 / 2 / 1 taps), all in ONE launch so the grid fills the chip
@@ -1020,13 +1156,14 @@ int p3d::conv2d_nhwc_run(const void* x, const void* w, void* y, int dtype, const
         }
     {
         if (h2t) {
+            if (dry) return P3D_OK;
             const int tiles = ((h + 1 + QH - 1) / QH) * ((wdt + 1 + QW - 1) / QW);          // class (0, 0) is the largest: (H + 1) x (W + 1) positions
             hipLaunchKernelGGL(convT_h2_f16_kernel, dim3(tiles, co / BN, n_img * 4), dim3(256), 0, s, a);
             count_launch(FAM_CONV);
             return check_launch("convT_h2_f16");
         }
     }
-    return launch_conv(a, dtype, s);
+    return launch_conv(a, dtype, s, workspace, workspace_bytes, query);
 }
 
 extern "C" int p3d_torgb_nhwc_f16(const void* x, const float* weight, const float* styles, const float* bias, float* y_nchw,

@@ -257,69 +257,128 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
         }
 }
 
-// sum the splits, cast, and write torch's layout gw[cs][cb][taps]
+// sum the splits, cast, and write torch's layout gw[cs][cb][taps].  One thread = four consecutive cb of one (tap, cs): 16-byte loads
+// along the workspace's fastest axis, four splits in flight at a time (the first version walked taps x splits with scalar loads from
+// 16 K threads and took 100-200 us for 50 MB).
 template <class T>
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, T* __restrict__ gw, int Cs, int Cb, int taps, int ksplit, int CsP, int CbP)
 {
-    const int64_t total = (int64_t)Cs * Cb;
+    const int cb4 = CbP / 4;
+    const int64_t total = (int64_t)taps * Cs * cb4;
+    const int64_t split_stride = (int64_t)taps * CsP * CbP;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int cb = (int)(e % Cb), cs = (int)(e / Cb);
-        for (int t = 0; t < taps; ++t) {
-            float sum = 0.f;
-            for (int k = 0; k < ksplit; ++k) sum += ws[(((int64_t)k * taps + t) * CsP + cs) * CbP + cb];
-            st(gw + e * taps + t, sum);
+        const int q = (int)(e % cb4);
+        const int cs = (int)((e / cb4) % Cs);
+        const int t = (int)(e / ((int64_t)cb4 * Cs));
+        const float* src = ws + ((int64_t)t * CsP + cs) * CbP + q * 4;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+        int k = 0;
+        for (; k + 4 <= ksplit; k += 4) {
+            const f32x4 a0 = *(const f32x4*)(src + (k + 0) * split_stride), a1 = *(const f32x4*)(src + (k + 1) * split_stride);
+            const f32x4 a2 = *(const f32x4*)(src + (k + 2) * split_stride), a3 = *(const f32x4*)(src + (k + 3) * split_stride);
+            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+        }
+        for (; k < ksplit; ++k) s0 += *(const f32x4*)(src + k * split_stride);
+        const f32x4 sum = (s0 + s1) + (s2 + s3);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int cb = q * 4 + c;
+            if (cb < Cb) st(gw + ((int64_t)cs * Cb + cb) * taps + t, sum[c]);
         }
     }
 }
 
-// ---- skinny 1x1: y[n, p, o] = sum_i x[n, p, i] * w[o, i] with a handful of channels on one side -------------------------------------
-// Any dense layout by element strides; w is addressed by (w_so, w_si) so the data gradient passes the same tensor transposed.
-// One thread = one pixel x up to 8 consecutive outputs; the channel loop reads 16-byte vectors when the input channels are
-// contiguous.  Memory-bound by construction (ToRGB reads Ci * sizeof(T) per pixel for 3 outputs).
+// ---- skinny 1x1: y[n, p, o] = sum_i x[n, p, i] * w[o, i] with a handful of channels on one side, channels-last ---------------------
+// Memory-bound by construction (ToRGB reads Ci * sizeof(T) per pixel for 3 outputs; fromrgb writes Co * sizeof(T) per pixel from 6
+// inputs).  w is addressed by (w_so, w_si) so the data gradient passes the same tensor transposed.  The weights sit in LDS as fp32.
+//
+// contract (few outputs): LPP = min(64, Ci / EPC) lanes share a pixel, each owning EPC-channel groups lane, lane + LPP, ...; a lane
+// accumulates its partial dot products for up to 8 outputs and the group folds them with xor-shuffles.  Every load is a full 16-byte
+// vector and a wave instruction covers whole contiguous pixel rows.
 template <class T>
-__global__ void __launch_bounds__(256) conv1x1_skinny_kernel(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ y, int N, int HW, int Ci, int Co,
-                                                             int64_t xs_n, int64_t xs_c, int64_t xs_p, int64_t ys_n, int64_t ys_c, int64_t ys_p,
-                                                             int64_t w_so, int64_t w_si)
+__global__ void __launch_bounds__(256) skinny_contract_kernel(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ y, int64_t npix, int Ci, int Co,
+                                                              int64_t w_so, int64_t w_si, int lpp)
 {
     constexpr int EPC = 16 / sizeof(T);
-    const int ogroups = (Co + 7) / 8;
-    const int64_t total = (int64_t)N * HW * ogroups;
-    const bool vec = xs_c == 1 && (Ci % EPC) == 0 && (xs_p % EPC) == 0 && (xs_n % EPC) == 0 && ((uintptr_t)x & 15u) == 0;
+    extern __shared__ float wl[];                                                // [Co][Ci]
+    for (int e = threadIdx.x; e < Co * Ci; e += blockDim.x) wl[e] = ld(w + (e / Ci) * w_so + (e % Ci) * w_si);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (lpp - 1), slot = lane / lpp, ppw = 64 / lpp;         // lane within its pixel group, group within the wave
+    const int groups = Ci / EPC;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t p0 = wave * ppw; p0 < npix; p0 += nwaves * ppw) {
+        const int64_t p = p0 + slot;
+        const bool live = p < npix;
+        for (int o0 = 0; o0 < Co; o0 += 8) {
+            float acc[8];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+            for (int g = sub; g < groups; g += lpp) {
+                T xv[EPC];
+                *(f32x4*)xv = live ? *(const f32x4*)(x + p * Ci + g * EPC) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int o = 0; o < 8; ++o)
+                    if (o0 + o < Co) {
+                        const float* wr = wl + (o0 + o) * Ci + g * EPC;
+#pragma unroll
+                        for (int q = 0; q < EPC; ++q) acc[o] = fmaf(ld(xv + q), wr[q], acc[o]);
+                    }
+            }
+#pragma unroll
+            for (int o = 0; o < 8; ++o)
+                for (int m = lpp >> 1; m > 0; m >>= 1) acc[o] += __shfl_xor(acc[o], m, 64);
+            if (live && sub == 0)
+#pragma unroll
+                for (int o = 0; o < 8; ++o)
+                    if (o0 + o < Co) st(y + p * Co + o0 + o, acc[o]);
+        }
+    }
+}
+
+// expand (few inputs): one thread = one pixel x 8 consecutive outputs (one 16-byte store; the Co / 8 lanes of a pixel write its whole
+// channel run); the pixel's inputs are read once per thread (same addresses across the lanes of a pixel: one fetch), the weights come
+// from LDS (lanes of one output group read the same words: broadcast).
+template <class T>
+__global__ void __launch_bounds__(256) skinny_expand_kernel(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ y, int64_t npix, int Ci, int Co,
+                                                            int64_t w_so, int64_t w_si)
+{
+    extern __shared__ float wl[];                                                // [Ci][CoP], CoP = Co rounded up to 8
+    const int CoP = (Co + 7) & ~7;
+    for (int e = threadIdx.x; e < Ci * CoP; e += blockDim.x) {
+        const int i = e / CoP, o = e - i * CoP;
+        wl[e] = o < Co ? ld(w + o * w_so + i * w_si) : 0.f;
+    }
+    __syncthreads();
+    const int ogroups = CoP / 8;
+    const int64_t total = npix * ogroups;
+    const bool vec = (Co & 7) == 0 && sizeof(T) == 2 && ((uintptr_t)y & 15u) == 0;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int og = (int)(e % ogroups);
-        const int64_t np = e / ogroups;
-        const int p = (int)(np % HW), n = (int)(np / HW);
-        const int o0 = og * 8;
-        const T* xp = x + n * xs_n + p * xs_p;
+        const int64_t p = e / ogroups;
         float acc[8];
 #pragma unroll
         for (int o = 0; o < 8; ++o) acc[o] = 0.f;
-        if (vec) {
-            for (int i0 = 0; i0 < Ci; i0 += EPC) {
-                const f32x4 raw = *(const f32x4*)(xp + i0);
-                T xv[EPC];
-                *(f32x4*)xv = raw;
+        for (int i = 0; i < Ci; ++i) {
+            const float xv = ld(x + p * Ci + i);
+            const f32x4 w0 = *(const f32x4*)(wl + i * CoP + og * 8), w1 = *(const f32x4*)(wl + i * CoP + og * 8 + 4);
 #pragma unroll
-                for (int o = 0; o < 8; ++o) {
-                    if (o0 + o < Co) {
-                        const T* wr = w + (o0 + o) * w_so + i0 * w_si;
-#pragma unroll
-                        for (int q = 0; q < EPC; ++q) acc[o] = fmaf(ld(xv + q), ld(wr + q * w_si), acc[o]);
-                    }
-                }
-            }
-        } else {
-            for (int i = 0; i < Ci; ++i) {
-                const float xv = ld(xp + i * xs_c);
-#pragma unroll
-                for (int o = 0; o < 8; ++o)
-                    if (o0 + o < Co) acc[o] = fmaf(xv, ld(w + (o0 + o) * w_so + i * w_si), acc[o]);
-            }
+            for (int o = 0; o < 4; ++o) { acc[o] = fmaf(xv, w0[o], acc[o]); acc[4 + o] = fmaf(xv, w1[o], acc[4 + o]); }
         }
-        T* yp = y + n * ys_n + p * ys_p;
+        T* yp = y + p * Co + og * 8;
+        if (vec) {
+            h8 hv;
 #pragma unroll
-        for (int o = 0; o < 8; ++o)
-            if (o0 + o < Co) st(yp + (o0 + o) * ys_c, acc[o]);
+            for (int o = 0; o < 8; ++o) hv[o] = (_Float16)acc[o];
+            *(h8*)yp = hv;
+        } else if ((Co & 7) == 0 && sizeof(T) == 4 && ((uintptr_t)y & 15u) == 0) {
+            *(f32x4*)yp = f32x4{acc[0], acc[1], acc[2], acc[3]};
+            *(f32x4*)(yp + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+        } else {
+#pragma unroll
+            for (int o = 0; o < 8; ++o)
+                if (og * 8 + o < Co) st(yp + o, acc[o]);
+        }
     }
 }
 
@@ -361,10 +420,12 @@ static int relayout(const void* w, void* dst, int dtype, int A, int B, int taps,
 
 static bool mfma_channels_ok(int dtype, int ci) { return ci % (dtype == P3D_F16 ? 64 : 32) == 0; }
 
-extern "C" int p3d_conv2d_forward(const void* x, const void* weight, void* y, void* w_scratch, const void* zeros128, int dtype,
-                                  int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int32_t kernel_size, int32_t stride,
-                                  int32_t transposed, int32_t out_h, int32_t out_w, p3d_stream_t stream)
+static int conv_forward_impl(const void* x, const void* weight, void* y, void* w_scratch, const void* zeros128, int dtype,
+                             int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int32_t kernel_size, int32_t stride,
+                             int32_t transposed, int32_t out_h, int32_t out_w, void* workspace, int64_t workspace_bytes, int64_t* query, p3d_stream_t stream)
 {
+    const bool dry = query != nullptr;
+    if (dry) { *query = 0; x = weight = zeros128 = (const void*)(uintptr_t)16; y = w_scratch = (void*)(uintptr_t)16; }
     P3D_REQUIRE(x && weight && y, "conv2d_forward: null pointer");
     P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32, "conv2d_forward: dtype must be fp16 or fp32");
     P3D_REQUIRE(n_img >= 1 && h >= 1 && wdt >= 1 && ci >= 1 && co >= 1, "conv2d_forward: bad sizes");
@@ -373,43 +434,73 @@ extern "C" int p3d_conv2d_forward(const void* x, const void* weight, void* y, vo
     const int taps = kernel_size * kernel_size;
     if (kernel_size == 1 && (!mfma_channels_ok(dtype, ci) || co < 32)) {
         // skinny 1x1 (either direction: a transposed 1x1 is the same product with the weight read transposed), channels-last
-        const int64_t hw = (int64_t)h * wdt;
-        const int64_t total = (int64_t)n_img * hw * ((co + 7) / 8);
-        const int blocks = (int)((total + 255) / 256 < 16 * kNumCU ? (total + 255) / 256 : 16 * kNumCU);
+        if (dry) return P3D_OK;
+        const int64_t npix = (int64_t)n_img * h * wdt;
         const int64_t w_so = transposed ? 1 : ci, w_si = transposed ? co : 1;   // conv2d: w[o][i]; conv_transpose2d: w[i][o]
-        if (dtype == P3D_F16) hipLaunchKernelGGL(conv1x1_skinny_kernel<__half>, dim3(blocks), dim3(256), 0, s, (const __half*)x, (const __half*)weight, (__half*)y, n_img, (int)hw, ci, co,
-                                                 hw * ci, (int64_t)1, (int64_t)ci, hw * co, (int64_t)1, (int64_t)co, w_so, w_si);
-        else                  hipLaunchKernelGGL(conv1x1_skinny_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, (const float*)weight, (float*)y, n_img, (int)hw, ci, co,
-                                                 hw * ci, (int64_t)1, (int64_t)ci, hw * co, (int64_t)1, (int64_t)co, w_so, w_si);
+        const int epc = dtype == P3D_F16 ? 8 : 4;
+        P3D_REQUIRE((int64_t)ci * ((co + 7) & ~7) * 4 <= 64 * 1024, "conv2d_forward: skinny 1x1 weights must fit 64 KB of LDS");
+        if (co <= ci && ci % epc == 0 && (((uintptr_t)x) & 15u) == 0) {                            // many -> few
+            int lpp = 1;
+            while (lpp < 64 && lpp * 2 <= ci / epc) lpp *= 2;
+            const int ppw = 64 / lpp;
+            int64_t blocks = (npix + 4 * ppw - 1) / (4 * ppw);
+            if (blocks > 8 * kNumCU) blocks = 8 * kNumCU;
+            const size_t lds = (size_t)ci * co * 4;
+            if (dtype == P3D_F16) hipLaunchKernelGGL(skinny_contract_kernel<__half>, dim3((int)blocks), dim3(256), lds, s, (const __half*)x, (const __half*)weight, (__half*)y, npix, ci, co, w_so, w_si, lpp);
+            else                  hipLaunchKernelGGL(skinny_contract_kernel<float>, dim3((int)blocks), dim3(256), lds, s, (const float*)x, (const float*)weight, (float*)y, npix, ci, co, w_so, w_si, lpp);
+            count_launch(FAM_CONV);
+            return check_launch("skinny_contract");
+        }
+        const int64_t total = npix * ((co + 7) / 8);
+        int64_t blocks = (total + 255) / 256;
+        if (blocks > 16 * kNumCU) blocks = 16 * kNumCU;
+        const size_t lds = (size_t)ci * ((co + 7) & ~7) * 4;
+        if (dtype == P3D_F16) hipLaunchKernelGGL(skinny_expand_kernel<__half>, dim3((int)blocks), dim3(256), lds, s, (const __half*)x, (const __half*)weight, (__half*)y, npix, ci, co, w_so, w_si);
+        else                  hipLaunchKernelGGL(skinny_expand_kernel<float>, dim3((int)blocks), dim3(256), lds, s, (const float*)x, (const float*)weight, (float*)y, npix, ci, co, w_so, w_si);
         count_launch(FAM_CONV);
-        return check_launch("conv1x1_skinny");
+        return check_launch("skinny_expand");
     }
     P3D_REQUIRE(w_scratch && zeros128, "conv2d_forward: the MFMA route needs w_scratch (Co*Ci*k*k elements) and zeros128");
     if (!mfma_channels_ok(dtype, ci) && !(dtype == P3D_F16 && transposed && stride == 2 && ci % 32 == 0 && co % 128 == 0 && h >= 32 && wdt >= 32))
         return fail(P3D_ERR_UNSUPPORTED, "conv2d_forward: Ci=%d must be a multiple of %d (pad the channels)", ci, dtype == P3D_F16 ? 64 : 32);
     int rc;
     if (!transposed) {
-        rc = relayout(weight, w_scratch, dtype, co, ci, taps, 0, 0, s);                          // wm[o][t][i] = w[o][i][t]
+        rc = dry ? P3D_OK : relayout(weight, w_scratch, dtype, co, ci, taps, 0, 0, s);           // wm[o][t][i] = w[o][i][t]
         if (rc != P3D_OK) return rc;
-        return conv2d_nhwc_run(x, w_scratch, y, dtype, nullptr, nullptr, nullptr, zeros128, n_img, h, wdt, ci, co, 0, kernel_size, stride == 2 ? 2 : 0, 0, 1.f, -1.f, 0, 0, stream);
+        return conv2d_nhwc_run(x, w_scratch, y, dtype, nullptr, nullptr, nullptr, zeros128, n_img, h, wdt, ci, co, 0, kernel_size, stride == 2 ? 2 : 0, 0, 1.f, -1.f, 0, 0, workspace, workspace_bytes, query, stream);
     }
     if (stride == 1) {                                                                            // = correlation with mirrored taps and swapped channel axes
-        rc = relayout(weight, w_scratch, dtype, ci, co, taps, 1, 1, s);                          // wm[o][t][i] = w[i][o][taps-1-t]
+        rc = dry ? P3D_OK : relayout(weight, w_scratch, dtype, ci, co, taps, 1, 1, s);           // wm[o][t][i] = w[i][o][taps-1-t]
         if (rc != P3D_OK) return rc;
-        return conv2d_nhwc_run(x, w_scratch, y, dtype, nullptr, nullptr, nullptr, zeros128, n_img, h, wdt, ci, co, 0, kernel_size, 0, 0, 1.f, -1.f, 0, 0, stream);
+        return conv2d_nhwc_run(x, w_scratch, y, dtype, nullptr, nullptr, nullptr, zeros128, n_img, h, wdt, ci, co, 0, kernel_size, 0, 0, 1.f, -1.f, 0, 0, workspace, workspace_bytes, query, stream);
     }
-    rc = relayout(weight, w_scratch, dtype, ci, co, taps, 1, 0, s);                              // wm[o][t][i] = w[i][o][t]
+    rc = dry ? P3D_OK : relayout(weight, w_scratch, dtype, ci, co, taps, 1, 0, s);               // wm[o][t][i] = w[i][o][t]
     if (rc != P3D_OK) return rc;
-    return conv2d_nhwc_run(x, w_scratch, y, dtype, nullptr, nullptr, nullptr, zeros128, n_img, h, wdt, ci, co, 0, kernel_size, 1, 0, 1.f, -1.f, out_h, out_w, stream);
+    return conv2d_nhwc_run(x, w_scratch, y, dtype, nullptr, nullptr, nullptr, zeros128, n_img, h, wdt, ci, co, 0, kernel_size, 1, 0, 1.f, -1.f, out_h, out_w, workspace, workspace_bytes, query, stream);
+}
+
+extern "C" int p3d_conv2d_forward(const void* x, const void* weight, void* y, void* w_scratch, const void* zeros128, int dtype,
+                                  int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int32_t kernel_size, int32_t stride,
+                                  int32_t transposed, int32_t out_h, int32_t out_w, void* workspace, int64_t workspace_bytes, p3d_stream_t stream)
+{
+    return conv_forward_impl(x, weight, y, w_scratch, zeros128, dtype, n_img, h, wdt, ci, co, kernel_size, stride, transposed, out_h, out_w, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int64_t p3d_conv2d_forward_workspace(int dtype, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int32_t kernel_size, int32_t stride,
+                                                int32_t transposed)
+{
+    int64_t bytes = 0;
+    const int rc = conv_forward_impl(nullptr, nullptr, nullptr, nullptr, nullptr, dtype, n_img, h, wdt, ci, co, kernel_size, stride, transposed, 0, 0, nullptr, 0, &bytes, nullptr);
+    return rc == P3D_OK ? bytes : 0;
 }
 
 extern "C" int p3d_conv2d_bwd_data(const void* gy, const void* weight, void* gx, void* w_scratch, const void* zeros128, int dtype,
                                    int32_t n_img, int32_t gy_h, int32_t gy_w, int32_t ci, int32_t co, int32_t kernel_size, int32_t stride,
-                                   int32_t transposed, int32_t x_h, int32_t x_w, p3d_stream_t stream)
+                                   int32_t transposed, int32_t x_h, int32_t x_w, void* workspace, int64_t workspace_bytes, p3d_stream_t stream)
 {
     // d(input) of op(transposed) is op(!transposed) over the same weight tensor with input / output channels trading places
     // (conv2d_gradfix.py:139-143); x_h / x_w fix the output_padding when that op is the transposed one
-    return p3d_conv2d_forward(gy, weight, gx, w_scratch, zeros128, dtype, n_img, gy_h, gy_w, co, ci, kernel_size, stride, !transposed, x_h, x_w, stream);
+    return conv_forward_impl(gy, weight, gx, w_scratch, zeros128, dtype, n_img, gy_h, gy_w, co, ci, kernel_size, stride, !transposed, x_h, x_w, workspace, workspace_bytes, nullptr, stream);
 }
 
 extern "C" int64_t p3d_conv2d_bwd_weight_workspace(int dtype, int32_t n_img, int32_t small_h, int32_t small_w, int32_t c_small, int32_t c_big, int32_t kernel_size)
@@ -443,8 +534,8 @@ extern "C" int p3d_conv2d_bwd_weight(const void* small_img, const void* big_img,
     count_launch(FAM_CONV);
     int rc = check_launch("conv_wgrad");
     if (rc != P3D_OK) return rc;
-    const int64_t total = (int64_t)c_small * c_big;
-    const int rblocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    const int64_t total = (int64_t)taps * c_small * (a.CbP / 4);
+    const int rblocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (dtype == P3D_F16) hipLaunchKernelGGL(wgrad_reduce_kernel<__half>, dim3(rblocks), dim3(256), 0, s, a.ws, (__half*)gw, c_small, c_big, taps, a.ksplit, a.CsP, a.CbP);
     else                  hipLaunchKernelGGL(wgrad_reduce_kernel<float>, dim3(rblocks), dim3(256), 0, s, a.ws, (float*)gw, c_small, c_big, taps, a.ksplit, a.CsP, a.CbP);
     count_launch(FAM_CONV);

@@ -88,8 +88,9 @@ native = True              # device tensors of the covered family go to libp3d_h
 native_calls = {'forward': 0, 'weight_grad': 0, 'aten': 0}      # which route the dense arithmetic took (tests)
 
 _vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
-_lib.register('p3d_conv2d_forward', ctypes.c_int, [_vp] * 5 + [ctypes.c_int] + [_i32] * 10 + [_vp])
-_lib.register('p3d_conv2d_bwd_data', ctypes.c_int, [_vp] * 5 + [ctypes.c_int] + [_i32] * 10 + [_vp])
+_lib.register('p3d_conv2d_forward', ctypes.c_int, [_vp] * 5 + [ctypes.c_int] + [_i32] * 10 + [_vp, _i64, _vp])
+_lib.register('p3d_conv2d_bwd_data', ctypes.c_int, [_vp] * 5 + [ctypes.c_int] + [_i32] * 10 + [_vp, _i64, _vp])
+_lib.register('p3d_conv2d_forward_workspace', _i64, [ctypes.c_int] + [_i32] * 8)
 _lib.register('p3d_conv2d_bwd_weight_workspace', _i64, [ctypes.c_int] + [_i32] * 6)
 _lib.register('p3d_conv2d_bwd_weight', ctypes.c_int, [_vp] * 4 + [_i64, ctypes.c_int] + [_i32] * 10 + [_vp])
 
@@ -146,8 +147,12 @@ def _native_conv(x, w, cfg, k, stride):
         x, ci = xp, cip
     y = torch.empty([n, co, oh, ow], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     scratch = None if skinny else torch.empty([co * ci * k * k], dtype=x.dtype, device=x.device)
-    code = _lib.lib().p3d_conv2d_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), _lib.ptr(scratch), _lib.ptr(_zeros_page(x.device)), _lib.DTYPE_CODE[x.dtype],
-                                         n, h, wd, ci, co, k, stride, int(tr), oh if tr and stride == 2 else 0, ow if tr and stride == 2 else 0, _lib.stream_of(x))
+    code_dtype = _lib.DTYPE_CODE[x.dtype]
+    nbytes = 0 if skinny else int(_lib.lib().p3d_conv2d_forward_workspace(code_dtype, n, h, wd, ci, co, k, stride, int(tr)))
+    work = torch.empty([nbytes // 4], dtype=torch.float32, device=x.device) if nbytes > 0 else None      # split-K partial tiles (low-resolution layers)
+    code = _lib.lib().p3d_conv2d_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), _lib.ptr(scratch), _lib.ptr(_zeros_page(x.device)), code_dtype,
+                                         n, h, wd, ci, co, k, stride, int(tr), oh if tr and stride == 2 else 0, ow if tr and stride == 2 else 0,
+                                         _lib.ptr(work), nbytes, _lib.stream_of(x))
     _lib.check(code, 'conv2d_forward')
     native_calls['forward'] += 1
     return y

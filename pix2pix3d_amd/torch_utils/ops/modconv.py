@@ -39,6 +39,8 @@ def take_plan(layer):
 _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 _lib.register('p3d_modulate_weights', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp])
 _lib.register('p3d_conv2d_nhwc', ctypes.c_int, [_vp] * 3 + [ctypes.c_int] + [_vp] * 4 + [_i32] * 5 + [_i64, _i32, _i32, _i32, _f32, _f32, _vp])
+_lib.register('p3d_conv2d_nhwc_ws', ctypes.c_int, [_vp] * 3 + [ctypes.c_int] + [_vp] * 4 + [_i32] * 5 + [_i64, _i32, _i32, _i32, _f32, _f32, _vp, _i64, _vp])
+_lib.register('p3d_conv2d_nhwc_workspace', _i64, [ctypes.c_int] + [_i32] * 5 + [_i64, _i32, _i32])
 
 _lib.register('p3d_fir4_bias_act_nhwc', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int] + [_i32] * 9 + [_f32, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _vp])
 _lib.register('p3d_fc_forward', ctypes.c_int, [_vp] * 4 + [_i32] * 3 + [_i64, _f32, _f32, _i32, _f32, _f32, _f32, _vp])
@@ -150,10 +152,13 @@ def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None
     b32 = None if bias is None else bias.detach().float().contiguous()
     nz = None if noise is None else noise.detach().float().contiguous()
     ns = None if noise is None else noise_strength.detach().float().reshape(1).contiguous()
+    mode = 1 if transposed else (2 if down == 2 else 0)
+    nbytes = int(_lib.lib().p3d_conv2d_nhwc_workspace(_lib.DTYPE_CODE[x.dtype], n, h, w, ci, co, stride, k, mode))
+    work = torch.empty([nbytes // 4], dtype=torch.float32, device=x.device) if nbytes > 0 else None          # split-K partial tiles (low-resolution layers)
     with _lib.kernel_timer('conv_f16' if x.dtype == torch.float16 else 'conv_f32', x):
-        code = _lib.lib().p3d_conv2d_nhwc(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), _lib.DTYPE_CODE[x.dtype], _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns),
-                                          _lib.ptr(_zeros_page(x.device)), n, h, w, ci, co, stride, k, (1 if transposed else (2 if down == 2 else 0)), int(act), float(gain), float(clamp),
-                                          _lib.stream_of(x))
+        code = _lib.lib().p3d_conv2d_nhwc_ws(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), _lib.DTYPE_CODE[x.dtype], _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns),
+                                             _lib.ptr(_zeros_page(x.device)), n, h, w, ci, co, stride, k, mode, int(act), float(gain), float(clamp),
+                                             _lib.ptr(work), nbytes, _lib.stream_of(x))
     _lib.check(code, 'conv2d_nhwc')
     log = _lib.kernel_events.get('conv_flops')
     if log is not None:                                  # bench.py: FLOPs of the launches it is timing (2*Ci*Co*k*k per output / input pixel)

@@ -97,7 +97,7 @@ def main():
         c0 = dict(conv2d_gradfix.native_calls)
         ms = timed(fn)
         torch.cuda.reset_peak_memory_stats()
-        cen = census(fn)
+        cen = census(fn) if '--no-census' not in sys.argv else dict(kernel_ms=0.0, p3d_ms=0.0, other={}, vendor={})     # (under rocprofv3 the two tracers collide)
         calls = {k: conv2d_gradfix.native_calls[k] - c0[k] for k in c0}
         print(f'{name} pass, batch {n}: {ms:.1f} ms wall ({n / ms * 1e3:.1f} img/s), kernels {cen["kernel_ms"]:.1f} ms of which p3d:: {cen["p3d_ms"]:.1f} ms; '
               f'conv calls over 6 passes {calls}; peak mem {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB')

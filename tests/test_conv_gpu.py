@@ -190,3 +190,33 @@ def test_halo_kernels_at_their_own_sizes(hip_lib, dtype, ci, co, h, w, with_nois
     ref = (F.leaky_relu(ref + bias.reshape(1, -1, 1, 1), 0.2) * 1.3).clamp(-3.0, 3.0)
     assert y.shape == ref.shape and y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
     assert rel_err(y.float().cpu().numpy(), ref.cpu().numpy()) < (2e-3 if dtype == torch.float16 else 1e-5)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16], ids=['f32', 'f16'])
+@pytest.mark.parametrize('res', [4, 8, 16, 32])
+def test_lowres_512_channel_layers_take_the_split_k_schedule(hip_lib, dtype, res):
+    """The backbone's 512-channel layers at 4^2 .. 32^2: a handful of output tiles with a 144-step K loop.  The generic kernel deals
+    the K steps to many work-groups (fp32 partial tiles + a finishing launch that also applies noise / bias / lrelu / gain / clamp);
+    per-sample weights, shared weights (batch folded into the GEMM rows) and the x2 transposed form, against fp64 torch."""
+    from pix2pix3d_amd import _lib
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    torch.manual_seed(res)
+    n, ci, co = 4, 512, 512
+    x = _nhwc(torch.randn(n, ci, res, res, device='cuda').to(dtype))
+    weight = torch.randn(co, ci, 3, 3, device='cuda')
+    styles = torch.randn(n, ci, device='cuda') + 1
+    wmod = modconv.modulate_weights(weight, styles, dtype=dtype)
+    mode = 0
+    assert int(_lib.lib().p3d_conv2d_nhwc_workspace(_lib.DTYPE_CODE[dtype], n, res, res, ci, co, co * 9 * ci, 3, mode)) > 0 or (dtype == torch.float16 and res == 32)
+    wq = wmod.double().reshape(n, co, 3, 3, ci).permute(0, 1, 4, 2, 3)
+    bias, noise, strength = torch.randn(co, device='cuda'), torch.randn(res, res, device='cuda'), torch.tensor(0.3, device='cuda')
+    tol = 2e-5 if dtype == torch.float32 else 3e-3
+    y = modconv.conv3x3(x, wmod, bias=bias, noise=noise, noise_strength=strength, act=1, gain=2 ** 0.5, clamp=1.5)
+    yr = torch.stack([F.conv2d(x[i:i + 1].double(), wq[i], padding=1)[0] for i in range(n)])
+    yr = (F.leaky_relu(yr + (noise * strength).double() + bias.double().view(1, -1, 1, 1), 0.2) * 2 ** 0.5).clamp(-1.5, 1.5)
+    assert rel_err(y.double().cpu().numpy(), yr.cpu().numpy()) < tol
+    y3 = modconv.conv3x3(x, wmod[:1])                                       # shared weights
+    assert rel_err(y3.double().cpu().numpy(), F.conv2d(x.double(), wq[0], padding=1).cpu().numpy()) < tol
+    yt = modconv.conv2d(x, wmod, transposed=True)
+    ytr = torch.stack([F.conv_transpose2d(x[i:i + 1].double(), wq[i].transpose(0, 1), stride=2)[0] for i in range(n)])
+    assert rel_err(yt.double().cpu().numpy(), ytr.cpu().numpy()) < tol
