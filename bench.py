@@ -2,15 +2,19 @@
 """Headline benchmark: rendered img/s of ``G.synthesis`` (seg2cat, 512^2 output, 128^2 rays x 128 depth samples).
 
     python bench.py --gpus N --steps K --warmup W           (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --train-step                   (BASELINE config 3 instead: one training iteration per step)
 
 A "step" is one pass of the hot path — StyleGAN2 tri-plane backbone -> fused tri-plane ray-marcher -> two
 super-resolution heads — over one batch of synthetic inputs already resident in HBM (random-init weights of the
 real architecture, N(0,1) latents, orbit cameras).  Inference shards by image: every rank renders its own batch,
 no data-path collective ("weak" scaling); the only collectives are the barriers bracketing the timed region and a
-MAX-reduce of the elapsed time.  Rank 0 prints ONE JSON line (contract in the task statement) with two extra
-objects: ``roofline`` for the dominant hand-written kernel (the fused ray-marcher; HIP-event timed inside the
-timed region, on the stream it is launched on) and ``cpu_baseline`` (the CPU oracle — a port of the reference's
-force_fp32 CPU path — timed on the host cores on a bounded sample: batch 1, same resolution and sample counts).
+MAX-reduce of the elapsed time.  Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
+``roofline`` for the dominant hand-written kernel (the fused ray-marcher; HIP-event timed inside the timed region, on the
+stream it is launched on; ``frac`` against the HBM roofline on the survey's tap-bytes convention and ``mfma_frac`` against the
+fp32 matrix-core floor of its decoder, which is what actually bounds it), ``cpu_baseline`` (the REFERENCE itself in a child
+process when its checkout is reachable — ``kind: "reference"`` — else the CPU oracle, a port of the reference's force_fp32 CPU
+path — ``kind: "port"``; a bounded sample: batch 1, same resolution and sample counts) and ``train_step`` (one training
+iteration of BASELINE config 3 on the same GPUs: G pass, D pass with R1, flat gradient all-reduce over RCCL).
 """
 import argparse
 import json
@@ -26,7 +30,10 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec (MI355X_MICROARCH.md)
+F32_MFMA_PEAK_TF = 157.3          # v_mfma_f32_32x32x2_f32: the fp32 vector rate (MI355X_MICROARCH.md)
 BYTES_PER_SAMPLE = 1543.0         # algorithmic bytes per ray-sample of the ray-marcher (SURVEY §8d / DESIGN.md)
+MLP_FLOP_PER_SAMPLE = 16640.0     # two-net OSG decoder, per evaluated point; the coarse pass evaluates layer 1 of the density
+COARSE_FACTOR = 1.125             # net only on half the samples: + 1/8 of a full decode per final sample
 FLOP_PER_IMG = 485e9              # modulated-conv FLOPs per 512^2 image
 
 
@@ -43,6 +50,9 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--miopen-find', action='store_true', help='let MIOpen benchmark its solvers for the vendor-library convs (slow warm-up)')
     p.add_argument('--cpu-reps', type=int, default=2)
+    p.add_argument('--train-step', action='store_true', help='time training iterations of BASELINE config 3 (G pass + D pass with R1 + gradient all-reduce) instead of inference')
+    p.add_argument('--no-train-step', action='store_true', help='skip the short train_step extra of the default run')
+    p.add_argument('--train-nrr', type=int, default=128, help='neural rendering resolution of the training passes (train.py: 128 for the 512^2 configs)')
     return p.parse_args()
 
 
@@ -65,26 +75,163 @@ def build(args, device):
     return G, kw, info, ws, c
 
 
+def _reference_root():
+    root = os.environ.get('P3D_REFERENCE', '/root/reference')
+    return root if os.path.isfile(os.path.join(root, 'training', 'triplane_cond.py')) else None
+
+
 def cpu_baseline(args, G_cpu, kw, info, ws, c):
-    """The oracle's synthesis (port of the reference CPU path) on the host cores, batch 1."""
+    """CPU path of the same workload on the host cores, batch 1.  The reference itself (child process: its packages share names with
+    this repository's mirrors) wherever its checkout exists; the oracle's port of it otherwise (the GPU box has no checkout)."""
+    import subprocess
+    nrr, rk = info['nrr'], kw['rendering_kwargs']
+    what = f'batch 1, {nrr}^2 rays x {args.depth} samples -> {info["res"]}^2, fp32'
+    ref = _reference_root()
+    if ref is not None:
+        cmd = [sys.executable, os.path.join(ROOT, 'oracle', 'ref_baseline.py'), args.dataset, str(nrr), str(rk['depth_resolution']), str(rk['depth_resolution_importance']),
+               str(args.cpu_reps)]
+        r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, P3D_REFERENCE=ref), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+        if r.returncode == 0:
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            t = d['seconds_per_image']
+            return {'value': round(1.0 / t, 4), 'unit': 'img/s', 'cores': d['threads'], 'kind': 'reference',
+                    'sample': f'reference G.synthesis imported from {ref} in a child process (its force_fp32 CPU fallbacks), {what}, median of {d["reps"]} '
+                              f'after 1 warm-up ({t:.2f} s/img; host has {d["logical_cores"]} logical cores)'}
     from oracle import model_oracle as M
     from pix2pix3d_amd import configs
     cfg = configs.oracle_cfg(args.dataset, depth=(args.depth // 2, args.depth // 2))
     sd = {k: v.float() for k, v in G_cpu.state_dict().items()}
-    nrr, rk = info['nrr'], kw['rendering_kwargs']
     torch.manual_seed(1)
     u_c = torch.rand(1, nrr * nrr, rk['depth_resolution'], 1)
     u_f = torch.rand(nrr * nrr, rk['depth_resolution_importance'])
-    times = []
-    with torch.no_grad():
-        for i in range(args.cpu_reps + 1):
-            t0 = time.perf_counter()
+
+    def run():
+        t0 = time.perf_counter()
+        with torch.no_grad():
             M.synthesis(sd, cfg, ws[:1], c[:1], u_c, u_f, nrr=nrr, noise_mode='const')
-            times.append(time.perf_counter() - t0)
-    t = float(np.median(times[1:])) if len(times) > 1 else times[0]
-    return {'value': round(1.0 / t, 4), 'unit': 'img/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'oracle.model_oracle.synthesis, batch 1, {nrr}^2 rays x {args.depth} samples -> {info["res"]}^2, fp32, '
-                      f'median of {max(len(times) - 1, 1)} after 1 warm-up ({t:.2f} s/img; host has {os.cpu_count()} logical cores)'}
+        return time.perf_counter() - t0
+    # the box has far more logical cores than this problem can use: time it at every core and at 32 threads, report the faster
+    all_threads = torch.get_num_threads()
+    best = None
+    for threads in sorted({all_threads, min(all_threads, 32)}, reverse=True):
+        torch.set_num_threads(threads)
+        run()                                                        # warm-up at this thread count
+        ts = [run() for _ in range(max(args.cpu_reps - 1, 1))]
+        t = float(np.median(ts))
+        if best is None or t < best[0]:
+            best = (t, threads, len(ts))
+    torch.set_num_threads(all_threads)
+    t, threads, reps = best
+    return {'value': round(1.0 / t, 4), 'unit': 'img/s', 'cores': threads, 'kind': 'port',
+            'sample': f'oracle.model_oracle.synthesis (the reference checkout is not reachable here), {what}, median of {reps} after 1 warm-up at the '
+                      f'faster of {all_threads} / {min(all_threads, 32)} threads ({t:.2f} s/img; host has {os.cpu_count()} logical cores)'}
+
+
+def render_traffic(args, nrr):
+    """Memory-side bytes per launch of the ray-marcher from the committed PMC passes (profiles/render_pmc.json, written by
+    tests/gpu_pmc_traffic.py) — only for the workload it was taken on and only while the kernel sources are the ones it was taken from."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'render_pmc.json')))
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        from gpu_pmc_traffic import kernel_source_hash
+        if args.batch == 4 and args.depth == 128 and nrr == 128 and pmc.get('kernel_src_sha16') == kernel_source_hash():
+            return pmc['traffic_bytes_per_launch']
+    except (OSError, KeyError, ValueError, ImportError):
+        pass
+    return None
+
+
+def train_setup(args, device, world):
+    """BASELINE config 3 per GPU: seg2cat generator in training mode (unfused modulation, fp16 SR heads) and the dual discriminator
+    (fp16 top blocks, conv_clamp 256, train.py:289-318, 381-387, 509-512), batch 4, 128^2 rays x 48+48 samples."""
+    from pix2pix3d_amd import configs, dnnlib
+    kw = configs.generator_kwargs(args.dataset, depth=(48, 48))
+    rk = kw['rendering_kwargs']
+    info = configs.dataset_info(args.dataset)
+    torch.manual_seed(0)
+    G = dnnlib.util.construct_class_by_name(**kw).to(device).train().requires_grad_(True)
+    D = dnnlib.util.construct_class_by_name(class_name='training.dual_discriminator.DualDiscriminator', c_dim=25, img_resolution=info['res'], img_channels=3,
+                                            channel_base=32768, channel_max=512, num_fp16_res=4, conv_clamp=256, disc_c_noise=0,
+                                            block_kwargs=dict(freeze_layers=0), mapping_kwargs={}, epilogue_kwargs=dict(mbstd_group_size=4)).to(device).train().requires_grad_(True)
+    n = args.batch
+    g = torch.Generator().manual_seed(99 + int(os.environ.get('RANK', 0)))
+    ws = torch.randn(n, G.backbone.num_ws, 512, generator=g).to(device)
+    c = torch.tensor(np.stack([configs.orbit_camera(7 * k + 3, radius=rk['avg_camera_radius'], pivot=rk['avg_camera_pivot']) for k in range(n)]), dtype=torch.float32).to(device)
+    real = {'image': torch.randn(n, 3, info['res'], info['res'], generator=g).to(device), 'image_raw': torch.randn(n, 3, args.train_nrr, args.train_nrr, generator=g).to(device)}
+    return G, D, ws, c, real
+
+
+def train_iteration(G, D, ws, c, real, nrr, world, timers):
+    """One iteration: G pass (synthesis forward + backward of an image loss; loss.py:440-470 without the loss networks), flat
+    all-reduce of G's gradients (training_loop.py:531-542), D pass on real images with the R1 penalty (loss.py:849-891), flat
+    all-reduce of D's gradients.  ``timers``: dict of lists of (start, end) event pairs per stage."""
+    from pix2pix3d_amd import dp
+    from pix2pix3d_amd.torch_utils.ops import conv2d_gradfix
+
+    def mark(key):
+        e = torch.cuda.Event(enable_timing=True); e.record()
+        timers.setdefault(key, []).append(e)
+    mark('t0')
+    out = G.synthesis(ws, c, neural_rendering_resolution=nrr, noise_mode='random')
+    loss = out['image'].float().square().mean() + out['semantic'].float().square().mean() + out['image_raw'].square().mean()
+    loss.backward()
+    mark('g_done')
+    flat_g = dp.allreduce_gradients(G, world_size=world)
+    mark('g_sync')
+    img = {k: v.detach().requires_grad_(True) for k, v in real.items()}
+    logits = D(img, c)
+    with conv2d_gradfix.no_weight_gradients():
+        grads = torch.autograd.grad(outputs=[logits.sum()], inputs=list(img.values()), create_graph=True, only_inputs=True)
+    r1 = sum(gr.square().sum([1, 2, 3]) for gr in grads)
+    (torch.nn.functional.softplus(-logits) + r1 * 5).mean().backward()
+    mark('d_done')
+    flat_d = dp.allreduce_gradients(D, world_size=world)
+    mark('d_sync')
+    sizes = (flat_g.numel() * 4, flat_d.numel() * 4)
+    for m in (G, D):
+        for p in m.parameters():
+            p.grad = None
+    return sizes
+
+
+def train_summary(timers, sizes, world, batch, wall_ms):
+    def avg(a, b):
+        return float(np.mean([x.elapsed_time(y) for x, y in zip(timers[a], timers[b])]))
+    g_ms, gs_ms, d_ms, ds_ms = avg('t0', 'g_done'), avg('g_done', 'g_sync'), avg('g_sync', 'd_done'), avg('d_done', 'd_sync')
+    bus = lambda nbytes, ms: round(2 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 1) if world > 1 and ms > 0 else None
+    return {'what': 'BASELINE config 3 per GPU: G pass (synthesis fwd + bwd, training mode) + flat gradient all-reduce + D pass on real images with R1 + all-reduce; '
+                    f'batch {batch}/GPU; every convolution forward / data gradient / weight gradient on libp3d_hip.so',
+            'ms_per_iteration': round(wall_ms, 2), 'img_per_s': round(batch * world / (wall_ms * 1e-3), 2),
+            'g_pass_ms': round(g_ms, 2), 'd_pass_ms': round(d_ms, 2),
+            'allreduce': {'g_bytes': sizes[0], 'd_bytes': sizes[1], 'g_ms': round(gs_ms, 3), 'd_ms': round(ds_ms, 3), 'g_bus_GBps': bus(sizes[0], gs_ms), 'd_bus_GBps': bus(sizes[1], ds_ms),
+                          'note': 'world 1: concatenate + nan_to_num + scatter only' if world == 1 else 'RCCL ring over xGMI; bus GB/s = 2(p-1)/p x bytes / time'}}
+
+
+def run_train(args, device, world, dist, iters, warm):
+    G, D, ws, c, real = train_setup(args, device, world)
+    timers = {}
+    for _ in range(warm):
+        sizes = train_iteration(G, D, ws, c, real, args.train_nrr, world, {})
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        sizes = train_iteration(G, D, ws, c, real, args.train_nrr, world, timers)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    summary = train_summary(timers, sizes, world, args.batch, elapsed / iters * 1e3)
+    del G, D
+    torch.cuda.empty_cache()
+    return summary, elapsed
 
 
 def main():
@@ -93,6 +240,7 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    local = local % torch.cuda.device_count()                      # (ranks > devices only in the one-GPU RCCL smoke run, tests/gpu_rccl_smoke.sh)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     dist = None
@@ -108,6 +256,20 @@ def main():
     conv2d_gradfix.enabled = True                                   # training_loop.py:281
     rmod.fused_policy = 'require'
     torch.backends.cudnn.benchmark = bool(args.miopen_find)         # training_loop.py:280 sets True; find-mode costs ~100 s of warm-up per fresh box
+
+    if args.train_step:                                              # BASELINE config 3 as the timed workload
+        summary, elapsed = run_train(args, device, world, dist, args.steps, max(args.warmup, 1))
+        if rank == 0:
+            line = {'metric': 'training img/s (seg2cat 512^2, batch 4/GPU, 128^2 rays x 48+48 samples; G pass + D/R1 pass + gradient all-reduce)',
+                    'value': summary['img_per_s'], 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                    'ms_per_step': summary['ms_per_iteration'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                    'dtype': 'f32 (backbone, ray-marcher) + f16/f32-acc (super-resolution, discriminator top blocks), as train.py configures', 'data': 'synthetic',
+                    'config': {'workload': summary['what'], 'launch': 'eager', 'parallelism': f'dp{world} (batch sharded, flat fp32 gradient all-reduce per phase)'},
+                    'train_step': summary}
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     G_cpu, kw, info, ws_cpu, c_cpu = build(args, device)
     cpu = None
@@ -136,8 +298,8 @@ def main():
     for _ in range(max(args.warmup, 1)):
         out = step()
     torch.cuda.synchronize()
-    # vendor-library convolutions (small backbone layers) may still be compiling / selecting kernels on a fresh box:
-    # keep warming (untimed) until three consecutive steps agree within 5 %, at most 40 extra steps
+    # a fresh box may still be loading code objects / growing the allocator's pools: keep warming (untimed) until three
+    # consecutive steps agree within 5 %, at most 40 extra steps
     hist = []
     for _ in range(40):
         t0 = time.perf_counter(); step(); torch.cuda.synchronize(); hist.append(time.perf_counter() - t0)
@@ -215,19 +377,24 @@ def main():
         h.remove()
     stage_ms = {k: (sum(a.elapsed_time(b) for a, b in v) / n_prof if v else 0.0) for k, v in stage_events.items()}
 
+    train = None
+    if not args.no_train_step:                                       # short: 2 warm-up + 3 timed iterations
+        del graph
+        G = G.cpu()
+        torch.cuda.empty_cache()
+        try:
+            train, _ = run_train(args, device, world, dist, 3, 2)
+        except Exception as e:                                       # noqa: BLE001 - the headline line must still be printed
+            train = {'error': f'{type(e).__name__}: {e}'[:300]}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         imgs = args.batch * world * args.steps
         samples_per_launch = args.batch * nrr * nrr * args.depth
         render_s = render_kernel_ms * 1e-3
         achieved = samples_per_launch * BYTES_PER_SAMPLE / render_s / 1e9 if render_s > 0 else 0.0
-        traffic = None                                              # memory-side bytes per launch from the committed PMC pass (same workload only)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'render_pmc.json')))
-            if args.batch == 4 and args.depth == 128 and nrr == 128:
-                traffic = pmc['traffic_bytes_per_launch']
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic = render_traffic(args, nrr)                         # memory-side bytes per launch (committed PMC passes of THIS kernel, else null)
+        mfma_floor_ms = samples_per_launch * MLP_FLOP_PER_SAMPLE * COARSE_FACTOR / (F32_MFMA_PEAK_TF * 1e12) * 1e3
         line = {
             'metric': f'rendered img/s ({info["res"]}^2, {args.depth} depth)',
             'value': round(imgs / elapsed, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -241,11 +408,14 @@ def main():
             'conv_tflops': round(FLOP_PER_IMG * args.batch / ((stage_ms['backbone'] + stage_ms['sr']) * 1e-3) / 1e12, 2) if stage_ms['backbone'] + stage_ms['sr'] > 0 else None,
             'roofline': {'kernel': 'render_forward_kernel (fused tri-plane ray-marcher)', 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                         'mfma_frac': round(mfma_floor_ms / render_kernel_ms, 4) if render_kernel_ms > 0 else None, 'mfma_floor_ms': round(mfma_floor_ms, 4),
+                         'bound_note': 'taps are served by L1/L2 (traffic << algorithmic bytes): the decoder on the fp32 matrix cores (mfma_frac) is the binding floor',
                          'ms_per_launch': round(render_kernel_ms, 4), 'launches_timed': len(kern), 'units_per_launch': samples_per_launch, 'bytes_per_unit': BYTES_PER_SAMPLE},
             'mfma_conv': {k: {'ms_per_step': round(conv_ms[k], 3), 'tflops': round(conv_fl[k] / (conv_ms[k] * 1e-3) / 1e12, 1) if conv_ms[k] > 0 else None,
                               'frac_of_peak': round(conv_fl[k] / (conv_ms[k] * 1e-3) / 1e12 / (2500.0 if k == 'conv_f16' else 157.3), 3) if conv_ms[k] > 0 else None}
                           for k in ('conv_f16', 'conv_f32')},
             'cpu_baseline': cpu,
+            'train_step': train,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -8,6 +8,7 @@ training/networks_stylegan2.py:34-69, 81-91), ``conv2d_resample`` (:114-136), th
 per-sample "fused" modulation, enough pixels to fill 128-row MFMA tiles); every other case keeps the generic route.
 """
 import ctypes
+import os
 
 import torch
 
@@ -49,8 +50,11 @@ _lib.register('p3d_noise_bias_act', ctypes.c_int, [_vp] * 5 + [_i32] * 4 + [_f32
 
 min_pixels = 1               # every layer takes this module (the vendor conv library is never entered: its choices for the small
                              # layers — naive kernels on a fresh box — cost milliseconds)
-gemm_max_pixels = 1024       # layers whose input has at most this many pixels per image cannot fill 128-pixel MFMA tiles: they run as
-                             # im2col/col2im + one batched library GEMM per layer (weight-bandwidth bound, tens of microseconds)
+gemm_max_pixels = int(os.environ.get('P3D_GEMM_MAX_PIXELS', 0))
+# Layers whose input has at most this many pixels per image run as im2col / col2im + one batched LIBRARY GEMM per layer.  0 (default):
+# no such layer — the low-resolution layers (4^2 .. 32^2, K = 4608) take the MFMA kernel too, with its K steps dealt out to many
+# work-groups (split-K, csrc/conv2d.hip): same speed as the library GEMM route on the benchmark (402 vs 402 img/s), no vendor GEMM
+# and no im2col / col2im launches.  The GEMM route is kept behind the environment variable for A/B measurements only.
 
 _zero_pages = {}
 
@@ -79,7 +83,7 @@ def _dense_dev(x):
     return x.is_cuda and x.dtype in (torch.float16, torch.float32) and x.ndim == 4 and (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last))
 
 
-gemm_max_pixels_up = 256     # the x2 layers leave the GEMM route earlier: col2im of a 65^2 image costs more than the four polyphase MFMA GEMMs
+gemm_max_pixels_up = int(os.environ.get('P3D_GEMM_MAX_PIXELS_UP', 0))     # same switch for the x2 layers (see gemm_max_pixels)
 
 
 def is_small(x, up=1):
