@@ -155,14 +155,16 @@ def train_setup(args, device, world):
                                             block_kwargs=dict(freeze_layers=0), mapping_kwargs={}, epilogue_kwargs=dict(mbstd_group_size=4)).to(device).train().requires_grad_(True)
     n = args.batch
     g = torch.Generator().manual_seed(99 + int(os.environ.get('RANK', 0)))
-    ws = torch.randn(n, G.backbone.num_ws, 512, generator=g).to(device)
+    z = torch.randn(n, 512, generator=g).to(device)
+    mask = torch.randint(0, info['sem'], [n, 1, info['res'], info['res']], generator=g).to(device) if info['data_type'] == 'seg' else \
+        (torch.rand([n, 1, info['res'], info['res']], generator=g) * 2 - 1).to(device)
     c = torch.tensor(np.stack([configs.orbit_camera(7 * k + 3, radius=rk['avg_camera_radius'], pivot=rk['avg_camera_pivot']) for k in range(n)]), dtype=torch.float32).to(device)
     real = {'image': torch.randn(n, 3, info['res'], info['res'], generator=g).to(device), 'image_raw': torch.randn(n, 3, args.train_nrr, args.train_nrr, generator=g).to(device)}
-    return G, D, ws, c, real
+    return G, D, (z, mask), c, real
 
 
-def train_iteration(G, D, ws, c, real, nrr, world, timers):
-    """One iteration: G pass (synthesis forward + backward of an image loss; loss.py:440-470 without the loss networks), flat
+def train_iteration(G, D, zm, c, real, nrr, world, timers):
+    """One iteration: G pass (mapping + synthesis forward + backward of an image loss; loss.py:440-470 without the loss networks), flat
     all-reduce of G's gradients (training_loop.py:531-542), D pass on real images with the R1 penalty (loss.py:849-891), flat
     all-reduce of D's gradients.  ``timers``: dict of lists of (start, end) event pairs per stage."""
     from pix2pix3d_amd import dp
@@ -172,6 +174,7 @@ def train_iteration(G, D, ws, c, real, nrr, world, timers):
         e = torch.cuda.Event(enable_timing=True); e.record()
         timers.setdefault(key, []).append(e)
     mark('t0')
+    ws = G.mapping(zm[0], c, {'mask': zm[1], 'pose': c}, update_emas=False)     # label-map Encoder + MLP: every run_G of the loop starts here (loss.py:440)
     out = G.synthesis(ws, c, neural_rendering_resolution=nrr, noise_mode='random')
     loss = out['image'].float().square().mean() + out['semantic'].float().square().mean() + out['image_raw'].square().mean()
     loss.backward()
@@ -199,7 +202,7 @@ def train_summary(timers, sizes, world, batch, wall_ms):
         return float(np.mean([x.elapsed_time(y) for x, y in zip(timers[a], timers[b])]))
     g_ms, gs_ms, d_ms, ds_ms = avg('t0', 'g_done'), avg('g_done', 'g_sync'), avg('g_sync', 'd_done'), avg('d_done', 'd_sync')
     bus = lambda nbytes, ms: round(2 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 1) if world > 1 and ms > 0 else None
-    return {'what': 'BASELINE config 3 per GPU: G pass (synthesis fwd + bwd, training mode) + flat gradient all-reduce + D pass on real images with R1 + all-reduce; '
+    return {'what': 'BASELINE config 3 per GPU: G pass (mapping incl. the label-map Encoder + synthesis, fwd + bwd, training mode) + flat gradient all-reduce + D pass on real images with R1 + all-reduce; '
                     f'batch {batch}/GPU; every convolution forward / data gradient / weight gradient on libp3d_hip.so',
             'ms_per_iteration': round(wall_ms, 2), 'img_per_s': round(batch * world / (wall_ms * 1e-3), 2),
             'g_pass_ms': round(g_ms, 2), 'd_pass_ms': round(d_ms, 2),
@@ -208,17 +211,17 @@ def train_summary(timers, sizes, world, batch, wall_ms):
 
 
 def run_train(args, device, world, dist, iters, warm):
-    G, D, ws, c, real = train_setup(args, device, world)
+    G, D, zm, c, real = train_setup(args, device, world)
     timers = {}
     for _ in range(warm):
-        sizes = train_iteration(G, D, ws, c, real, args.train_nrr, world, {})
+        sizes = train_iteration(G, D, zm, c, real, args.train_nrr, world, {})
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
-        sizes = train_iteration(G, D, ws, c, real, args.train_nrr, world, timers)
+        sizes = train_iteration(G, D, zm, c, real, args.train_nrr, world, timers)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
