@@ -71,6 +71,34 @@ int p3d_upfirdn2d(const void* x, const float* f, void* y, int dtype,
                   int32_t up_x, int32_t up_y, int32_t down_x, int32_t down_y,
                   int32_t pad_x0, int32_t pad_y0, int32_t flip, float gain, p3d_stream_t stream);
 
+/* ---- filtered_lrelu ----------------------------------------------------------------------------
+ * Replaces filtered_lrelu_plugin.filtered_lrelu (torch_utils/ops/filtered_lrelu.cpp:20-213; kernel parameters filtered_lrelu.h:18-72,
+ * kernels filtered_lrelu.cu:143-1103):  y = fir_down( clamp( lrelu( fir_up(x + b) * up^2 * gain ) ) )  per (n, c) plane, in one pass.
+ * Sizes are {W, H, C, N} and strides (in elements) use the same order.  fu / fd: dense fp32 tables [f_h][f_w] (a separable filter is
+ * passed as its outer product, an absent one as the 1x1 table {1}).  The caller computes the sizes exactly as the plugin does
+ * (filtered_lrelu.cpp:73-97): up-sampled extent c = x*up + pad0 + pad1 - (fu-1), y = (c - (fd-1) + down-1) / down, and for the sign
+ * tensor s_h = y_h*down - (down-1) + (fd_h-1), active width likewise, rounded up to 16 elements, 4 elements per byte.
+ * sign_mode 0: none.  1: WRITE the sign tensor s (uint8 [N][C][s_height][s_width_bytes], contiguous): element (x, y) of the up-sampled
+ *   grid -> byte ((x + s_ofs_x) >> 2) of row (y + s_ofs_y), bits ((x + s_ofs_x) & 3) * 2: 0 passed, 1 negative (IEEE sign bit, as
+ *   filtered_lrelu.cu:497-500), 2 clamped.  2: READ it instead of comparing (the backward configuration, filtered_lrelu.py:240-270):
+ *   code & 1 -> times slope, code & 2 -> 0, elements outside the tensor pass unchanged; clamp is not applied.
+ * sw_limit: valid bytes per sign row ((active width + 3) >> 2).  clamp = +inf disables clamping.
+ * Returns P3D_ERR_UNSUPPORTED (-1, the plugin's "no specialised kernel" code, filtered_lrelu.cpp:56-60) when the tiles of this geometry
+ * do not fit 64 KB of LDS or s_ofs_x is not a multiple of 4 in write mode: the caller then takes the generic route
+ * (upfirdn2d -> p3d_filtered_lrelu_act -> upfirdn2d), as the reference does.                                                        */
+int p3d_filtered_lrelu(const void* x, const float* fu, const float* fd, const void* b, uint8_t* s, void* y, int dtype,
+                       const int32_t x_size[4], const int64_t x_stride[4], const int32_t y_size[4], const int64_t y_stride[4], int64_t b_stride,
+                       int32_t fu_w, int32_t fu_h, int32_t fd_w, int32_t fd_h, int32_t up, int32_t down, int32_t pad_x0, int32_t pad_y0,
+                       int32_t s_width_bytes, int32_t s_height, int32_t s_ofs_x, int32_t s_ofs_y, int32_t sw_limit,
+                       float gain, float slope, float clamp, int32_t flip_filters, int32_t sign_mode, p3d_stream_t stream);
+/* filtered_lrelu_plugin.filtered_lrelu_act_ (filtered_lrelu.cpp:217-296, kernel filtered_lrelu.cu:1109-1213): in place on x (fp16, fp32
+ * or fp64):  x = clamp(lrelu(x * gain)).  sign_mode 1 writes s [N][C][H][s_width/4] with s_width = W rounded up to 16 ELEMENTS (code 1
+ * when the scaled value is < 0 — not the sign bit: the two kernels differ on -0.0, filtered_lrelu.cu:1140-1149); sign_mode 2 reads s
+ * [N][C][s_height][s_width/4] at (x + s_ofs_x, y + s_ofs_y), elements outside pass with the gain only.                              */
+int p3d_filtered_lrelu_act(void* x, uint8_t* s, int dtype, const int32_t x_size[4], const int64_t x_stride[4],
+                           int32_t s_width, int32_t s_height, int32_t s_ofs_x, int32_t s_ofs_y, float gain, float slope, float clamp,
+                           int32_t sign_mode, p3d_stream_t stream);
+
 /* ---- fused tri-plane ray-marcher -----------------------------------------------------------
  * Stands in for the tensor-op pipeline of training/volumetric_rendering:
  *   ImportanceRenderer.forward   renderer.py:88-140   (p3d_render_forward)

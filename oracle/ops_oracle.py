@@ -228,3 +228,99 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
     if noise is not None:
         y = y + np.asarray(noise, np.float64)
     return y.astype(x.dtype)
+
+
+# ---- filtered_lrelu with the bit-packed sign tensor -------------------------------------------------------------------------------
+def _filter2d(f):
+    f = np.ones([1, 1], np.float32) if f is None else np.asarray(f, np.float32)
+    return np.outer(f, f) if f.ndim == 1 else f
+
+
+def filtered_lrelu_sizes(x_shape, fu, fd, up, down, padding):
+    """Sizes the plugin derives (torch_utils/ops/filtered_lrelu.cpp:62-97): up-sampled extent (cw, ch), output (yw, yh), sign tensor
+    (rows sh, active width, bytes per row)."""
+    n, c, xh, xw = x_shape
+    fu2, fd2 = _filter2d(fu), _filter2d(fd)
+    px0, px1, py0, py1 = _pad4(padding)
+    cw, ch = xw * up + px0 + px1 - (fu2.shape[1] - 1), xh * up + py0 + py1 - (fu2.shape[0] - 1)
+    yw, yh = (cw - (fd2.shape[1] - 1) + down - 1) // down, (ch - (fd2.shape[0] - 1) + down - 1) // down
+    sw_active, sh = yw * down - (down - 1) + fd2.shape[1] - 1, yh * down - (down - 1) + fd2.shape[0] - 1
+    return dict(cw=cw, ch=ch, yw=yw, yh=yh, sh=sh, sw_active=sw_active, sw_bytes=((sw_active + 15) & ~15) >> 2)
+
+
+def pack_signs(codes):
+    """[..., H, W] array of 2-bit codes -> uint8 [..., H, ceil16(W)/4]: element x in byte x >> 2, bits (x & 3) * 2
+    (filtered_lrelu.cu:480-487, 512-523)."""
+    h, w = codes.shape[-2:]
+    wp = (w + 15) & ~15
+    padded = np.zeros(codes.shape[:-1] + (wp,), np.uint8)
+    padded[..., :w] = codes
+    q = padded.reshape(codes.shape[:-1] + (wp // 4, 4))
+    return (q[..., 0] | (q[..., 1] << 2) | (q[..., 2] << 4) | (q[..., 3] << 6)).astype(np.uint8)
+
+
+def unpack_signs(packed, x, y):
+    """2-bit code of sign-tensor element (x, y) per plane; 0 where (x, y) falls outside the tensor (those elements pass unchanged,
+    filtered_lrelu.cu:566-576)."""
+    sh, swb = packed.shape[-2:]
+    ok = (x >= 0) & ((x >> 2) < swb) & (y >= 0) & (y < sh)
+    xs, ys = np.where(ok, x, 0), np.where(ok, y, 0)
+    byte = packed[..., ys, xs >> 2]
+    return np.where(ok, (byte >> ((xs & 3) * 2)) & 3, 0)
+
+
+def filtered_lrelu(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=np.sqrt(2), slope=0.2, clamp=None, flip_filter=False,
+                   signs=None, sign_offset=(0, 0), write_signs=False):
+    """bias -> up-sampling FIR (gain up^2) -> lrelu * gain, clamp -> down-sampling FIR
+    (torch_utils/ops/filtered_lrelu.py:123-148; fused kernel filtered_lrelu.cu:143-1103).
+
+    ``signs`` given: the backward configuration — instead of comparing, each element of the up-sampled grid takes its saved 2-bit
+    code at (x + ox, y + oy): & 1 -> times slope, & 2 -> zero, outside the tensor -> unchanged; no clamp (filtered_lrelu.cu:566-576).
+    ``write_signs``: also return the packed sign tensor over the plugin's extent: code 1 where the scaled value has its IEEE sign bit
+    set, 2 (replacing it) where it was clamped (:497-508).  float64 arithmetic on the inputs' values."""
+    x = np.asarray(x)
+    n, c, xh, xw = x.shape
+    px0, px1, py0, py1 = _pad4(padding)
+    sz = filtered_lrelu_sizes(x.shape, fu, fd, up, down, padding)
+    v = x.astype(np.float64) + (0 if b is None else np.asarray(b, np.float64).reshape(1, -1, 1, 1))
+    # the up-sampled grid out to the sign tensor's extent (zeros beyond the data: what the kernel's zero-filled footprint gives)
+    ext_w, ext_h = max(sz['cw'], (sz['sw_active'] + 3) & ~3), max(sz['ch'], sz['sh'])
+    fu2 = _filter2d(fu)
+    pad_r, pad_b = px1 + (ext_w - sz['cw']), py1 + (ext_h - sz['ch'])
+    u = upfirdn2d(v, fu2, up=up, padding=[px0, pad_r, py0, pad_b], flip_filter=flip_filter, gain=1).astype(np.float64)
+    u = u * (np.float32(up) * np.float32(up) * np.float32(gain)).astype(np.float64)
+    ys, xs = np.meshgrid(np.arange(u.shape[2]), np.arange(u.shape[3]), indexing='ij')
+    packed = None
+    if signs is not None:
+        code = unpack_signs(np.asarray(signs), xs + sign_offset[0], ys + sign_offset[1])
+        u = np.where(code & 1, u * slope, u)
+        u = np.where(code & 2, 0.0, u)
+    else:
+        neg = np.signbit(u)
+        u = np.where(neg, u * slope, u)
+        code = neg.astype(np.uint8)
+        if clamp is not None:
+            hit = np.abs(u) > clamp
+            u = np.clip(u, -clamp, clamp)
+            code = np.where(hit, 2, code).astype(np.uint8)
+        if write_signs:
+            packed = pack_signs(code[..., :sz['sh'], :min(code.shape[-1], (sz['sw_active'] + 3) & ~3)])
+            packed = packed[..., :sz['sw_bytes']]
+    y = upfirdn2d(u[..., :sz['ch'], :sz['cw']], _filter2d(fd), down=down, flip_filter=flip_filter)
+    y = y.astype(x.dtype)
+    return (y, packed) if write_signs else y
+
+
+def filtered_lrelu_backward(dy, fu, fd, x_shape, signs, up=1, down=1, padding=0, gain=np.sqrt(2), slope=0.2, flip_filter=False):
+    """d/dx of filtered_lrelu as the SAME op with up <-> down, fu <-> fd, mirrored filters and the saved signs
+    (torch_utils/ops/filtered_lrelu.py:240-270)."""
+    fu2, fd2 = _filter2d(fu), _filter2d(fd)
+    _, _, xh, xw = x_shape
+    _, _, yh, yw = np.asarray(dy).shape
+    px0, px1, py0, py1 = _pad4(padding)
+    pp = [(fu2.shape[1] - 1) + (fd2.shape[1] - 1) - px0, xw * up - yw * down + px0 - (up - 1),
+          (fu2.shape[0] - 1) + (fd2.shape[0] - 1) - py0, xh * up - yh * down + py0 - (up - 1)]
+    gg = gain * (up ** 2) / (down ** 2)
+    off = (-(fu2.shape[1] - 1) + px0, -(fu2.shape[0] - 1) + py0)
+    return filtered_lrelu(dy, fu=fd2, fd=fu2, b=None, up=down, down=up, padding=pp, gain=gg, slope=slope, clamp=None, flip_filter=not flip_filter,
+                          signs=signs, sign_offset=off)

@@ -161,11 +161,11 @@ def test_filtered_lrelu_on_gpu(hip_lib, dtype):
         fu, fd = g[f'{i}.fu'], g[f'{i}.fd']
         x = torch.tensor(g[f'{i}.x'], device='cuda', dtype=dtype, requires_grad=True)
         clamp = float(g[f'{i}.clamp'])
-        n0 = _lib.launch_count('upfirdn2d') + _lib.launch_count('bias_act')
+        n0 = _lib.launch_count('upfirdn2d') + _lib.launch_count('bias_act') + _lib.launch_count('filtered_lrelu')
         y = filtered_lrelu.filtered_lrelu(x, fu=None if fu.size == 0 else torch.tensor(fu, device='cuda'), fd=None if fd.size == 0 else torch.tensor(fd, device='cuda'),
                                           b=torch.tensor(g[f'{i}.b'], device='cuda', dtype=dtype), up=up, down=down, padding=g[f'{i}.pad'].tolist(),
                                           gain=1.3, slope=0.15, clamp=None if clamp < 0 else clamp, flip_filter=bool(flip))
-        assert _lib.launch_count('upfirdn2d') + _lib.launch_count('bias_act') > n0
+        assert _lib.launch_count('upfirdn2d') + _lib.launch_count('bias_act') + _lib.launch_count('filtered_lrelu') > n0
         tol = 2e-5 if dtype == torch.float32 else 2e-7
         assert rel_err(y.detach().cpu().numpy(), g[f'{i}.y']) < tol, i
         gx, = torch.autograd.grad(y, x, torch.tensor(g[f'{i}.gy'], device='cuda', dtype=dtype))

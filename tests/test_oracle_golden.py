@@ -60,3 +60,25 @@ def test_conv_oracles_match_reference():
         y = O.modulated_conv2d(g[f'm{i}.x'], g[f'm{i}.w'], g[f'm{i}.s'], noise=None if noise.size == 0 else noise, up=up, padding=k // 2,
                                resample_filter=f, demodulate=bool(demod), flip_weight=(up == 1))
         assert rel_err(y, g[f'm{i}.y']) < 5e-6, i
+
+
+def test_oracle_filtered_lrelu_and_its_sign_tensor_backward():
+    """The oracle's filtered_lrelu against the reference's records — forward, and the backward pass driven ONLY by the packed sign
+    tensor (the reference's plugin formulation, filtered_lrelu.py:240-270) against the gradient the reference's autograd gives:
+    this is what pins the sign codes, their packing, the sign offsets and the adjoint's padding."""
+    g = load_golden('ops_filtered_lrelu')
+    for i in range(int(g['num'])):
+        up, down, flip = g[f'{i}.cfg'].tolist()
+        fu, fd = g[f'{i}.fu'], g[f'{i}.fd']
+        fu, fd = (None if fu.size == 0 else fu), (None if fd.size == 0 else fd)
+        clamp = float(g[f'{i}.clamp'])
+        clamp = None if clamp < 0 else clamp
+        pad = g[f'{i}.pad'].tolist()
+        y, signs = O.filtered_lrelu(g[f'{i}.x'], fu, fd, g[f'{i}.b'], up, down, pad, 1.3, 0.15, clamp, bool(flip), write_signs=True)
+        sz = O.filtered_lrelu_sizes(g[f'{i}.x'].shape, fu, fd, up, down, pad)
+        assert signs.dtype == np.uint8 and signs.shape[-2:] == (sz['sh'], sz['sw_bytes']) and sz['sw_bytes'] % 4 == 0
+        assert rel_err(y, g[f'{i}.y']) < 1e-6
+        gx = O.filtered_lrelu_backward(g[f'{i}.gy'], fu, fd, g[f'{i}.x'].shape, signs, up, down, pad, 1.3, 0.15, bool(flip))
+        assert rel_err(gx, g[f'{i}.gx']) < 1e-6
+        codes = O.unpack_signs(signs, *np.meshgrid(np.arange(sz['sw_active']), np.arange(sz['sh']), indexing='xy'))
+        assert set(np.unique(codes)) <= {0, 1, 2} and (clamp is not None or 2 not in codes)
