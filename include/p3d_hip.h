@@ -152,6 +152,24 @@ int p3d_render_forward(const float* planes_cl, const float* decoder, const float
                        const p3d_render_desc* desc, float* feat, float* depth, float* wsum, uint32_t* minmax_ws,
                        float* dbg_fine, float* dbg_wcoarse, p3d_stream_t stream);
 
+/* ---- two plane sets: ImportanceSemanticRenderer (training/volumetric_rendering/renderer.py:256-438) --------------------------------
+ * The renderer of TriPlaneSemanticGenerator (training/triplane_cond.py:746-758): a texture and a semantic tri-plane set of the same
+ * size and layout.  The label decoder (OSGDecoder_semantic, FC 32-64-33) reads the semantic planes' features and gives density +
+ * 32 label channels; the colour decoder (OSGDecoder over 64 inputs, FC 64-64-33, density row unused) reads cat(texture, semantic)
+ * features (renderer.py:324-333).  Sampling, merging and compositing are ImportanceRenderer's over cat(colour, label): outputs as
+ * p3d_render_forward with n_nets = 2 (feat [N*M][64]; desc->semantic_sigmoid squashes the labels too).  Inference only.
+ * p3d_pack_decoder_dual: raw FullyConnectedLayer parameters (w1_tex [64][64], b1_tex [64], w2_tex [33][64], b2_tex [33]; w1_sem [64][32],
+ * ...) -> p3d_render_decoder_floats_dual() floats.  p3d_sample_points_dual = run_model: rgb [N*P][64] = cat(colour, label), sigma [N*P]. */
+int p3d_render_decoder_floats_dual(void);
+int p3d_pack_decoder_dual(const float* w1_tex, const float* b1_tex, const float* w2_tex, const float* b2_tex,
+                          const float* w1_sem, const float* b1_sem, const float* w2_sem, const float* b2_sem,
+                          float lr_mul, float* packed, p3d_stream_t stream);
+int p3d_render_forward_dual(const float* planes_tex_cl, const float* planes_sem_cl, const float* decoder_dual, const float* ray_o, const float* ray_d,
+                            const float* u_coarse, const float* u_fine, const float* t_start, const float* t_end,
+                            const p3d_render_desc* desc, float* feat, float* depth, float* wsum, uint32_t* minmax_ws, p3d_stream_t stream);
+int p3d_sample_points_dual(const float* planes_tex_cl, const float* planes_sem_cl, const float* decoder_dual, const float* coords,
+                           const p3d_render_desc* desc, int32_t pts_per_img, float* rgb, float* sigma, p3d_stream_t stream);
+
 /* ---- backward of p3d_render_forward (training configs) ------------------------------------------
  * What autograd derives for ImportanceRenderer.forward (renderer.py:88-140) in the reference, as two recomputing launches
  * (csrc/render_bwd.hip): the forward sweep again, driven by g_feat, hands every sample its compositing scalars on a tape; a

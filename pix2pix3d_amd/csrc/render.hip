@@ -41,7 +41,7 @@ __global__ void render_clamp_depth_kernel(float* depth, int n, const unsigned* m
 }
 
 // ---- point queries: sample -> decode, no compositing (renderer.py:142-148 run_model) ---------------
-template <int NNETS>
+template <int NNETS, bool DUAL = false>
 __global__ void __launch_bounds__(kWavesPerBlock * 64, 2)
 sample_points_kernel(RenderArgs a, const float* coords, int pts_per_img, int total_pts, float* rgb, float* sigma_out)
 {
@@ -51,23 +51,26 @@ sample_points_kernel(RenderArgs a, const float* coords, int pts_per_img, int tot
     {
         const f32x4* src = (const f32x4*)a.decoder;
         f32x4* dst = (f32x4*)lds;
-        for (int i = tid; i < kDecoderFloats / 4; i += blockDim.x) dst[i] = src[i];
+        for (int i = tid; i < (DUAL ? kDecoderFloatsDual : kDecoderFloats) / 4; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
     const int SN = NNETS - 1;
     const rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.planes, 0, a.planes_total_bytes, 0x00020000);
+    const rsrc_t rsrc_sem = DUAL ? __builtin_amdgcn_make_buffer_rsrc((void*)a.planes2, 0, a.planes_total_bytes, 0x00020000) : rsrc;
     const int tiles = (total_pts + 31) / 32;
     for (int t = blockIdx.x * kWavesPerBlock + wave; t < tiles; t += gridDim.x * kWavesPerBlock) {
         const int p = min(t * 32 + j, total_pts - 1);
         const bool live = (t * 32 + j) < total_pts;
         const unsigned img = (unsigned)(p / pts_per_img) * a.img_bytes;
         const float cs = a.coord_scale;
-        float feat[16];
-        gather_features<true>(a, rsrc, img, h, cs * coords[(size_t)p * 3], cs * coords[(size_t)p * 3 + 1], cs * coords[(size_t)p * 3 + 2], feat);
+        float feat[16], feat_tex[16];
+        gather_features<!DUAL>(a, rsrc_sem, img, h, cs * coords[(size_t)p * 3], cs * coords[(size_t)p * 3 + 1], cs * coords[(size_t)p * 3 + 2], feat);
+        if (DUAL) gather_features<false>(a, rsrc, img, h, cs * coords[(size_t)p * 3], cs * coords[(size_t)p * 3 + 1], cs * coords[(size_t)p * 3 + 2], feat_tex);
 #pragma unroll
         for (int n = 0; n < NNETS; ++n) {
             f32x16 h0, h1, o;
-            mlp_layer1(lds, n, lane, h, feat, h0, h1);
+            if (DUAL && n == 0) mlp_layer1<false, true>(lds, n, lane, h, feat_tex, h0, h1, feat);
+            else                mlp_layer1(lds, n, lane, h, feat, h0, h1);
             if (n == SN) { const float s = mlp_sigma(lds, h, h0, h1); if (live && h == 0) sigma_out[p] = s; }
             mlp_layer2(lds, n, lane, h, h0, h1, o);
             const bool squash = (n == 0) || (NNETS == 1) || a.sem_sigmoid;
@@ -126,22 +129,29 @@ __global__ void __launch_bounds__(256) planes_to_cl_kernel(const float* __restri
 
 struct PackArgs {
     const float* w1[2]; const float* b1[2]; const float* w2[2]; const float* b2[2];
-    int n_nets; float wg1, wg2, bg;                  // FullyConnectedLayer gains (networks_stylegan2.py:111-120)
+    int n_nets; float wg1[2], wg2, bg;               // FullyConnectedLayer gains (networks_stylegan2.py:111-120); wg1 per net (fan-in 32 or 64)
+    int w1_in[2];                                    // inputs of each net's first layer (row length of w1): 32, or 64 for the dual colour net
+    int total;                                       // kDecoderFloats or kDecoderFloatsDual
 };
 
 __global__ void __launch_bounds__(256) pack_decoder_kernel(PackArgs p, float* out)
 {
     const int SN = p.n_nets - 1;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kDecoderFloats; i += gridDim.x * blockDim.x) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p.total; i += gridDim.x * blockDim.x) {
         float v = 0.f;
-        if (i < 2 * kNetStride) {
+        if (i >= OFF_W1X) {                                     // dual colour net, first layer, inputs 32..63: same per-lane order as block q < 32
+            const int e = i - OFF_W1X;
+            const int q4 = e / 256, lane = (e % 256) / 4, q = q4 * 4 + (e & 3);
+            const int row = lane & 31, h = lane >> 5, t = q >> 4, kk = q & 15;
+            v = p.w1[0][(32 * t + row) * p.w1_in[0] + 32 + 16 * h + kk] * p.wg1[0];
+        } else if (i < 2 * kNetStride) {
             const int n = i / kNetStride, e = i % kNetStride;
             const int q4 = e / 256, lane = (e % 256) / 4, q = q4 * 4 + (e & 3);
             const int row = lane & 31, h = lane >> 5;
             if (n < p.n_nets) {
                 if (q < 32) {                                   // layer 1: tile t, k-step kk
                     const int t = q >> 4, kk = q & 15;
-                    v = p.w1[n][(32 * t + row) * 32 + 16 * h + kk] * p.wg1;
+                    v = p.w1[n][(32 * t + row) * p.w1_in[n] + 16 * h + kk] * p.wg1[n];
                 } else {                                        // layer 2: colour row `row`, hidden pi(s, h)
                     const int s = q - 32, t = s >> 4, r = s & 15;
                     const int hid = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -206,10 +216,29 @@ extern "C" int p3d_pack_decoder(const float* w1_a, const float* b1_a, const floa
     p.w1[0] = w1_a; p.b1[0] = b1_a; p.w2[0] = w2_a; p.b2[0] = b2_a;
     p.w1[1] = w1_b; p.b1[1] = b1_b; p.w2[1] = w2_b; p.b2[1] = b2_b;
     p.n_nets = n_nets;
-    p.wg1 = lr_mul / sqrtf(32.f); p.wg2 = lr_mul / sqrtf(64.f); p.bg = lr_mul;
+    p.wg1[0] = p.wg1[1] = lr_mul / sqrtf(32.f); p.wg2 = lr_mul / sqrtf(64.f); p.bg = lr_mul;
+    p.w1_in[0] = p.w1_in[1] = 32; p.total = kDecoderFloats;
     hipLaunchKernelGGL(pack_decoder_kernel, dim3((kDecoderFloats + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, packed);
     count_launch(FAM_AUX);
     return check_launch("pack_decoder");
+}
+
+extern "C" int p3d_render_decoder_floats_dual(void) { return kDecoderFloatsDual; }
+
+extern "C" int p3d_pack_decoder_dual(const float* w1_tex, const float* b1_tex, const float* w2_tex, const float* b2_tex,
+                                     const float* w1_sem, const float* b1_sem, const float* w2_sem, const float* b2_sem,
+                                     float lr_mul, float* packed, p3d_stream_t stream)
+{
+    P3D_REQUIRE(w1_tex && b1_tex && w2_tex && b2_tex && w1_sem && b1_sem && w2_sem && b2_sem && packed, "pack_decoder_dual: null weights");
+    PackArgs p;
+    p.w1[0] = w1_tex; p.b1[0] = b1_tex; p.w2[0] = w2_tex; p.b2[0] = b2_tex;     // net 0: colours from cat(texture, semantic) features, [64, 64] first layer
+    p.w1[1] = w1_sem; p.b1[1] = b1_sem; p.w2[1] = w2_sem; p.b2[1] = b2_sem;     // net 1: density + labels from the semantic features
+    p.n_nets = 2;
+    p.wg1[0] = lr_mul / sqrtf(64.f); p.wg1[1] = lr_mul / sqrtf(32.f); p.wg2 = lr_mul / sqrtf(64.f); p.bg = lr_mul;
+    p.w1_in[0] = 64; p.w1_in[1] = 32; p.total = kDecoderFloatsDual;
+    hipLaunchKernelGGL(pack_decoder_kernel, dim3((kDecoderFloatsDual + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, packed);
+    count_launch(FAM_AUX);
+    return check_launch("pack_decoder_dual");
 }
 
 static void fill_args(RenderArgs& a, const p3d_render_desc* d)
@@ -224,14 +253,16 @@ static void fill_args(RenderArgs& a, const p3d_render_desc* d)
     a.planes_total_bytes = (unsigned)((int64_t)d->n_img * a.img_stride * 4);
 }
 
-extern "C" int p3d_render_forward(const float* planes_cl, const float* decoder, const float* ray_o, const float* ray_d,
-                                  const float* u_coarse, const float* u_fine, const float* t_start, const float* t_end,
-                                  const p3d_render_desc* d, float* feat, float* depth, float* wsum, uint32_t* minmax_ws,
-                                  float* dbg_fine, float* dbg_wcoarse, p3d_stream_t stream)
+static int render_forward_impl(const float* planes_cl, const float* planes_sem_cl, const float* decoder, const float* ray_o, const float* ray_d,
+                               const float* u_coarse, const float* u_fine, const float* t_start, const float* t_end,
+                               const p3d_render_desc* d, float* feat, float* depth, float* wsum, uint32_t* minmax_ws,
+                               float* dbg_fine, float* dbg_wcoarse, p3d_stream_t stream)
 {
+    const bool dual = planes_sem_cl != nullptr;
     int rc = check_render_common(d);
     if (rc != P3D_OK) return rc;
     P3D_REQUIRE(planes_cl && decoder && ray_o && ray_d && u_coarse && feat && depth && wsum && minmax_ws, "render_forward: null pointer");
+    P3D_REQUIRE(!dual || d->n_nets == 2, "render_forward_dual: the two-plane-set renderer has two decoders (n_nets = 2)");
     P3D_REQUIRE(d->n_img >= 0 && d->rays_per_img >= 1, "render_forward: bad ray counts");
     P3D_REQUIRE((t_start == nullptr) == (t_end == nullptr), "render_forward: t_start/t_end must be given together");
     if (d->depth_resolution < 4 || d->depth_resolution > kMaxS || d->depth_resolution_importance < 1 ||
@@ -243,19 +274,23 @@ extern "C" int p3d_render_forward(const float* planes_cl, const float* decoder, 
     if (total == 0) return P3D_OK;
     RenderArgs a{};
     fill_args(a, d);
-    a.planes = planes_cl; a.decoder = decoder; a.ray_o = ray_o; a.ray_d = ray_d; a.u_coarse = u_coarse; a.u_fine = u_fine;
+    a.planes = planes_cl; a.planes2 = planes_sem_cl; a.decoder = decoder; a.ray_o = ray_o; a.ray_d = ray_d; a.u_coarse = u_coarse; a.u_fine = u_fine;
     a.t_start = t_start; a.t_end = t_end; a.feat = feat; a.depth = depth; a.wsum = wsum;
     a.dbg_fine = dbg_fine; a.dbg_wcoarse = dbg_wcoarse; a.minmax = minmax_ws;
     a.total_rays = (int)total; a.rays_per_img = d->rays_per_img;
     { int r = 1; while (r * r < d->rays_per_img) ++r; a.res = (r * r == d->rays_per_img && d->raster_order) ? r : 0; }
     hipStream_t s = (hipStream_t)stream;
     // a block is one-per-CU (LDS): small launches take fewer waves per block so that every CU still gets one
-    int wpb = kWavesPerBlock;
+    int wpb = dual ? kWavesPerBlockDual : kWavesPerBlock;
     while (wpb > 2 && (total + wpb * 32 - 1) / (wpb * 32) < kNumCU) wpb >>= 1;
-    const size_t lds_bytes = (size_t)(kDecoderFloats + kWavesPerBlock * kWaveTile) * sizeof(float);
+    const size_t lds_bytes = (size_t)(dual ? kDecoderFloatsDual + kWavesPerBlockDual * kWaveTile : kDecoderFloats + kWavesPerBlock * kWaveTile) * sizeof(float);
     const int blocks = (int)((total + wpb * 32 - 1) / (wpb * 32));
     hipLaunchKernelGGL(render_init_minmax_kernel, dim3(1), dim3(1), 0, s, minmax_ws);
-    if (d->n_nets == 1) {
+    if (dual) {
+        static std::atomic<uint64_t> onced_devs{0}; const hipError_t onced = reserve_lds_once((const void*)render_forward_kernel<2, false, true>, (int)lds_bytes, onced_devs);
+        if (onced != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_forward_dual: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(onced));
+        hipLaunchKernelGGL((render_forward_kernel<2, false, true>), dim3(blocks), dim3(wpb * 64), lds_bytes, s, a);
+    } else if (d->n_nets == 1) {
         static std::atomic<uint64_t> once1_devs{0}; const hipError_t once1 = reserve_lds_once((const void*)render_forward_kernel<1, false>, (int)lds_bytes, once1_devs);
         if (once1 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_forward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(once1));
         hipLaunchKernelGGL((render_forward_kernel<1, false>), dim3(blocks), dim3(wpb * 64), lds_bytes, s, a);
@@ -272,28 +307,60 @@ extern "C" int p3d_render_forward(const float* planes_cl, const float* decoder, 
     return check_launch("render_clamp_depth");
 }
 
-extern "C" int p3d_sample_points(const float* planes_cl, const float* decoder, const float* coords, const p3d_render_desc* d,
-                                 int32_t pts_per_img, float* rgb, float* sigma, p3d_stream_t stream)
+extern "C" int p3d_render_forward(const float* planes_cl, const float* decoder, const float* ray_o, const float* ray_d,
+                                  const float* u_coarse, const float* u_fine, const float* t_start, const float* t_end,
+                                  const p3d_render_desc* d, float* feat, float* depth, float* wsum, uint32_t* minmax_ws,
+                                  float* dbg_fine, float* dbg_wcoarse, p3d_stream_t stream)
 {
+    return render_forward_impl(planes_cl, nullptr, decoder, ray_o, ray_d, u_coarse, u_fine, t_start, t_end, d, feat, depth, wsum, minmax_ws, dbg_fine, dbg_wcoarse, stream);
+}
+
+extern "C" int p3d_render_forward_dual(const float* planes_tex_cl, const float* planes_sem_cl, const float* decoder_dual, const float* ray_o, const float* ray_d,
+                                       const float* u_coarse, const float* u_fine, const float* t_start, const float* t_end,
+                                       const p3d_render_desc* d, float* feat, float* depth, float* wsum, uint32_t* minmax_ws, p3d_stream_t stream)
+{
+    P3D_REQUIRE(planes_sem_cl, "render_forward_dual: null semantic planes");
+    return render_forward_impl(planes_tex_cl, planes_sem_cl, decoder_dual, ray_o, ray_d, u_coarse, u_fine, t_start, t_end, d, feat, depth, wsum, minmax_ws, nullptr, nullptr, stream);
+}
+
+static int sample_points_impl(const float* planes_cl, const float* planes_sem_cl, const float* decoder, const float* coords, const p3d_render_desc* d,
+                              int32_t pts_per_img, float* rgb, float* sigma, p3d_stream_t stream)
+{
+    const bool dual = planes_sem_cl != nullptr;
     int rc = check_render_common(d);
     if (rc != P3D_OK) return rc;
     P3D_REQUIRE(planes_cl && decoder && coords && rgb && sigma, "sample_points: null pointer");
+    P3D_REQUIRE(!dual || d->n_nets == 2, "sample_points_dual: the two-plane-set renderer has two decoders (n_nets = 2)");
     P3D_REQUIRE(d->n_img >= 0 && pts_per_img >= 1, "sample_points: bad point counts");
     const int64_t total = (int64_t)d->n_img * pts_per_img;
     P3D_REQUIRE(total <= INT32_MAX / 64, "sample_points: too many points");
     if (total == 0) return P3D_OK;
     RenderArgs a{};
     fill_args(a, d);
-    a.planes = planes_cl; a.decoder = decoder;
+    a.planes = planes_cl; a.planes2 = planes_sem_cl; a.decoder = decoder;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds_bytes = (size_t)kDecoderFloats * sizeof(float);
+    const size_t lds_bytes = (size_t)(dual ? kDecoderFloatsDual : kDecoderFloats) * sizeof(float);
     int64_t tiles = (total + 31) / 32;
     int blocks = (int)((tiles + kWavesPerBlock - 1) / kWavesPerBlock);
     if (blocks > kNumCU * 2) blocks = kNumCU * 2;
-    if (d->n_nets == 1) hipLaunchKernelGGL(sample_points_kernel<1>, dim3(blocks), dim3(kWavesPerBlock * 64), lds_bytes, s, a, coords, pts_per_img, (int)total, rgb, sigma);
-    else                hipLaunchKernelGGL(sample_points_kernel<2>, dim3(blocks), dim3(kWavesPerBlock * 64), lds_bytes, s, a, coords, pts_per_img, (int)total, rgb, sigma);
+    if (dual)                hipLaunchKernelGGL((sample_points_kernel<2, true>), dim3(blocks), dim3(kWavesPerBlock * 64), lds_bytes, s, a, coords, pts_per_img, (int)total, rgb, sigma);
+    else if (d->n_nets == 1) hipLaunchKernelGGL(sample_points_kernel<1>, dim3(blocks), dim3(kWavesPerBlock * 64), lds_bytes, s, a, coords, pts_per_img, (int)total, rgb, sigma);
+    else                     hipLaunchKernelGGL(sample_points_kernel<2>, dim3(blocks), dim3(kWavesPerBlock * 64), lds_bytes, s, a, coords, pts_per_img, (int)total, rgb, sigma);
     count_launch(FAM_RENDER);
     return check_launch("sample_points");
+}
+
+extern "C" int p3d_sample_points(const float* planes_cl, const float* decoder, const float* coords, const p3d_render_desc* d,
+                                 int32_t pts_per_img, float* rgb, float* sigma, p3d_stream_t stream)
+{
+    return sample_points_impl(planes_cl, nullptr, decoder, coords, d, pts_per_img, rgb, sigma, stream);
+}
+
+extern "C" int p3d_sample_points_dual(const float* planes_tex_cl, const float* planes_sem_cl, const float* decoder_dual, const float* coords,
+                                      const p3d_render_desc* d, int32_t pts_per_img, float* rgb, float* sigma, p3d_stream_t stream)
+{
+    P3D_REQUIRE(planes_sem_cl, "sample_points_dual: null semantic planes");
+    return sample_points_impl(planes_tex_cl, planes_sem_cl, decoder_dual, coords, d, pts_per_img, rgb, sigma, stream);
 }
 
 extern "C" int p3d_importance_sample(const float* z_coarse, const float* w_coarse, const float* u_fine, float* z_fine,

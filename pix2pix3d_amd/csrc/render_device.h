@@ -16,6 +16,10 @@ constexpr int OFF_B2   = OFF_B1 + 128;           // [net][half][16]  colour bias
 constexpr int OFF_W2S  = OFF_B2 + 64;            // [half][32]       density row of the density net
 constexpr int OFF_B2S  = OFF_W2S + 64;           // [1]              density bias
 constexpr int kDecoderFloats = 8464;             // padded to 16 floats
+// Two-plane-set renderer (ImportanceSemanticRenderer, renderer.py:256-438): net 0's first layer reads 64 inputs, cat(texture features,
+// semantic features); the weights of inputs 32..63 follow the common stream as one more 32-step block in the same per-lane order.
+constexpr int OFF_W1X  = kDecoderFloats;
+constexpr int kDecoderFloatsDual = kDecoderFloats + 2048;
 constexpr int kPitch = 33;                       // LDS pitch of the per-wave [sample][ray] tile
 constexpr int kMaxS = 64;                        // max coarse / fine samples per ray
 constexpr int kWaveTile = kMaxS * kPitch + 128;  // + two 64-float scratch rows
@@ -23,7 +27,8 @@ constexpr int kWavesPerBlock = 8;
 
 struct RenderArgs {
     const float* planes;      // [N][3][H][W][32]
-    const float* decoder;     // kDecoderFloats, see p3d_pack_decoder
+    const float* planes2;     // DUAL kernels: the semantic plane set (same sizes and strides); `planes` is then the texture set
+    const float* decoder;     // kDecoderFloats (kDecoderFloatsDual for the DUAL kernels), see p3d_pack_decoder
     const float* ray_o;       // [N*M][3]
     const float* ray_d;       // [N*M][3]
     const float* u_coarse;    // [N*M][Sc]
@@ -206,9 +211,9 @@ __device__ __forceinline__ void gather_features(const RenderArgs& a, rsrc_t rsrc
 // ---- decoder pieces -------------------------------------------------------------------------------
 // Layer 1 of net `n` for this wave's 32 samples: returns the 64 hidden units (post-softplus) as two
 // accumulator tiles; lane (j,h) holds hidden unit 32t + (r&3) + 8(r>>2) + 4h of sample j in tile[t][r].
-template <bool LOG2 = false>
+template <bool LOG2 = false, bool WIDE = false>
 __device__ __forceinline__ void mlp_layer1(const float* lds, int n, int lane, int h, const float (&feat)[16],
-                                           f32x16& h0, f32x16& h1)
+                                           f32x16& h0, f32x16& h1, const float* feat_hi = nullptr)
 {
     const f32x4* b1 = (const f32x4*)(lds + OFF_B1 + (n * 2 + h) * 32);
 #pragma unroll
@@ -225,6 +230,18 @@ __device__ __forceinline__ void mlp_layer1(const float* lds, int n, int lane, in
         for (int e = 0; e < 4; ++e) {
             h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], feat[q * 4 + e], h0, 0, 0, 0);
             h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], feat[q * 4 + e], h1, 0, 0, 0);
+        }
+    }
+    if (WIDE) {                                              // inputs 32..63 of a 64-input first layer (the colour net of the two-plane-set renderer)
+        const f32x4* wx = (const f32x4*)(lds + OFF_W1X) + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a0 = wx[q * 64], a1 = wx[(4 + q) * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], feat_hi[q * 4 + e], h0, 0, 0, 0);
+                h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], feat_hi[q * 4 + e], h1, 0, 0, 0);
+            }
         }
     }
 #pragma unroll
@@ -332,10 +349,16 @@ __device__ __forceinline__ float bitonic_sort64(float v, int lane)
 // ---- the fused kernel -------------------------------------------------------------------------------
 // TAPE = false: the inference / forward kernel.  TAPE = true: the same sweep driven by dL/dfeat instead of writing feat: it records, per
 // ray, what the point-wise backward kernel needs (sample depth, colour weight 0.5 (w[k-1] + w[k]), dL/dsigma_k) — see render_bwd.hip.
-template <int NNETS, bool TAPE>
-__global__ void __launch_bounds__(kWavesPerBlock * 64, 2)
+// DUAL (NNETS == 2, inference only): two plane sets.  The label net (density + labels) reads the SEMANTIC planes' features, the colour
+// net reads cat(texture features, semantic features) through a 64-input first layer (renderer.py:324-333); everything else —
+// sampling, merge, compositing over cat(colour, label) — is the same sweep.
+constexpr int kWavesPerBlockDual = 4;            // the DUAL kernel keeps two feature vectors live: one wave per SIMD (512 registers) instead of spilling
+template <int NNETS, bool TAPE, bool DUAL = false>
+__global__ void __launch_bounds__((DUAL ? kWavesPerBlockDual : kWavesPerBlock) * 64, DUAL ? 1 : 2)
 render_forward_kernel(RenderArgs a)
 {
+    static_assert(!DUAL || (NNETS == 2 && !TAPE), "the two-plane-set variant is the two-net inference kernel");
+    constexpr int kDecFloats = DUAL ? kDecoderFloatsDual : kDecoderFloats;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -347,11 +370,11 @@ render_forward_kernel(RenderArgs a)
     {   // decoder stream -> LDS (16 B per lane)
         const f32x4* src = (const f32x4*)a.decoder;
         f32x4* dst = (f32x4*)lds;
-        for (int i = tid; i < kDecoderFloats / 4; i += blockDim.x) {
+        for (int i = tid; i < kDecFloats / 4; i += blockDim.x) {
             f32x4 v = src[i];
             if (LOG2) {
                 const int f = i * 4;
-                const bool first  = f < OFF_B1 ? (f & (kNetStride - 1)) < kNetStride / 2 : f < OFF_B2;      // layer-1 weights / biases
+                const bool first  = f >= OFF_W1X ? true : (f < OFF_B1 ? (f & (kNetStride - 1)) < kNetStride / 2 : f < OFF_B2);      // layer-1 weights / biases
                 const bool second = f < OFF_B1 ? !first : (f >= OFF_W2S && f < OFF_B2S);                    // layer-2 colour rows / density row
                 const float sc = first ? 1.4426950408889634f : (second ? 0.6931471805599453f : 1.f);
                 v = v * sc;
@@ -361,7 +384,7 @@ render_forward_kernel(RenderArgs a)
     }
     __syncthreads();
 
-    float* tile = lds + kDecoderFloats + wave * kWaveTile;      // [sample][kPitch] coarse weights, then fine depths
+    float* tile = lds + kDecFloats + wave * kWaveTile;          // [sample][kPitch] coarse weights, then fine depths
     float* sA = tile + kMaxS * kPitch;
     float* sB = sA + 64;
     const int SN = NNETS - 1;                                    // density comes from the last net (triplane_cond.py:958)
@@ -396,6 +419,7 @@ render_forward_kernel(RenderArgs a)
     const bool live = g_lane < a.total_rays;
     const int n_img = g / a.rays_per_img;
     const rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.planes, 0, a.planes_total_bytes, 0x00020000);
+    const rsrc_t rsrc_sem = DUAL ? __builtin_amdgcn_make_buffer_rsrc((void*)a.planes2, 0, a.planes_total_bytes, 0x00020000) : rsrc;   // density / labels read these
     const unsigned img = (unsigned)n_img * a.img_bytes;
     const float ox = a.ray_o[g * 3 + 0], oy = a.ray_o[g * 3 + 1], oz = a.ray_o[g * 3 + 2];
     const float dx = a.ray_d[g * 3 + 0], dy = a.ray_d[g * 3 + 1], dz = a.ray_d[g * 3 + 2];
@@ -408,7 +432,7 @@ render_forward_kernel(RenderArgs a)
         for (int i = 0; i < Sc; ++i) {
             const float z = coarse_depth(a, g, i, uc[i]);
             float feat[16];
-            gather_features<!TAPE>(a, rsrc, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
+            gather_features<!TAPE>(a, rsrc_sem, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
             f32x16 h0, h1;
             mlp_layer1<LOG2>(lds, SN, lane, h, feat, h0, h1);
             const float sigma = mlp_sigma(lds, h, h0, h1);
@@ -462,8 +486,9 @@ render_forward_kernel(RenderArgs a)
         if (take_c) { ++ic; zc = (ic < Sc) ? coarse_depth(a, g, ic, uc[ic]) : INFINITY; }
         else        { ++jf; zf = (jf < Sf) ? tile[jf * kPitch + j] : INFINITY; }
 
-        float feat[16];
-        gather_features<!TAPE>(a, rsrc, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
+        float feat[16], feat_tex[16];
+        gather_features<!TAPE && !DUAL>(a, rsrc_sem, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
+        if (DUAL) gather_features<false>(a, rsrc, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat_tex);
         // The density net goes first: its sigma closes interval k-1 (weight w), after which every net's
         // colours are folded into the accumulators as soon as its layer 2 retires — only `prev` (the
         // other end of the midpoint rule) stays live across samples.
@@ -473,7 +498,8 @@ render_forward_kernel(RenderArgs a)
         for (int idx = 0; idx < NNETS; ++idx) {
             const int n = (idx == 0) ? SN : idx - 1;
             f32x16 h0, h1, o;
-            mlp_layer1<LOG2>(lds, n, lane, h, feat, h0, h1);
+            if (DUAL && n == 0) mlp_layer1<LOG2, true>(lds, n, lane, h, feat_tex, h0, h1, feat);     // colour net: cat(texture, semantic)
+            else                mlp_layer1<LOG2>(lds, n, lane, h, feat, h0, h1);
             if (idx == 0) {
                 sigma = mlp_sigma(lds, h, h0, h1);
                 if (k == 0) z_first = z;

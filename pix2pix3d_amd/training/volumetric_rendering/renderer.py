@@ -43,6 +43,10 @@ _lib.register('p3d_render_backward', ctypes.c_int, [_vp] * 9 + [ctypes.POINTER(_
 _lib.register('p3d_render_forward', ctypes.c_int, [_vp] * 8 + [ctypes.POINTER(_RenderDesc)] + [_vp] * 6 + [_vp])
 _lib.register('p3d_sample_points', ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(_RenderDesc), _i32, _vp, _vp, _vp])
 _lib.register('p3d_importance_sample', ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp])
+_lib.register('p3d_render_decoder_floats_dual', ctypes.c_int, [])
+_lib.register('p3d_pack_decoder_dual', ctypes.c_int, [_vp] * 8 + [_f32, _vp, _vp])
+_lib.register('p3d_render_forward_dual', ctypes.c_int, [_vp] * 9 + [ctypes.POINTER(_RenderDesc)] + [_vp] * 4 + [_vp])
+_lib.register('p3d_sample_points_dual', ctypes.c_int, [_vp] * 4 + [ctypes.POINTER(_RenderDesc), _i32, _vp, _vp, _vp])
 
 
 def generate_planes():
@@ -340,25 +344,139 @@ class ImportanceRenderer(torch.nn.Module):
         return b0 + (u - c0) / span * (b1 - b0)
 
 
+def _osg_pair(decoder, n_in, squash_required=None):
+    """(fc1, fc2, lr_mul) of a single-MLP OSG decoder FC(n_in, 64) - Softplus - FC(64, 33), else None."""
+    seq = getattr(decoder, 'net', None)
+    if not (isinstance(seq, torch.nn.Sequential) and len(seq) == 3 and isinstance(seq[1], torch.nn.Softplus)) or hasattr(decoder, 'net_semantic'):
+        return None
+    fc1, fc2 = seq[0], seq[2]
+    if not all(hasattr(fc, 'weight_gain') and getattr(fc, 'activation', None) == 'linear' and fc.bias is not None for fc in (fc1, fc2)):
+        return None
+    if tuple(fc1.weight.shape) != (64, n_in) or tuple(fc2.weight.shape) != (33, 64) or seq[1].beta != 1 or seq[1].threshold != 20:
+        return None
+    lr = float(fc1.bias_gain)
+    if abs(fc1.weight_gain - lr / n_in ** 0.5) > 1e-12 or abs(fc2.weight_gain - lr / 8.0) > 1e-12 or fc2.bias_gain != lr:
+        return None
+    return fc1, fc2, lr
+
+
+def _plane_set_cl(planes):
+    """[N,3,32,H,W] planes as the kernels read them: (tensor, (image, plane, pixel) strides in floats).  A channels-last [N,96,H,W]
+    backbone output viewed as [N,3,32,H,W] is read in place; anything else goes through one re-layout pass to [N][3][H][W][32]."""
+    n, k, c, h, w = planes.shape
+    st = planes.stride()
+    if planes.dtype == torch.float32 and st[2] == 1 and st[1] == 32 and st[4] >= 96 and st[3] == w * st[4] and st[0] == h * st[3] and st[4] % 4 == 0 \
+            and planes.data_ptr() % 16 == 0:
+        return planes.detach(), (st[0], st[1], st[4])
+    src = _f32c(planes)
+    out = torch.empty([n, 3, h, w, 32], dtype=torch.float32, device=planes.device)
+    _lib.check(_lib.lib().p3d_planes_to_channels_last(_lib.ptr(src), _lib.ptr(out), n, h, w, _lib.stream_of(src)), 'planes_to_channels_last')
+    return out, (0, 0, 0)
+
+
 class ImportanceSemanticRenderer(ImportanceRenderer):
     """Renderer of the two-backbone generator (reference: renderer.py:256-438): a texture plane set and a semantic plane set; the label
     decoder reads the semantic features and provides density + labels, the colour decoder reads cat(texture, semantic).  Sampling
-    and compositing are ImportanceRenderer's, over the feature vector cat(colour, label).  train.py no longer selects the generator
-    that uses it (:375), so this is the plain tensor-op formulation on every device — no fused kernel, and ``fused_policy ==
-    'require'`` refuses device tensors here like everywhere else."""
+    and compositing are ImportanceRenderer's, over the feature vector cat(colour, label).
+
+    Device tensors without an autograd graph run the DUAL variant of the fused kernel (``p3d_render_forward_dual`` /
+    ``p3d_sample_points_dual``, csrc/render_device.h): both plane sets are gathered per sample, the colour net's first layer takes its
+    64 inputs as two 32-wide MFMA blocks.  Graphs that need gradients (train.py no longer selects this generator, :375) and CPU tensors
+    take the tensor-op formulation."""
+
+    def _dual_operands(self, planes_texture, planes_semantic, decoder_texture, decoder_semantic, options, needs_grad):
+        """Packed operands of the DUAL kernels, or the reason they do not apply."""
+        if fused_policy == 'never':
+            return 'fused_policy == never'
+        if planes_texture.device.type != 'cuda':
+            return 'CPU tensors'
+        if needs_grad:
+            return 'autograd graph requested (the two-plane-set kernel is inference only)'
+        if planes_texture.shape != planes_semantic.shape or planes_texture.ndim != 5 or tuple(planes_texture.shape[1:3]) != (3, 32):
+            return f'plane sets {tuple(planes_texture.shape)} / {tuple(planes_semantic.shape)} are not two [N,3,32,H,W] sets'
+        if options.get('density_noise', 0) > 0 or options.get('clamp_mode', 'softplus') != 'softplus':
+            return 'density_noise / clamp_mode outside the kernel'
+        tex, sem = _osg_pair(decoder_texture, 64), _osg_pair(decoder_semantic, 32)
+        if tex is None or sem is None or tex[2] != sem[2] or type(decoder_texture).__name__ != 'OSGDecoder' or not hasattr(decoder_semantic, 'final_sigmoid'):
+            return 'decoders are not OSGDecoder(64) + OSGDecoder_semantic(32)'
+        pt, st_t = _plane_set_cl(planes_texture)
+        ps, st_s = _plane_set_cl(planes_semantic)
+        if st_t != st_s:                                     # one descriptor describes both sets: bring the odd one to the default layout
+            if st_t != (0, 0, 0):
+                pt, st_t = _plane_set_cl(planes_texture.contiguous())
+            if st_s != (0, 0, 0):
+                ps, st_s = _plane_set_cl(planes_semantic.contiguous())
+        lib = _lib.lib()
+        packed = torch.empty([lib.p3d_render_decoder_floats_dual()], dtype=torch.float32, device=pt.device)
+        ws = [_f32c(t) for t in (tex[0].weight, tex[0].bias, tex[1].weight, tex[1].bias, sem[0].weight, sem[0].bias, sem[1].weight, sem[1].bias)]
+        _lib.check(lib.p3d_pack_decoder_dual(*[_lib.ptr(t) for t in ws], tex[2], _lib.ptr(packed), _lib.stream_of(packed)), 'pack_decoder_dual')
+        n, _, _, h, w = planes_texture.shape
+
+        def desc(rays_per_img=1, start=0.0, end=0.0):
+            return _RenderDesc(n, rays_per_img, h, w, 2, int(bool(decoder_semantic.final_sigmoid)), int(options.get('depth_resolution', 0)),
+                               int(options.get('depth_resolution_importance', 0)), int(bool(options.get('disparity_space_sampling', False))),
+                               int(bool(options.get('white_back', False))), float(start), float(end), float(options['box_warp']), *st_t, 1)
+        return pt, ps, packed, desc, ws
 
     def forward(self, planes_texture, planes_semantic, decoder_texture, decoder_semantic, ray_origins, ray_directions, rendering_options):
         self.plane_axes = self.plane_axes.to(ray_origins.device)
-        self._tensor_op_guard(planes_texture, 'two plane sets (ImportanceSemanticRenderer) have no fused kernel')
+        opt = rendering_options
+        needs_grad = torch.is_grad_enabled() and (planes_texture.requires_grad or planes_semantic.requires_grad or ray_origins.requires_grad
+                                                  or any(p.requires_grad for d in (decoder_texture, decoder_semantic) for p in d.parameters()))
+        ops = self._dual_operands(planes_texture, planes_semantic, decoder_texture, decoder_semantic, opt, needs_grad)
+        sc, sf = int(opt['depth_resolution']), int(opt['depth_resolution_importance'])
+        if not isinstance(ops, str) and not (4 <= sc <= 64 and 1 <= sf <= 64):
+            ops = 'sample counts outside the fused kernel envelope (4..64 coarse, 1..64 fine)'
+        if not isinstance(ops, str):
+            pt, ps, packed, desc, _keep = ops
+            n, m, _ = ray_origins.shape
+            dev = pt.device
+            auto = opt['ray_start'] == opt['ray_end'] == 'auto'
+            t0 = t1 = None
+            if auto:                                                        # tensor limits: the reference's rand_like fills a permuted [S,N,M,1] tensor
+                t0, t1 = self._ray_limits(ray_origins, ray_directions, opt)
+                u_c = torch.rand([sc, n, m, 1], device=dev, dtype=torch.float32).permute(1, 2, 0, 3)
+                t0, t1 = _f32c(t0).reshape(-1), _f32c(t1).reshape(-1)
+            else:
+                u_c = torch.rand([n, m, sc, 1], device=dev, dtype=torch.float32)    # rand_like(depths_coarse) (renderer.py:190)
+            u_f = torch.rand([n * m, sf], device=dev, dtype=torch.float32)           # sample_pdf's draw (:237)
+            feat = torch.empty([n, m, 64], device=dev, dtype=torch.float32)
+            depth = torch.empty([n, m, 1], device=dev, dtype=torch.float32)
+            wsum = torch.empty([n, m, 1], device=dev, dtype=torch.float32)
+            mm = torch.empty([2], device=dev, dtype=torch.int32)
+            d = desc(m, 0.0 if auto else opt['ray_start'], 0.0 if auto else opt['ray_end'])
+            code = _lib.lib().p3d_render_forward_dual(_lib.ptr(pt), _lib.ptr(ps), _lib.ptr(packed), _lib.ptr(_f32c(ray_origins)), _lib.ptr(_f32c(ray_directions)),
+                                                      _lib.ptr(_f32c(u_c)), _lib.ptr(u_f), _lib.ptr(t0), _lib.ptr(t1), ctypes.byref(d), _lib.ptr(feat), _lib.ptr(depth),
+                                                      _lib.ptr(wsum), _lib.ptr(mm), _lib.stream_of(feat))
+            _lib.check(code, 'render_forward_dual')
+            return feat, depth, wsum
+        self._tensor_op_guard(planes_texture, ops)
 
         def point_fn(pts, dirs):
-            out = self.run_model(planes_texture, planes_semantic, decoder_texture, decoder_semantic, pts, dirs, rendering_options)
+            out = self._run_model_tensor_ops(planes_texture, planes_semantic, decoder_texture, decoder_semantic, pts, dirs, rendering_options)
             return {'rgb': torch.cat([out['rgb'], out['semantic']], dim=-1), 'sigma': out['sigma']}
         return self._forward_tensor_ops(None, None, ray_origins, ray_directions, rendering_options, point_fn=point_fn)
 
     def run_model(self, planes_texture, planes_semantic, decoder_texture, decoder_semantic, sample_coordinates, sample_directions, options):
         """-> {'rgb': [N,P,32], 'sigma': [N,P,1], 'semantic': [N,P,32]}  (renderer.py:324-333)."""
         self.plane_axes = self.plane_axes.to(sample_coordinates.device)
+        needs_grad = torch.is_grad_enabled() and (planes_texture.requires_grad or planes_semantic.requires_grad or sample_coordinates.requires_grad
+                                                  or any(p.requires_grad for d in (decoder_texture, decoder_semantic) for p in d.parameters()))
+        ops = self._dual_operands(planes_texture, planes_semantic, decoder_texture, decoder_semantic, options, needs_grad)
+        if isinstance(ops, str):
+            self._tensor_op_guard(planes_texture, ops)
+            return self._run_model_tensor_ops(planes_texture, planes_semantic, decoder_texture, decoder_semantic, sample_coordinates, sample_directions, options)
+        pt, ps, packed, desc, _keep = ops
+        n, p, _ = sample_coordinates.shape
+        both = torch.empty([n, p, 64], device=pt.device, dtype=torch.float32)
+        sigma = torch.empty([n, p, 1], device=pt.device, dtype=torch.float32)
+        d = desc()
+        code = _lib.lib().p3d_sample_points_dual(_lib.ptr(pt), _lib.ptr(ps), _lib.ptr(packed), _lib.ptr(_f32c(sample_coordinates)), ctypes.byref(d), p,
+                                                 _lib.ptr(both), _lib.ptr(sigma), _lib.stream_of(both))
+        _lib.check(code, 'sample_points_dual')
+        return {'sigma': sigma, 'rgb': both[..., :32], 'semantic': both[..., 32:]}
+
+    def _run_model_tensor_ops(self, planes_texture, planes_semantic, decoder_texture, decoder_semantic, sample_coordinates, sample_directions, options):
         tex = sample_from_planes(self.plane_axes, planes_texture, sample_coordinates, padding_mode='zeros', box_warp=options['box_warp'])
         sem = sample_from_planes(self.plane_axes, planes_semantic, sample_coordinates, padding_mode='zeros', box_warp=options['box_warp'])
         label = decoder_semantic(sem, sample_directions)
