@@ -34,7 +34,10 @@ enum p3d_status {
     P3D_ERR_LAUNCH      = -3
 };
 
-enum p3d_dtype { P3D_F32 = 0, P3D_F16 = 1, P3D_F64 = 2 };
+enum p3d_dtype { P3D_F32 = 0, P3D_F16 = 1, P3D_F64 = 2,
+                 P3D_F32_BF16X3 = 3     /* conv entry points only: fp32 tensors, fp32 accumulation, every product formed as three bf16
+                                           products of (hi, lo) splits — ~2^-16 relative per product at up to 5x the fp32 matrix rate;
+                                           weights come from p3d_modulate_weights with the same code ([32 x hi | 32 x lo] K rows)      */ };
 
 /* ---- library services ------------------------------------------------------------------- */
 const char* p3d_last_error(void);        /* message of the last failure on this host thread      */

@@ -30,7 +30,31 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+
 constexpr int BM = 128, BN = 128;          // block tile; the K step is one 128-byte row: 64 halfs or 32 floats
+
+// ---- "bf16x3": fp32 convolution on the bf16 matrix cores --------------------------------------------------------------------------
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate, and the five big backbone layers are bound by it (117 of 157 TFLOP/s).  With
+// every fp32 operand written as hi + lo (hi = bf16(x), lo = bf16(x - hi): 16 significand bits), x * w = xh*wh + xh*wl + xl*wh up to
+// 2^-16 relative — three bf16 MFMAs with fp32 accumulation instead of one fp32 MFMA at 1/16 of their rate.  Activations stay fp32 in
+// HBM and LDS and are split in registers (v_cvt_pk_bf16_f32, VALU slots beside the MFMAs); weights are split once by
+// p3d_modulate_weights into 128-byte K rows [32 x hi | 32 x lo], i.e. the SAME bytes per row as 32 fp32 values, so staging is
+// untouched.  Selected by dtype P3D_F32_BF16X3; exact fp32 remains the default (P3D_F32).
+#ifndef P3D_BF16_TERMS
+#define P3D_BF16_TERMS 3
+#endif
+constexpr int kBf16Terms = P3D_BF16_TERMS;     // 3: xh*wh + xh*wl + xl*wh (term order: hh, hl, lh); 4 adds xl*wl (measured: no accuracy gain)
+__device__ __forceinline__ void split_bf16x8(const f32x4& a0, const f32x4& a1, bf8& hi, bf8& lo)
+{
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = a0[e], y = a1[e];
+        const __bf16 hx = (__bf16)x, hy = (__bf16)y;                  // round to nearest even
+        hi[e] = hx; hi[4 + e] = hy;
+        lo[e] = (__bf16)(x - (float)hx); lo[4 + e] = (__bf16)(y - (float)hy);
+    }
+}
 
 struct ConvTap { int dy, dx, widx; };
 
@@ -66,9 +90,10 @@ template <class T> struct ConvTraits;
 template <> struct ConvTraits<__half> { static constexpr int BK = 64; };      // elements per 128-byte K row
 template <> struct ConvTraits<float>  { static constexpr int BK = 32; };
 
-template <class T>
+template <class T, bool BF3 = false>
 __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
 {
+    static_assert(!BF3 || sizeof(T) == 4, "bf16x3 is a formulation of the fp32 convolution");
     constexpr int BK = ConvTraits<T>::BK;
     constexpr int EPC = 16 / sizeof(T);                                        // elements per 16-byte chunk
     __shared__ __attribute__((aligned(16))) f32x4 lds[2][2][BM * 8];          // [buffer][A|B][row*8 + chunk], 16-byte slots
@@ -172,6 +197,26 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
                 if (++t == ntaps) { t = 0; ++cc; }
                 if (s + 1 < s_end) stage(cc, t, buf ^ 1);
             }
+            if constexpr (BF3) {                                                // 2 x 16 channels: lane (frow, fk) owns channels 16 m + 8 fk + 0..7
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    bf8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int ra = wm * 64 + i * 32 + frow, rb = wn * 64 + i * 32 + frow;
+                        split_bf16x8(lds[buf][0][swz(ra, 4 * m + 2 * fk)], lds[buf][0][swz(ra, 4 * m + 2 * fk + 1)], ah[i], al[i]);
+                        bh[i] = __builtin_bit_cast(bf8, lds[buf][1][swz(rb, 2 * m + fk)]);          // weight row = [32 hi | 32 lo] bf16
+                        bl[i] = __builtin_bit_cast(bf8, lds[buf][1][swz(rb, 4 + 2 * m + fk)]);
+                    }
+#pragma unroll
+                    for (int term = 0; term < kBf16Terms; ++term)               // term outermost: consecutive MFMAs never share an accumulator
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(term >= 2 ? al[i] : ah[i], (term & 1) ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
+                }
+            } else
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {                                    // 4 x 32 bytes of K per 128-byte row
                 f32x4 fa[2], fb[2];
@@ -366,9 +411,10 @@ constexpr int PH = 8, PW = 16;                      // pixel patch of a block (P
 constexpr int SLAB_W = PW + 2, SLAB_ROWS = (PH + 2) * (PW + 2);          // 18, 180 slab pixels
 constexpr int SLAB_SLOTS = ((SLAB_ROWS + 7) / 8) * 8 * 8;                // padded to whole 8-row DMA groups, 16-byte slots
 
-template <class T>
+template <class T, bool BF3 = false>
 __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(ConvArgs a)
 {
+    static_assert(!BF3 || sizeof(T) == 4, "bf16x3 is a formulation of the fp32 convolution");
     constexpr int BK = ConvTraits<T>::BK;
     constexpr int EPC = 16 / sizeof(T);
     __shared__ __attribute__((aligned(16))) f32x4 slab[2][SLAB_SLOTS];       // [buffer][slab pixel * 8 + chunk]
@@ -441,6 +487,26 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(ConvArgs a)
             if (t == 0 && cc + 1 < kchunks) stage_slab(cc + 1, sb ^ 1);     // next chunk's slab streams in under this chunk's nine taps
         }
         const int toff = (t / 3 - 1) * SLAB_W + (t % 3 - 1);
+        if constexpr (BF3) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                bf8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int sr = arow[i] + toff, key = (sr >> 1) & 7, rb = wn * 64 + i * 32 + frow;
+                    split_bf16x8(slab[sb][sr * 8 + ((4 * m + 2 * fk) ^ key)], slab[sb][sr * 8 + ((4 * m + 2 * fk + 1) ^ key)], ah[i], al[i]);
+                    bh[i] = __builtin_bit_cast(bf8, wt[wb][swz(rb, 2 * m + fk)]);
+                    bl[i] = __builtin_bit_cast(bf8, wt[wb][swz(rb, 4 + 2 * m + fk)]);
+                }
+#pragma unroll
+                for (int term = 0; term < kBf16Terms; ++term)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(term >= 2 ? al[i] : ah[i], (term & 1) ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             f32x4 fa[2], fb[2];
@@ -882,7 +948,7 @@ __global__ void __launch_bounds__(256, 2) convT_h2_f16_kernel(ConvArgs a)
 // one block per (co, n): wm[i, t] = w[co, i, t] * s[n, i]; d = rsqrt(sum wm^2 + 1e-8) (if demodulate); out[n][co][t][i]
 template <class T>
 __global__ void __launch_bounds__(256) modulate_weights_kernel(const float* __restrict__ w, const float* __restrict__ styles, T* __restrict__ out,
-                                                               int Co, int Ci, int KT, int demodulate, float pre_scale, int oihw)
+                                                               int Co, int Ci, int KT, int demodulate, float pre_scale, int oihw, int split)
 {
     __shared__ float red[4];
     const int co = blockIdx.x, n = blockIdx.y;
@@ -901,6 +967,18 @@ __global__ void __launch_bounds__(256) modulate_weights_kernel(const float* __re
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
         __syncthreads();
         d = rsqrtf(red[0] + red[1] + red[2] + red[3] + 1e-8f);
+    }
+    if (split) {                                                     // bf16x3: K rows of [32 x hi | 32 x lo] bf16 (as many bytes as 32 floats)
+        __bf16* ob = (__bf16*)out + ((int64_t)n * Co + co) * total * 2;
+        for (int e = threadIdx.x; e < total; e += blockDim.x) {
+            const int t = e / Ci, i = e - t * Ci;
+            const float v = wr[i * KT + t] * pre_scale * s[i] * d;
+            const __bf16 hi = (__bf16)v;
+            const int64_t row = ((int64_t)t * Ci + (i & ~31)) * 2 + (i & 31);
+            ob[row] = hi;
+            ob[row + 32] = (__bf16)(v - (float)hi);
+        }
+        return;
     }
     T* o = out + ((int64_t)n * Co + co) * total;
     if (oihw) {                                                      // keep the source order [i][t] (GEMM route of the small layers)
@@ -980,9 +1058,10 @@ extern "C" int p3d_modulate_weights(const float* weight, const float* styles, vo
 {
     P3D_REQUIRE(weight && styles && out, "modulate_weights: null pointer");
     P3D_REQUIRE(n_img >= 1 && co >= 1 && ci >= 1 && taps >= 1, "modulate_weights: bad sizes");
-    P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32, "modulate_weights: dtype must be fp16 or fp32");
-    if (dtype == P3D_F16) hipLaunchKernelGGL(modulate_weights_kernel<__half>, dim3(co, n_img), dim3(256), 0, (hipStream_t)stream, weight, styles, (__half*)out, co, ci, taps, demodulate, pre_scale, oihw_order);
-    else                  hipLaunchKernelGGL(modulate_weights_kernel<float>,  dim3(co, n_img), dim3(256), 0, (hipStream_t)stream, weight, styles, (float*)out, co, ci, taps, demodulate, pre_scale, oihw_order);
+    P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32 || dtype == P3D_F32_BF16X3, "modulate_weights: dtype must be fp16, fp32 or fp32-as-bf16x3");
+    P3D_REQUIRE(dtype != P3D_F32_BF16X3 || (ci % 32 == 0 && !oihw_order), "modulate_weights: the bf16x3 layout needs Ci % 32 == 0 and tap-major order");
+    if (dtype == P3D_F16) hipLaunchKernelGGL(modulate_weights_kernel<__half>, dim3(co, n_img), dim3(256), 0, (hipStream_t)stream, weight, styles, (__half*)out, co, ci, taps, demodulate, pre_scale, oihw_order, 0);
+    else                  hipLaunchKernelGGL(modulate_weights_kernel<float>,  dim3(co, n_img), dim3(256), 0, (hipStream_t)stream, weight, styles, (float*)out, co, ci, taps, demodulate, pre_scale, oihw_order, dtype == P3D_F32_BF16X3);
     count_launch(FAM_CONV);
     return check_launch("modulate_weights");
 }
@@ -1033,14 +1112,15 @@ static int launch_conv(ConvArgs& a, int dtype, hipStream_t s, void* workspace, i
     if (query) { *query = need; return P3D_OK; }
     if (want > 1 && workspace && workspace_bytes >= need && (((uintptr_t)workspace) & 15u) == 0) { a.ksplit = want; a.partial = (float*)workspace; }
     dim3 grid(gx, gy, z * a.ksplit);
-    if (dtype == P3D_F16) hipLaunchKernelGGL(conv2d_nhwc_kernel<__half>, grid, dim3(256), 0, s, a);
-    else                  hipLaunchKernelGGL(conv2d_nhwc_kernel<float>, grid, dim3(256), 0, s, a);
+    if (dtype == P3D_F16)             hipLaunchKernelGGL(conv2d_nhwc_kernel<__half>, grid, dim3(256), 0, s, a);
+    else if (dtype == P3D_F32_BF16X3) hipLaunchKernelGGL((conv2d_nhwc_kernel<float, true>), grid, dim3(256), 0, s, a);
+    else                              hipLaunchKernelGGL(conv2d_nhwc_kernel<float>, grid, dim3(256), 0, s, a);
     count_launch(FAM_CONV);
     int rc = check_launch("conv2d_nhwc");
     if (rc != P3D_OK || a.ksplit == 1) return rc;
     const int64_t total = (int64_t)z * gx * BM * ((a.Co + 3) / 4);
     const int blocks = (int)((total + 255) / 256 < 8 * kNumCU ? (total + 255) / 256 : 8 * kNumCU);
-    if (dtype == P3D_F16) hipLaunchKernelGGL(splitk_epilogue_kernel<__half>, dim3(blocks), dim3(256), 0, s, a, gx * BM, gy * BN, z);
+    if (dtype == P3D_F16) hipLaunchKernelGGL(splitk_epilogue_kernel<__half>, dim3(blocks), dim3(256), 0, s, a, gx * BM, gy * BN, z);   // (P3D_F32_BF16X3: fp32 tensors)
     else                  hipLaunchKernelGGL(splitk_epilogue_kernel<float>, dim3(blocks), dim3(256), 0, s, a, gx * BM, gy * BN, z);
     count_launch(FAM_CONV);
     return check_launch("conv2d_nhwc split-K epilogue");
@@ -1086,7 +1166,7 @@ int p3d::conv2d_nhwc_run(const void* x, const void* w, void* y, int dtype, const
     P3D_REQUIRE(resample >= 0 && resample <= 2, "conv2d_nhwc: resample must be 0 (same), 1 (transposed x2) or 2 (valid, stride 2)");
     P3D_REQUIRE(x && w && y && zeros128, "conv2d_nhwc: null pointer");
     P3D_REQUIRE(n_img >= 1 && h >= 1 && wdt >= 1 && co >= 1, "conv2d_nhwc: bad sizes");
-    P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32, "conv2d_nhwc: dtype must be fp16 or fp32");
+    P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32 || dtype == P3D_F32_BF16X3, "conv2d_nhwc: dtype must be fp16, fp32 or fp32-as-bf16x3");
     P3D_REQUIRE(kernel_size == 3 || (kernel_size == 1 && !transposed_stride2), "conv2d_nhwc: kernel 3x3, or 1x1 without upsampling");
     static const bool no_h2t = getenv("P3D_CONV_NO_H2") != nullptr;
     const bool h2t = !no_h2t && resample == 1 && dtype == P3D_F16 && h >= 32 && wdt >= 32 && ci % 32 == 0 && co % BN == 0 && (((uintptr_t)y) & 15u) == 0;   // convT_h2_f16_kernel: 64-byte K rows
@@ -1131,8 +1211,9 @@ int p3d::conv2d_nhwc_run(const void* x, const void* w, void* y, int dtype, const
         if (halo_ok && !prefer_split) {                                   // halo-reuse kernel for the plain 3x3 layers
             if (dry) return P3D_OK;
             dim3 grid(((h + PH - 1) / PH) * ((wdt + PW - 1) / PW), (co + BN - 1) / BN, n_img);
-            if (dtype == P3D_F16) hipLaunchKernelGGL(conv3x3_halo_kernel<__half>, grid, dim3(256), 0, s, a);
-            else                  hipLaunchKernelGGL(conv3x3_halo_kernel<float>, grid, dim3(256), 0, s, a);
+            if (dtype == P3D_F16)             hipLaunchKernelGGL(conv3x3_halo_kernel<__half>, grid, dim3(256), 0, s, a);
+            else if (dtype == P3D_F32_BF16X3) hipLaunchKernelGGL((conv3x3_halo_kernel<float, true>), grid, dim3(256), 0, s, a);
+            else                              hipLaunchKernelGGL(conv3x3_halo_kernel<float>, grid, dim3(256), 0, s, a);
             count_launch(FAM_CONV);
             return check_launch("conv3x3_halo");
         }

@@ -110,15 +110,27 @@ def torgb_supported(x, weight, styles, fused_modconv):
     return _is_nhwc(x) and x.shape[1] % (64 if x.dtype == torch.float16 else 32) == 0      # 1x1 through the MFMA kernel
 
 
+BF16X3 = 'bf16x3'            # dtype tag: fp32 tensors whose products run as three bf16 MFMAs of (hi, lo) splits (csrc/conv2d.hip)
+DTYPE_F32_BF16X3 = 3         # p3d_dtype code of that formulation (include/p3d_hip.h)
+split_bf16 = os.environ.get('P3D_BF16X3', '1') != '0'      # use it for the fp32 layers that are bound by the fp32 matrix rate
+split_bf16_min_pixels = 4096                                # ... i.e. from 64^2 on (SURVEY §8 addendum 4: the five M >= 4096 layers)
+
+
+def use_split_bf16(x, ci):
+    return split_bf16 and x.dtype == torch.float32 and x.shape[2] * x.shape[3] >= split_bf16_min_pixels and ci % 32 == 0
+
+
 def modulate_weights(weight, styles, demodulate=True, pre_scale=1.0, dtype=torch.float16, oihw=False):
-    """weight [O,I,kh,kw] fp32, styles [N,I] -> ``dtype`` [N][O][kh*kw][I] (or [N][O][I][kh*kw] with ``oihw``), demodulation folded in."""
+    """weight [O,I,kh,kw] fp32, styles [N,I] -> ``dtype`` [N][O][kh*kw][I] (or [N][O][I][kh*kw] with ``oihw``), demodulation folded in.
+    ``dtype=BF16X3``: an fp32-typed tensor of the same shape whose K rows hold [32 x bf16 hi | 32 x bf16 lo] per 32 input channels."""
     o, i, kh, kw = weight.shape
     n = styles.shape[0]
     w32 = weight.detach().float().contiguous()
     s32 = styles.detach().float().contiguous()
-    out = torch.empty([n, o, i, kh * kw] if oihw else [n, o, kh * kw, i], dtype=dtype, device=weight.device)
-    code = _lib.lib().p3d_modulate_weights(_lib.ptr(w32), _lib.ptr(s32), _lib.ptr(out), _lib.DTYPE_CODE[dtype], n, o, i, kh * kw, int(demodulate), float(pre_scale),
-                                           int(oihw), _lib.stream_of(out))
+    split = dtype == BF16X3
+    out = torch.empty([n, o, i, kh * kw] if oihw else [n, o, kh * kw, i], dtype=torch.float32 if split else dtype, device=weight.device)
+    code = _lib.lib().p3d_modulate_weights(_lib.ptr(w32), _lib.ptr(s32), _lib.ptr(out), DTYPE_F32_BF16X3 if split else _lib.DTYPE_CODE[dtype], n, o, i, kh * kw,
+                                           int(demodulate), float(pre_scale), int(oihw), _lib.stream_of(out))
     _lib.check(code, 'modulate_weights')
     return out
 
@@ -140,7 +152,7 @@ def _pad_channels(x, wmod, transposed=False):
     return xp, wp
 
 
-def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None, act=0, gain=1.0, clamp=-1.0, down=1):
+def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None, act=0, gain=1.0, clamp=-1.0, down=1, split=False):
     """x NHWC [N,Ci,H,W] (channels_last strides), wmod [N or 1][Co][k*k][Ci] of the same dtype -> NHWC, same dtype.
     k*k = 9: 3x3 "same" correlation, or (transposed) the stride-2 transposed conv [N,Co,2H+1,2W+1], or (down=2) the valid
     stride-2 correlation [N,Co,(H-3)//2+1,(W-3)//2+1]; k*k = 1: 1x1."""
@@ -157,10 +169,12 @@ def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None
     nz = None if noise is None else noise.detach().float().contiguous()
     ns = None if noise is None else noise_strength.detach().float().reshape(1).contiguous()
     mode = 1 if transposed else (2 if down == 2 else 0)
-    nbytes = int(_lib.lib().p3d_conv2d_nhwc_workspace(_lib.DTYPE_CODE[x.dtype], n, h, w, ci, co, stride, k, mode))
+    code_dtype = DTYPE_F32_BF16X3 if split else _lib.DTYPE_CODE[x.dtype]          # split: wmod came from modulate_weights(dtype=BF16X3)
+    assert not split or x.dtype == torch.float32
+    nbytes = int(_lib.lib().p3d_conv2d_nhwc_workspace(code_dtype, n, h, w, ci, co, stride, k, mode))
     work = torch.empty([nbytes // 4], dtype=torch.float32, device=x.device) if nbytes > 0 else None          # split-K partial tiles (low-resolution layers)
     with _lib.kernel_timer('conv_f16' if x.dtype == torch.float16 else 'conv_f32', x):
-        code = _lib.lib().p3d_conv2d_nhwc_ws(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), _lib.DTYPE_CODE[x.dtype], _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns),
+        code = _lib.lib().p3d_conv2d_nhwc_ws(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), code_dtype, _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns),
                                              _lib.ptr(_zeros_page(x.device)), n, h, w, ci, co, stride, k, mode, int(act), float(gain), float(clamp),
                                              _lib.ptr(work), nbytes, _lib.stream_of(x))
     _lib.check(code, 'conv2d_nhwc')
@@ -325,6 +339,8 @@ def premodulate(weight, styles, up, in_pixels, dtype):
     small = in_pixels <= (gemm_max_pixels if up == 1 else gemm_max_pixels_up)
     if small:
         return modulate_weights(weight, styles, demodulate=True, dtype=dtype, oihw=(up == 1)), ('gemm', up, dtype)
+    if split_bf16 and dtype == torch.float32 and in_pixels >= split_bf16_min_pixels and weight.shape[1] % 32 == 0:
+        return modulate_weights(weight, styles, demodulate=True, dtype=BF16X3), ('mfma', up, BF16X3)
     return modulate_weights(weight, styles, demodulate=True, dtype=dtype), ('mfma', up, dtype)
 
 
@@ -332,7 +348,9 @@ def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=No
     """Whole SynthesisLayer body after the style affine: modulated 3x3 conv (x2 up when ``up == 2``) + noise + bias + act.
     ``pre`` = (modulated weights, route tag) from ``premodulate`` — used when the tag matches the route taken here."""
     small = is_small(x, up)
-    wpre = pre[0] if pre is not None and pre[1] == ('gemm' if small else 'mfma', up, x.dtype) else None
+    split = (not small) and use_split_bf16(x, weight.shape[1])
+    wtag = BF16X3 if split else x.dtype
+    wpre = pre[0] if pre is not None and pre[1] == ('gemm' if small else 'mfma', up, wtag) else None
     if small:
         y = _small_layer(x, weight, styles, up, wpre)
         if up == 2:
@@ -342,16 +360,16 @@ def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=No
         if noise_const is not None:
             y = y.add_((noise_const * noise_strength).to(y.dtype))
         return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
-    wmod = wpre if wpre is not None else modulate_weights(weight, styles, demodulate=True, dtype=x.dtype)
+    wmod = wpre if wpre is not None else modulate_weights(weight, styles, demodulate=True, dtype=wtag)
     act_idx = {'linear': 0, 'lrelu': 1}.get(act)
     clampv = -1.0 if clamp is None else float(clamp)
     if up == 1 and act_idx is not None:
-        return conv2d(x, wmod, bias=bias, noise=noise_const, noise_strength=noise_strength, act=act_idx, gain=act_gain, clamp=clampv)
+        return conv2d(x, wmod, bias=bias, noise=noise_const, noise_strength=noise_strength, act=act_idx, gain=act_gain, clamp=clampv, split=split)
     if up == 1:
-        y = conv2d(x, wmod, noise=noise_const, noise_strength=noise_strength)
+        y = conv2d(x, wmod, noise=noise_const, noise_strength=noise_strength, split=split)
         return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
     # x2: stride-2 transposed conv as four polyphase GEMMs, then the 4x4 low-pass with gain 4 (conv2d_resample.py:114-131)
-    y = conv2d(x, wmod, transposed=True)
+    y = conv2d(x, wmod, transposed=True, split=split)
     if act_idx is not None and tuple(resample_filter.shape) == (4, 4) and y.shape[1] % (64 if y.dtype == torch.float16 else 32) == 0:
         return fir4_bias_act(y, resample_filter, bias, noise_const, noise_strength, act, act_gain, clampv)     # FIR + noise + bias + act in one pass
     y = upfirdn2d.upfirdn2d(y, resample_filter, padding=[1, 1, 1, 1], gain=4)

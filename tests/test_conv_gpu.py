@@ -220,3 +220,32 @@ def test_lowres_512_channel_layers_take_the_split_k_schedule(hip_lib, dtype, res
     yt = modconv.conv2d(x, wmod, transposed=True)
     ytr = torch.stack([F.conv_transpose2d(x[i:i + 1].double(), wq[i].transpose(0, 1), stride=2)[0] for i in range(n)])
     assert rel_err(yt.double().cpu().numpy(), ytr.cpu().numpy()) < tol
+
+
+@pytest.mark.parametrize('ci,co,res,transposed', [(256, 256, 64, False), (128, 128, 128, False), (256, 128, 64, True), (64, 96, 70, False)])
+def test_bf16x3_formulation_of_the_fp32_convolution(hip_lib, ci, co, res, transposed):
+    """P3D_F32_BF16X3: every fp32 product as three bf16 MFMAs of (hi, lo) splits with fp32 accumulation.  Bar: <= 1e-5
+    of the output's maximum against an fp64 convolution of the same fp32 operands, per layer (measured 4-5e-6; the exact fp32 MFMA
+    kernel: ~2e-6), with the fused epilogue on top."""
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    torch.manual_seed(ci + res)
+    n = 2
+    x = _nhwc(torch.randn(n, ci, res, res, device='cuda'))
+    weight = torch.randn(co, ci, 3, 3, device='cuda')
+    styles = torch.randn(n, ci, device='cuda') + 1
+    w32 = modconv.modulate_weights(weight, styles, dtype=torch.float32)
+    w3 = modconv.modulate_weights(weight, styles, dtype=modconv.BF16X3)
+    assert w3.dtype == torch.float32 and w3.shape == w32.shape
+    wq = w32.double().reshape(n, co, 3, 3, ci).permute(0, 1, 4, 2, 3).cpu()
+    xd = x.double().cpu()
+    if transposed:
+        y = modconv.conv2d(x, w3, transposed=True, split=True)
+        ref = torch.stack([F.conv_transpose2d(xd[i:i + 1], wq[i].transpose(0, 1), stride=2)[0] for i in range(n)])
+    else:
+        bias, noise, strength = torch.randn(co, device='cuda'), torch.randn(res, res, device='cuda'), torch.tensor(0.3, device='cuda')
+        y = modconv.conv2d(x, w3, bias=bias, noise=noise, noise_strength=strength, act=1, gain=2 ** 0.5, split=True)
+        ref = torch.stack([F.conv2d(xd[i:i + 1], wq[i], padding=1)[0] for i in range(n)])
+        ref = F.leaky_relu(ref + (noise * strength).double().cpu() + bias.double().cpu().view(1, -1, 1, 1), 0.2) * 2 ** 0.5
+    e = rel_err(y.double().cpu().numpy(), ref.numpy())
+    print((ci, co, res, transposed), e)
+    assert e < 1e-5, e
