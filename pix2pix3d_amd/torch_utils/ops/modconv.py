@@ -173,14 +173,14 @@ def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None
     assert not split or x.dtype == torch.float32
     nbytes = int(_lib.lib().p3d_conv2d_nhwc_workspace(code_dtype, n, h, w, ci, co, stride, k, mode))
     work = torch.empty([nbytes // 4], dtype=torch.float32, device=x.device) if nbytes > 0 else None          # split-K partial tiles (low-resolution layers)
-    with _lib.kernel_timer('conv_f16' if x.dtype == torch.float16 else 'conv_f32', x):
+    with _lib.kernel_timer('conv_bf16x3' if split else ('conv_f16' if x.dtype == torch.float16 else 'conv_f32'), x):
         code = _lib.lib().p3d_conv2d_nhwc_ws(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), code_dtype, _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns),
                                              _lib.ptr(_zeros_page(x.device)), n, h, w, ci, co, stride, k, mode, int(act), float(gain), float(clamp),
                                              _lib.ptr(work), nbytes, _lib.stream_of(x))
     _lib.check(code, 'conv2d_nhwc')
     log = _lib.kernel_events.get('conv_flops')
     if log is not None:                                  # bench.py: FLOPs of the launches it is timing (2*Ci*Co*k*k per output / input pixel)
-        log.append((str(x.dtype), 2.0 * n * ci * co * k * k * (oh * ow if down == 2 else h * w)))
+        log.append(('bf16x3' if split else str(x.dtype), 2.0 * n * ci * co * k * k * (oh * ow if down == 2 else h * w)))
     return y
 
 
