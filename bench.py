@@ -393,7 +393,7 @@ def main():
 
     if rank == 0:
         from pix2pix3d_amd.torch_utils.ops import modconv as _mc
-        bb = ('f32 tensors + f32 accumulation; the five M >= 4096 backbone layers form each product as 3 bf16 MFMAs of (hi, lo) splits ("bf16x3", <= 5e-6 of the '
+        bb = ('f32 tensors + f32 accumulation; the 3x3 backbone layers form each product as 3 bf16 MFMAs of (hi, lo) splits ("bf16x3", <= 5e-6 of the '
               'output range vs fp64 per layer; P3D_BF16X3=0 = exact f32 MFMA)') if _mc.split_bf16 else 'f32 (exact f32 MFMA)'
         dtype_desc = f'backbone: {bb}; ray-marcher: f32; super-resolution: ' + ('f32' if args.force_fp32 else 'f16 storage / f32 accumulation (the reference GPU config)')
         ms_per_step = elapsed / args.steps * 1e3

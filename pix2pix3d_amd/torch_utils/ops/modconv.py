@@ -113,7 +113,7 @@ def torgb_supported(x, weight, styles, fused_modconv):
 BF16X3 = 'bf16x3'            # dtype tag: fp32 tensors whose products run as three bf16 MFMAs of (hi, lo) splits (csrc/conv2d.hip)
 DTYPE_F32_BF16X3 = 3         # p3d_dtype code of that formulation (include/p3d_hip.h)
 split_bf16 = os.environ.get('P3D_BF16X3', '1') != '0'      # use it for the fp32 layers that are bound by the fp32 matrix rate
-split_bf16_min_pixels = 4096                                # ... i.e. from 64^2 on (SURVEY §8 addendum 4: the five M >= 4096 layers)
+split_bf16_min_pixels = int(os.environ.get('P3D_BF16X3_MIN_PIXELS', 16))       # every fp32 3x3 layer (measured: 4096 -> 462, 1024 -> 472, 256 -> 474, 16 -> 476 img/s)
 
 
 def use_split_bf16(x, ci):
