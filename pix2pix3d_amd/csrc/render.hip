@@ -132,6 +132,7 @@ struct PackArgs {
     int n_nets; float wg1[2], wg2, bg;               // FullyConnectedLayer gains (networks_stylegan2.py:111-120); wg1 per net (fan-in 32 or 64)
     int w1_in[2];                                    // inputs of each net's first layer (row length of w1): 32, or 64 for the dual colour net
     int total;                                       // kDecoderFloats or kDecoderFloatsDual
+    int bf16_order;                                  // weights in the [block][lane][8] order of the bf16x3 decoder (render_device.h) instead of the f32-MFMA order
 };
 
 __global__ void __launch_bounds__(256) pack_decoder_kernel(PackArgs p, float* out)
@@ -144,6 +145,20 @@ __global__ void __launch_bounds__(256) pack_decoder_kernel(PackArgs p, float* ou
             const int q4 = e / 256, lane = (e % 256) / 4, q = q4 * 4 + (e & 3);
             const int row = lane & 31, h = lane >> 5, t = q >> 4, kk = q & 15;
             v = p.w1[0][(32 * t + row) * p.w1_in[0] + 32 + 16 * h + kk] * p.wg1[0];
+        } else if (i < 2 * kNetStride && p.bf16_order) {
+            const int n = i / kNetStride, f = i % kNetStride;
+            const int block = f / 512, lane = (f % 512) / 8, e = f & 7;
+            const int row = lane & 31, kb = lane >> 5;
+            if (n < p.n_nets) {
+                if (block < 4) {                                 // layer 1: tile t, k-step s; k (kb, e) <-> input channel 16 kb + 8 s + e
+                    const int t = block >> 1, ks = block & 1;
+                    v = p.w1[n][(32 * t + row) * p.w1_in[n] + 16 * kb + 8 * ks + e] * p.wg1[n];
+                } else {                                         // layer 2: k-step s; k (kb, e) <-> the hidden unit accumulator register 8 (s & 1) + e of tile s >> 1 holds
+                    const int ks = block - 4, r = 8 * (ks & 1) + e;
+                    const int hid = 32 * (ks >> 1) + (r & 3) + 8 * (r >> 2) + 4 * kb;
+                    v = p.w2[n][(1 + row) * 64 + hid] * p.wg2;
+                }
+            }
         } else if (i < 2 * kNetStride) {
             const int n = i / kNetStride, e = i % kNetStride;
             const int q4 = e / 256, lane = (e % 256) / 4, q = q4 * 4 + (e & 3);
@@ -205,9 +220,9 @@ extern "C" int p3d_planes_to_channels_last(const float* planes_nchw, float* plan
     return check_launch("planes_to_channels_last");
 }
 
-extern "C" int p3d_pack_decoder(const float* w1_a, const float* b1_a, const float* w2_a, const float* b2_a,
-                                const float* w1_b, const float* b1_b, const float* w2_b, const float* b2_b,
-                                int32_t n_nets, float lr_mul, float* packed, p3d_stream_t stream)
+static int pack_decoder_impl(const float* w1_a, const float* b1_a, const float* w2_a, const float* b2_a,
+                             const float* w1_b, const float* b1_b, const float* w2_b, const float* b2_b,
+                             int32_t n_nets, float lr_mul, float* packed, int bf16_order, p3d_stream_t stream)
 {
     P3D_REQUIRE(n_nets == 1 || n_nets == 2, "pack_decoder: n_nets must be 1 or 2");
     P3D_REQUIRE(w1_a && b1_a && w2_a && b2_a && packed, "pack_decoder: null weights");
@@ -217,10 +232,24 @@ extern "C" int p3d_pack_decoder(const float* w1_a, const float* b1_a, const floa
     p.w1[1] = w1_b; p.b1[1] = b1_b; p.w2[1] = w2_b; p.b2[1] = b2_b;
     p.n_nets = n_nets;
     p.wg1[0] = p.wg1[1] = lr_mul / sqrtf(32.f); p.wg2 = lr_mul / sqrtf(64.f); p.bg = lr_mul;
-    p.w1_in[0] = p.w1_in[1] = 32; p.total = kDecoderFloats;
+    p.w1_in[0] = p.w1_in[1] = 32; p.total = kDecoderFloats; p.bf16_order = bf16_order;
     hipLaunchKernelGGL(pack_decoder_kernel, dim3((kDecoderFloats + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, packed);
     count_launch(FAM_AUX);
     return check_launch("pack_decoder");
+}
+
+extern "C" int p3d_pack_decoder(const float* w1_a, const float* b1_a, const float* w2_a, const float* b2_a,
+                                const float* w1_b, const float* b1_b, const float* w2_b, const float* b2_b,
+                                int32_t n_nets, float lr_mul, float* packed, p3d_stream_t stream)
+{
+    return pack_decoder_impl(w1_a, b1_a, w2_a, b2_a, w1_b, b1_b, w2_b, b2_b, n_nets, lr_mul, packed, 0, stream);
+}
+
+extern "C" int p3d_pack_decoder_bf16x3(const float* w1_a, const float* b1_a, const float* w2_a, const float* b2_a,
+                                       const float* w1_b, const float* b1_b, const float* w2_b, const float* b2_b,
+                                       int32_t n_nets, float lr_mul, float* packed, p3d_stream_t stream)
+{
+    return pack_decoder_impl(w1_a, b1_a, w2_a, b2_a, w1_b, b1_b, w2_b, b2_b, n_nets, lr_mul, packed, 1, stream);
 }
 
 extern "C" int p3d_render_decoder_floats_dual(void) { return kDecoderFloatsDual; }
@@ -235,7 +264,7 @@ extern "C" int p3d_pack_decoder_dual(const float* w1_tex, const float* b1_tex, c
     p.w1[1] = w1_sem; p.b1[1] = b1_sem; p.w2[1] = w2_sem; p.b2[1] = b2_sem;     // net 1: density + labels from the semantic features
     p.n_nets = 2;
     p.wg1[0] = lr_mul / sqrtf(64.f); p.wg1[1] = lr_mul / sqrtf(32.f); p.wg2 = lr_mul / sqrtf(64.f); p.bg = lr_mul;
-    p.w1_in[0] = 64; p.w1_in[1] = 32; p.total = kDecoderFloatsDual;
+    p.w1_in[0] = 64; p.w1_in[1] = 32; p.total = kDecoderFloatsDual; p.bf16_order = 0;
     hipLaunchKernelGGL(pack_decoder_kernel, dim3((kDecoderFloatsDual + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, packed);
     count_launch(FAM_AUX);
     return check_launch("pack_decoder_dual");
@@ -290,6 +319,16 @@ static int render_forward_impl(const float* planes_cl, const float* planes_sem_c
         static std::atomic<uint64_t> onced_devs{0}; const hipError_t onced = reserve_lds_once((const void*)render_forward_kernel<2, false, true>, (int)lds_bytes, onced_devs);
         if (onced != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_forward_dual: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(onced));
         hipLaunchKernelGGL((render_forward_kernel<2, false, true>), dim3(blocks), dim3(wpb * 64), lds_bytes, s, a);
+    } else if (d->mlp_bf16x3) {
+        if (d->n_nets == 1) {
+            static std::atomic<uint64_t> onceb1_devs{0}; const hipError_t e1 = reserve_lds_once((const void*)render_forward_kernel<1, false, false, true>, (int)lds_bytes, onceb1_devs);
+            if (e1 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_forward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e1));
+            hipLaunchKernelGGL((render_forward_kernel<1, false, false, true>), dim3(blocks), dim3(wpb * 64), lds_bytes, s, a);
+        } else {
+            static std::atomic<uint64_t> onceb2_devs{0}; const hipError_t e2 = reserve_lds_once((const void*)render_forward_kernel<2, false, false, true>, (int)lds_bytes, onceb2_devs);
+            if (e2 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_forward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e2));
+            hipLaunchKernelGGL((render_forward_kernel<2, false, false, true>), dim3(blocks), dim3(wpb * 64), lds_bytes, s, a);
+        }
     } else if (d->n_nets == 1) {
         static std::atomic<uint64_t> once1_devs{0}; const hipError_t once1 = reserve_lds_once((const void*)render_forward_kernel<1, false>, (int)lds_bytes, once1_devs);
         if (once1 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_forward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(once1));

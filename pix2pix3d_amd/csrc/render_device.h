@@ -289,6 +289,82 @@ __device__ __forceinline__ float mlp_sigma(const float* lds, int h, const f32x16
     return s + lds[OFF_B2S];
 }
 
+// ---- the decoder as bf16x3 (inference) ---------------------------------------------------------------
+// The f32-input MFMA runs at 1/16 of the bf16 rate and the decoder's 128 of them per sample are 38 % of this kernel's SIMD time (and its
+// floor: 1.0 ms per launch).  Same split as the convolutions (csrc/conv2d.hip): x = hi + lo in bf16, x * w = xh*wh + xh*wl + xl*wh, fp32
+// accumulation — 48 bf16 MFMAs of half the duration per sample.  The transposed formulation is kept: weights are the A operand (LDS,
+// pre-split when the block loads its decoder copy), the lane's own registers are the B operand (features, then hidden units straight
+// from the accumulator layout), split in registers.  v_mfma_f32_32x32x16_bf16: lane (j, h) supplies k = 8h + e, e = 0..7.
+//   layer 1, tile t, k-step s: k (h, e) <-> input channel 16h + 8s + e            (the lane's feat[8s + e])
+//   layer 2,         k-step s: k (h, e) <-> hidden unit 32(s>>1) + pi(8(s&1) + e) + 4h, pi(r) = (r&3) + 8(r>>2)   (the lane's h_{s>>1}[8(s&1) + e])
+// LDS image per net (16 KB, the fp32 stream's size): [hi | lo] x [block 8][lane 64][8 bf16]; blocks 0..3 = layer 1 (t, s), 4..7 = layer 2 (s).
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split8(const float* v, bf8& hi, bf8& lo)
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = v[e];
+        const __bf16 hx = (__bf16)x;
+        hi[e] = hx;
+        lo[e] = (__bf16)(x - (float)hx);
+    }
+}
+__device__ __forceinline__ f32x16 mfma3(const bf8& ah, const bf8& al, const bf8& bh, const bf8& bl, f32x16 c)
+{
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+}
+// hidden units of net n (post-softplus, log2 domain) from the split features fh / fl (k-steps 0, 1)
+__device__ __forceinline__ void mlp_layer1_bf3(const float* lds, int n, int lane, int h, const bf8 (&fh)[2], const bf8 (&fl)[2], f32x16& h0, f32x16& h1)
+{
+    const f32x4* b1 = (const f32x4*)(lds + OFF_B1 + (n * 2 + h) * 32);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v0 = b1[q], v1 = b1[4 + q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h0[q * 4 + e] = v0[e]; h1[q * 4 + e] = v1[e]; }
+    }
+    const bf8* whi = (const bf8*)(lds + n * kNetStride) + lane;          // [block][lane] 16-byte entries
+    const bf8* wlo = whi + 8 * 64;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {                                        // interleave the two tiles: consecutive MFMAs on different accumulators
+        const bf8 a0h = whi[(0 * 2 + s) * 64], a0l = wlo[(0 * 2 + s) * 64], a1h = whi[(1 * 2 + s) * 64], a1l = wlo[(1 * 2 + s) * 64];
+        h0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, fh[s], h0, 0, 0, 0);
+        h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, fh[s], h1, 0, 0, 0);
+        h0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, fh[s], h0, 0, 0, 0);
+        h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, fh[s], h1, 0, 0, 0);
+        h0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, fl[s], h0, 0, 0, 0);
+        h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, fl[s], h1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { h0[r] = softplus20_log2(h0[r]); h1[r] = softplus20_log2(h1[r]); }
+}
+// colour rows of net n from its hidden units
+__device__ __forceinline__ void mlp_layer2_bf3(const float* lds, int n, int lane, int h, const f32x16& h0, const f32x16& h1, f32x16& out)
+{
+    const f32x4* b2 = (const f32x4*)(lds + OFF_B2 + (n * 2 + h) * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = b2[q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[q * 4 + e] = v[e];
+    }
+    const bf8* whi = (const bf8*)(lds + n * kNetStride) + 4 * 64 + lane;
+    const bf8* wlo = whi + 8 * 64;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {                                        // (one accumulator: a second one to break the dependence spills at 256 registers)
+        float hv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hv[e] = (s < 2) ? h0[8 * (s & 1) + e] : h1[8 * (s & 1) + e];
+        bf8 xh, xl;
+        split8(hv, xh, xl);
+        const bf8 ah = whi[s * 64], al = wlo[s * 64];
+        out = mfma3(ah, al, xh, xl, out);
+    }
+}
+
 // ---- importance sampling for one ray, wave-cooperative (renderer.py:194-253) ----------------------
 // lane i holds coarse weight w_i (i < Sc-1) and coarse depth z_i (i < Sc); lane j returns fine depth j
 // (unsorted), +inf for j >= Sf.  sA / sB: two 64-float LDS scratch rows of this wave.
@@ -353,11 +429,12 @@ __device__ __forceinline__ float bitonic_sort64(float v, int lane)
 // net reads cat(texture features, semantic features) through a 64-input first layer (renderer.py:324-333); everything else —
 // sampling, merge, compositing over cat(colour, label) — is the same sweep.
 constexpr int kWavesPerBlockDual = 4;            // the DUAL kernel keeps two feature vectors live: one wave per SIMD (512 registers) instead of spilling
-template <int NNETS, bool TAPE, bool DUAL = false>
+template <int NNETS, bool TAPE, bool DUAL = false, bool BF3 = false>
 __global__ void __launch_bounds__((DUAL ? kWavesPerBlockDual : kWavesPerBlock) * 64, DUAL ? 1 : 2)
 render_forward_kernel(RenderArgs a)
 {
     static_assert(!DUAL || (NNETS == 2 && !TAPE), "the two-plane-set variant is the two-net inference kernel");
+    static_assert(!BF3 || (!TAPE && !DUAL), "the bf16x3 decoder is the one-plane-set inference kernel");
     constexpr int kDecFloats = DUAL ? kDecoderFloatsDual : kDecoderFloats;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -379,6 +456,13 @@ render_forward_kernel(RenderArgs a)
                 const float sc = first ? 1.4426950408889634f : (second ? 0.6931471805599453f : 1.f);
                 v = v * sc;
             }
+            if (BF3 && i * 4 < 2 * kNetStride) {                  // weights: the stream is [net][block][lane][8] floats (p3d_pack_decoder_bf16x3) -> [hi | lo] bf16
+                const int f = i * 4, n = f / kNetStride, e = f - n * kNetStride;          // e: float index inside the net, a multiple of 4
+                __bf16* hi = (__bf16*)(lds + n * kNetStride) + e;                       // same [block][lane][8] position, 2-byte elements
+                __bf16* lo = hi + kNetStride;                                           // lo image: 8 KB further
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const __bf16 hx = (__bf16)v[c]; hi[c] = hx; lo[c] = (__bf16)(v[c] - (float)hx); }
+            } else
             dst[i] = v;
         }
     }
@@ -434,6 +518,11 @@ render_forward_kernel(RenderArgs a)
             float feat[16];
             gather_features<!TAPE>(a, rsrc_sem, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
             f32x16 h0, h1;
+            if constexpr (BF3) {
+                bf8 fh[2], fl[2];
+                split8(feat, fh[0], fl[0]); split8(feat + 8, fh[1], fl[1]);
+                mlp_layer1_bf3(lds, SN, lane, h, fh, fl, h0, h1);
+            } else
             mlp_layer1<LOG2>(lds, SN, lane, h, feat, h0, h1);
             const float sigma = mlp_sigma(lds, h, h0, h1);
             if (i > 0) {
@@ -494,11 +583,14 @@ render_forward_kernel(RenderArgs a)
         // other end of the midpoint rule) stays live across samples.
         float sigma = 0.f, hw = 0.f;
         float t_alpha = 0.f, t_T = 0.f, t_sm = 0.f, t_A = 0.f;               // TAPE: record of interval k-1
+        bf8 fh[2], fl[2];                                                    // BF3: the sample's features, split once for both nets
+        if constexpr (BF3) { split8(feat, fh[0], fl[0]); split8(feat + 8, fh[1], fl[1]); }
 #pragma unroll
         for (int idx = 0; idx < NNETS; ++idx) {
             const int n = (idx == 0) ? SN : idx - 1;
             f32x16 h0, h1, o;
-            if (DUAL && n == 0) mlp_layer1<LOG2, true>(lds, n, lane, h, feat_tex, h0, h1, feat);     // colour net: cat(texture, semantic)
+            if constexpr (BF3)  mlp_layer1_bf3(lds, n, lane, h, fh, fl, h0, h1);
+            else if (DUAL && n == 0) mlp_layer1<LOG2, true>(lds, n, lane, h, feat_tex, h0, h1, feat);     // colour net: cat(texture, semantic)
             else                mlp_layer1<LOG2>(lds, n, lane, h, feat, h0, h1);
             if (idx == 0) {
                 sigma = mlp_sigma(lds, h, h0, h1);
@@ -514,7 +606,8 @@ render_forward_kernel(RenderArgs a)
                     wz_sum = fmaf(w, 0.5f * (z_prev + z), wz_sum);
                 }
             }
-            mlp_layer2(lds, n, lane, h, h0, h1, o);
+            if constexpr (BF3) mlp_layer2_bf3(lds, n, lane, h, h0, h1, o);
+            else               mlp_layer2(lds, n, lane, h, h0, h1, o);
             const bool squash = (n == 0) || (NNETS == 1) || a.sem_sigmoid;     // raw logits for the label net (triplane_cond.py:960-964)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

@@ -12,6 +12,7 @@ device.  ``fused_policy = 'require'`` turns any silent use of the tensor-op path
 into an error.
 """
 import ctypes
+import os
 
 import torch
 
@@ -22,6 +23,7 @@ from .ray_marcher import MipRayMarcher2
 fused_policy = 'auto'          # 'auto' | 'require' | 'never'
 fused_training = True          # graphs that need gradients: fused forward + recompute-in-backward (see _FusedRenderFn)
 fused_backward = True          # ... with the backward on the device kernels of csrc/render_bwd.hip (False: replay the tensor-op renderer)
+mlp_bf16x3 = os.environ.get('P3D_MLP_BF16X3', '1') != '0'      # inference: the decoder MLPs as three bf16 MFMAs per fp32 product (csrc/render_device.h)
 
 
 class _RenderDesc(ctypes.Structure):          # p3d_render_desc (include/p3d_hip.h)
@@ -29,13 +31,15 @@ class _RenderDesc(ctypes.Structure):          # p3d_render_desc (include/p3d_hip
                 ('n_nets', ctypes.c_int32), ('semantic_sigmoid', ctypes.c_int32), ('depth_resolution', ctypes.c_int32),
                 ('depth_resolution_importance', ctypes.c_int32), ('disparity_space_sampling', ctypes.c_int32), ('white_back', ctypes.c_int32),
                 ('ray_start', ctypes.c_float), ('ray_end', ctypes.c_float), ('box_warp', ctypes.c_float),
-                ('image_stride', ctypes.c_int64), ('plane_stride', ctypes.c_int64), ('pixel_stride', ctypes.c_int64), ('raster_order', ctypes.c_int32)]
+                ('image_stride', ctypes.c_int64), ('plane_stride', ctypes.c_int64), ('pixel_stride', ctypes.c_int64), ('raster_order', ctypes.c_int32),
+                ('mlp_bf16x3', ctypes.c_int32)]
 
 
 _vp, _i32, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
 _lib.register('p3d_render_decoder_floats', ctypes.c_int, [])
 _lib.register('p3d_planes_to_channels_last', ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp])
 _lib.register('p3d_pack_decoder', ctypes.c_int, [_vp] * 8 + [_i32, _f32, _vp, _vp])
+_lib.register('p3d_pack_decoder_bf16x3', ctypes.c_int, [_vp] * 8 + [_i32, _f32, _vp, _vp])
 _lib.register('p3d_render_bwd_decoder_floats', ctypes.c_int, [])
 _lib.register('p3d_render_grad_decoder_floats', ctypes.c_int, [])
 _lib.register('p3d_pack_decoder_bwd', ctypes.c_int, [_vp] * 4 + [ctypes.c_int32, ctypes.c_float, _vp, _vp])
@@ -123,8 +127,9 @@ def _f32c(t):
 class _FusedContext:
     """Device-side operands shared by the fused entry points: channels-last planes + packed decoder."""
 
-    def __init__(self, planes, decoder_info):
+    def __init__(self, planes, decoder_info, bf16x3=False):
         nets, lr_mul, sem_sigmoid = decoder_info
+        self.bf16x3 = bool(bf16x3)
         lib = _lib.lib()
         n, k, c, h, w = planes.shape
         assert k == 3 and c == 32
@@ -145,7 +150,8 @@ class _FusedContext:
         for fc1, fc2 in nets:
             ws += [_f32c(fc1.weight), _f32c(fc1.bias), _f32c(fc2.weight), _f32c(fc2.bias)]
         ptrs = [_lib.ptr(t) for t in ws] + [None] * (8 - len(ws))
-        _lib.check(lib.p3d_pack_decoder(*ptrs, len(nets), lr_mul, _lib.ptr(self.packed), _lib.stream_of(src)), 'pack_decoder')
+        pack = lib.p3d_pack_decoder_bf16x3 if self.bf16x3 else lib.p3d_pack_decoder
+        _lib.check(pack(*ptrs, len(nets), lr_mul, _lib.ptr(self.packed), _lib.stream_of(src)), 'pack_decoder')
         self._keep = ws
         self.n_nets, self.sem_sigmoid, self.n, self.h, self.w = len(nets), sem_sigmoid, n, h, w
 
@@ -153,7 +159,7 @@ class _FusedContext:
         return _RenderDesc(self.n, rays_per_img, self.h, self.w, self.n_nets, int(self.sem_sigmoid),
                            int(options.get('depth_resolution', 0)), int(options.get('depth_resolution_importance', 0)),
                            int(bool(options.get('disparity_space_sampling', False))), int(bool(options.get('white_back', False))),
-                           float(start), float(end), float(options['box_warp']), *self.strides, int(raster))
+                           float(start), float(end), float(options['box_warp']), *self.strides, int(raster), int(self.bf16x3))
 
 
 class ImportanceRenderer(torch.nn.Module):
@@ -415,7 +421,7 @@ class ImportanceSemanticRenderer(ImportanceRenderer):
         def desc(rays_per_img=1, start=0.0, end=0.0):
             return _RenderDesc(n, rays_per_img, h, w, 2, int(bool(decoder_semantic.final_sigmoid)), int(options.get('depth_resolution', 0)),
                                int(options.get('depth_resolution_importance', 0)), int(bool(options.get('disparity_space_sampling', False))),
-                               int(bool(options.get('white_back', False))), float(start), float(end), float(options['box_warp']), *st_t, 1)
+                               int(bool(options.get('white_back', False))), float(start), float(end), float(options['box_warp']), *st_t, 1, 0)
         return pt, ps, packed, desc, ws
 
     def forward(self, planes_texture, planes_semantic, decoder_texture, decoder_semantic, ray_origins, ray_directions, rendering_options):
@@ -525,7 +531,7 @@ class _FusedRenderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, renderer, decoder, opt, u_c, u_f, t0, t1, planes, ray_o, ray_d, *params):
-        out = fused_render(planes, decoder, ray_o, ray_d, opt, u_c, u_f, t0, t1)
+        out = fused_render(planes, decoder, ray_o, ray_d, opt, u_c, u_f, t0, t1, exact_fp32=True)
         if out is None:
             raise RuntimeError('fused training render: sample counts outside the kernel envelope')
         ctx.renderer, ctx.decoder, ctx.opt = renderer, decoder, opt
@@ -612,7 +618,7 @@ def fused_render_backward(planes, decoder, ray_origins, ray_directions, opt, u_c
     return g_planes, g_params
 
 
-def fused_render(planes, decoder, ray_origins, ray_directions, opt, u_coarse, u_fine, t_start=None, t_end=None, debug=False):
+def fused_render(planes, decoder, ray_origins, ray_directions, opt, u_coarse, u_fine, t_start=None, t_end=None, debug=False, exact_fp32=False):
     """One launch of the fused ray-marcher with explicit uniforms (u_coarse [N,M,Sc(,1)], u_fine [N*M,Sf]).
     Returns (feat [N,M,C], depth [N,M,1], wsum [N,M,1]) and, with debug, the sorted fine depths [N*M,Sf] and the
     coarse weights [N*M,Sc-1] the kernel used."""
@@ -622,7 +628,7 @@ def fused_render(planes, decoder, ray_origins, ray_directions, opt, u_coarse, u_
     n, m, _ = ray_origins.shape
     sc, sf = int(opt['depth_resolution']), int(opt['depth_resolution_importance'])
     dev = planes.device
-    ctx = _FusedContext(planes, info)
+    ctx = _FusedContext(planes, info, bf16x3=mlp_bf16x3 and not exact_fp32)      # (the training forward stays exact fp32: its backward recomputes in fp32)
     auto = t_start is not None
     t0 = _f32c(t_start).reshape(-1) if auto else None
     t1 = _f32c(t_end).reshape(-1) if auto else None
