@@ -395,14 +395,16 @@ def main():
         from pix2pix3d_amd.torch_utils.ops import modconv as _mc
         bb = ('f32 tensors + f32 accumulation; the 3x3 backbone layers form each product as 3 bf16 MFMAs of (hi, lo) splits ("bf16x3", <= 5e-6 of the '
               'output range vs fp64 per layer; P3D_BF16X3=0 = exact f32 MFMA)') if _mc.split_bf16 else 'f32 (exact f32 MFMA)'
-        dtype_desc = f'backbone: {bb}; ray-marcher: f32; super-resolution: ' + ('f32' if args.force_fp32 else 'f16 storage / f32 accumulation (the reference GPU config)')
+        rm = 'f32 gather / sampling / compositing, decoder MLPs as bf16x3 (P3D_MLP_BF16X3=0 = exact f32 MFMA)' if rmod.mlp_bf16x3 else 'f32'
+        dtype_desc = f'backbone: {bb}; ray-marcher: {rm}; super-resolution: ' + ('f32' if args.force_fp32 else 'f16 storage / f32 accumulation (the reference GPU config)')
         ms_per_step = elapsed / args.steps * 1e3
         imgs = args.batch * world * args.steps
         samples_per_launch = args.batch * nrr * nrr * args.depth
         render_s = render_kernel_ms * 1e-3
         achieved = samples_per_launch * BYTES_PER_SAMPLE / render_s / 1e9 if render_s > 0 else 0.0
         traffic = render_traffic(args, nrr)                         # memory-side bytes per launch (committed PMC passes of THIS kernel, else null)
-        mfma_floor_ms = samples_per_launch * MLP_FLOP_PER_SAMPLE * COARSE_FACTOR / (F32_MFMA_PEAK_TF * 1e12) * 1e3
+        mlp_bf3 = bool(rmod.mlp_bf16x3)                          # decoder MLPs as three bf16 MFMAs per fp32 product (csrc/render_device.h)
+        mfma_floor_ms = samples_per_launch * MLP_FLOP_PER_SAMPLE * COARSE_FACTOR * (3.0 / (2500.0e12) if mlp_bf3 else 1.0 / (F32_MFMA_PEAK_TF * 1e12)) * 1e3
         line = {
             'metric': f'rendered img/s ({info["res"]}^2, {args.depth} depth)',
             'value': round(imgs / elapsed, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -417,7 +419,9 @@ def main():
             'roofline': {'kernel': 'render_forward_kernel (fused tri-plane ray-marcher)', 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                          'mfma_frac': round(mfma_floor_ms / render_kernel_ms, 4) if render_kernel_ms > 0 else None, 'mfma_floor_ms': round(mfma_floor_ms, 4),
-                         'bound_note': 'taps are served by L1/L2 (traffic << algorithmic bytes): the decoder on the fp32 matrix cores (mfma_frac) is the binding floor',
+                         'decoder_mfma': 'bf16x3 (3 bf16 MFMAs per fp32 product, vs 2.5 PF)' if mlp_bf3 else 'f32-input MFMA (vs 157.3 TF)',
+                         'bound_note': 'taps are served by L1/L2 (traffic << algorithmic bytes) and the decoder is off the fp32 matrix rate: what remains is gather latency at 2 waves per SIMD'
+                                       if mlp_bf3 else 'taps are served by L1/L2 (traffic << algorithmic bytes): the decoder on the fp32 matrix cores (mfma_frac) is the binding floor',
                          'ms_per_launch': round(render_kernel_ms, 4), 'launches_timed': len(kern), 'units_per_launch': samples_per_launch, 'bytes_per_unit': BYTES_PER_SAMPLE},
             # conv_f32: exact fp32 MFMA kernels vs the 157.3 TF fp32 matrix peak.  conv_bf16x3: the fp32 layers computed as three bf16 MFMAs per
             # product: 'tflops' counts each fp32 multiply-add once (fp32-equivalent), 'frac_of_peak' the 3x bf16 MFMA work it executes vs 2.5 PF

@@ -326,11 +326,12 @@ __device__ __forceinline__ void mlp_layer1_bf3(const float* lds, int n, int lane
 #pragma unroll
         for (int e = 0; e < 4; ++e) { h0[q * 4 + e] = v0[e]; h1[q * 4 + e] = v1[e]; }
     }
-    const bf8* whi = (const bf8*)(lds + n * kNetStride) + lane;          // [block][lane] 16-byte entries
-    const bf8* wlo = whi + 8 * 64;
+    // ONE lane-dependent base (lane * 16 bytes); net, block and hi/lo are compile-time byte offsets that fold into ds_read_b128 immediates
+    const char* wb = (const char*)lds + lane * 16 + n * (kNetStride * 4);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {                                        // interleave the two tiles: consecutive MFMAs on different accumulators
-        const bf8 a0h = whi[(0 * 2 + s) * 64], a0l = wlo[(0 * 2 + s) * 64], a1h = whi[(1 * 2 + s) * 64], a1l = wlo[(1 * 2 + s) * 64];
+        const bf8 a0h = *(const bf8*)(wb + (0 * 2 + s) * 1024), a0l = *(const bf8*)(wb + 8192 + (0 * 2 + s) * 1024);
+        const bf8 a1h = *(const bf8*)(wb + (1 * 2 + s) * 1024), a1l = *(const bf8*)(wb + 8192 + (1 * 2 + s) * 1024);
         h0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, fh[s], h0, 0, 0, 0);
         h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, fh[s], h1, 0, 0, 0);
         h0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, fh[s], h0, 0, 0, 0);
@@ -351,8 +352,7 @@ __device__ __forceinline__ void mlp_layer2_bf3(const float* lds, int n, int lane
 #pragma unroll
         for (int e = 0; e < 4; ++e) out[q * 4 + e] = v[e];
     }
-    const bf8* whi = (const bf8*)(lds + n * kNetStride) + 4 * 64 + lane;
-    const bf8* wlo = whi + 8 * 64;
+    const char* wb = (const char*)lds + lane * 16 + n * (kNetStride * 4) + 4 * 1024;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {                                        // (one accumulator: a second one to break the dependence spills at 256 registers)
         float hv[8];
@@ -360,7 +360,7 @@ __device__ __forceinline__ void mlp_layer2_bf3(const float* lds, int n, int lane
         for (int e = 0; e < 8; ++e) hv[e] = (s < 2) ? h0[8 * (s & 1) + e] : h1[8 * (s & 1) + e];
         bf8 xh, xl;
         split8(hv, xh, xl);
-        const bf8 ah = whi[s * 64], al = wlo[s * 64];
+        const bf8 ah = *(const bf8*)(wb + s * 1024), al = *(const bf8*)(wb + 8192 + s * 1024);
         out = mfma3(ah, al, xh, xl, out);
     }
 }
