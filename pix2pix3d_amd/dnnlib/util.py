@@ -5,18 +5,13 @@ from typing import Any
 
 class EasyDict(dict):
     """dict whose items are also attributes (reference: dnnlib/util.py:42-55)."""
+    __setattr__ = dict.__setitem__
+    __delattr__ = dict.__delitem__
 
     def __getattr__(self, name: str) -> Any:
-        try:
+        if name in self:
             return self[name]
-        except KeyError:
-            raise AttributeError(name)
-
-    def __setattr__(self, name: str, value: Any) -> None:
-        self[name] = value
-
-    def __delattr__(self, name: str) -> None:
-        del self[name]
+        raise AttributeError(name)
 
 
 def get_module_from_obj_name(obj_name: str):

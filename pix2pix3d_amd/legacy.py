@@ -29,16 +29,12 @@ def load_network_pkl(f, force_fp16=False):
     assert isinstance(data, dict), 'not a network checkpoint'
     for key, value in list(data.items()):
         data[key] = persistence.rebuild(value)
-    if 'training_set_kwargs' not in data:
-        data['training_set_kwargs'] = None
-    if 'augment_pipe' not in data:
-        data['augment_pipe'] = None
-
-    assert isinstance(data['G'], torch.nn.Module)
-    assert isinstance(data['D'], torch.nn.Module)
-    assert isinstance(data['G_ema'], torch.nn.Module)
-    assert isinstance(data['training_set_kwargs'], (dict, type(None)))
-    assert isinstance(data['augment_pipe'], (torch.nn.Module, type(None)))
+    for optional in ('training_set_kwargs', 'augment_pipe'):              # older snapshots lack them (:36-40)
+        data.setdefault(optional, None)
+    expected = {'G': torch.nn.Module, 'D': torch.nn.Module, 'G_ema': torch.nn.Module,
+                'training_set_kwargs': (dict, type(None)), 'augment_pipe': (torch.nn.Module, type(None))}
+    for key, kind in expected.items():
+        assert isinstance(data[key], kind), f'checkpoint entry {key!r} has type {type(data[key]).__name__}'
 
     if force_fp16:                                                                   # :49-60
         for key in ['G', 'D', 'G_ema']:

@@ -121,16 +121,16 @@ def copy_params_and_buffers(src_module, dst_module, require_all=False, allow_mis
 def check_ddp_consistency(module, ignore_regex=None):
     """Assert every rank holds rank 0's values (reference: misc.py:194-205)."""
     assert isinstance(module, torch.nn.Module)
+    prefix = type(module).__name__ + '.'
+    skip = re.compile(ignore_regex) if ignore_regex is not None else None
     for name, tensor in named_params_and_buffers(module):
-        fullname = type(module).__name__ + '.' + name
-        if ignore_regex is not None and re.fullmatch(ignore_regex, fullname):
+        if skip is not None and skip.fullmatch(prefix + name):
             continue
-        tensor = tensor.detach()
-        if tensor.is_floating_point():
-            tensor = nan_to_num(tensor)
-        other = tensor.clone()
-        torch.distributed.broadcast(tensor=other, src=0)
-        assert (tensor == other).all(), fullname
+        mine = tensor.detach()
+        mine = nan_to_num(mine) if mine.is_floating_point() else mine
+        theirs = mine.clone()
+        torch.distributed.broadcast(tensor=theirs, src=0)
+        assert bool((mine == theirs).all()), prefix + name
 
 
 def __getattr__(name):

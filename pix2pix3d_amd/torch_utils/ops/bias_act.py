@@ -88,24 +88,16 @@ def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None, 
 
 def _bias_act_ref(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None):
     """Plain-torch path for CPU tensors (and impl='ref'); differentiable to any order through autograd."""
-    assert isinstance(x, torch.Tensor)
-    assert clamp is None or clamp >= 0
+    assert isinstance(x, torch.Tensor) and (clamp is None or clamp >= 0)
     spec = activation_funcs[act]
-    alpha = float(alpha if alpha is not None else spec.def_alpha)
-    gain = float(gain if gain is not None else spec.def_gain)
-    clamp = float(clamp if clamp is not None else -1)
+    alpha = float(spec.def_alpha if alpha is None else alpha)
+    gain = float(spec.def_gain if gain is None else gain)
     if b is not None:
-        assert isinstance(b, torch.Tensor) and b.ndim == 1
-        assert 0 <= dim < x.ndim and b.shape[0] == x.shape[dim]
-        shape = [1] * x.ndim
-        shape[dim] = -1
-        x = x + b.reshape(shape)
-    x = spec.func(x, alpha=alpha)
-    if gain != 1:
-        x = x * gain
-    if clamp >= 0:
-        x = x.clamp(-clamp, clamp)
-    return x
+        assert isinstance(b, torch.Tensor) and b.ndim == 1 and 0 <= dim < x.ndim and b.shape[0] == x.shape[dim]
+        x = x + b.reshape([-1 if d == dim else 1 for d in range(x.ndim)])
+    y = spec.func(x, alpha=alpha)
+    y = y if gain == 1 else y * gain
+    return y if clamp is None or clamp < 0 else y.clamp(-float(clamp), float(clamp))
 
 
 class _Spec:

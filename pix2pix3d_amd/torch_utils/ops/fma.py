@@ -20,21 +20,18 @@ def _reduce_to(t, shape):
 
 
 class _Fma(torch.autograd.Function):
+    """out = a * b + c; every gradient is a product reduced back to its operand's (possibly broadcast) shape (fma.py:30-47)."""
+
     @staticmethod
     def forward(ctx, a, b, c):
-        out = torch.addcmul(c, a, b)
         ctx.save_for_backward(a, b)
         ctx.c_shape = c.shape
-        return out
+        return torch.addcmul(c, a, b)
 
     @staticmethod
     def backward(ctx, dout):
         a, b = ctx.saved_tensors
-        da = db = dc = None
-        if ctx.needs_input_grad[0]:
-            da = _reduce_to(dout * b, a.shape)
-        if ctx.needs_input_grad[1]:
-            db = _reduce_to(dout * a, b.shape)
-        if ctx.needs_input_grad[2]:
-            dc = _reduce_to(dout, ctx.c_shape)
-        return da, db, dc
+        need_a, need_b, need_c = ctx.needs_input_grad
+        return (_reduce_to(dout * b, a.shape) if need_a else None,
+                _reduce_to(dout * a, b.shape) if need_b else None,
+                _reduce_to(dout, ctx.c_shape) if need_c else None)

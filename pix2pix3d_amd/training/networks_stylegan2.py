@@ -124,16 +124,17 @@ class Conv2dLayer(torch.nn.Module):
         self.act_gain = bias_act.activation_funcs[activation].def_gain
         fmt = torch.channels_last if channels_last else torch.contiguous_format
         weight = torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=fmt)
-        bias = torch.zeros([out_channels]) if bias else None
-        if trainable:
-            self.weight = torch.nn.Parameter(weight)
-            self.bias = torch.nn.Parameter(bias) if bias is not None else None
+        # frozen layers (freeze_layers of the discriminator) keep the same names as buffers, so checkpoints map either way
+        self._hold('weight', weight, trainable)
+        self._hold('bias', torch.zeros([out_channels]) if bias else None, trainable)
+
+    def _hold(self, name, tensor, trainable):
+        if tensor is None:
+            setattr(self, name, None)
+        elif trainable:
+            setattr(self, name, torch.nn.Parameter(tensor))
         else:
-            self.register_buffer('weight', weight)
-            if bias is not None:
-                self.register_buffer('bias', bias)
-            else:
-                self.bias = None
+            self.register_buffer(name, tensor)
 
     def forward(self, x, gain=1):
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
@@ -180,12 +181,8 @@ class MappingNetwork(torch.nn.Module):
                  activation='lrelu', lr_multiplier=0.01, w_avg_beta=0.998, **unused_kwargs):
         super().__init__()
         self.z_dim, self.c_dim, self.w_dim, self.num_ws, self.num_layers, self.w_avg_beta = z_dim, c_dim, w_dim, num_ws, num_layers, w_avg_beta
-        if embed_features is None:
-            embed_features = w_dim
-        if c_dim == 0:
-            embed_features = 0
-        if layer_features is None:
-            layer_features = w_dim
+        embed_features = 0 if c_dim == 0 else (w_dim if embed_features is None else embed_features)
+        layer_features = w_dim if layer_features is None else layer_features
         sizes = [z_dim + embed_features] + [layer_features] * (num_layers - 1) + [w_dim]
         if c_dim > 0:
             self.embed = FullyConnectedLayer(c_dim, embed_features)
@@ -230,13 +227,14 @@ class SynthesisLayer(torch.nn.Module):
         self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
         fmt = torch.channels_last if channels_last else torch.contiguous_format
         self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=fmt))
-        if use_noise:
-            self.register_buffer('noise_const', torch.randn([resolution, resolution]))
-            self.noise_strength = torch.nn.Parameter(torch.zeros([]))
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+        if use_noise:                                # fixed noise image for noise_mode='const' + its learned strength (starts at 0)
+            self.noise_strength = torch.nn.Parameter(torch.zeros([]))
+            self.register_buffer('noise_const', torch.randn([resolution, resolution]))
 
     def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1):
-        assert noise_mode in ['random', 'const', 'none']
+        if noise_mode not in ('random', 'const', 'none'):
+            raise AssertionError(f'unknown noise_mode {noise_mode!r}')
         in_res = self.resolution // self.up
         misc.assert_shape(x, [None, self.in_channels, in_res, in_res])
         planned = modconv.take_plan(self) if modconv._plan else None
@@ -502,13 +500,14 @@ class Generator(torch.nn.Module):
     def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs={}, **synthesis_kwargs):
         super().__init__()
         self.z_dim, self.c_dim, self.w_dim, self.img_resolution, self.img_channels = z_dim, c_dim, w_dim, img_resolution, img_channels
-        self.synthesis = SynthesisNetwork(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels, **synthesis_kwargs)
-        self.num_ws = self.synthesis.num_ws
+        synthesis = SynthesisNetwork(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels, **synthesis_kwargs)
+        self.num_ws = synthesis.num_ws               # one w per modulated layer, which only the synthesis network can count
+        self.synthesis = synthesis
         self.mapping = MappingNetwork(z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws, **mapping_kwargs)
 
     def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
-        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
-        return self.synthesis(ws, update_emas=update_emas, **synthesis_kwargs)
+        return self.synthesis(self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas),
+                              update_emas=update_emas, **synthesis_kwargs)
 
 
 @persistence.persistent_class
@@ -522,16 +521,16 @@ class DiscriminatorBlock(torch.nn.Module):
         super().__init__()
         self.in_channels, self.resolution, self.img_channels, self.first_layer_idx = in_channels, resolution, img_channels, first_layer_idx
         self.architecture, self.use_fp16 = architecture, use_fp16
-        self.channels_last = (use_fp16 and fp16_channels_last)
         self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
-        self.num_layers = 0
+        self.channels_last = (use_fp16 and fp16_channels_last)
+        self.num_layers = 0                          # layers created so far; layer k of the whole network is trainable iff k >= freeze_layers
 
-        def trainable_gen():
-            while True:
+        class _Flags:
+            def __next__(flags):
                 flag = (self.first_layer_idx + self.num_layers) >= freeze_layers
                 self.num_layers += 1
-                yield flag
-        trainable = trainable_gen()
+                return flag
+        trainable = _Flags()
         if in_channels == 0 or architecture == 'skip':
             self.fromrgb = Conv2dLayer(img_channels, tmp_channels, kernel_size=1, activation=activation, trainable=next(trainable),
                                        conv_clamp=conv_clamp, channels_last=self.channels_last)
@@ -576,7 +575,7 @@ class DiscriminatorBlock(torch.nn.Module):
         return dtype, fmt
 
     def extra_repr(self):
-        return f'resolution={self.resolution:d}, architecture={self.architecture:s}'
+        return 'resolution={:d}, architecture={:s}'.format(self.resolution, self.architecture)
 
 
 @persistence.persistent_class
@@ -611,16 +610,19 @@ class DiscriminatorEpilogue(torch.nn.Module):
         assert architecture in ['orig', 'skip', 'resnet']
         super().__init__()
         self.in_channels, self.cmap_dim, self.resolution, self.img_channels, self.architecture = in_channels, cmap_dim, resolution, img_channels, architecture
+        out_features = cmap_dim if cmap_dim > 0 else 1          # projection discriminator: dotted with the label embedding afterwards
+        self.mbstd = None
+        if mbstd_num_channels > 0:
+            self.mbstd = MinibatchStdLayer(group_size=mbstd_group_size, num_channels=mbstd_num_channels)
         if architecture == 'skip':
             self.fromrgb = Conv2dLayer(img_channels, in_channels, kernel_size=1, activation=activation)
-        self.mbstd = MinibatchStdLayer(group_size=mbstd_group_size, num_channels=mbstd_num_channels) if mbstd_num_channels > 0 else None
         self.conv = Conv2dLayer(in_channels + mbstd_num_channels, in_channels, kernel_size=3, activation=activation, conv_clamp=conv_clamp)
         self.fc = FullyConnectedLayer(in_channels * (resolution ** 2), in_channels, activation=activation)
-        self.out = FullyConnectedLayer(in_channels, 1 if cmap_dim == 0 else cmap_dim)
+        self.out = FullyConnectedLayer(in_channels, out_features)
 
     def forward(self, x, img, cmap, force_fp32=False):
+        del force_fp32                                           # the 4x4 tail always runs in fp32
         misc.assert_shape(x, [None, self.in_channels, self.resolution, self.resolution])
-        _ = force_fp32
         x = x.to(dtype=torch.float32, memory_format=torch.contiguous_format)
         if self.architecture == 'skip':
             misc.assert_shape(img, [None, self.img_channels, self.resolution, self.resolution])
@@ -635,7 +637,7 @@ class DiscriminatorEpilogue(torch.nn.Module):
         return x
 
     def extra_repr(self):
-        return f'resolution={self.resolution:d}, architecture={self.architecture:s}'
+        return 'resolution={:d}, architecture={:s}'.format(self.resolution, self.architecture)
 
 
 @persistence.persistent_class

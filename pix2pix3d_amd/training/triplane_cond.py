@@ -90,12 +90,13 @@ class Encoder(torch.nn.Module):
         self.projector = EqualConv2d(channels[4], self.out_dim, 4, padding=0, bias=False)
         self.register_buffer('alpha', torch.scalar_tensor(-1))
 
-    def set_alpha(self, alpha):
-        if alpha is not None:
-            self.alpha.fill_(alpha)
-
     def set_resolution(self, res):
-        self.curr_status = res
+        self.curr_status = res                       # progressive-growing hook of the original encoder; nothing here reads it
+
+    def set_alpha(self, alpha):
+        if alpha is None:
+            return
+        self.alpha.fill_(alpha)
 
     def forward(self, inputs, **block_kwargs):
         img = inputs['img'] if isinstance(inputs, dict) else inputs
@@ -280,8 +281,9 @@ class Generator_cond(torch.nn.Module):
     def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs={}, **synthesis_kwargs):
         super().__init__()
         self.z_dim, self.c_dim, self.w_dim, self.img_resolution, self.img_channels = z_dim, c_dim, w_dim, img_resolution, img_channels
-        self.synthesis = SynthesisNetwork(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels, **synthesis_kwargs)
-        self.num_ws = self.synthesis.num_ws
+        synthesis = SynthesisNetwork(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels, **synthesis_kwargs)
+        self.num_ws = synthesis.num_ws
+        self.synthesis = synthesis
         self.mapping = dnnlib.util.construct_class_by_name(**mapping_kwargs, z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws)
 
     def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
