@@ -93,8 +93,20 @@ class FullyConnectedLayer(torch.nn.Module):
         """``out_scale`` multiplies the result (ToRGBLayer folds its weight gain in here instead of a separate launch)."""
         if modconv.fc_supported(x, self.weight, self.bias, self.activation):
             return modconv.fc(x, self.weight, self.bias, self.weight_gain, self.bias_gain, self.activation, out_scale)
-        y = self._forward(x)
+        y = self._forward_as_conv(x) if self._conv_route(x) else self._forward(x)
         return y if out_scale == 1 else y * out_scale
+
+    def _conv_route(self, x):
+        """Training passes on the device: the affine map runs as a 1x1 convolution over a [N, in, 1, 1] image, i.e. on the native
+        conv2d_gradfix kernels (forward, data gradient, weight gradient, any order) instead of a vendor GEMM."""
+        return (x.is_cuda and x.ndim == 2 and x.dtype in (torch.float32, torch.float16) and conv2d_gradfix.enabled and conv2d_gradfix.native
+                and torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad))
+
+    def _forward_as_conv(self, x):
+        w = (self.weight.to(x.dtype) * self.weight_gain)[:, :, None, None]
+        y = conv2d_gradfix.conv2d(x[:, :, None, None], w)[:, :, 0, 0]
+        b = None if self.bias is None else self.bias.to(x.dtype) * self.bias_gain
+        return bias_act.bias_act(y, b, act=self.activation)
 
     def _forward(self, x):
         """Generic route: equalised-learning-rate gains applied at run time, the affine map as one library call, anything but the

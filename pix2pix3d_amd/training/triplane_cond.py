@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from .. import dnnlib
 from ..torch_utils import misc
 from ..torch_utils import persistence
+from ..torch_utils.ops import conv2d_gradfix
 from .networks_stylegan2 import SynthesisNetwork, FullyConnectedLayer, normalize_2nd_moment, DiscriminatorBlock, track_w_avg, truncate_ws
 from .networks_stylegan2 import Generator as StyleGAN2Backbone
 from .triplane import OSGDecoder, _osg_mlp, _TriPlaneCore
@@ -37,7 +38,11 @@ class EqualConv2d(torch.nn.Module):
         co, ci, kh, kw = self.weight.shape
         if self.padding == 0 and tuple(input.shape[2:]) == (kh, kw):
             # the Encoder's 4x4 projector sees a 4x4 image: a plain matrix product (and no trip through the vendor conv library)
-            y = input.reshape(input.shape[0], ci * kh * kw) @ (self.weight * self.scale).reshape(co, ci * kh * kw).t()
+            flat_x, flat_w = input.reshape(input.shape[0], ci * kh * kw), (self.weight * self.scale).reshape(co, ci * kh * kw)
+            if input.is_cuda and conv2d_gradfix.enabled and conv2d_gradfix.native and torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad):
+                y = conv2d_gradfix.conv2d(flat_x[:, :, None, None], flat_w[:, :, None, None])[:, :, 0, 0]      # training: native kernels, every gradient order
+            else:
+                y = flat_x @ flat_w.t()
             if self.bias is not None:
                 y = y + self.bias
             return y.reshape(input.shape[0], co, 1, 1)
