@@ -243,7 +243,8 @@ int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype, const floa
  *   forward            conv2d_gradfix.py:37-45, 107-131   F.conv2d / F.conv_transpose2d
  *   p3d_conv2d_bwd_data    :139-143   "grad_input = the transposed op" with output_padding from the shapes (:95-104)
  *   p3d_conv2d_bwd_weight  :155-194   Conv2dGradWeight (aten::convolution_backward with mask [F,T,F]; a matmul for 1x1)
- * All tensors channels-last ([N][H][W][C]), fp16 or fp32 with fp32 accumulation, groups = 1, dilation = 1, weights SHARED across the
+ * All tensors channels-last ([N][H][W][C]), fp16 or fp32 with fp32 accumulation (dtype P3D_F32_BF16X3 for forward / bwd_data: fp32 tensors,
+ * products as three bf16 MFMAs), groups = 1, dilation = 1, weights SHARED across the
  * batch and passed in torch's own layout and in the activation dtype.  The family (what conv2d_resample.py:96-136 ever asks for):
  *   transposed = 0: conv2d,            weight [Co][Ci][k][k]:  k in {1, 3} at stride 1 / padding k/2,  k = 3 at stride 2 / padding 0
  *   transposed = 1: conv_transpose2d,  weight [Ci][Co][k][k]:  the same two geometries; at stride 2 the output is [2H+1 | 2H+2]

@@ -23,8 +23,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- weight re-layout: torch [A][B][taps] -> tap-major [O][taps][I] in the same dtype ------------------------------------------------
 // swap == 0: O = A, I = B (conv2d weights).  swap != 0: O = B, I = A (conv_transpose2d weights [in][out]).  flip mirrors the taps.
+// split != 0 (T = float, I % 32 == 0): the bf16x3 layout of csrc/conv2d.hip — K rows of [32 x bf16 hi | 32 x bf16 lo] per 32 input channels.
 template <class T>
-__global__ void __launch_bounds__(256) weight_relayout_kernel(const T* __restrict__ src, T* __restrict__ dst, int A, int B, int taps, int swap, int flip)
+__global__ void __launch_bounds__(256) weight_relayout_kernel(const T* __restrict__ src, T* __restrict__ dst, int A, int B, int taps, int swap, int flip, int split)
 {
     const int O = swap ? B : A, I = swap ? A : B;
     const int64_t total = (int64_t)O * taps * I;
@@ -34,6 +35,16 @@ __global__ void __launch_bounds__(256) weight_relayout_kernel(const T* __restric
         const int o = (int)(e / ((int64_t)I * taps));
         const int ts = flip ? taps - 1 - t : t;
         const int64_t s = swap ? ((int64_t)i * B + o) * taps + ts : ((int64_t)o * B + i) * taps + ts;
+        if constexpr (sizeof(T) == 4) {
+            if (split) {
+                const float v = src[s];
+                const __bf16 hi = (__bf16)v;
+                __bf16* row = (__bf16*)dst + (e - i + (i & ~31)) * 2 + (i & 31);
+                row[0] = hi;
+                row[32] = (__bf16)(v - (float)hi);
+                continue;
+            }
+        }
         dst[e] = src[s];
     }
 }
@@ -412,13 +423,13 @@ static int relayout(const void* w, void* dst, int dtype, int A, int B, int taps,
 {
     const int64_t total = (int64_t)A * B * taps;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    if (dtype == P3D_F16) hipLaunchKernelGGL(weight_relayout_kernel<__half>, dim3(blocks), dim3(256), 0, s, (const __half*)w, (__half*)dst, A, B, taps, swap, flip);
-    else                  hipLaunchKernelGGL(weight_relayout_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)w, (float*)dst, A, B, taps, swap, flip);
+    if (dtype == P3D_F16) hipLaunchKernelGGL(weight_relayout_kernel<__half>, dim3(blocks), dim3(256), 0, s, (const __half*)w, (__half*)dst, A, B, taps, swap, flip, 0);
+    else                  hipLaunchKernelGGL(weight_relayout_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)w, (float*)dst, A, B, taps, swap, flip, dtype == P3D_F32_BF16X3);
     count_launch(FAM_CONV);
     return check_launch("conv weight relayout");
 }
 
-static bool mfma_channels_ok(int dtype, int ci) { return ci % (dtype == P3D_F16 ? 64 : 32) == 0; }
+static bool mfma_channels_ok(int dtype, int ci) { return ci % (dtype == P3D_F16 ? 64 : 32) == 0; }      // (P3D_F32_BF16X3: fp32 tensors, 32)
 
 static int conv_forward_impl(const void* x, const void* weight, void* y, void* w_scratch, const void* zeros128, int dtype,
                              int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int32_t kernel_size, int32_t stride,
@@ -427,12 +438,13 @@ static int conv_forward_impl(const void* x, const void* weight, void* y, void* w
     const bool dry = query != nullptr;
     if (dry) { *query = 0; x = weight = zeros128 = (const void*)(uintptr_t)16; y = w_scratch = (void*)(uintptr_t)16; }
     P3D_REQUIRE(x && weight && y, "conv2d_forward: null pointer");
-    P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32, "conv2d_forward: dtype must be fp16 or fp32");
+    P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32 || dtype == P3D_F32_BF16X3, "conv2d_forward: dtype must be fp16, fp32 or fp32-as-bf16x3");
     P3D_REQUIRE(n_img >= 1 && h >= 1 && wdt >= 1 && ci >= 1 && co >= 1, "conv2d_forward: bad sizes");
     P3D_REQUIRE((kernel_size == 3 && (stride == 1 || stride == 2)) || (kernel_size == 1 && stride == 1), "conv2d_forward: 3x3 at stride 1 / 2 or 1x1 at stride 1");
     hipStream_t s = (hipStream_t)stream;
     const int taps = kernel_size * kernel_size;
     if (kernel_size == 1 && (!mfma_channels_ok(dtype, ci) || co < 32)) {
+        if (dtype == P3D_F32_BF16X3) dtype = P3D_F32;                       // the skinny kernels are plain fp32 VALU
         // skinny 1x1 (either direction: a transposed 1x1 is the same product with the weight read transposed), channels-last
         if (dry) return P3D_OK;
         const int64_t npix = (int64_t)n_img * h * wdt;

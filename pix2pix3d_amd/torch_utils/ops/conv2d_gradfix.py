@@ -13,6 +13,7 @@ Anything else (groups, dilation, other strides; CPU tensors) takes torch's own o
 """
 import contextlib
 import ctypes
+import os
 
 import torch
 
@@ -85,6 +86,8 @@ class _Cfg:
 
 
 native = True              # device tensors of the covered family go to libp3d_hip.so; False = torch's operators everywhere
+split_bf16 = os.environ.get('P3D_TRAIN_BF16X3', '1') != '0'      # fp32 forward / data-gradient convolutions as three bf16 MFMAs per product (csrc/conv2d.hip,
+                                                                 # "bf16x3": ~5e-6 of the output range, 2.5x the fp32 matrix rate); weight gradients stay exact fp32
 native_calls = {'forward': 0, 'weight_grad': 0, 'aten': 0}      # which route the dense arithmetic took (tests)
 
 _vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
@@ -147,7 +150,7 @@ def _native_conv(x, w, cfg, k, stride):
         x, ci = xp, cip
     y = torch.empty([n, co, oh, ow], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     scratch = None if skinny else torch.empty([co * ci * k * k], dtype=x.dtype, device=x.device)
-    code_dtype = _lib.DTYPE_CODE[x.dtype]
+    code_dtype = 3 if (split_bf16 and x.dtype == torch.float32 and not skinny and k == 3 and ci % 32 == 0) else _lib.DTYPE_CODE[x.dtype]     # 3 = P3D_F32_BF16X3
     nbytes = 0 if skinny else int(_lib.lib().p3d_conv2d_forward_workspace(code_dtype, n, h, wd, ci, co, k, stride, int(tr)))
     work = torch.empty([nbytes // 4], dtype=torch.float32, device=x.device) if nbytes > 0 else None      # split-K partial tiles (low-resolution layers)
     code = _lib.lib().p3d_conv2d_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), _lib.ptr(scratch), _lib.ptr(_zeros_page(x.device)), code_dtype,

@@ -13,7 +13,7 @@ from conftest import rel_err
 
 pytestmark = pytest.mark.gpu
 
-TOL = {torch.float32: 2e-5, torch.float16: 4e-3}
+TOL = {torch.float32: 2e-5, torch.float16: 4e-3}      # fp32: forward / data gradient run as bf16x3 by default (measured <= 6e-6), the weight gradient exact
 
 # (name, transposed, k, stride, Ci, Co, H, W, N, output_padding)
 GEOM = [

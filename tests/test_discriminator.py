@@ -17,7 +17,12 @@ CASES = dict(dual=dict(class_name='training.dual_discriminator.DualDiscriminator
                          channel_max=16, num_fp16_res=0, conv_clamp=None))
 
 
-def _dboth(name, device, tol):
+def _l2_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def _dboth(name, device, tol, grad_err=rel_err):
     from pix2pix3d_amd import dnnlib
     from pix2pix3d_amd.torch_utils.ops import conv2d_gradfix
     g = {k.split('.', 1)[1]: v for k, v in load_golden('discriminator').items() if k.startswith(name + '.')}
@@ -35,9 +40,9 @@ def _dboth(name, device, tol):
         grads = torch.autograd.grad(outputs=[logits.sum()], inputs=list(img.values()), create_graph=True, only_inputs=True)
     r1 = sum(gr.square().sum([1, 2, 3]) for gr in grads)
     (torch.nn.functional.softplus(-logits) + r1 * 5).mean().backward()
-    assert rel_err(grads[0].detach().cpu().numpy(), g['g_img']) < tol
+    assert grad_err(grads[0].detach().cpu().numpy(), g['g_img']) < tol
     if name != 'single':
-        assert rel_err(grads[1].detach().cpu().numpy(), g['g_raw']) < tol
+        assert grad_err(grads[1].detach().cpu().numpy(), g['g_raw']) < tol
     assert rel_err(r1.detach().cpu().numpy(), g['r1']) < tol
     params = dict(D.named_parameters())
     names = [n for n, p in params.items() if p.grad is not None]
@@ -63,12 +68,23 @@ def test_discriminator_dboth_phase_matches_reference_device(name):
 @pytest.mark.parametrize('name', list(CASES))
 def test_discriminator_dboth_phase_on_the_native_convolutions(hip_lib, name):
     """The same phase as the training loop runs it (conv2d_gradfix.enabled = True, training_loop.py:281): every convolution, its
-    data gradient, the R1 double-backward and the weight gradients go through libp3d_hip.so — none through torch's operators."""
+    data gradient, the R1 double-backward and the weight gradients go through libp3d_hip.so — none through torch's operators.
+
+    The fp32 layers run as bf16x3 here (conv2d_gradfix.split_bf16): every convolution is within 1e-5 of fp32 (tests/gpu_probe_split_d.py
+    compares them call by call), but the golden of the 'dual' case holds one pre-activation at -9e-8 of a range of 1.5 which that
+    rounding carries across zero; leaky-ReLU's slope jumps 0.2 -> 1 there and the image gradient moves by 3 % of its maximum around
+    that one pixel.  So the image gradients are held in relative L2 norm here (a single flipped slope is ~1e-3 of it), and in
+    max norm with split_bf16 off."""
     from pix2pix3d_amd.torch_utils.ops import conv2d_gradfix
     prev, conv2d_gradfix.enabled = conv2d_gradfix.enabled, True
     c0 = dict(conv2d_gradfix.native_calls)
     try:
-        _dboth(name, 'cuda', 2e-3)
+        _dboth(name, 'cuda', 2e-3, grad_err=_l2_err)
+        prev_split, conv2d_gradfix.split_bf16 = conv2d_gradfix.split_bf16, False
+        try:
+            _dboth(name, 'cuda', 2e-3)
+        finally:
+            conv2d_gradfix.split_bf16 = prev_split
     finally:
         conv2d_gradfix.enabled = prev
     assert conv2d_gradfix.native_calls['aten'] == c0['aten'], conv2d_gradfix.native_calls
