@@ -289,6 +289,18 @@ int64_t p3d_conv2d_nhwc_workspace(int dtype, int32_t n_img, int32_t h, int32_t w
 int p3d_torgb_nhwc_f16(const void* x, const float* weight, const float* styles, const float* bias, float* y_nchw,
                        int32_t n_img, int32_t hw, int32_t ci, int32_t co, float clamp, int32_t accumulate, p3d_stream_t stream);
 
+/* ---- the x2 synthesis layer in one launch (fp16) -----------------------------------------------
+ * conv_transpose2d(stride 2, 3x3; torch_utils/ops/conv2d_resample.py:114-127) -> 4x4 low-pass, pad 1 (:128) -> + noise -> + bias ->
+ * lrelu(0.2) * act_gain -> clamp (training/networks_stylegan2.py:319-332), i.e. p3d_conv2d_nhwc(resample = 1) followed by
+ * p3d_fir4_bias_act_nhwc without the [N][2H+1][2W+1][Co] intermediate in memory.  x [N][H][W][Ci] fp16, w [N or 1][Co][9][Ci] fp16
+ * (as for p3d_conv2d_nhwc), y [N][2H][2W][Co] fp16.  fir_yx_host: EIGHT floats in HOST memory, fy[0..3] then fx[0..3], the separable
+ * filter in correlation order with its gain folded in: out[oy][ox] = sum fy[a] fx[b] ct[oy - 1 + a][ox - 1 + b].  conv_gain scales the
+ * transposed conv's output before it is rounded to fp16.  act: 0 linear, 1 lrelu(0.2); bias / noise may be null; clamp < 0 = off.
+ * Ci and Co must be multiples of 32, else P3D_ERR_UNSUPPORTED (callers then use the two-launch form).                       */
+int p3d_up2_fir_f16(const void* x, const void* w, void* y, const void* zeros128, const float* bias, const float* noise,
+                    const float* noise_strength, const float* fir_yx_host, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co,
+                    int64_t w_img_stride, float conv_gain, int32_t act, float act_gain, float clamp, p3d_stream_t stream);
+
 /* ---- 4x4 FIR + layer epilogue, channels-last --------------------------------------------------
  * The tail of every x2 synthesis layer in one pass: upfirdn2d(up = down = 1, 4x4 filter f [4][4] fp32 contiguous,
  * gain) (torch_utils/ops/conv2d_resample.py:128) followed by "+ noise" and bias_act (networks_stylegan2.py:319-332):

@@ -1,0 +1,341 @@
+// The x2 synthesis layer in ONE kernel (fp16 storage, fp32 accumulation), gfx950:
+//     conv_transpose2d(stride 2)  ->  4x4 low-pass (pad 1, gain 4)  ->  + noise  ->  + bias  ->  lrelu * gain  ->  clamp
+// (reference: torch_utils/ops/conv2d_resample.py:114-131 for the first two, training/networks_stylegan2.py:319-332 for the rest).
+// The two-kernel form (convT_h2_f16_kernel + fir4_cl_fused_kernel) writes the (2H+1)^2 transposed-conv image to HBM and reads it
+// back: 269 MB each way for the 256 -> 128 channel, 512^2 layer of the SR heads, more time in the FIR than in the matrix cores.
+//
+// Work split.  A block owns a 28 x 28 tile of FINAL pixels x 32 output channels.  The FIR needs transposed-conv rows
+// 28 ty - 1 .. 28 ty + 29, i.e. the 16 x 16 patch of class positions starting at 14 ty - 1 in EACH of the four output-parity
+// classes (class (py, px), position (i, j) = transposed-conv pixel (2 i + py, 2 j + px)); positions outside the image evaluate to
+// zero by themselves because every tap then reads the zero page, which is exactly the FIR's zero padding.  (16 / 14)^2 = 1.31x
+// recomputation is the price of never storing the intermediate.
+//
+// All four classes are accumulated AT ONCE: the nine taps of the 3x3 kernel fall into the classes 4 / 2 / 2 / 1, every tap's input
+// offset is in {-1, 0}^2, so one 17 x 17 halo slab per 32-channel chunk feeds all of them and the K loop is the plain 3x3 loop of
+// conv3x3_h2_f16_kernel with the accumulator chosen by the tap: 4 waves x (64 positions x 32 channels x 4 classes) = 128 accumulator
+// VGPRs, 36 MFMAs per wave and chunk.  32 output channels per block is what makes the four classes fit; the weights of a chunk are
+// 18 KB, re-filled a third at a time (three barriers per chunk, each a full chunk ahead of its use), the slab is double-buffered:
+// 62 KB of LDS, two blocks per CU, so one block's FIR (VALU) runs under the other's K loop (MFMA).
+//
+// Epilogue: the four class tiles go to LDS as ONE fp16 image [32][32][32 ch] (the rounding the reference's fp16 conv_transpose2d
+// output has), then each thread slides the separable 4 + 4 tap filter down a 14-row strip for 8 channels (16-byte LDS reads, fp32
+// arithmetic) and applies noise / bias / activation / clamp on the way out.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "p3d_common.h"
+#include "../../include/p3d_hip.h"
+
+namespace p3d {
+
+typedef _Float16 uh8 __attribute__((ext_vector_type(8)));
+typedef float uf16 __attribute__((ext_vector_type(16)));
+typedef float uf4 __attribute__((ext_vector_type(4)));
+typedef float uf2 __attribute__((ext_vector_type(2)));
+
+constexpr int UF_PITCH = 20;                                    // slab pixels per slab row (a multiple of 4: see conv3x3_h2_f16_kernel)
+constexpr int UF_SLAB_ROWS = 17 * UF_PITCH;                     // 340 pixel rows of 64 bytes
+constexpr int UF_SLAB_PIECES = (UF_SLAB_ROWS + 15) / 16;        // 22 DMA pieces of 1 KB
+constexpr int UF_SLAB_BUF = UF_SLAB_PIECES * 1024;              // 22528
+constexpr int UF_BN = 32;                                       // output channels per block
+constexpr int UF_TAP = UF_BN * 64;                              // bytes of one tap's weight tile (32 rows x 32 channels)
+constexpr int UF_WT_BASE = 2 * UF_SLAB_BUF;                     // 45056
+constexpr int UF_TILE = 28;                                     // final pixels per tile side
+constexpr int UF_CT_BYTES = 32 * 32 * UF_BN * 2;                // 65536: the transposed-conv tile, fp16
+constexpr int UF_LDS = UF_CT_BYTES + UF_TILE * UF_TILE * 4;     // + the tile's noise = 68672 (>= 45056 + 9 * 2048)
+
+struct Up2Args {
+    const void* x;         // [N][H][W][Ci] fp16
+    const void* w;         // [N or 1][Co][9][Ci] fp16 (modulated, tap-major: what p3d_conv2d_nhwc takes for resample = 1)
+    void* y;               // [N][2H][2W][Co] fp16
+    const void* zeros;     // >= 128 zero bytes
+    const float* bias;     // [Co] or null
+    const float* noise;    // [2H][2W] or null
+    const float* noise_strength;
+    int N, H, W, Ci, Co;
+    int64_t w_img_stride;
+    float conv_gain;       // on the transposed conv's output, before the fp16 rounding
+    float fy[4], fx[4];    // separable FIR, already in correlation order and with its gain: out[o] = sum_k f[k] * ct[o - 1 + k]
+    int act;               // 0 linear, 1 lrelu(0.2)
+    float act_gain, clamp; // clamp < 0: off
+    int tiles_x, tiles;    // 28 x 28 tiles per row / per image
+    int debug;
+};
+
+template <int N> __device__ __forceinline__ void uf_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// slot s of a chunk's nine weight tiles holds tap kTapW[s] (ky * 3 + kx); phase p = slots 3p .. 3p+2.  The tap's class is
+// (ky & 1) * 2 + (kx & 1) and its input offset (-(ky >> 1), -(kx >> 1)); phase 0 reads offset (0,0) only, phase 1 (0,0) and (-1,0),
+// phase 2 (0,-1) and (-1,-1).
+__device__ constexpr int kTapW[9]   = {0, 1, 3,   4, 6, 7,   2, 5, 8};
+__device__ constexpr int kTapCls[9] = {0, 1, 2,   3, 0, 1,   0, 2, 0};
+__device__ constexpr int kTapA[9]   = {0, 0, 0,   0, 1, 1,   0, 0, 1};      // which of the phase's (up to two) A offsets
+__device__ constexpr int kPhaseDy[3][2] = {{0, 0}, {0, -1}, {0, -1}};
+__device__ constexpr int kPhaseDx[3][2] = {{0, 0}, {0, 0}, {-1, -1}};
+__device__ constexpr int kPhaseNA[3] = {1, 2, 2};
+
+__global__ void __launch_bounds__(256, 2) up2_fir_f16_kernel(Up2Args a)
+{
+    __shared__ __attribute__((aligned(16))) char lds_b[UF_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.z;
+    const int ncb = a.Co / UF_BN;
+    int mt, cb;
+    {   // consecutive block ids go round the 8 XCDs: ids 8q .. 8q+7 are eight tiles of one channel block, 8(q+1).. the same tiles of
+        // the next channel block — an XCD's L2 serves a tile's slab to all of its channel blocks
+        const int L = blockIdx.x, q = L >> 3, r = L & 7;
+        cb = q % ncb; mt = (q / ncb) * 8 + r;
+    }
+    if (mt >= a.tiles) return;
+    const int ty = mt / a.tiles_x, tx = mt - ty * a.tiles_x;
+    const int cy0 = 14 * ty - 1, cx0 = 14 * tx - 1, co0 = cb * UF_BN;           // class-grid origin of the 16 x 16 patch
+    const char* const xin_b = (const char*)((const __half*)a.x + (int64_t)n * a.H * a.W * a.Ci);
+    const char* const wgt_b = (const char*)((const __half*)a.w + (int64_t)n * a.w_img_stride);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const int pos = lane & 3, prow = lane >> 2;                                 // DMA lane: 16-byte position / row within a 16-row piece
+    const int kchunks = a.Ci / 32;
+    const bool two = wave < 2;                                                  // waves 0, 1 carry the extra weight piece and slab piece
+
+    // ---- DMA sources --------------------------------------------------------------------------------------------------------
+    unsigned woff;                                                              // this wave stages rows 16 (wave & 1) .. +15 of a tap tile
+    {
+        const int row = (wave & 1) * 16 + prow;
+        woff = (unsigned)(((co0 + row) * 9 * a.Ci + (pos ^ ((row >> 2) & 3)) * 8) * 2);
+    }
+    unsigned soff[6]; bool sok[6];
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+        const int q = (wave + 4 * g) * 16 + prow;
+        const int sy = q / UF_PITCH, sx = q - sy * UF_PITCH;
+        const int iy = cy0 - 1 + sy, ix = cx0 - 1 + sx;
+        sok[g] = (q < UF_SLAB_ROWS) & (sx < 17) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
+        soff[g] = (unsigned)(((iy * a.W + ix) * a.Ci + (pos ^ ((sx >> 2) & 3)) * 8) * 2);
+    }
+    auto stage_slab = [&](int cc) {
+        const int buf = (cc & 1) * UF_SLAB_BUF;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            if (g < 5 || two) {
+                const char* src = sok[g] ? xin_b + soff[g] + cc * 64 : (const char*)a.zeros;
+                __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(lds_b + buf + (wave + 4 * g) * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto stage_w = [&](int cc, int p) {                                         // p is a compile-time constant at every call
+        const int half = (wave & 1) * 1024;
+        const int j0 = wave >> 1;                                               // piece `wave`: tap j0 of the phase, rows of `half`
+        const int t0 = j0 ? kTapW[p * 3 + 1] : kTapW[p * 3];
+        __builtin_amdgcn_global_load_lds((glb_ptr)(wgt_b + woff + (t0 * a.Ci + cc * 32) * 2),
+                                         (lds_ptr)(lds_b + UF_WT_BASE + (p * 3 + j0) * UF_TAP + half), 16, 0, 0);
+        if (two)                                                                // piece wave + 4: the phase's third tap
+            __builtin_amdgcn_global_load_lds((glb_ptr)(wgt_b + woff + (kTapW[p * 3 + 2] * a.Ci + cc * 32) * 2),
+                                             (lds_ptr)(lds_b + UF_WT_BASE + (p * 3 + 2) * UF_TAP + half), 16, 0, 0);
+    };
+
+    // ---- fragment addresses ------------------------------------------------------------------------------------------------
+    const int frow = lane & 31, fk = lane >> 5, acol = frow & 15;
+    int preA[2][2], preB[2];                                                    // [1 + dx][kk]
+#pragma unroll
+    for (int tx2 = 0; tx2 < 2; ++tx2)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+            preA[tx2][kk] = ((wave * 4 + (frow >> 4)) * UF_PITCH + acol + tx2) * 64 + (((kk * 2 + fk) ^ (((acol + tx2) >> 2) & 3)) << 4);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) preB[kk] = UF_WT_BASE + frow * 64 + (((kk * 2 + fk) ^ ((frow >> 2) & 3)) << 4);
+
+    uf4 fa[2][2][2], fb[2][3];                                                  // [register buffer][A offset of the phase][i], [..][tap of the phase]
+    // loads of micro-step (p, kk) of the chunk whose slab sits at `sbuf`; p, kk, reg are compile-time constants
+#define UF_LOAD(p, kk, reg, sbuf)                                                                                                        \
+    do {                                                                                                                                \
+        _Pragma("unroll") for (int ao = 0; ao < kPhaseNA[p]; ++ao) {                                                                    \
+            const int base = preA[1 + kPhaseDx[p][ao]][kk] + (sbuf);                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                               \
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[reg][ao][i]) : "v"(base), "n"((2 * i + 1 + kPhaseDy[p][ao]) * UF_PITCH * 64) : "memory"); \
+        }                                                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                                                   \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[reg][j]) : "v"(preB[kk]), "n"(((p) * 3 + j) * UF_TAP) : "memory");   \
+    } while (0)
+#define UF_MFMA(p, reg)                                                                                                                  \
+    do {                                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                                              \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                                                   \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                               \
+                acc[kTapCls[(p) * 3 + j]][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(uh8, fa[reg][kTapA[(p) * 3 + j]][i]), \
+                                                                                      __builtin_bit_cast(uh8, fb[reg][j]), acc[kTapCls[(p) * 3 + j]][i], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                                              \
+    } while (0)
+
+    uf16 acc[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][i][r] = 0.f;
+
+    // ---- K loop --------------------------------------------------------------------------------------------------------------
+    // DMA groups of a wave: W = 2 (waves 0, 1) or 1 pieces, S = 6 or 5.  At the rendezvous that ends phase p of chunk c everything
+    // but the NEWEST group must have landed: after phase 0 that is W(c, 2) [-> W(c, 1) is in], after phase 1 W(c+1, 0) + slab(c+1)
+    // [-> W(c, 2) is in], after phase 2 W(c+1, 1) [-> W(c+1, 0) and the slab are in]; then the phase's slots take chunk c+1's taps.
+    stage_slab(0);
+    stage_w(0, 0);
+    stage_w(0, 1);
+    stage_w(0, 2);
+    if (two) uf_wait_vmcnt<4>(); else uf_wait_vmcnt<2>();                        // slab 0 and phase 0's taps
+    __builtin_amdgcn_s_barrier();
+    UF_LOAD(0, 0, 0, 0);
+    for (int cc = 0; cc < ((a.debug & 2) ? 0 : kchunks); ++cc) {
+        const bool more = cc + 1 < kchunks;
+        const int sb = (cc & 1) * UF_SLAB_BUF, sn = UF_SLAB_BUF - sb;
+        // phase 0
+        UF_LOAD(0, 1, 1, sb);
+        asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+        UF_MFMA(0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (two) uf_wait_vmcnt<2>(); else uf_wait_vmcnt<1>();
+        __builtin_amdgcn_s_barrier();
+        if (more) { stage_w(cc + 1, 0); stage_slab(cc + 1); }
+        UF_LOAD(1, 0, 0, sb);
+        UF_MFMA(0, 1);
+        // phase 1
+        UF_LOAD(1, 1, 1, sb);
+        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+        UF_MFMA(1, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (more) { if (two) uf_wait_vmcnt<8>(); else uf_wait_vmcnt<6>(); }
+        else uf_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (more) stage_w(cc + 1, 1);
+        UF_LOAD(2, 0, 0, sb);
+        UF_MFMA(1, 1);
+        // phase 2
+        UF_LOAD(2, 1, 1, sb);
+        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+        UF_MFMA(2, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (more) {
+            if (two) uf_wait_vmcnt<2>(); else uf_wait_vmcnt<1>();
+            __builtin_amdgcn_s_barrier();
+            stage_w(cc + 1, 2);
+            UF_LOAD(0, 0, 0, sn);
+        }
+        UF_MFMA(2, 1);
+    }
+#undef UF_LOAD
+#undef UF_MFMA
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uf_wait_vmcnt<0>();
+    if (a.debug & 1) { if (acc[0][0][0] == 123.f) ((float*)a.y)[0] = 1.f; return; }
+    __syncthreads();                                                            // slabs and taps are dead: the LDS becomes the epilogue's
+
+    // ---- the four class tiles -> one fp16 image [32][32][32 ch] --------------------------------------------------------------
+    __half* const ct = (__half*)lds_b;
+    float* const nz = (float*)(lds_b + UF_CT_BYTES);
+    if (!(a.debug & 16))
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int py = c >> 1, px = c & 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                const int row = 2 * (p >> 4) + py, col = 2 * (p & 15) + px;
+                ct[(row * 32 + col) * UF_BN + frow] = __float2half(acc[c][i][r] * a.conv_gain);
+            }
+    }
+    const int OH = 2 * a.H, OW = 2 * a.W;
+    const int oy0 = UF_TILE * ty, ox0 = UF_TILE * tx;
+    {
+        const float ns = a.noise ? a.noise_strength[0] : 0.f;
+        for (int e = tid; e < UF_TILE * UF_TILE; e += 256) {
+            const int oy = oy0 + e / UF_TILE, ox = ox0 + e % UF_TILE;
+            nz[e] = (a.noise && oy < OH && ox < OW) ? a.noise[(int64_t)oy * OW + ox] * ns : 0.f;
+        }
+    }
+    __syncthreads();
+
+    // ---- separable 4-tap FIR down a 14-row strip, 8 channels per thread ------------------------------------------------------
+    const int slot = tid >> 2, chunk = tid & 3;
+    const int strip = slot / UF_TILE, xo = slot - strip * UF_TILE;
+    if (strip >= 2) return;
+    const int ox = ox0 + xo;
+    if (ox >= OW) return;
+    float bias[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bias[k] = a.bias ? a.bias[co0 + chunk * 8 + k] : 0.f;
+    __half* const yout = (__half*)a.y + (int64_t)n * OH * OW * a.Co + co0 + chunk * 8;
+    float out[4][8];                                                            // rows m .. m+3 of the strip, rotating
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[q][k] = 0.f;
+    if (a.debug & 8) return;
+#pragma unroll
+    for (int j = 0; j < 17; ++j) {                                              // transposed-conv row strip * 14 + 1 + j of the tile
+        float h[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) h[k] = 0.f;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            const uh8 v = *(const uh8*)(ct + (((strip * 14 + 1 + j) * 32 + xo + 1 + kx) * UF_BN + chunk * 8));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) h[k] = fmaf((float)v[k], a.fx[kx], h[k]);
+        }
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            const int m = j - ky;                                               // the strip row this input row feeds through tap ky
+            if (m >= 0 && m < 14) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) out[m & 3][k] = fmaf(h[k], a.fy[ky], out[m & 3][k]);
+            }
+        }
+        const int m = j - 3;                                                    // complete now
+        if (m >= 0) {
+            const int oy = oy0 + strip * 14 + m;
+            const float nzv = nz[(strip * 14 + m) * UF_TILE + xo];
+            uh8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float v = out[m & 3][k] + nzv + bias[k];
+                if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
+                v *= a.act_gain;
+                if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
+                o[k] = (_Float16)v;
+                out[m & 3][k] = 0.f;
+            }
+            if (oy < OH && (!(a.debug & 4) || o[0] == (_Float16)123.f)) *(uh8*)(yout + ((int64_t)oy * OW + ox) * a.Co) = o;
+        }
+    }
+}
+
+} // namespace p3d
+
+extern "C" int p3d_up2_fir_f16(const void* x, const void* w, void* y, const void* zeros128, const float* bias, const float* noise,
+                               const float* noise_strength, const float* fir_yx_host, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co,
+                               int64_t w_img_stride, float conv_gain, int32_t act, float act_gain, float clamp, p3d_stream_t stream)
+{
+    using namespace p3d;
+    P3D_REQUIRE(x && w && y && zeros128 && fir_yx_host, "up2_fir_f16: null pointer");
+    P3D_REQUIRE(n_img >= 1 && h >= 1 && wdt >= 1, "up2_fir_f16: bad sizes");
+    P3D_REQUIRE(act == 0 || act == 1, "up2_fir_f16: act must be 0 (linear) or 1 (lrelu)");
+    if (ci % 32 != 0 || co % UF_BN != 0) return fail(P3D_ERR_UNSUPPORTED, "up2_fir_f16: Ci=%d and Co=%d must be multiples of 32", ci, co);
+    P3D_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)zeros128) & 15u) == 0, "up2_fir_f16: pointers must be 16-byte aligned");
+    P3D_REQUIRE((int64_t)h * wdt * ci * 2 < (1ll << 31) && (int64_t)co * 9 * ci * 2 < (1ll << 31), "up2_fir_f16: image or weight panel beyond 32-bit offsets");
+    Up2Args a{};
+    a.x = x; a.w = w; a.y = y; a.zeros = zeros128; a.bias = bias; a.noise = noise; a.noise_strength = noise_strength;
+    a.N = n_img; a.H = h; a.W = wdt; a.Ci = ci; a.Co = co; a.w_img_stride = w_img_stride; a.conv_gain = conv_gain;
+    for (int k = 0; k < 4; ++k) { a.fy[k] = fir_yx_host[k]; a.fx[k] = fir_yx_host[4 + k]; }
+    a.act = act; a.act_gain = act_gain; a.clamp = clamp;
+    const int tiles_y = (2 * h + UF_TILE - 1) / UF_TILE;
+    a.tiles_x = (2 * wdt + UF_TILE - 1) / UF_TILE;
+    a.tiles = a.tiles_x * tiles_y;
+    { const char* d = getenv("P3D_UP2_DEBUG"); a.debug = d ? atoi(d) : 0; }
+    const int64_t blocks = (int64_t)((a.tiles + 7) / 8 * 8) * (co / UF_BN);
+    P3D_REQUIRE(blocks < (1ll << 31) && n_img < 65536, "up2_fir_f16: bad launch size");
+    hipLaunchKernelGGL(up2_fir_f16_kernel, dim3((unsigned)blocks, 1, n_img), dim3(256), 0, (hipStream_t)stream, a);
+    count_launch(FAM_CONV);
+    return check_launch("up2_fir_f16");
+}

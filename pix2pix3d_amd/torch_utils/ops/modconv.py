@@ -43,6 +43,7 @@ _lib.register('p3d_conv2d_nhwc', ctypes.c_int, [_vp] * 3 + [ctypes.c_int] + [_vp
 _lib.register('p3d_conv2d_nhwc_ws', ctypes.c_int, [_vp] * 3 + [ctypes.c_int] + [_vp] * 4 + [_i32] * 5 + [_i64, _i32, _i32, _i32, _f32, _f32, _vp, _i64, _vp])
 _lib.register('p3d_conv2d_nhwc_workspace', _i64, [ctypes.c_int] + [_i32] * 5 + [_i64, _i32, _i32])
 
+_lib.register('p3d_up2_fir_f16', ctypes.c_int, [_vp] * 8 + [_i32] * 5 + [ctypes.c_int64, _f32, _i32, _f32, _f32, _vp])
 _lib.register('p3d_fir4_bias_act_nhwc', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int] + [_i32] * 9 + [_f32, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _vp])
 _lib.register('p3d_fc_forward', ctypes.c_int, [_vp] * 4 + [_i32] * 3 + [_i64, _f32, _f32, _i32, _f32, _f32, _f32, _vp])
 _lib.register('p3d_im2col3x3', ctypes.c_int, [_vp, _vp] + [_i32] * 6 + [_i64] * 4 + [_vp])
@@ -112,6 +113,7 @@ def torgb_supported(x, weight, styles, fused_modconv):
 
 BF16X3 = 'bf16x3'            # dtype tag: fp32 tensors whose products run as three bf16 MFMAs of (hi, lo) splits (csrc/conv2d.hip)
 DTYPE_F32_BF16X3 = 3         # p3d_dtype code of that formulation (include/p3d_hip.h)
+fuse_up2 = os.environ.get('P3D_FUSE_UP2', '1') != '0'       # fp16 x2 layers: transposed conv + FIR + epilogue in one kernel (csrc/up2_fir.hip); 0 = the two-kernel form
 split_bf16 = os.environ.get('P3D_BF16X3', '1') != '0'      # use it for the fp32 layers that are bound by the fp32 matrix rate
 split_bf16_min_pixels = int(os.environ.get('P3D_BF16X3_MIN_PIXELS', 16))       # every fp32 3x3 layer (measured: 4096 -> 462, 1024 -> 472, 256 -> 474, 16 -> 476 img/s)
 
@@ -368,6 +370,10 @@ def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=No
     if up == 1:
         y = conv2d(x, wmod, noise=noise_const, noise_strength=noise_strength, split=split)
         return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
+    if fuse_up2 and act_idx is not None and x.dtype == torch.float16 and x.shape[1] % 32 == 0 and wmod.shape[1] % 32 == 0:
+        taps = _separable_fir(resample_filter)
+        if taps is not None:
+            return up2_fir(x, wmod, taps, bias, noise_const, noise_strength, act_idx, act_gain, clampv)
     # x2: stride-2 transposed conv as four polyphase GEMMs, then the 4x4 low-pass with gain 4 (conv2d_resample.py:114-131)
     y = conv2d(x, wmod, transposed=True, split=split)
     if act_idx is not None and tuple(resample_filter.shape) == (4, 4) and y.shape[1] % (64 if y.dtype == torch.float16 else 32) == 0:
@@ -376,6 +382,45 @@ def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=No
     if noise_const is not None:
         y = y.add_((noise_const * noise_strength).to(y.dtype))
     return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
+
+
+def _separable_fir(f):
+    """The 4x4 low-pass of the x2 layers as (fy, fx) in correlation order with the gain 4 folded in — eight host floats for
+    p3d_up2_fir_f16 — or None when ``f`` is not 4x4 / not an outer product (setup_filter of a 1-D filter always is).  One device
+    read per filter tensor, cached."""
+    if tuple(f.shape) != (4, 4):
+        return None
+
+    def make():
+        f64 = f.detach().double().cpu()
+        r, c, tot = f64.sum(1), f64.sum(0), f64.sum()
+        if float(tot) == 0.0 or not torch.allclose(torch.outer(r, c) / tot, f64, rtol=1e-6, atol=1e-9):
+            return (None,)
+        vals = [4.0 * float(r[3 - k]) / float(tot) for k in range(4)] + [float(c[3 - k]) for k in range(4)]       # upfirdn2d flips f (flip_filter = False)
+        return ((ctypes.c_float * 8)(*vals),)
+    return _cached_weight(f, 'fir_sep', make)[0]
+
+
+def up2_fir(x, wmod, taps, bias, noise, noise_strength, act, act_gain, clamp):
+    """The whole x2 layer in one launch: x NHWC fp16 [N,Ci,H,W], wmod [N or 1][Co][9][Ci] -> NHWC fp16 [N,Co,2H,2W]
+    (csrc/up2_fir.hip: transposed conv, 4x4 FIR, noise, bias, activation, clamp; the (2H+1)^2 intermediate stays in LDS)."""
+    assert _is_nhwc_f16(x) and wmod.dtype == torch.float16 and wmod.is_contiguous() and wmod.shape[2] == 9
+    n, ci, h, w = x.shape
+    co = wmod.shape[1]
+    assert wmod.shape[0] in (1, n) and wmod.shape[3] == ci
+    y = torch.empty([n, co, 2 * h, 2 * w], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    stride = 0 if wmod.shape[0] == 1 else co * 9 * ci
+    b32 = None if bias is None else bias.detach().float().contiguous()
+    nz = None if noise is None else noise.detach().float().contiguous()
+    ns = None if noise is None else noise_strength.detach().float().reshape(1).contiguous()
+    with _lib.kernel_timer('conv_f16', x):
+        code = _lib.lib().p3d_up2_fir_f16(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), _lib.ptr(_zeros_page(x.device)), _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns),
+                                          ctypes.cast(taps, ctypes.c_void_p), n, h, w, ci, co, stride, 1.0, int(act), float(act_gain), float(clamp), _lib.stream_of(x))
+    _lib.check(code, 'up2_fir_f16')
+    log = _lib.kernel_events.get('conv_flops')
+    if log is not None:
+        log.append((str(x.dtype), 2.0 * n * ci * co * 9 * h * w))
+    return y
 
 
 def fir4_bias_act(y, f, bias, noise, noise_strength, act, act_gain, clamp):

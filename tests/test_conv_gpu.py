@@ -249,3 +249,56 @@ def test_bf16x3_formulation_of_the_fp32_convolution(hip_lib, ci, co, res, transp
     e = rel_err(y.double().cpu().numpy(), ref.numpy())
     print((ci, co, res, transposed), e)
     assert e < 1e-5, e
+
+
+@pytest.mark.parametrize('ci,co,h,w,n,noise,act,clamp', [
+    (32, 256, 128, 128, 2, True, 'lrelu', 256.0),      # SR block0.conv0 (one 32-channel chunk)
+    (256, 128, 64, 64, 2, True, 'lrelu', 256.0),       # SR block1.conv0's channels (eight chunks), several tiles
+    (64, 32, 14, 14, 1, False, 'linear', None),        # exactly one 28 x 28 tile
+    (64, 64, 15, 29, 3, True, 'lrelu', 0.5),           # ragged tiles on both axes, odd chunk count below, clamp active
+    (96, 96, 33, 20, 2, True, 'lrelu', None),          # three chunks (odd): both slab buffers end a loop
+    (32, 32, 3, 5, 2, True, 'lrelu', None),            # image smaller than a tile
+])
+def test_x2_layer_in_one_kernel(hip_lib, ci, co, h, w, n, noise, act, clamp):
+    """csrc/up2_fir.hip: conv_transpose2d(stride 2) + 4x4 FIR (pad 1, gain 4) + noise + bias + act + clamp against the same chain in
+    fp64 torch on the fp16-rounded operands (with the fp16 rounding of the transposed conv's output the reference has), and
+    against the two-kernel form.  Tolerance: one fp16 rounding of the result + one of the intermediate (2e-3 of the range)."""
+    from pix2pix3d_amd import _lib
+    from pix2pix3d_amd.torch_utils.ops import modconv, upfirdn2d
+    torch.manual_seed(ci + co + h)
+    x = _nhwc(torch.randn(n, ci, h, w, device='cuda').half())
+    weight = torch.randn(co, ci, 3, 3, device='cuda')
+    styles = torch.randn(n, ci, device='cuda') + 1
+    bias = torch.randn(co, device='cuda')
+    nz = torch.randn(2 * h, 2 * w, device='cuda') if noise else None
+    ns = torch.tensor(0.3, device='cuda') if noise else None
+    f = upfirdn2d.setup_filter([1, 3, 3, 1], device=torch.device('cuda'))
+    gain = float(np.sqrt(2)) if act == 'lrelu' else 1.0
+    prev = modconv.fuse_up2
+    try:
+        modconv.fuse_up2 = True
+        n0, u0 = _lib.launch_count('conv'), _lib.launch_count('upfirdn2d')
+        y1 = modconv.synthesis_layer(x, weight, styles, bias, 2, f, noise_const=nz, noise_strength=ns, act=act, act_gain=gain, clamp=clamp)
+        assert _lib.launch_count("conv") == n0 + 2 and _lib.launch_count("upfirdn2d") == u0      # weight modulation + ONE layer launch, no separate FIR
+        modconv.fuse_up2 = False
+        y0 = modconv.synthesis_layer(x, weight, styles, bias, 2, f, noise_const=nz, noise_strength=ns, act=act, act_gain=gain, clamp=clamp)
+    finally:
+        modconv.fuse_up2 = prev
+    assert y1.shape == (n, co, 2 * h, 2 * w) and y1.dtype == torch.float16 and y1.is_contiguous(memory_format=torch.channels_last)
+    wmod = modconv.modulate_weights(weight, styles)
+    wq = wmod.double().reshape(n, co, 3, 3, ci).permute(0, 1, 4, 2, 3).cpu()
+    xd = x.double().cpu()
+    ct = torch.stack([F.conv_transpose2d(xd[i:i + 1], wq[i].transpose(0, 1), stride=2)[0] for i in range(n)]).half().double()
+    fd = (f.double().cpu() * 4).flip([0, 1])
+    yr = F.conv2d(F.pad(ct, [1, 1, 1, 1]).reshape(n * co, 1, 2 * h + 3, 2 * w + 3), fd[None, None]).reshape(n, co, 2 * h, 2 * w)
+    if noise:
+        yr = yr + (nz.double().cpu() * 0.3)
+    yr = yr + bias.double().cpu().view(1, -1, 1, 1)
+    if act == 'lrelu':
+        yr = F.leaky_relu(yr, 0.2)
+    yr = yr * gain
+    if clamp is not None:
+        yr = yr.clamp(-clamp, clamp)
+    e1, e0 = rel_err(y1.double().cpu().numpy(), yr.numpy()), rel_err(y0.double().cpu().numpy(), yr.numpy())
+    print(ci, co, h, w, 'fused', e1, 'two-kernel', e0)
+    assert e1 < 2e-3 and e0 < 2e-3
