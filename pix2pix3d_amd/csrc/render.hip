@@ -312,7 +312,8 @@ static int render_forward_impl(const float* planes_cl, const float* planes_sem_c
     // a block is one-per-CU (LDS): small launches take fewer waves per block so that every CU still gets one
     int wpb = dual ? kWavesPerBlockDual : kWavesPerBlock;
     while (wpb > 2 && (total + wpb * 32 - 1) / (wpb * 32) < kNumCU) wpb >>= 1;
-    const size_t lds_bytes = (size_t)(dual ? kDecoderFloatsDual + kWavesPerBlockDual * kWaveTile : kDecoderFloats + kWavesPerBlock * kWaveTile) * sizeof(float);
+    const size_t lds_bytes = (size_t)(dual ? kDecoderFloatsDual + kWavesPerBlockDual * kWaveTile
+                                           : kDecoderFloats + kWavesPerBlock * (kWaveTile + kFeatTile)) * sizeof(float);      // + the cooperative gather's hand-over tiles
     const int blocks = (int)((total + wpb * 32 - 1) / (wpb * 32));
     hipLaunchKernelGGL(render_init_minmax_kernel, dim3(1), dim3(1), 0, s, minmax_ws);
     if (dual) {

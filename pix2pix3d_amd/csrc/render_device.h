@@ -24,6 +24,8 @@ constexpr int kPitch = 33;                       // LDS pitch of the per-wave [s
 constexpr int kMaxS = 64;                        // max coarse / fine samples per ray
 constexpr int kWaveTile = kMaxS * kPitch + 128;  // + two 64-float scratch rows
 constexpr int kWavesPerBlock = 8;
+constexpr int kFeatPitch = 36;                   // floats per ray in the cooperative gather's hand-over tile (144 B: 16 consecutive rays start on 16 different bank quads)
+constexpr int kFeatTile = 32 * kFeatPitch;       // per wave
 
 struct RenderArgs {
     const float* planes;      // [N][3][H][W][32]
@@ -206,6 +208,74 @@ __device__ __forceinline__ void gather_features(const RenderArgs& a, rsrc_t rsrc
     }
 #pragma unroll
     for (int c = 0; c < 16; ++c) feat[c] = acc[c] * (1.f / 3.f);
+}
+
+// ---- cooperative gather (inference kernels) ---------------------------------------------------------
+// gather_features has lane (j, h) fetch half a texel (64 B) of ITS ray in four 16-byte loads: every load instruction of the wave
+// touches 32 texels and uses 32 bytes of each 128-byte line, and the four instructions of a tap walk the same 32 lines four times.
+// The texture path pays per line, so the kernel ran at the L1's request rate, not at anything the memory behind it could give.
+// Here EIGHT lanes share a texel: in group i (0..3) lane l fetches the 16-byte chunk l & 7 of the taps of wave ray 8 i + (l >> 3),
+// so one load instruction reads 8 whole lines and a tap of the wave's 32 rays is 4 instructions x 8 lines instead of 4 x 32.
+// Each lane therefore works out the taps of four rays (positions from the owner lanes' depths by shuffle, ray origins / directions
+// held per lane), blends its 4 channels in the same order as gather_features (bit-identical sums) and drops them into a per-wave
+// [32 rays][36] LDS tile, from which lane (j, h) picks up the 16 channels the decoder wants.  Groups are pipelined two deep: 24
+// loads in flight per lane, as before.
+struct CoopRays { float ox[4], oy[4], oz[4], dx[4], dy[4], dz[4]; unsigned img[4]; };
+
+__device__ __forceinline__ void coop_issue(const RenderArgs& a, rsrc_t rsrc, unsigned base, float px, float py, float pz, f32x4 (&buf)[12], float (&w)[12])
+{
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const PlaneTaps t = plane_taps(a, base, 0, p, px, py, pz);
+        buf[4 * p + 0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, t.o00, 0, 0));
+        buf[4 * p + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, t.o10, 0, 0));
+        buf[4 * p + 2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, t.o01, 0, 0));
+        buf[4 * p + 3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, t.o11, 0, 0));
+        w[4 * p + 0] = t.w00; w[4 * p + 1] = t.w10; w[4 * p + 2] = t.w01; w[4 * p + 3] = t.w11;
+    }
+}
+__device__ __forceinline__ void coop_blend(const f32x4 (&buf)[12], const float (&w)[12], float* dst)
+{
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 12; t += 2)                       // (left, right) of the top row, then of the bottom row, plane by plane: gather_features' order
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(buf[t + 1][e], w[t + 1], fmaf(buf[t][e], w[t], acc[e]));
+    *(f32x4*)dst = acc * (1.f / 3.f);
+}
+__device__ __forceinline__ void gather_features_coop(const RenderArgs& a, rsrc_t rsrc, const CoopRays& cr, int lane, float z, float* ftile, float (&feat)[16])
+{
+    const int sub = lane >> 3, chunk = lane & 7;
+    const float cs = a.coord_scale;
+    f32x4 bufA[12], bufB[12];
+    float wA[12], wB[12];
+    float* const dst = ftile + sub * kFeatPitch + chunk * 4;
+#define P3D_COOP_ISSUE(i, buf, w)                                                                                               \
+    do {                                                                                                                        \
+        const float zr = __shfl(z, 8 * (i) + sub, 64);                                                                          \
+        coop_issue(a, rsrc, cr.img[i] + chunk * 16, cs * fmaf(zr, cr.dx[i], cr.ox[i]), cs * fmaf(zr, cr.dy[i], cr.oy[i]),        \
+                   cs * fmaf(zr, cr.dz[i], cr.oz[i]), buf, w);                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    } while (0)
+    P3D_COOP_ISSUE(0, bufA, wA);
+    P3D_COOP_ISSUE(1, bufB, wB);
+    coop_blend(bufA, wA, dst);
+    __builtin_amdgcn_sched_barrier(0);
+    P3D_COOP_ISSUE(2, bufA, wA);
+    coop_blend(bufB, wB, dst + 8 * kFeatPitch);
+    __builtin_amdgcn_sched_barrier(0);
+    P3D_COOP_ISSUE(3, bufB, wB);
+    coop_blend(bufA, wA, dst + 16 * kFeatPitch);
+    coop_blend(bufB, wB, dst + 24 * kFeatPitch);
+#undef P3D_COOP_ISSUE
+    // same wave wrote it: LDS operations of a wave complete in order, no barrier
+    const f32x4* src = (const f32x4*)(ftile + (lane & 31) * kFeatPitch + (lane >> 5) * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = src[q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) feat[q * 4 + e] = v[e];
+    }
 }
 
 // ---- decoder pieces -------------------------------------------------------------------------------
@@ -509,6 +579,18 @@ render_forward_kernel(RenderArgs a)
     const float dx = a.ray_d[g * 3 + 0], dy = a.ray_d[g * 3 + 1], dz = a.ray_d[g * 3 + 2];
     const float cs = a.coord_scale;
     const float* uc = a.u_coarse + (size_t)g * Sc;
+    constexpr bool COOP = !TAPE && !DUAL;                         // the inference kernels gather eight lanes to a texel
+    float* const ftile = lds + kDecFloats + wpb * kWaveTile + wave * kFeatTile;
+    CoopRays cr;
+    if constexpr (COOP) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int src = 8 * i + (lane >> 3);                  // the owner lane (h = 0) of this lane's i-th gather ray
+            cr.ox[i] = __shfl(ox, src, 64); cr.oy[i] = __shfl(oy, src, 64); cr.oz[i] = __shfl(oz, src, 64);
+            cr.dx[i] = __shfl(dx, src, 64); cr.dy[i] = __shfl(dy, src, 64); cr.dz[i] = __shfl(dz, src, 64);
+            cr.img[i] = (unsigned)__shfl((int)img, src, 64);
+        }
+    }
 
     // ------------------------------ phase A: coarse densities -> weights ------------------------------
     {
@@ -516,7 +598,8 @@ render_forward_kernel(RenderArgs a)
         for (int i = 0; i < Sc; ++i) {
             const float z = coarse_depth(a, g, i, uc[i]);
             float feat[16];
-            gather_features<!TAPE>(a, rsrc_sem, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
+            if constexpr (COOP) gather_features_coop(a, rsrc_sem, cr, lane, z, ftile, feat);
+            else gather_features<!TAPE>(a, rsrc_sem, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
             f32x16 h0, h1;
             if constexpr (BF3) {
                 bf8 fh[2], fl[2];
@@ -576,7 +659,8 @@ render_forward_kernel(RenderArgs a)
         else        { ++jf; zf = (jf < Sf) ? tile[jf * kPitch + j] : INFINITY; }
 
         float feat[16], feat_tex[16];
-        gather_features<!TAPE && !DUAL>(a, rsrc_sem, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
+        if constexpr (COOP) gather_features_coop(a, rsrc_sem, cr, lane, z, ftile, feat);
+        else gather_features<false>(a, rsrc_sem, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
         if (DUAL) gather_features<false>(a, rsrc, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat_tex);
         // The density net goes first: its sigma closes interval k-1 (weight w), after which every net's
         // colours are folded into the accumulators as soon as its layer 2 retires — only `prev` (the

@@ -104,8 +104,8 @@ def test_bench_sized_backward_properties(hip_lib):
     # central difference of the forward IS the derivative the backward computes.  (Along the planes the forward would also move its
     # importance samples, which the gradient deliberately treats as constants, renderer.py:198, 211 — see the last check instead.)
     def loss(pl):
-        feat, _, _ = R.fused_render(pl, dec, o, d, op, uc, uf)
-        return float((feat.double() * g1.double()).sum())
+        feat, _, _ = R.fused_render(pl, dec, o, d, op, uc, uf, exact_fp32=True)      # the forward the backward differentiates (the training forward; the
+        return float((feat.double() * g1.double()).sum())                             # inference default, a bf16x3 decoder, adds 1e-6-level noise to a difference quotient)
     names = [k for k, _ in dec.named_parameters()]
     colour = [i for i, k in enumerate(names) if k.startswith('net.')]
     assert len(colour) == 4
