@@ -164,6 +164,9 @@ render_backward_kernel(RenderArgs a, const float* __restrict__ bwd_stream, float
     const float dx = a.ray_d[g * 3 + 0], dy = a.ray_d[g * 3 + 1], dz = a.ray_d[g * 3 + 2];
     const float cs = a.coord_scale;
     const float4* const tape = (const float4*)a.tape_s + (size_t)g * S;
+    static_assert(TP == kFeatPitch, "T_f is the cooperative gather's tile");
+    CoopRays cr;
+    coop_rays(cr, lane, ox, oy, oz, dx, dy, dz, img);
 
     float dC[NNETS][16];                                          // dL/dC (= 2 dL/dfeat) of this lane's channels
 #pragma unroll
@@ -190,10 +193,8 @@ render_backward_kernel(RenderArgs a, const float* __restrict__ bwd_stream, float
         const float z = rec.x, wgt = live ? rec.y : 0.f, dsig = live ? rec.z : 0.f;
         const float px = cs * fmaf(z, dx, ox), py = cs * fmaf(z, dy, oy), pz = cs * fmaf(z, dz, oz);
         float feat[16];
-        gather_features<false>(a, rsrc, img, h, px, py, pz, feat);
         wave_sync();                                              // the previous sample's readers of T_f are done
-#pragma unroll
-        for (int c = 0; c < 16; ++c) Tf[(16 * h + c) * TP + j] = feat[c];
+        gather_features_coop<true>(a, rsrc, cr, lane, z, Tf, feat);      // eight lanes to a texel; lands in T_f as [channel][ray] and in the lane's registers
         f32x16 df;
 #pragma unroll
         for (int r = 0; r < 16; ++r) df[r] = 0.f;
@@ -405,7 +406,7 @@ extern "C" int p3d_render_backward(const float* planes_cl, const float* decoder,
         // a block is one-per-CU (LDS): small launches take fewer waves per block so that every CU still gets one
         int wpb = kWavesPerBlock;
         while (wpb > 2 && (total + wpb * 32 - 1) / (wpb * 32) < kNumCU) wpb >>= 1;
-        const size_t lds_bytes = (size_t)(kDecoderFloats + kWavesPerBlock * kWaveTile) * sizeof(float);
+        const size_t lds_bytes = (size_t)(kDecoderFloats + kWavesPerBlock * (kWaveTile + kFeatTile)) * sizeof(float);
         const int blocks = (int)((total + wpb * 32 - 1) / (wpb * 32));
         if (d->n_nets == 1) {
             static std::atomic<uint64_t> once1_devs{0}; const hipError_t once1 = reserve_lds_once((const void*)render_forward_kernel<1, true>, (int)lds_bytes, once1_devs);

@@ -234,6 +234,8 @@ __device__ __forceinline__ void coop_issue(const RenderArgs& a, rsrc_t rsrc, uns
         w[4 * p + 0] = t.w00; w[4 * p + 1] = t.w10; w[4 * p + 2] = t.w01; w[4 * p + 3] = t.w11;
     }
 }
+// TRANSPOSED: the tile is [channel][ray] (the backward kernel's T_f, which its weight-gradient MFMAs read) instead of [ray][channel]
+template <bool TRANSPOSED>
 __device__ __forceinline__ void coop_blend(const f32x4 (&buf)[12], const float (&w)[12], float* dst)
 {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -241,15 +243,23 @@ __device__ __forceinline__ void coop_blend(const f32x4 (&buf)[12], const float (
     for (int t = 0; t < 12; t += 2)                       // (left, right) of the top row, then of the bottom row, plane by plane: gather_features' order
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = fmaf(buf[t + 1][e], w[t + 1], fmaf(buf[t][e], w[t], acc[e]));
-    *(f32x4*)dst = acc * (1.f / 3.f);
+    acc = acc * (1.f / 3.f);
+    if (TRANSPOSED) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e * kFeatPitch] = acc[e];
+    } else
+        *(f32x4*)dst = acc;
 }
+template <bool TRANSPOSED = false>
 __device__ __forceinline__ void gather_features_coop(const RenderArgs& a, rsrc_t rsrc, const CoopRays& cr, int lane, float z, float* ftile, float (&feat)[16])
 {
     const int sub = lane >> 3, chunk = lane & 7;
     const float cs = a.coord_scale;
     f32x4 bufA[12], bufB[12];
     float wA[12], wB[12];
-    float* const dst = ftile + sub * kFeatPitch + chunk * 4;
+    constexpr int RS = TRANSPOSED ? 1 : kFeatPitch;        // tile stride of a ray / of a channel
+    constexpr int CS = TRANSPOSED ? kFeatPitch : 1;
+    float* const dst = ftile + sub * RS + chunk * 4 * CS;
 #define P3D_COOP_ISSUE(i, buf, w)                                                                                               \
     do {                                                                                                                        \
         const float zr = __shfl(z, 8 * (i) + sub, 64);                                                                          \
@@ -259,22 +269,38 @@ __device__ __forceinline__ void gather_features_coop(const RenderArgs& a, rsrc_t
     } while (0)
     P3D_COOP_ISSUE(0, bufA, wA);
     P3D_COOP_ISSUE(1, bufB, wB);
-    coop_blend(bufA, wA, dst);
+    coop_blend<TRANSPOSED>(bufA, wA, dst);
     __builtin_amdgcn_sched_barrier(0);
     P3D_COOP_ISSUE(2, bufA, wA);
-    coop_blend(bufB, wB, dst + 8 * kFeatPitch);
+    coop_blend<TRANSPOSED>(bufB, wB, dst + 8 * RS);
     __builtin_amdgcn_sched_barrier(0);
     P3D_COOP_ISSUE(3, bufB, wB);
-    coop_blend(bufA, wA, dst + 16 * kFeatPitch);
-    coop_blend(bufB, wB, dst + 24 * kFeatPitch);
+    coop_blend<TRANSPOSED>(bufA, wA, dst + 16 * RS);
+    coop_blend<TRANSPOSED>(bufB, wB, dst + 24 * RS);
 #undef P3D_COOP_ISSUE
     // same wave wrote it: LDS operations of a wave complete in order, no barrier
-    const f32x4* src = (const f32x4*)(ftile + (lane & 31) * kFeatPitch + (lane >> 5) * 16);
+    if (TRANSPOSED) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 v = src[q];
+        for (int c = 0; c < 16; ++c) feat[c] = ftile[((lane >> 5) * 16 + c) * kFeatPitch + (lane & 31)];
+    } else {
+        const f32x4* src = (const f32x4*)(ftile + (lane & 31) * kFeatPitch + (lane >> 5) * 16);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) feat[q * 4 + e] = v[e];
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = src[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) feat[q * 4 + e] = v[e];
+        }
+    }
+}
+// the four gather rays of a lane: origins / directions / image offsets from their owner lanes
+__device__ __forceinline__ void coop_rays(CoopRays& cr, int lane, float ox, float oy, float oz, float dx, float dy, float dz, unsigned img)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int src = 8 * i + (lane >> 3);                  // the owner lane (h = 0) of this lane's i-th gather ray
+        cr.ox[i] = __shfl(ox, src, 64); cr.oy[i] = __shfl(oy, src, 64); cr.oz[i] = __shfl(oz, src, 64);
+        cr.dx[i] = __shfl(dx, src, 64); cr.dy[i] = __shfl(dy, src, 64); cr.dz[i] = __shfl(dz, src, 64);
+        cr.img[i] = (unsigned)__shfl((int)img, src, 64);
     }
 }
 
@@ -579,18 +605,10 @@ render_forward_kernel(RenderArgs a)
     const float dx = a.ray_d[g * 3 + 0], dy = a.ray_d[g * 3 + 1], dz = a.ray_d[g * 3 + 2];
     const float cs = a.coord_scale;
     const float* uc = a.u_coarse + (size_t)g * Sc;
-    constexpr bool COOP = !TAPE && !DUAL;                         // the inference kernels gather eight lanes to a texel
+    constexpr bool COOP = !DUAL;                                  // one plane set: eight lanes to a texel
     float* const ftile = lds + kDecFloats + wpb * kWaveTile + wave * kFeatTile;
     CoopRays cr;
-    if constexpr (COOP) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int src = 8 * i + (lane >> 3);                  // the owner lane (h = 0) of this lane's i-th gather ray
-            cr.ox[i] = __shfl(ox, src, 64); cr.oy[i] = __shfl(oy, src, 64); cr.oz[i] = __shfl(oz, src, 64);
-            cr.dx[i] = __shfl(dx, src, 64); cr.dy[i] = __shfl(dy, src, 64); cr.dz[i] = __shfl(dz, src, 64);
-            cr.img[i] = (unsigned)__shfl((int)img, src, 64);
-        }
-    }
+    if constexpr (COOP) coop_rays(cr, lane, ox, oy, oz, dx, dy, dz, img);
 
     // ------------------------------ phase A: coarse densities -> weights ------------------------------
     {
@@ -599,7 +617,7 @@ render_forward_kernel(RenderArgs a)
             const float z = coarse_depth(a, g, i, uc[i]);
             float feat[16];
             if constexpr (COOP) gather_features_coop(a, rsrc_sem, cr, lane, z, ftile, feat);
-            else gather_features<!TAPE>(a, rsrc_sem, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
+            else gather_features<true>(a, rsrc_sem, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
             f32x16 h0, h1;
             if constexpr (BF3) {
                 bf8 fh[2], fl[2];
