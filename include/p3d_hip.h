@@ -289,6 +289,23 @@ int64_t p3d_conv2d_nhwc_workspace(int dtype, int32_t n_img, int32_t h, int32_t w
 int p3d_torgb_nhwc_f16(const void* x, const float* weight, const float* styles, const float* bias, float* y_nchw,
                        int32_t n_img, int32_t hw, int32_t ci, int32_t co, float clamp, int32_t accumulate, p3d_stream_t stream);
 
+/* ---- per-(image, channel) scaling and its gradient reductions ----------------------------------
+ * The element-wise half of the unfused modulated convolution of the training passes (training/networks_stylegan2.py:70-79:
+ * x * styles before the convolution, fma(y, dcoefs, noise) after it; torch_utils/ops/fma.py:17-60) and the bias-gradient sums of
+ * bias_act (bias_act.py:190-193).  A dense activation tensor is passed as [n][a][b], b contiguous: NCHW -> channels_last = 0, a = C,
+ * b = H*W; channels-last -> channels_last = 1, a = H*W, b = C.  dtype fp16 or fp32, fp32 arithmetic, one rounding; b must be a multiple
+ * of 8 (fp16) / 4 (fp32) else P3D_ERR_UNSUPPORTED.
+ *   p3d_bcast_fma:    y = x * scale[n][c] + z[z_per_image ? n : 0][pixel]      scale fp32 [n][C]; z in x's dtype, [1 or n][H*W], or null
+ *   p3d_channel_dot:  out[n][c] = sum over the pixels of p * q  (q null: of p)  fp32 out; channels-last needs a workspace of
+ *                     p3d_channel_dot_workspace(...) bytes (partial sums of 256-row chunks; deterministic, no atomics)
+ *   p3d_pixel_sum:    out[n][pixel] = sum over the channels of p               fp32 out                                          */
+int p3d_bcast_fma(const void* x, const float* scale, const void* z, void* y, int dtype, int32_t channels_last, int32_t n, int32_t a, int32_t b,
+                  int32_t z_per_image, p3d_stream_t stream);
+int64_t p3d_channel_dot_workspace(int32_t channels_last, int32_t n, int32_t a, int32_t b);
+int p3d_channel_dot(const void* p, const void* q, float* out, void* workspace, int64_t workspace_bytes, int dtype, int32_t channels_last,
+                    int32_t n, int32_t a, int32_t b, p3d_stream_t stream);
+int p3d_pixel_sum(const void* p, float* out, int dtype, int32_t channels_last, int32_t n, int32_t a, int32_t b, p3d_stream_t stream);
+
 /* ---- the x2 synthesis layer in one launch (fp16) -----------------------------------------------
  * conv_transpose2d(stride 2, 3x3; torch_utils/ops/conv2d_resample.py:114-127) -> 4x4 low-pass, pad 1 (:128) -> + noise -> + bias ->
  * lrelu(0.2) * act_gain -> clamp (training/networks_stylegan2.py:319-332), i.e. p3d_conv2d_nhwc(resample = 1) followed by

@@ -125,6 +125,9 @@ def _run(spec, grad, x, b, xref, yref, dy):
 
 
 def _sum_to_bias(t, dim):
+    from . import bcast
+    if bcast.bias_sum_supported(t, dim):                  # one read of the tensor (csrc/bcast_ops.hip) instead of a generic reduction
+        return bcast.bias_sum(t)
     return t.sum([i for i in range(t.ndim) if i != dim])
 
 

@@ -237,7 +237,8 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
             gw = _ConvWeightGrad.apply(gy, x, cfg)
         if ctx.needs_input_grad[2]:
-            gb = gy.sum([0, 2, 3])
+            from . import bcast
+            gb = bcast.bias_sum(gy) if bcast.bias_sum_supported(gy, 1) else gy.sum([0, 2, 3])
         return gx, gw, gb, None
 
 

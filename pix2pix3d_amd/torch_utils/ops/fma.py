@@ -3,6 +3,9 @@ import torch
 
 
 def fma(a, b, c):
+    from . import bcast
+    if bcast.fma_supported(a, b, c):                      # dense device activations: one fused kernel forward, fused reductions backward
+        return bcast.fma(a, b, c)
     return _Fma.apply(a, b, c)
 
 

@@ -9,7 +9,7 @@ import torch
 
 from ..torch_utils import misc
 from ..torch_utils import persistence
-from ..torch_utils.ops import conv2d_resample, conv2d_gradfix, upfirdn2d, bias_act, fma, modconv
+from ..torch_utils.ops import conv2d_resample, conv2d_gradfix, upfirdn2d, bias_act, fma, modconv, bcast
 
 
 @misc.profiled_function
@@ -66,14 +66,18 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
         y = _per_sample_conv(x, w_each, **resample)
         return y if noise is None else y.add_(noise)
 
-    y = conv2d_resample.conv2d_resample(x=x * styles.to(x.dtype).reshape(n, cin, 1, 1), w=weight.to(x.dtype), **resample)
+    if bcast.scale_channels_supported(x, styles):         # dense device activations: fused scaling, fused gradient reductions
+        x_mod = bcast.scale_channels(x, styles)
+    else:
+        x_mod = x * styles.to(x.dtype).reshape(n, cin, 1, 1)
+    y = conv2d_resample.conv2d_resample(x=x_mod, w=weight.to(x.dtype), **resample)
     scale = None if demod is None else demod.to(y.dtype).reshape(n, cout, 1, 1)
     if noise is not None:
         noise = noise.to(y.dtype)
     if scale is not None and noise is not None:
         return fma.fma(y, scale, noise)
     if scale is not None:
-        return y * scale
+        return bcast.scale_channels(y, demod) if bcast.scale_channels_supported(y, demod) else y * scale
     return y if noise is None else y.add_(noise)
 
 
