@@ -313,7 +313,7 @@ static int render_forward_impl(const float* planes_cl, const float* planes_sem_c
     int wpb = dual ? kWavesPerBlockDual : kWavesPerBlock;
     while (wpb > 2 && (total + wpb * 32 - 1) / (wpb * 32) < kNumCU) wpb >>= 1;
     const size_t lds_bytes = (size_t)(dual ? kDecoderFloatsDual + kWavesPerBlockDual * kWaveTile
-                                           : kDecoderFloats + kWavesPerBlock * (kWaveTile + kFeatTile)) * sizeof(float);      // + the cooperative gather's hand-over tiles
+                                           : kDecoderFloats + kWavesPerBlock * (kWaveTile + kFeatTile + kTapTile)) * sizeof(float);      // + the cooperative gather's tiles
     const int blocks = (int)((total + wpb * 32 - 1) / (wpb * 32));
     hipLaunchKernelGGL(render_init_minmax_kernel, dim3(1), dim3(1), 0, s, minmax_ws);
     if (dual) {

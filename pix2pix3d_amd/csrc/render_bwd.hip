@@ -28,7 +28,7 @@ constexpr int kBwdNetStride = 4096;              // per net: 64 MFMA steps x 64 
 constexpr int kBwdFloats = 2 * kBwdNetStride;
 constexpr int kBwdWaves = 4;
 constexpr int TP = 36;                           // pitch (floats) of the transposed [row][ray] tiles: conflict-free b32 writes / b128 reads
-constexpr int kBwdWaveLds = (32 + 64 + 32) * TP + 32;     // T_f, T_x (h, then da), T_do, T_dsigma
+constexpr int kBwdWaveLds = (32 + 64 + 32) * TP + 32 + kTapTile;     // T_f, T_x (h, then da), T_do, T_dsigma, tap table
 // gradient record of one net (floats), effective (gain-scaled) weights: W1 [64][32], b1 [64], W2 [33][64], b2 [33]
 constexpr int D_W1 = 0, D_B1 = 2048, D_W2 = 2112, D_B2 = 4224, kGradNetStride = 4260;
 
@@ -149,6 +149,7 @@ render_backward_kernel(RenderArgs a, const float* __restrict__ bwd_stream, float
     float* const Tx  = Tf + 32 * TP;                              // [64 hidden][TP]: h, then da
     float* const Tdo = Tx + 64 * TP;                              // [32 colour channels][TP]
     float* const Tds = Tdo + 32 * TP;                             // [32 rays] dL/dsigma
+    float* const Tt  = Tds + 32;                                  // the cooperative gather's tap table (rays 16..31)
     const int SN = NNETS - 1;
     const int S = a.Sc + a.Sf;
 
@@ -165,8 +166,6 @@ render_backward_kernel(RenderArgs a, const float* __restrict__ bwd_stream, float
     const float cs = a.coord_scale;
     const float4* const tape = (const float4*)a.tape_s + (size_t)g * S;
     static_assert(TP == kFeatPitch, "T_f is the cooperative gather's tile");
-    CoopRays cr;
-    coop_rays(cr, lane, ox, oy, oz, dx, dy, dz, img);
 
     float dC[NNETS][16];                                          // dL/dC (= 2 dL/dfeat) of this lane's channels
 #pragma unroll
@@ -194,7 +193,7 @@ render_backward_kernel(RenderArgs a, const float* __restrict__ bwd_stream, float
         const float px = cs * fmaf(z, dx, ox), py = cs * fmaf(z, dy, oy), pz = cs * fmaf(z, dz, oz);
         float feat[16];
         wave_sync();                                              // the previous sample's readers of T_f are done
-        gather_features_coop<true>(a, rsrc, cr, lane, z, Tf, feat);      // eight lanes to a texel; lands in T_f as [channel][ray] and in the lane's registers
+        gather_features_coop<true>(a, rsrc, img, lane, px, py, pz, Tf, Tt, feat);      // eight lanes to a texel; lands in T_f as [channel][ray] and in the lane's registers
         f32x16 df;
 #pragma unroll
         for (int r = 0; r < 16; ++r) df[r] = 0.f;
@@ -406,7 +405,7 @@ extern "C" int p3d_render_backward(const float* planes_cl, const float* decoder,
         // a block is one-per-CU (LDS): small launches take fewer waves per block so that every CU still gets one
         int wpb = kWavesPerBlock;
         while (wpb > 2 && (total + wpb * 32 - 1) / (wpb * 32) < kNumCU) wpb >>= 1;
-        const size_t lds_bytes = (size_t)(kDecoderFloats + kWavesPerBlock * (kWaveTile + kFeatTile)) * sizeof(float);
+        const size_t lds_bytes = (size_t)(kDecoderFloats + kWavesPerBlock * (kWaveTile + kFeatTile + kTapTile)) * sizeof(float);
         const int blocks = (int)((total + wpb * 32 - 1) / (wpb * 32));
         if (d->n_nets == 1) {
             static std::atomic<uint64_t> once1_devs{0}; const hipError_t once1 = reserve_lds_once((const void*)render_forward_kernel<1, true>, (int)lds_bytes, once1_devs);

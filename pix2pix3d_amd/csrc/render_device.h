@@ -216,22 +216,36 @@ __device__ __forceinline__ void gather_features(const RenderArgs& a, rsrc_t rsrc
 // The texture path pays per line, so the kernel ran at the L1's request rate, not at anything the memory behind it could give.
 // Here EIGHT lanes share a texel: in group i (0..3) lane l fetches the 16-byte chunk l & 7 of the taps of wave ray 8 i + (l >> 3),
 // so one load instruction reads 8 whole lines and a tap of the wave's 32 rays is 4 instructions x 8 lines instead of 4 x 32.
-// Each lane therefore works out the taps of four rays (positions from the owner lanes' depths by shuffle, ray origins / directions
-// held per lane), blends its 4 channels in the same order as gather_features (bit-identical sums) and drops them into a per-wave
-// [32 rays][36] LDS tile, from which lane (j, h) picks up the 16 channels the decoder wants.  Groups are pipelined two deep: 24
-// loads in flight per lane, as before.
-struct CoopRays { float ox[4], oy[4], oz[4], dx[4], dy[4], dz[4]; unsigned img[4]; };
-
-__device__ __forceinline__ void coop_issue(const RenderArgs& a, rsrc_t rsrc, unsigned base, float px, float py, float pz, f32x4 (&buf)[12], float (&w)[12])
+// The taps (offsets, weights) of the wave's 32 rays x 3 planes are computed ONCE per step by the rays' owner lanes and passed through
+// a 3 KB LDS table (a first version had every lane recompute the taps of its four rays: 8x the arithmetic, and the kernel went from
+// line-rate-bound to VALU-bound).  Each lane blends its 4 channels in the same order as gather_features (bit-identical sums) and
+// drops them into a per-wave [32 rays][36] LDS tile, from which lane (j, h) picks up the 16 channels the decoder wants.  Groups are
+// pipelined two deep: 24 loads in flight per lane, as before.
+// Tap table of one sample step: [ray][plane][4 byte offsets | 4 weights] = 96 B per ray.  Rays 16..31 live in the wave's `ttile`; rays 0..15 in
+// the bytes of ftile rows 16..31, which the step does not write before groups 0 and 1 (the only readers of those entries) have issued.
+constexpr int kTapRow = 24;                      // floats per ray
+constexpr int kTapTile = 16 * kTapRow;           // per wave, beside ftile
+__device__ __forceinline__ float* tap_entry(float* ftile, float* ttile, int ray)
+{
+    return ray < 16 ? ftile + 16 * kFeatPitch + ray * kTapRow : ttile + (ray - 16) * kTapRow;
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void put_taps(float* e, const PlaneTaps& t)
+{
+    *(u32x4*)e = u32x4{t.o00, t.o10, t.o01, t.o11};
+    *(f32x4*)(e + 4) = f32x4{t.w00, t.w10, t.w01, t.w11};
+}
+__device__ __forceinline__ void coop_issue(rsrc_t rsrc, const float* e, unsigned chunk_off, f32x4 (&buf)[12], float (&w)[12])
 {
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        const PlaneTaps t = plane_taps(a, base, 0, p, px, py, pz);
-        buf[4 * p + 0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, t.o00, 0, 0));
-        buf[4 * p + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, t.o10, 0, 0));
-        buf[4 * p + 2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, t.o01, 0, 0));
-        buf[4 * p + 3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, t.o11, 0, 0));
-        w[4 * p + 0] = t.w00; w[4 * p + 1] = t.w10; w[4 * p + 2] = t.w01; w[4 * p + 3] = t.w11;
+        const u32x4 o = *(const u32x4*)(e + 8 * p);
+        const f32x4 wv = *(const f32x4*)(e + 8 * p + 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            buf[4 * p + t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o[t] + chunk_off, 0, 0));
+            w[4 * p + t] = wv[t];
+        }
     }
 }
 // TRANSPOSED: the tile is [channel][ray] (the backward kernel's T_f, which its weight-gradient MFMAs read) instead of [ray][channel]
@@ -250,57 +264,57 @@ __device__ __forceinline__ void coop_blend(const f32x4 (&buf)[12], const float (
     } else
         *(f32x4*)dst = acc;
 }
+// (px, py, pz): the sample point of the lane's OWN ray (lane & 31); img: its image's byte offset.  The taps of the wave's 96 (ray, plane)
+// pairs are worked out once — lane (j, h) does plane 2h, the h = 0 half plane 1 as well — and handed round through the tap table.
 template <bool TRANSPOSED = false>
-__device__ __forceinline__ void gather_features_coop(const RenderArgs& a, rsrc_t rsrc, const CoopRays& cr, int lane, float z, float* ftile, float (&feat)[16])
+__device__ __forceinline__ void gather_features_coop(const RenderArgs& a, rsrc_t rsrc, unsigned img, int lane, float px, float py, float pz,
+                                                     float* ftile, float* ttile, float (&feat)[16])
 {
-    const int sub = lane >> 3, chunk = lane & 7;
-    const float cs = a.coord_scale;
+    const int sub = lane >> 3, chunk = lane & 7, j = lane & 31, h = lane >> 5;
+    // Lanes exchange data through LDS here.  The hardware keeps a wave's LDS operations in order; wave_sync() is what tells the COMPILER
+    // that other lanes read what this lane wrote (without it a build of the bf16x3 kernel hoisted the feature reads above the blends' stores).
+    wave_sync();                                           // the previous step's feature reads are done: the table may overwrite rows 16..31
+    {
+        float* const e = tap_entry(ftile, ttile, j);
+        put_taps(e + 16 * h, plane_taps(a, img, 0, 2 * h, px, py, pz));
+        if (h == 0) put_taps(e + 8, plane_taps(a, img, 0, 1, px, py, pz));
+    }
+    wave_sync();
     f32x4 bufA[12], bufB[12];
     float wA[12], wB[12];
     constexpr int RS = TRANSPOSED ? 1 : kFeatPitch;        // tile stride of a ray / of a channel
     constexpr int CS = TRANSPOSED ? kFeatPitch : 1;
     float* const dst = ftile + sub * RS + chunk * 4 * CS;
-#define P3D_COOP_ISSUE(i, buf, w)                                                                                               \
-    do {                                                                                                                        \
-        const float zr = __shfl(z, 8 * (i) + sub, 64);                                                                          \
-        coop_issue(a, rsrc, cr.img[i] + chunk * 16, cs * fmaf(zr, cr.dx[i], cr.ox[i]), cs * fmaf(zr, cr.dy[i], cr.oy[i]),        \
-                   cs * fmaf(zr, cr.dz[i], cr.oz[i]), buf, w);                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    } while (0)
-    P3D_COOP_ISSUE(0, bufA, wA);
-    P3D_COOP_ISSUE(1, bufB, wB);
+    const unsigned c16 = (unsigned)chunk * 16u;
+    const float* const e_lo = ftile + 16 * kFeatPitch + sub * kTapRow;     // rays sub, 8 + sub
+    const float* const e_hi = ttile + sub * kTapRow;                       // rays 16 + sub, 24 + sub
+    coop_issue(rsrc, e_lo, c16, bufA, wA);
+    __builtin_amdgcn_sched_barrier(0);
+    coop_issue(rsrc, e_lo + 8 * kTapRow, c16, bufB, wB);
+    __builtin_amdgcn_sched_barrier(0);
     coop_blend<TRANSPOSED>(bufA, wA, dst);
     __builtin_amdgcn_sched_barrier(0);
-    P3D_COOP_ISSUE(2, bufA, wA);
+    coop_issue(rsrc, e_hi, c16, bufA, wA);
+    __builtin_amdgcn_sched_barrier(0);
     coop_blend<TRANSPOSED>(bufB, wB, dst + 8 * RS);
     __builtin_amdgcn_sched_barrier(0);
-    P3D_COOP_ISSUE(3, bufB, wB);
+    coop_issue(rsrc, e_hi + 8 * kTapRow, c16, bufB, wB);
+    __builtin_amdgcn_sched_barrier(0);
+    wave_sync();                                           // every lane has read its table entries of rays 0..15: rows 16..31 may take features
     coop_blend<TRANSPOSED>(bufA, wA, dst + 16 * RS);
     coop_blend<TRANSPOSED>(bufB, wB, dst + 24 * RS);
-#undef P3D_COOP_ISSUE
-    // same wave wrote it: LDS operations of a wave complete in order, no barrier
+    wave_sync();
     if (TRANSPOSED) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) feat[c] = ftile[((lane >> 5) * 16 + c) * kFeatPitch + (lane & 31)];
+        for (int c = 0; c < 16; ++c) feat[c] = ftile[(h * 16 + c) * kFeatPitch + j];
     } else {
-        const f32x4* src = (const f32x4*)(ftile + (lane & 31) * kFeatPitch + (lane >> 5) * 16);
+        const f32x4* src = (const f32x4*)(ftile + j * kFeatPitch + h * 16);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 v = src[q];
 #pragma unroll
             for (int e = 0; e < 4; ++e) feat[q * 4 + e] = v[e];
         }
-    }
-}
-// the four gather rays of a lane: origins / directions / image offsets from their owner lanes
-__device__ __forceinline__ void coop_rays(CoopRays& cr, int lane, float ox, float oy, float oz, float dx, float dy, float dz, unsigned img)
-{
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int src = 8 * i + (lane >> 3);                  // the owner lane (h = 0) of this lane's i-th gather ray
-        cr.ox[i] = __shfl(ox, src, 64); cr.oy[i] = __shfl(oy, src, 64); cr.oz[i] = __shfl(oz, src, 64);
-        cr.dx[i] = __shfl(dx, src, 64); cr.dy[i] = __shfl(dy, src, 64); cr.dz[i] = __shfl(dz, src, 64);
-        cr.img[i] = (unsigned)__shfl((int)img, src, 64);
     }
 }
 
@@ -396,6 +410,11 @@ __device__ __forceinline__ float mlp_sigma(const float* lds, int h, const f32x16
 // LDS image per net (16 KB, the fp32 stream's size): [hi | lo] x [block 8][lane 64][8 bf16]; blocks 0..3 = layer 1 (t, s), 4..7 = layer 2 (s).
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
+// HAZARD (measured on gfx950, ROCm 7.2 hipcc): an MFMA that reads, as SrcB, a register written by v_cvt_pk_bf16_f32 two wait states
+// earlier — the distance the compiler's own hazard nops give — now and then sees the OLD value of one 16-lane group: 5 % of the rays of a
+// render off by 1e-3, and whether a build shows it depends on how the scheduler happened to interleave conversions and MFMAs (one
+// version of this kernel was clean, the next two were not, with identical decoder code).  The empty asm below makes every converted
+// register complete before the first MFMA that uses any of them (>= 5 wait states in the code that results), which is clean.
 __device__ __forceinline__ void split8(const float* v, bf8& hi, bf8& lo)
 {
 #pragma unroll
@@ -405,6 +424,7 @@ __device__ __forceinline__ void split8(const float* v, bf8& hi, bf8& lo)
         hi[e] = hx;
         lo[e] = (__bf16)(x - (float)hx);
     }
+    asm volatile("s_nop 0" : "+v"(hi), "+v"(lo));
 }
 __device__ __forceinline__ f32x16 mfma3(const bf8& ah, const bf8& al, const bf8& bh, const bf8& bl, f32x16 c)
 {
@@ -607,8 +627,7 @@ render_forward_kernel(RenderArgs a)
     const float* uc = a.u_coarse + (size_t)g * Sc;
     constexpr bool COOP = !DUAL;                                  // one plane set: eight lanes to a texel
     float* const ftile = lds + kDecFloats + wpb * kWaveTile + wave * kFeatTile;
-    CoopRays cr;
-    if constexpr (COOP) coop_rays(cr, lane, ox, oy, oz, dx, dy, dz, img);
+    float* const ttile = lds + kDecFloats + wpb * (kWaveTile + kFeatTile) + wave * kTapTile;
 
     // ------------------------------ phase A: coarse densities -> weights ------------------------------
     {
@@ -616,7 +635,7 @@ render_forward_kernel(RenderArgs a)
         for (int i = 0; i < Sc; ++i) {
             const float z = coarse_depth(a, g, i, uc[i]);
             float feat[16];
-            if constexpr (COOP) gather_features_coop(a, rsrc_sem, cr, lane, z, ftile, feat);
+            if constexpr (COOP) gather_features_coop(a, rsrc_sem, img, lane, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), ftile, ttile, feat);
             else gather_features<true>(a, rsrc_sem, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
             f32x16 h0, h1;
             if constexpr (BF3) {
@@ -677,7 +696,7 @@ render_forward_kernel(RenderArgs a)
         else        { ++jf; zf = (jf < Sf) ? tile[jf * kPitch + j] : INFINITY; }
 
         float feat[16], feat_tex[16];
-        if constexpr (COOP) gather_features_coop(a, rsrc_sem, cr, lane, z, ftile, feat);
+        if constexpr (COOP) gather_features_coop(a, rsrc_sem, img, lane, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), ftile, ttile, feat);
         else gather_features<false>(a, rsrc_sem, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
         if (DUAL) gather_features<false>(a, rsrc, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat_tex);
         // The density net goes first: its sigma closes interval k-1 (weight w), after which every net's
