@@ -347,6 +347,19 @@ int p3d_fir4_bias_act_nhwc(const void* x, const float* f, void* y, int dtype, in
  *   y = clamp(act(x + noise[hw] * noise_strength[0] + bias[c]) * gain);  hw % 4 == 0; x may equal y; noise / bias may be null. */
 int p3d_fc_forward(const float* x, const float* w, const float* b, float* y, int32_t n_rows, int32_t in_features, int32_t out_features,
                    int64_t x_row_stride, float weight_gain, float bias_gain, int32_t act, float alpha, float act_gain, float out_scale, p3d_stream_t stream);
+
+/* Several FullyConnectedLayer evaluations on the same number of rows in ONE launch (the style affines of a synthesis network:
+ * SynthesisLayer.affine / ToRGBLayer.affine, training/networks_stylegan2.py:305, 352): jobs_host is a HOST array, its contents travel in
+ * the kernel arguments.  Each job is p3d_fc_forward's argument list.  At most P3D_FC_MAX_JOBS jobs.                                  */
+#define P3D_FC_MAX_JOBS 40
+typedef struct p3d_fc_job {
+    const float* x; const float* w; const float* b; float* y;
+    int64_t x_row_stride;
+    int32_t in_features, out_features;
+    float weight_gain, bias_gain;
+    int32_t act; float alpha, act_gain, out_scale;
+} p3d_fc_job;
+int p3d_fc_multi(const p3d_fc_job* jobs_host, int32_t n_jobs, int32_t n_rows, p3d_stream_t stream);
 int p3d_im2col3x3(const float* x, float* cols, int32_t n_img, int32_t c, int32_t h, int32_t w, int32_t pad, int32_t stride,
                   int64_t stride_n, int64_t stride_c, int64_t stride_y, int64_t stride_x, p3d_stream_t stream);
 int p3d_noise_bias_act(const float* x, float* y, const float* noise, const float* noise_strength, const float* bias, int32_t n_img,

@@ -8,6 +8,7 @@
 //   p3d_noise_bias_act  : + noise * strength, + bias, activation, gain, clamp on a [N, C, HW] tensor in one pass
 //                         (networks_stylegan2.py:326-332 after the GEMM).
 #include "p3d_common.h"
+#include "../../include/p3d_hip.h"
 
 namespace p3d {
 
@@ -15,18 +16,17 @@ namespace p3d {
 // One wave per output feature: the wave streams W[o, :] once (coalesced float4), keeps the (few) input rows in LDS and
 // reduces with DPP-free shuffles.  n_rows <= 16.
 constexpr int FC_MAXN = 16;
-__global__ void __launch_bounds__(256) fc_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
-                                                 float* __restrict__ y, int n_rows, int in_f, int out_f, int64_t x_stride, float wg, float bg,
-                                                 int act, float alpha, float act_gain, float out_scale)
+__device__ __forceinline__ void fc_block(float* xs, int block, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                         float* __restrict__ y, int n_rows, int in_f, int out_f, int64_t x_stride, float wg, float bg,
+                                         int act, float alpha, float act_gain, float out_scale)
 {
-    extern __shared__ float xs[];                                   // [n_rows][in_f]
     for (int e = threadIdx.x * 4; e < n_rows * in_f; e += 256 * 4) {
         const int n = e / in_f, k = e - n * in_f;
         *(float4*)(xs + e) = *(const float4*)(x + n * x_stride + k);
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int o = blockIdx.x * 4 + wave;
+    const int o = block * 4 + wave;
     if (o >= out_f) return;
     float acc[FC_MAXN];
 #pragma unroll
@@ -62,6 +62,27 @@ __global__ void __launch_bounds__(256) fc_kernel(const float* __restrict__ x, co
             }
         }
     }
+}
+__global__ void __launch_bounds__(256) fc_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                 float* __restrict__ y, int n_rows, int in_f, int out_f, int64_t x_stride, float wg, float bg,
+                                                 int act, float alpha, float act_gain, float out_scale)
+{
+    extern __shared__ float xs[];                                   // [n_rows][in_f]
+    fc_block(xs, blockIdx.x, x, w, b, y, n_rows, in_f, out_f, x_stride, wg, bg, act, alpha, act_gain, out_scale);
+}
+
+// Several independent FC layers in ONE launch (the 20 style affines of a synthesis network are 20 launches of ~6 us each otherwise):
+// the jobs travel in the kernel arguments; first_block[j] is the first block of job j.
+constexpr int FC_MAX_JOBS = P3D_FC_MAX_JOBS;
+struct FcJobs { p3d_fc_job job[FC_MAX_JOBS]; int first_block[FC_MAX_JOBS + 1]; int njobs; int n_rows; };
+__global__ void __launch_bounds__(256) fc_multi_kernel(FcJobs a)
+{
+    extern __shared__ float xs[];
+    int j = 0;
+    while (j + 1 < a.njobs && (int)blockIdx.x >= a.first_block[j + 1]) ++j;
+    const p3d_fc_job& q = a.job[j];
+    fc_block(xs, blockIdx.x - a.first_block[j], q.x, q.w, q.b, q.y, a.n_rows, q.in_features, q.out_features, q.x_row_stride, q.weight_gain, q.bias_gain,
+             q.act, q.alpha, q.act_gain, q.out_scale);
 }
 
 // ---- im2col, 3x3: cols[n][ci*9 + t][p] = x[n, ci, oy*stride + t/3 - pad, ox*stride + t%3 - pad] ------------------------
@@ -177,6 +198,33 @@ extern "C" int p3d_fc_forward(const float* x, const float* w, const float* b, fl
                        out_features, x_row_stride, weight_gain, bias_gain, act, alpha, act_gain, out_scale);
     count_launch(FAM_AUX);
     return check_launch("fc_forward");
+}
+
+extern "C" int p3d_fc_multi(const p3d_fc_job* jobs_host, int32_t n_jobs, int32_t n_rows, p3d_stream_t stream)
+{
+    using namespace p3d;
+    P3D_REQUIRE(jobs_host && n_jobs >= 1 && n_jobs <= FC_MAX_JOBS, "fc_multi: 1 .. %d jobs", FC_MAX_JOBS);
+    P3D_REQUIRE(n_rows >= 1 && n_rows <= FC_MAXN, "fc_multi: n_rows=%d outside [1, %d]", n_rows, FC_MAXN);
+    FcJobs a{};
+    a.njobs = n_jobs; a.n_rows = n_rows;
+    int blocks = 0, max_in = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const p3d_fc_job& q = jobs_host[j];
+        P3D_REQUIRE(q.x && q.w && q.y, "fc_multi: null pointer in job %d", j);
+        P3D_REQUIRE(q.in_features >= 4 && q.in_features % 4 == 0 && q.out_features >= 1, "fc_multi: in_features must be a positive multiple of 4");
+        P3D_REQUIRE(q.act == 1 || q.act == 3, "fc_multi: act must be linear (1) or lrelu (3)");
+        P3D_REQUIRE(((((uintptr_t)q.x) | ((uintptr_t)q.w)) & 15u) == 0 && q.x_row_stride % 4 == 0, "fc_multi: x, its rows and w must be 16-byte aligned");
+        a.job[j] = q;
+        a.first_block[j] = blocks;
+        blocks += (q.out_features + 3) / 4;
+        if (q.in_features > max_in) max_in = q.in_features;
+    }
+    a.first_block[n_jobs] = blocks;
+    const size_t shm = (size_t)n_rows * max_in * sizeof(float);
+    P3D_REQUIRE(shm <= 64 * 1024, "fc_multi: n_rows * in_features too large for the LDS stage");
+    hipLaunchKernelGGL(fc_multi_kernel, dim3(blocks), dim3(256), shm, (hipStream_t)stream, a);
+    count_launch(FAM_AUX);
+    return check_launch("fc_multi");
 }
 
 extern "C" int p3d_im2col3x3(const float* x, float* cols, int32_t n_img, int32_t c, int32_t h, int32_t w, int32_t pad, int32_t stride,

@@ -294,6 +294,39 @@ def fc(x, weight, bias, weight_gain, bias_gain, activation='linear', out_scale=1
     return y
 
 
+class _FcJob(ctypes.Structure):
+    _fields_ = [('x', ctypes.c_void_p), ('w', ctypes.c_void_p), ('b', ctypes.c_void_p), ('y', ctypes.c_void_p), ('x_row_stride', ctypes.c_int64),
+                ('in_features', ctypes.c_int32), ('out_features', ctypes.c_int32), ('weight_gain', ctypes.c_float), ('bias_gain', ctypes.c_float),
+                ('act', ctypes.c_int32), ('alpha', ctypes.c_float), ('act_gain', ctypes.c_float), ('out_scale', ctypes.c_float)]
+
+
+FC_MAX_JOBS = 40
+_lib.register('p3d_fc_multi', ctypes.c_int, [ctypes.c_void_p, _i32, _i32, _vp])
+
+
+def fc_multi(jobs):
+    """Several FullyConnectedLayer evaluations in one launch.  ``jobs``: list of (x [n, in], layer, out_scale) with ``layer`` a
+    FullyConnectedLayer every one of which passes fc_supported and all x with the same row count; returns the list of outputs."""
+    n = jobs[0][0].shape[0]
+    outs, keep = [], []
+    arr = (_FcJob * len(jobs))()
+    for k, (x, layer, out_scale) in enumerate(jobs):
+        x32 = x.detach()
+        if x32.stride(1) != 1 or x32.stride(0) % 4 != 0 or x32.data_ptr() % 16 != 0:
+            x32 = x32.contiguous()
+        w32 = layer.weight.detach().contiguous()
+        b32 = None if layer.bias is None else layer.bias.detach().float().contiguous()
+        y = torch.empty([n, w32.shape[0]], dtype=torch.float32, device=x.device)
+        keep.append((x32, w32, b32))
+        outs.append(y)
+        arr[k] = _FcJob(_lib.ptr(x32), _lib.ptr(w32), _lib.ptr(b32), _lib.ptr(y), x32.stride(0) if n > 1 else x.shape[1], x.shape[1], w32.shape[0],
+                        float(layer.weight_gain), float(layer.bias_gain), {'linear': 1, 'lrelu': 3}[layer.activation], 0.2,
+                        float(bias_act.activation_funcs[layer.activation].def_gain), float(out_scale))
+    code = _lib.lib().p3d_fc_multi(ctypes.cast(arr, ctypes.c_void_p), len(jobs), n, _lib.stream_of(outs[0]))
+    _lib.check(code, 'fc_multi')
+    return outs
+
+
 def im2col3x3(x, pad=1, stride=1):
     """[N, C, H, W] fp32 in any dense layout -> [N, C*9, OH*OW] (pad 1, stride 1: = F.unfold(x, 3, padding=1)), one launch for the batch."""
     n, c, h, w = x.shape

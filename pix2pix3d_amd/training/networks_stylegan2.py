@@ -435,6 +435,7 @@ def prefetch_styles(blocks, block_ws, block_kwargs):
     side.wait_stream(main)
     modconv._plan.clear()
     with torch.cuda.stream(side):
+        todo = []                                          # (layer, latent row, out_scale, input pixels or None for ToRGB, dtype)
         for block, cur in zip(blocks, block_ws):
             if block.fused_modconv_default is not True and fused is None and block.training:
                 continue
@@ -443,16 +444,19 @@ def prefetch_styles(blocks, block_ws, block_kwargs):
             ws_iter = iter(cur.unbind(dim=1))
             layers = [(block.conv1, res)] if block.in_channels == 0 else [(block.conv0, res // block._in_div), (block.conv1, res)]
             for layer, in_res in layers:
-                styles = layer.affine(next(ws_iter))
-                pre = modconv.premodulate(layer.weight, styles, layer.up, in_res * in_res, dtype)
-                ev = torch.cuda.Event()
-                ev.record(side)
-                modconv._plan[id(layer)] = (styles, pre, ev)
+                todo.append((layer, next(ws_iter), 1, in_res * in_res, dtype))
             if block.is_last or block.architecture == 'skip':
-                styles = block.torgb.affine(next(ws_iter), out_scale=block.torgb.weight_gain)
-                ev = torch.cuda.Event()
-                ev.record(side)
-                modconv._plan[id(block.torgb)] = (styles, None, ev)
+                todo.append((block.torgb, next(ws_iter), block.torgb.weight_gain, None, dtype))
+        # every style affine of the network in one launch (they are ~6 us of launch latency each on their own)
+        batched = (0 < len(todo) <= modconv.FC_MAX_JOBS and len({t[1].shape[0] for t in todo}) == 1
+                   and all(modconv.fc_supported(w, l.affine.weight, l.affine.bias, l.affine.activation) for l, w, *_ in todo))
+        all_styles = (modconv.fc_multi([(w, l.affine, sc) for l, w, sc, _, _ in todo]) if batched
+                      else [l.affine(w) if sc == 1 else l.affine(w, out_scale=sc) for l, w, sc, _, _ in todo])
+        for (layer, _, _, in_pixels, dtype), styles in zip(todo, all_styles):
+            pre = None if in_pixels is None else modconv.premodulate(layer.weight, styles, layer.up, in_pixels, dtype)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            modconv._plan[id(layer)] = (styles, pre, ev)
     return True
 
 

@@ -302,3 +302,23 @@ def test_x2_layer_in_one_kernel(hip_lib, ci, co, h, w, n, noise, act, clamp):
     e1, e0 = rel_err(y1.double().cpu().numpy(), yr.numpy()), rel_err(y0.double().cpu().numpy(), yr.numpy())
     print(ci, co, h, w, 'fused', e1, 'two-kernel', e0)
     assert e1 < 2e-3 and e0 < 2e-3
+
+
+def test_style_affines_in_one_launch(hip_lib):
+    """p3d_fc_multi (every style affine of a synthesis network in one launch) equals the per-layer kernel and the torch formulation."""
+    from pix2pix3d_amd.training.networks_stylegan2 import FullyConnectedLayer
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    torch.manual_seed(1)
+    layers = [FullyConnectedLayer(512, o, bias_init=1).cuda().requires_grad_(False) for o in (512, 512, 256, 128, 96, 3, 70)]
+    layers.append(FullyConnectedLayer(64, 32, activation='lrelu', lr_multiplier=0.01).cuda().requires_grad_(False))
+    ws = torch.randn(4, len(layers), 512, device='cuda')
+    xs = [ws[:, k] for k in range(len(layers) - 1)] + [torch.randn(4, 64, device='cuda')]
+    scales = [1, 1, 0.5, 1, 2.0, 1 / 16, 1, 1]
+    outs = modconv.fc_multi([(x, l, sc) for x, l, sc in zip(xs, layers, scales)])
+    for x, l, sc, y in zip(xs, layers, scales, outs):
+        y1 = modconv.fc(x, l.weight, l.bias, l.weight_gain, l.bias_gain, l.activation, sc)
+        assert torch.equal(y, y1)
+        yr = torch.nn.functional.linear(x.double(), l.weight.double() * l.weight_gain, l.bias.double() * l.bias_gain)
+        if l.activation == 'lrelu':
+            yr = torch.nn.functional.leaky_relu(yr, 0.2) * np.sqrt(2)
+        assert rel_err(y.double().cpu().numpy(), (yr * sc).cpu().numpy()) < 1e-5
