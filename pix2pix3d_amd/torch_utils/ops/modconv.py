@@ -127,7 +127,9 @@ def modulate_weights(weight, styles, demodulate=True, pre_scale=1.0, dtype=torch
     ``dtype=BF16X3``: an fp32-typed tensor of the same shape whose K rows hold [32 x bf16 hi | 32 x bf16 lo] per 32 input channels."""
     o, i, kh, kw = weight.shape
     n = styles.shape[0]
-    w32 = weight.detach().float().contiguous()
+    w32 = weight.detach()
+    if w32.dtype != torch.float32 or not w32.is_contiguous():      # (channels-last parameters of the fp16 blocks: one copy per weight version, not per call)
+        w32 = _cached_weight(weight, 'f32_contiguous', lambda: weight.detach().float().contiguous())
     s32 = styles.detach().float().contiguous()
     split = dtype == BF16X3
     out = torch.empty([n, o, i, kh * kw] if oihw else [n, o, kh * kw, i], dtype=torch.float32 if split else dtype, device=weight.device)
@@ -469,6 +471,13 @@ def fir4_bias_act(y, f, bias, noise, noise_strength, act, act_gain, clamp):
                                              _lib.stream_of(y))
     _lib.check(code, 'fir4_bias_act_nhwc')
     return out
+
+
+def torgb_accumulates(x, weight, out):
+    """True when torgb(..., out=out) adds into ``out`` inside its own kernel (the fp16 streaming route) rather than with a separate add."""
+    n, ci, h, w = x.shape
+    return (_is_nhwc_f16(x) and ci in (64, 128, 256) and weight.shape[0] <= 32 and (h * w) % 4 == 0 and out.dtype == torch.float32 and out.is_contiguous()
+            and tuple(out.shape) == (n, weight.shape[0], h, w) and not out.requires_grad)
 
 
 def torgb(x, weight, styles, bias, clamp=None, out=None):

@@ -293,11 +293,14 @@ class ToRGBLayer(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
         self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
 
-    def forward(self, x, w, fused_modconv=True):
+    def forward(self, x, w, fused_modconv=True, accumulate_into=None):
+        """``accumulate_into`` (device inference): an fp32 image the native kernel may add its result to in place — the skip-image sum of
+        SynthesisBlock without a separate launch.  The return value is then that image; callers check identity."""
         planned = modconv.take_plan(self) if modconv._plan else None
         styles = planned[0] if planned is not None else self.affine(w, out_scale=self.weight_gain)
         if modconv.torgb_supported(x, self.weight, styles, fused_modconv):
-            return modconv.torgb(x, self.weight, styles, self.bias, clamp=self.conv_clamp)      # fp32 NCHW, bias + clamp fused
+            out = accumulate_into if accumulate_into is not None and modconv.torgb_accumulates(x, self.weight, accumulate_into) else None
+            return modconv.torgb(x, self.weight, styles, self.bias, clamp=self.conv_clamp, out=out)      # fp32 NCHW, bias + clamp fused
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
         return bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
 
@@ -389,7 +392,8 @@ class SynthesisBlock(torch.nn.Module):
             misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
             img = upfirdn2d.upsample2d(img, self.resample_filter)
         if self.is_last or self.architecture == 'skip':
-            img = self._accumulate_image(img, self.torgb(x, per_layer[self.num_conv], fused_modconv=fused_modconv), fmt)
+            y = self.torgb(x, per_layer[self.num_conv], fused_modconv=fused_modconv, accumulate_into=img)
+            img = img if y is img else self._accumulate_image(img, y, fmt)
 
         assert x.dtype == dtype and (img is None or img.dtype == torch.float32)
         return x, img

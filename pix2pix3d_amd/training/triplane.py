@@ -69,7 +69,12 @@ class _TriPlaneCore(torch.nn.Module):
         planes = self._planes(ws, update_emas, synthesis_kwargs, cache_backbone, use_cached_backbone)
         feat, depth, _ = self.renderer(planes, self.decoder, ray_o, ray_d, self.rendering_kwargs)
         r = self.neural_rendering_resolution
-        feature_image = feat.permute(0, 2, 1).reshape(n, feat.shape[-1], r, r).contiguous()
+        if feat.is_cuda and not torch.is_grad_enabled():
+            # the fused renderer's [N, rays, C] IS the channels-last image: the SR heads (channels-last, fp16) convert their half of it in the
+            # one pass they need anyway, instead of after an NCHW copy of all of it.  Same values, same shape; only the strides differ.
+            feature_image = feat.reshape(n, r, r, feat.shape[-1]).permute(0, 3, 1, 2)
+        else:
+            feature_image = feat.permute(0, 2, 1).reshape(n, feat.shape[-1], r, r).contiguous()
         depth_image = depth.permute(0, 2, 1).reshape(n, 1, r, r)
         return feature_image, depth_image
 
