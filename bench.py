@@ -420,7 +420,8 @@ def main():
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                          'mfma_frac': round(mfma_floor_ms / render_kernel_ms, 4) if render_kernel_ms > 0 else None, 'mfma_floor_ms': round(mfma_floor_ms, 4),
                          'decoder_mfma': 'bf16x3 (3 bf16 MFMAs per fp32 product, vs 2.5 PF)' if mlp_bf3 else 'f32-input MFMA (vs 157.3 TF)',
-                         'bound_note': 'taps are served by L1/L2 (traffic << algorithmic bytes) and the decoder is off the fp32 matrix rate: what remains is gather latency at 2 waves per SIMD'
+                         'bound_note': 'taps are served by L1/L2 (traffic << algorithmic bytes), whole 128-byte lines per load instruction, so frac (algorithmic tap bytes / '
+                                       'time vs the HBM peak) can exceed 1; the decoder is off the fp32 matrix rate (mfma_frac); the kernel is VALU-bound (DESIGN.md 2.1)'
                                        if mlp_bf3 else 'taps are served by L1/L2 (traffic << algorithmic bytes): the decoder on the fp32 matrix cores (mfma_frac) is the binding floor',
                          'ms_per_launch': round(render_kernel_ms, 4), 'launches_timed': len(kern), 'units_per_launch': samples_per_launch, 'bytes_per_unit': BYTES_PER_SAMPLE},
             # conv_f32: exact fp32 MFMA kernels vs the 157.3 TF fp32 matrix peak.  conv_bf16x3: the fp32 layers computed as three bf16 MFMAs per

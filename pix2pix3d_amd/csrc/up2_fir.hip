@@ -60,7 +60,7 @@ struct Up2Args {
     int act;               // 0 linear, 1 lrelu(0.2)
     float act_gain, clamp; // clamp < 0: off
     int tiles_x, tiles;    // 28 x 28 tiles per row / per image
-    int debug;
+    int debug;             // measurement only (P3D_UP2_DEBUG): 1 stop after the K loop, 2 skip the K loop, 4 no stores, 8 no FIR, 16 no tile writes
 };
 
 template <int N> __device__ __forceinline__ void uf_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
@@ -332,7 +332,7 @@ extern "C" int p3d_up2_fir_f16(const void* x, const void* w, void* y, const void
     const int tiles_y = (2 * h + UF_TILE - 1) / UF_TILE;
     a.tiles_x = (2 * wdt + UF_TILE - 1) / UF_TILE;
     a.tiles = a.tiles_x * tiles_y;
-    { const char* d = getenv("P3D_UP2_DEBUG"); a.debug = d ? atoi(d) : 0; }
+    { static const int dbg = [] { const char* d = getenv("P3D_UP2_DEBUG"); return d ? atoi(d) : 0; }(); a.debug = dbg; }      // phase switches of tests/gpu_probe_up2.py (0 = the layer)
     const int64_t blocks = (int64_t)((a.tiles + 7) / 8 * 8) * (co / UF_BN);
     P3D_REQUIRE(blocks < (1ll << 31) && n_img < 65536, "up2_fir_f16: bad launch size");
     hipLaunchKernelGGL(up2_fir_f16_kernel, dim3((unsigned)blocks, 1, n_img), dim3(256), 0, (hipStream_t)stream, a);
