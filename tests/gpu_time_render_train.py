@@ -26,7 +26,7 @@ def step():
         p.grad = None
 
 
-for policy in ('fused', True, False):
+for policy in (('fused',) if os.environ.get('P3D_ONLY_FUSED') else ('fused', True, False)):
     R.fused_backward = policy == 'fused'
     R.fused_training = bool(policy)
     if not policy:
