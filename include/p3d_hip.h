@@ -280,6 +280,17 @@ int p3d_conv2d_nhwc_ws(const void* x, const void* w, void* y, int dtype, const f
                        const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
                        int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, void* workspace, int64_t workspace_bytes,
                        p3d_stream_t stream);
+/* p3d_conv2d_nhwc_ws with a per-(image, output channel) factor on the accumulator, ahead of noise / bias / activation: out_scale fp32
+ * [N][Co].  With p3d_demod_coefs and p3d_bcast_fma this is the SHARED-weight form of the modulated convolution
+ * (training/networks_stylegan2.py:70-79: x * styles -> convolution with the unmodulated weights -> * demodulation coefficients), which for
+ * the low-resolution layers of a batch reads one weight tensor instead of one per image.  fp32 tensors (P3D_F32 / P3D_F32_BF16X3). */
+int p3d_conv2d_nhwc_scaled(const void* x, const void* w, void* y, int dtype, const float* out_scale, const float* bias, const float* noise,
+                           const float* noise_strength, const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co,
+                           int64_t w_img_stride, int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, void* workspace,
+                           int64_t workspace_bytes, p3d_stream_t stream);
+/* d[n][o] = rsqrt(sum_i styles[n][i]^2 * w2[o][i] + 1e-8) with w2[o][i] = sum over the taps of weight[o][i][.]^2 (networks_stylegan2.py:57-63) */
+int p3d_demod_coefs(const float* styles, const float* w2, float* d, int32_t n_rows, int32_t ci, int32_t co, p3d_stream_t stream);
+
 int64_t p3d_conv2d_nhwc_workspace(int dtype, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride, int32_t kernel_size,
                                   int32_t resample);
 

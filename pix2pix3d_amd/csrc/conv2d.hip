@@ -83,6 +83,8 @@ struct ConvArgs {
     int ksplit;            // > 1 (generic kernel): the K steps of a tile are dealt to `ksplit` work-groups (blockIdx.z % ksplit) whose fp32
     float* partial;        // partial tiles go to partial[split][z][Mpad][CoP] and are summed + finished by splitk_epilogue_kernel — the
                            // low-resolution layers (K = 4608, a handful of tiles) otherwise run 144 serial K steps on 8 of 256 CUs
+    const float* oscale;   // [N][Co] or null (generic kernel, fp32 tensors): the accumulator is multiplied by oscale[image][channel] before the
+                           // rest of the epilogue — the demodulation coefficient of the SHARED-weight form of the modulated convolution
 };
 
 // 16-B slot of (row, chunk).  Two 128-byte tile rows share one 256-byte LDS bank row, so the XOR key is (row >> 1) & 7:
@@ -354,6 +356,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
                 for (int r = 0; r < 16; ++r) {
                     if (opix[i][r] < 0) continue;
                     float v = acc[i][j][r];
+                    if (a.oscale) v *= a.oscale[(a.fold ? opix[i][r] / (a.OH * a.OW) : n) * a.Co + co];
                     if (a.noise) v = fmaf(a.noise[a.fold ? opix[i][r] % (a.OH * a.OW) : opix[i][r]], ns, v);
                     v += b;
                     if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
@@ -395,7 +398,9 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(ConvArgs a, int Mp
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (co + c >= a.Co) break;
-            float v = sum[c] + nz;
+            float v = sum[c];
+            if (a.oscale) v *= a.oscale[n * a.Co + co + c];
+            v += nz;
             if (a.bias) v += a.bias[co + c];
             if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
             v *= a.gain;
@@ -1167,7 +1172,7 @@ extern "C" int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype,
                                int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, p3d_stream_t stream)
 {
     return p3d::conv2d_nhwc_run(x, w, y, dtype, bias, noise, noise_strength, zeros128, n_img, h, wdt, ci, co, w_img_stride, kernel_size, resample, act, gain, clamp,
-                                0, 0, nullptr, 0, nullptr, stream);
+                                0, 0, nullptr, 0, nullptr, nullptr, stream);
 }
 
 extern "C" int p3d_conv2d_nhwc_ws(const void* x, const void* w, void* y, int dtype, const float* bias, const float* noise, const float* noise_strength,
@@ -1176,7 +1181,16 @@ extern "C" int p3d_conv2d_nhwc_ws(const void* x, const void* w, void* y, int dty
                                   p3d_stream_t stream)
 {
     return p3d::conv2d_nhwc_run(x, w, y, dtype, bias, noise, noise_strength, zeros128, n_img, h, wdt, ci, co, w_img_stride, kernel_size, resample, act, gain, clamp,
-                                0, 0, workspace, workspace_bytes, nullptr, stream);
+                                0, 0, workspace, workspace_bytes, nullptr, nullptr, stream);
+}
+
+extern "C" int p3d_conv2d_nhwc_scaled(const void* x, const void* w, void* y, int dtype, const float* out_scale, const float* bias, const float* noise,
+                                      const float* noise_strength, const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co,
+                                      int64_t w_img_stride, int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, void* workspace,
+                                      int64_t workspace_bytes, p3d_stream_t stream)
+{
+    return p3d::conv2d_nhwc_run(x, w, y, dtype, bias, noise, noise_strength, zeros128, n_img, h, wdt, ci, co, w_img_stride, kernel_size, resample, act, gain, clamp,
+                                0, 0, workspace, workspace_bytes, nullptr, out_scale, stream);
 }
 
 extern "C" int64_t p3d_conv2d_nhwc_workspace(int dtype, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride, int32_t kernel_size,
@@ -1184,7 +1198,7 @@ extern "C" int64_t p3d_conv2d_nhwc_workspace(int dtype, int32_t n_img, int32_t h
 {
     int64_t bytes = 0;
     const int rc = p3d::conv2d_nhwc_run(nullptr, nullptr, nullptr, dtype, nullptr, nullptr, nullptr, nullptr, n_img, h, wdt, ci, co, w_img_stride, kernel_size, resample, 0, 1.f, -1.f,
-                                        0, 0, nullptr, 0, &bytes, nullptr);
+                                        0, 0, nullptr, 0, &bytes, nullptr, nullptr);
     return rc == P3D_OK ? bytes : 0;
 }
 
@@ -1193,7 +1207,7 @@ extern "C" int64_t p3d_conv2d_nhwc_workspace(int dtype, int32_t n_img, int32_t h
 int p3d::conv2d_nhwc_run(const void* x, const void* w, void* y, int dtype, const float* bias, const float* noise, const float* noise_strength,
                          const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
                          int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, int32_t out_h, int32_t out_w,
-                         void* workspace, int64_t workspace_bytes, int64_t* query, p3d_stream_t stream)
+                         void* workspace, int64_t workspace_bytes, int64_t* query, const float* out_scale, p3d_stream_t stream)
 {
     // query != null: dry run — *query = bytes of split-K scratch this call would like (0: none); nothing is launched
     const bool dry = query != nullptr;
@@ -1204,6 +1218,7 @@ int p3d::conv2d_nhwc_run(const void* x, const void* w, void* y, int dtype, const
     P3D_REQUIRE(n_img >= 1 && h >= 1 && wdt >= 1 && co >= 1, "conv2d_nhwc: bad sizes");
     P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32 || dtype == P3D_F32_BF16X3, "conv2d_nhwc: dtype must be fp16, fp32 or fp32-as-bf16x3");
     P3D_REQUIRE(kernel_size == 3 || (kernel_size == 1 && !transposed_stride2), "conv2d_nhwc: kernel 3x3, or 1x1 without upsampling");
+    P3D_REQUIRE(!out_scale || dtype != P3D_F16, "conv2d_nhwc: the per-image output scale is implemented for fp32 tensors");
     static const bool no_h2t = getenv("P3D_CONV_NO_H2") != nullptr;
     const bool h2t = !no_h2t && resample == 1 && dtype == P3D_F16 && h >= 32 && wdt >= 32 && ci % 32 == 0 && co % BN == 0 && (((uintptr_t)y) & 15u) == 0;   // convT_h2_f16_kernel: 64-byte K rows
     const int bk = dtype == P3D_F16 ? 64 : 32;
@@ -1212,7 +1227,7 @@ int p3d::conv2d_nhwc_run(const void* x, const void* w, void* y, int dtype, const
     ConvArgs a{};
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.noise = noise; a.noise_strength = noise_strength; a.zeros = zeros128;
     a.N = n_img; a.H = h; a.W = wdt; a.Ci = ci; a.Co = co; a.KT = kernel_size * kernel_size; a.w_img_stride = w_img_stride;
-    a.act = act; a.gain = gain; a.clamp = clamp; a.isy = a.isx = 1;
+    a.act = act; a.gain = gain; a.clamp = clamp; a.isy = a.isx = 1; a.oscale = out_scale;
     hipStream_t s = (hipStream_t)stream;
     if (down2) {                                                     // valid (unpadded) correlation at stride 2: conv2d_resample.py:108-111 after its FIR
         P3D_REQUIRE(h >= kernel_size && wdt >= kernel_size, "conv2d_nhwc: image smaller than the kernel");
@@ -1232,7 +1247,7 @@ int p3d::conv2d_nhwc_run(const void* x, const void* w, void* y, int dtype, const
         // no scratch); a 512-channel layer at 16^2 / 32^2 is 32 / 128 work-groups with a 144-step K loop — that goes to the generic
         // kernel with its K steps dealt out
         const bool h2_ok = !no_h2 && !no_halo && kernel_size == 3 && dtype == P3D_F16 && h >= 32 && wdt >= 32 && ci % 64 == 0 && co % BN == 0 && (((uintptr_t)y) & 15u) == 0;
-        const bool halo_ok = kernel_size == 3 && h >= PH && wdt >= PW && !no_halo;
+        const bool halo_ok = kernel_size == 3 && h >= PH && wdt >= PW && !no_halo && !out_scale;      // (the per-image output scale lives in the generic kernel's epilogue)
         const int64_t own_blocks = h2_ok ? (int64_t)((h + QH - 1) / QH) * ((wdt + QW - 1) / QW) * (co / BN) * n_img
                                          : (int64_t)((h + PH - 1) / PH) * ((wdt + PW - 1) / PW) * ((co + BN - 1) / BN) * n_img;
         const bool have_ws = dry || (workspace != nullptr && workspace_bytes > 0);

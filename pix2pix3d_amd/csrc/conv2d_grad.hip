@@ -479,16 +479,16 @@ static int conv_forward_impl(const void* x, const void* weight, void* y, void* w
     if (!transposed) {
         rc = dry ? P3D_OK : relayout(weight, w_scratch, dtype, co, ci, taps, 0, 0, s);           // wm[o][t][i] = w[o][i][t]
         if (rc != P3D_OK) return rc;
-        return conv2d_nhwc_run(x, w_scratch, y, dtype, nullptr, nullptr, nullptr, zeros128, n_img, h, wdt, ci, co, 0, kernel_size, stride == 2 ? 2 : 0, 0, 1.f, -1.f, 0, 0, workspace, workspace_bytes, query, stream);
+        return conv2d_nhwc_run(x, w_scratch, y, dtype, nullptr, nullptr, nullptr, zeros128, n_img, h, wdt, ci, co, 0, kernel_size, stride == 2 ? 2 : 0, 0, 1.f, -1.f, 0, 0, workspace, workspace_bytes, query, nullptr, stream);
     }
     if (stride == 1) {                                                                            // = correlation with mirrored taps and swapped channel axes
         rc = dry ? P3D_OK : relayout(weight, w_scratch, dtype, ci, co, taps, 1, 1, s);           // wm[o][t][i] = w[i][o][taps-1-t]
         if (rc != P3D_OK) return rc;
-        return conv2d_nhwc_run(x, w_scratch, y, dtype, nullptr, nullptr, nullptr, zeros128, n_img, h, wdt, ci, co, 0, kernel_size, 0, 0, 1.f, -1.f, 0, 0, workspace, workspace_bytes, query, stream);
+        return conv2d_nhwc_run(x, w_scratch, y, dtype, nullptr, nullptr, nullptr, zeros128, n_img, h, wdt, ci, co, 0, kernel_size, 0, 0, 1.f, -1.f, 0, 0, workspace, workspace_bytes, query, nullptr, stream);
     }
     rc = dry ? P3D_OK : relayout(weight, w_scratch, dtype, ci, co, taps, 1, 0, s);               // wm[o][t][i] = w[i][o][t]
     if (rc != P3D_OK) return rc;
-    return conv2d_nhwc_run(x, w_scratch, y, dtype, nullptr, nullptr, nullptr, zeros128, n_img, h, wdt, ci, co, 0, kernel_size, 1, 0, 1.f, -1.f, out_h, out_w, workspace, workspace_bytes, query, stream);
+    return conv2d_nhwc_run(x, w_scratch, y, dtype, nullptr, nullptr, nullptr, zeros128, n_img, h, wdt, ci, co, 0, kernel_size, 1, 0, 1.f, -1.f, out_h, out_w, workspace, workspace_bytes, query, nullptr, stream);
 }
 
 extern "C" int p3d_conv2d_forward(const void* x, const void* weight, void* y, void* w_scratch, const void* zeros128, int dtype,

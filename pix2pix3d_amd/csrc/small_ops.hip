@@ -71,6 +71,36 @@ __global__ void __launch_bounds__(256) fc_kernel(const float* __restrict__ x, co
     fc_block(xs, blockIdx.x, x, w, b, y, n_rows, in_f, out_f, x_stride, wg, bg, act, alpha, act_gain, out_scale);
 }
 
+// Demodulation coefficients of the shared-weight form of the modulated convolution (networks_stylegan2.py:57-63 with the sum over the
+// taps taken first): d[n][o] = rsqrt(sum_i styles[n][i]^2 * w2[o][i] + 1e-8), w2[o][i] = sum_taps w[o][i][t]^2.  One wave per output channel.
+__global__ void __launch_bounds__(256) demod_coefs_kernel(const float* __restrict__ styles, const float* __restrict__ w2, float* __restrict__ d, int n_rows, int ci, int co)
+{
+    extern __shared__ float xs[];                                   // [n_rows][ci] of styles^2
+    for (int e = threadIdx.x; e < n_rows * ci; e += 256) { const float v = styles[e]; xs[e] = v * v; }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + wave;
+    if (o >= co) return;
+    float acc[FC_MAXN];
+#pragma unroll
+    for (int n = 0; n < FC_MAXN; ++n) acc[n] = 0.f;
+    for (int k = lane; k < ci; k += 64) {
+        const float wv = w2[(int64_t)o * ci + k];
+#pragma unroll
+        for (int n = 0; n < FC_MAXN; ++n)
+            if (n < n_rows) acc[n] = fmaf(wv, xs[n * ci + k], acc[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < FC_MAXN; ++n) {
+        if (n < n_rows) {
+            float v = acc[n];
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+            if (lane == 0) d[(int64_t)n * co + o] = rsqrtf(v + 1e-8f);
+        }
+    }
+}
+
 // Several independent FC layers in ONE launch (the 20 style affines of a synthesis network are 20 launches of ~6 us each otherwise):
 // the jobs travel in the kernel arguments; first_block[j] is the first block of job j.
 constexpr int FC_MAX_JOBS = P3D_FC_MAX_JOBS;
@@ -198,6 +228,18 @@ extern "C" int p3d_fc_forward(const float* x, const float* w, const float* b, fl
                        out_features, x_row_stride, weight_gain, bias_gain, act, alpha, act_gain, out_scale);
     count_launch(FAM_AUX);
     return check_launch("fc_forward");
+}
+
+extern "C" int p3d_demod_coefs(const float* styles, const float* w2, float* d, int32_t n_rows, int32_t ci, int32_t co, p3d_stream_t stream)
+{
+    using namespace p3d;
+    P3D_REQUIRE(styles && w2 && d, "demod_coefs: null pointer");
+    P3D_REQUIRE(n_rows >= 1 && n_rows <= FC_MAXN && ci >= 1 && co >= 1, "demod_coefs: 1 .. %d rows", FC_MAXN);
+    const size_t shm = (size_t)n_rows * ci * sizeof(float);
+    P3D_REQUIRE(shm <= 64 * 1024, "demod_coefs: n_rows * ci too large for the LDS stage");
+    hipLaunchKernelGGL(demod_coefs_kernel, dim3((co + 3) / 4), dim3(256), shm, (hipStream_t)stream, styles, w2, d, n_rows, ci, co);
+    count_launch(FAM_AUX);
+    return check_launch("demod_coefs");
 }
 
 extern "C" int p3d_fc_multi(const p3d_fc_job* jobs_host, int32_t n_jobs, int32_t n_rows, p3d_stream_t stream)

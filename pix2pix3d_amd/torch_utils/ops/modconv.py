@@ -43,6 +43,8 @@ _lib.register('p3d_conv2d_nhwc', ctypes.c_int, [_vp] * 3 + [ctypes.c_int] + [_vp
 _lib.register('p3d_conv2d_nhwc_ws', ctypes.c_int, [_vp] * 3 + [ctypes.c_int] + [_vp] * 4 + [_i32] * 5 + [_i64, _i32, _i32, _i32, _f32, _f32, _vp, _i64, _vp])
 _lib.register('p3d_conv2d_nhwc_workspace', _i64, [ctypes.c_int] + [_i32] * 5 + [_i64, _i32, _i32])
 
+_lib.register('p3d_conv2d_nhwc_scaled', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp] + [_i32] * 5 + [ctypes.c_int64] + [_i32] * 3 + [_f32, _f32, _vp, ctypes.c_int64, _vp])
+_lib.register('p3d_demod_coefs', ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp])
 _lib.register('p3d_up2_fir_f16', ctypes.c_int, [_vp] * 8 + [_i32] * 5 + [ctypes.c_int64, _f32, _i32, _f32, _f32, _vp])
 _lib.register('p3d_fir4_bias_act_nhwc', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int] + [_i32] * 9 + [_f32, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _vp])
 _lib.register('p3d_fc_forward', ctypes.c_int, [_vp] * 4 + [_i32] * 3 + [_i64, _f32, _f32, _i32, _f32, _f32, _f32, _vp])
@@ -122,6 +124,46 @@ def use_split_bf16(x, ci):
     return split_bf16 and x.dtype == torch.float32 and x.shape[2] * x.shape[3] >= split_bf16_min_pixels and ci % 32 == 0
 
 
+shared_weight_max_pixels = int(os.environ.get('P3D_SHARED_W_MAX_PIXELS', 1024))    # fp32 layers whose input has at most this many pixels per image (<= 32^2)
+                                                                                  # take the shared-weight form at batch > 1; 0 = always per-image weights
+
+
+def use_shared_weights(x, weight, styles):
+    """The low-resolution fp32 layers of a batch are bound by their weights: N modulated copies of a 9.4 MB tensor are written and read back
+    for a few KB of activations.  The unfused form of the same function (networks_stylegan2.py:70-79: x * styles -> convolution with the
+    UNMODULATED weights -> * demodulation coefficients) reads one weight tensor for the whole batch, with the batch folded into the GEMM
+    rows; the scaling passes over the (tiny) activations instead."""
+    return (shared_weight_max_pixels > 0 and x.shape[0] > 1 and x.shape[0] <= 16 and x.dtype == torch.float32 and x.shape[2] * x.shape[3] <= shared_weight_max_pixels
+            and use_split_bf16(x, weight.shape[1]) and weight.shape[1] % 4 == 0 and tuple(weight.shape[2:]) == (3, 3))
+
+
+def shared_split_weights(weight):
+    """The unmodulated weights in the bf16x3 K-row layout, [1][Co][9][Ci]; once per weight version."""
+    def make():
+        ones = torch.ones([1, weight.shape[1]], dtype=torch.float32, device=weight.device)
+        return modulate_weights(weight, ones, demodulate=False, dtype=BF16X3)
+    return _cached_weight(weight, 'bf16x3_shared', make)
+
+
+def demod_coefs(weight, styles):
+    """rsqrt(sum over (i, taps) of (w * s)^2 + 1e-8) as [N, Co] fp32, from the per-(o, i) tap sums of w^2 (cached per weight version)."""
+    w2 = _cached_weight(weight, 'w2_tapsum', lambda: weight.detach().float().square().sum(dim=[2, 3]).contiguous())
+    s32 = styles.detach().float().contiguous()
+    n, ci = s32.shape
+    d = torch.empty([n, weight.shape[0]], dtype=torch.float32, device=weight.device)
+    code = _lib.lib().p3d_demod_coefs(_lib.ptr(s32), _lib.ptr(w2), _lib.ptr(d), n, ci, weight.shape[0], _lib.stream_of(d))
+    _lib.check(code, 'demod_coefs')
+    return d
+
+
+def scale_input(x, styles):
+    """x * styles[:, :, None, None] on a dense device tensor, one launch (csrc/bcast_ops.hip), no autograd (inference route)."""
+    from . import bcast
+    geo = bcast.layout(x)
+    assert geo is not None
+    return bcast._scale_fma(x, geo, styles.detach().float().contiguous(), None)
+
+
 def modulate_weights(weight, styles, demodulate=True, pre_scale=1.0, dtype=torch.float16, oihw=False):
     """weight [O,I,kh,kw] fp32, styles [N,I] -> ``dtype`` [N][O][kh*kw][I] (or [N][O][I][kh*kw] with ``oihw``), demodulation folded in.
     ``dtype=BF16X3``: an fp32-typed tensor of the same shape whose K rows hold [32 x bf16 hi | 32 x bf16 lo] per 32 input channels."""
@@ -156,7 +198,7 @@ def _pad_channels(x, wmod, transposed=False):
     return xp, wp
 
 
-def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None, act=0, gain=1.0, clamp=-1.0, down=1, split=False):
+def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None, act=0, gain=1.0, clamp=-1.0, down=1, split=False, out_scale=None):
     """x NHWC [N,Ci,H,W] (channels_last strides), wmod [N or 1][Co][k*k][Ci] of the same dtype -> NHWC, same dtype.
     k*k = 9: 3x3 "same" correlation, or (transposed) the stride-2 transposed conv [N,Co,2H+1,2W+1], or (down=2) the valid
     stride-2 correlation [N,Co,(H-3)//2+1,(W-3)//2+1]; k*k = 1: 1x1."""
@@ -178,9 +220,15 @@ def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None
     nbytes = int(_lib.lib().p3d_conv2d_nhwc_workspace(code_dtype, n, h, w, ci, co, stride, k, mode))
     work = torch.empty([nbytes // 4], dtype=torch.float32, device=x.device) if nbytes > 0 else None          # split-K partial tiles (low-resolution layers)
     with _lib.kernel_timer('conv_bf16x3' if split else ('conv_f16' if x.dtype == torch.float16 else 'conv_f32'), x):
-        code = _lib.lib().p3d_conv2d_nhwc_ws(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), code_dtype, _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns),
-                                             _lib.ptr(_zeros_page(x.device)), n, h, w, ci, co, stride, k, mode, int(act), float(gain), float(clamp),
-                                             _lib.ptr(work), nbytes, _lib.stream_of(x))
+        if out_scale is not None:                          # [N, Co] fp32 on the accumulator (shared-weight form: the demodulation coefficients)
+            assert out_scale.dtype == torch.float32 and out_scale.is_contiguous() and tuple(out_scale.shape) == (n, co) and x.dtype == torch.float32
+            code = _lib.lib().p3d_conv2d_nhwc_scaled(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), code_dtype, _lib.ptr(out_scale), _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns),
+                                                     _lib.ptr(_zeros_page(x.device)), n, h, w, ci, co, stride, k, mode, int(act), float(gain), float(clamp),
+                                                     _lib.ptr(work), nbytes, _lib.stream_of(x))
+        else:
+            code = _lib.lib().p3d_conv2d_nhwc_ws(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), code_dtype, _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns),
+                                                 _lib.ptr(_zeros_page(x.device)), n, h, w, ci, co, stride, k, mode, int(act), float(gain), float(clamp),
+                                                 _lib.ptr(work), nbytes, _lib.stream_of(x))
     _lib.check(code, 'conv2d_nhwc')
     log = _lib.kernel_events.get('conv_flops')
     if log is not None:                                  # bench.py: FLOPs of the launches it is timing (2*Ci*Co*k*k per output / input pixel)
@@ -377,6 +425,10 @@ def premodulate(weight, styles, up, in_pixels, dtype):
     if small:
         return modulate_weights(weight, styles, demodulate=True, dtype=dtype, oihw=(up == 1)), ('gemm', up, dtype)
     if split_bf16 and dtype == torch.float32 and in_pixels >= split_bf16_min_pixels and weight.shape[1] % 32 == 0:
+        if (shared_weight_max_pixels > 0 and 1 < styles.shape[0] <= 16 and in_pixels <= shared_weight_max_pixels and weight.shape[1] % 4 == 0
+                and tuple(weight.shape[2:]) == (3, 3)):
+            shared_split_weights(weight)                   # (warm the per-weight cache off the critical path)
+            return demod_coefs(weight, styles), ('shared', up, BF16X3)
         return modulate_weights(weight, styles, demodulate=True, dtype=BF16X3), ('mfma', up, BF16X3)
     return modulate_weights(weight, styles, demodulate=True, dtype=dtype), ('mfma', up, dtype)
 
@@ -397,9 +449,24 @@ def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=No
         if noise_const is not None:
             y = y.add_((noise_const * noise_strength).to(y.dtype))
         return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
-    wmod = wpre if wpre is not None else modulate_weights(weight, styles, demodulate=True, dtype=wtag)
     act_idx = {'linear': 0, 'lrelu': 1}.get(act)
     clampv = -1.0 if clamp is None else float(clamp)
+    if split and use_shared_weights(x, weight, styles):
+        d = pre[0] if pre is not None and pre[1] == ('shared', up, BF16X3) else demod_coefs(weight, styles)
+        xs, wsh = scale_input(x, styles), shared_split_weights(weight)
+        if up == 1 and act_idx is not None:
+            return conv2d(xs, wsh, bias=bias, noise=noise_const, noise_strength=noise_strength, act=act_idx, gain=act_gain, clamp=clampv, split=True, out_scale=d)
+        if up == 1:
+            y = conv2d(xs, wsh, noise=noise_const, noise_strength=noise_strength, split=True, out_scale=d)
+            return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
+        y = conv2d(xs, wsh, transposed=True, split=True, out_scale=d)
+        if act_idx is not None and tuple(resample_filter.shape) == (4, 4) and y.shape[1] % 32 == 0:
+            return fir4_bias_act(y, resample_filter, bias, noise_const, noise_strength, act, act_gain, clampv)
+        y = upfirdn2d.upfirdn2d(y, resample_filter, padding=[1, 1, 1, 1], gain=4)
+        if noise_const is not None:
+            y = y.add_((noise_const * noise_strength).to(y.dtype))
+        return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
+    wmod = wpre if wpre is not None else modulate_weights(weight, styles, demodulate=True, dtype=wtag)
     if up == 1 and act_idx is not None:
         return conv2d(x, wmod, bias=bias, noise=noise_const, noise_strength=noise_strength, act=act_idx, gain=act_gain, clamp=clampv, split=split)
     if up == 1:

@@ -322,3 +322,45 @@ def test_style_affines_in_one_launch(hip_lib):
         if l.activation == 'lrelu':
             yr = torch.nn.functional.leaky_relu(yr, 0.2) * np.sqrt(2)
         assert rel_err(y.double().cpu().numpy(), (yr * sc).cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('n,ci,co,res,up,act', [(4, 512, 512, 4, 1, 'lrelu'), (4, 512, 512, 4, 2, 'lrelu'), (4, 512, 512, 16, 1, 'lrelu'), (3, 256, 128, 32, 2, 'lrelu'),
+                                                (2, 64, 96, 8, 1, 'linear'), (4, 128, 64, 32, 1, 'lrelu'), (5, 96, 160, 12, 2, 'linear')])
+def test_shared_weight_form_of_the_low_resolution_layers(hip_lib, n, ci, co, res, up, act):
+    """x * styles -> convolution with the UNMODULATED weights (batch folded into the GEMM rows) -> * demodulation coefficients
+    (modconv.use_shared_weights) against the per-image-weights route and against fp64 torch: the same function, <= 1e-5 of the range."""
+    from pix2pix3d_amd.torch_utils.ops import modconv, upfirdn2d
+    torch.manual_seed(n * ci + res)
+    x = _nhwc(torch.randn(n, ci, res, res, device='cuda'))
+    weight = torch.randn(co, ci, 3, 3, device='cuda')
+    styles = torch.randn(n, ci, device='cuda') + 1
+    bias = torch.randn(co, device='cuda')
+    nz = torch.randn(res * up, res * up, device='cuda')
+    ns = torch.tensor(0.2, device='cuda')
+    f = upfirdn2d.setup_filter([1, 3, 3, 1], device=torch.device('cuda'))
+    gain = float(np.sqrt(2)) if act == 'lrelu' else 1.0
+    prev = modconv.shared_weight_max_pixels
+    try:
+        modconv.shared_weight_max_pixels = 1024
+        assert modconv.use_shared_weights(x, weight, styles)
+        y1 = modconv.synthesis_layer(x, weight, styles, bias, up, f, noise_const=nz, noise_strength=ns, act=act, act_gain=gain, clamp=None)
+        modconv.shared_weight_max_pixels = 0
+        y0 = modconv.synthesis_layer(x, weight, styles, bias, up, f, noise_const=nz, noise_strength=ns, act=act, act_gain=gain, clamp=None)
+    finally:
+        modconv.shared_weight_max_pixels = prev
+    wq = weight.double().cpu()[None] * styles.double().cpu()[:, None, :, None, None]
+    wq = wq * (wq.square().sum(dim=[2, 3, 4], keepdim=True) + 1e-8).rsqrt()
+    xd = x.double().cpu()
+    if up == 1:
+        yr = torch.stack([F.conv2d(xd[i:i + 1], wq[i], padding=1)[0] for i in range(n)])
+    else:
+        ct = torch.stack([F.conv_transpose2d(xd[i:i + 1], wq[i].transpose(0, 1), stride=2)[0] for i in range(n)])
+        fd = (f.double().cpu() * 4).flip([0, 1])
+        yr = F.conv2d(F.pad(ct, [1, 1, 1, 1]).reshape(n * co, 1, 2 * res + 3, 2 * res + 3), fd[None, None]).reshape(n, co, 2 * res, 2 * res)
+    yr = yr + nz.double().cpu() * 0.2 + bias.double().cpu().view(1, -1, 1, 1)
+    if act == 'lrelu':
+        yr = F.leaky_relu(yr, 0.2)
+    yr = yr * gain
+    e1, e0, e01 = rel_err(y1.double().cpu().numpy(), yr.numpy()), rel_err(y0.double().cpu().numpy(), yr.numpy()), rel_err(y1.cpu().numpy(), y0.cpu().numpy())
+    print(n, ci, co, res, up, 'shared', e1, 'per-image', e0, 'between', e01)
+    assert y1.shape == y0.shape and e1 < 1e-5 and e0 < 1e-5
