@@ -390,6 +390,8 @@ class SynthesisBlock(torch.nn.Module):
 
         if img is not None and self._in_div == 2:                # carry the running image to this block's resolution
             misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
+            if img.shape[1] <= 8 and img.is_cuda and not img.is_contiguous():
+                img = img.contiguous()                       # a narrow image stays NCHW: the layout the streaming ToRGB kernel accumulates into
             img = upfirdn2d.upsample2d(img, self.resample_filter)
         if self.is_last or self.architecture == 'skip':
             y = self.torgb(x, per_layer[self.num_conv], fused_modconv=fused_modconv, accumulate_into=img)
