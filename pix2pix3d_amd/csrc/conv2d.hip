@@ -83,6 +83,13 @@ struct ConvArgs {
     int ksplit;            // > 1 (generic kernel): the K steps of a tile are dealt to `ksplit` work-groups (blockIdx.z % ksplit) whose fp32
     float* partial;        // partial tiles go to partial[split][z][Mpad][CoP] and are summed + finished by splitk_epilogue_kernel — the
                            // low-resolution layers (K = 4608, a handful of tiles) otherwise run 144 serial K steps on 8 of 256 CUs
+    // fused ToRGB (conv3x3_h2_f16_kernel with Co == 128, no noise): the block's finished [256 pixels][128 channels] tile is contracted with
+    // the image's modulated 1x1 weights and ADDED into the fp32 NCHW skip image — the layer's output is not read back by a ToRGB launch
+    const float* rgb_w;    // [N][rgb_co][128] fp32 (weight * styles), or null
+    const float* rgb_bias; // [rgb_co] or null
+    float* rgb_out;        // [N][rgb_co][H][W] fp32, accumulated into
+    int rgb_co;            // <= 8
+    float rgb_clamp;       // on (sum + bias) before the accumulation; < 0: off
     const float* oscale;   // [N][Co] or null (generic kernel, fp32 tensors): the accumulator is multiplied by oscale[image][channel] before the
                            // rest of the epilogue — the demodulation coefficient of the SHARED-weight form of the modulated convolution
 };
@@ -770,6 +777,33 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
         if (oy < a.H && ox < a.W && co < a.Co)
             *(f32x4*)(yout + ((int64_t)oy * a.W + ox) * a.Co + co) = *(const f32x4*)(ot + p * OP + ch * 8);
     }
+    if (a.rgb_out) {                                                             // (host: Co == 128, one channel block, no noise)
+        const int p = tid, oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
+        if (oy < a.H && ox < a.W) {
+            float sum[8];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) sum[o] = 0.f;
+            const float* const wn = a.rgb_w + (int64_t)n * a.rgb_co * 128;
+#pragma unroll
+            for (int c8 = 0; c8 < 16; ++c8) {
+                const h8 v = *(const h8*)(ot + p * OP + c8 * 8);
+#pragma unroll
+                for (int o = 0; o < 8; ++o)
+                    if (o < a.rgb_co) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) sum[o] = fmaf((float)v[e], wn[o * 128 + c8 * 8 + e], sum[o]);
+                    }
+            }
+#pragma unroll
+            for (int o = 0; o < 8; ++o)
+                if (o < a.rgb_co) {
+                    float v = sum[o] + (a.rgb_bias ? a.rgb_bias[o] : 0.f);
+                    if (a.rgb_clamp >= 0.f) v = fminf(fmaxf(v, -a.rgb_clamp), a.rgb_clamp);
+                    float* dst = a.rgb_out + (((int64_t)n * a.rgb_co + o) * a.H + oy) * a.W + ox;
+                    *dst += v;
+                }
+        }
+    }
 }
 
 // ---- stride-2 transposed 3x3 conv on the two-blocks-per-CU structure (fp16) ------------------------------------------------
@@ -1182,6 +1216,30 @@ extern "C" int p3d_conv2d_nhwc_ws(const void* x, const void* w, void* y, int dty
 {
     return p3d::conv2d_nhwc_run(x, w, y, dtype, bias, noise, noise_strength, zeros128, n_img, h, wdt, ci, co, w_img_stride, kernel_size, resample, act, gain, clamp,
                                 0, 0, workspace, workspace_bytes, nullptr, nullptr, stream);
+}
+
+extern "C" int p3d_conv3x3_torgb_f16(const void* x, const void* w, void* y, const float* bias, const void* zeros128, const float* rgb_w, const float* rgb_bias,
+                                     float* rgb_out, int32_t rgb_co, float rgb_clamp, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co,
+                                     int64_t w_img_stride, int32_t act, float gain, float clamp, p3d_stream_t stream)
+{
+    using namespace p3d;
+    P3D_REQUIRE(x && w && y && zeros128 && rgb_w && rgb_out, "conv3x3_torgb_f16: null pointer");
+    P3D_REQUIRE(rgb_co >= 1 && rgb_co <= 8, "conv3x3_torgb_f16: 1 .. 8 image channels");
+    P3D_REQUIRE(act == 0 || act == 1, "conv3x3_torgb_f16: act must be 0 (linear) or 1 (lrelu)");
+    if (co != BN || ci % 64 != 0 || h < 32 || wdt < 32 || ((uintptr_t)y & 15u))
+        return fail(P3D_ERR_UNSUPPORTED, "conv3x3_torgb_f16: needs Co = 128, Ci %% 64 = 0, an image of 32 x 32 or more (got %d, %d, %d x %d)", co, ci, h, wdt);
+    P3D_REQUIRE((((uintptr_t)x) & 15u) == 0 && (((uintptr_t)w) & 15u) == 0 && (((uintptr_t)zeros128) & 15u) == 0, "conv3x3_torgb_f16: x, w and zeros128 must be 16-byte aligned");
+    ConvArgs a{};
+    a.x = x; a.w = w; a.y = y; a.bias = bias; a.zeros = zeros128;
+    a.N = n_img; a.H = h; a.W = wdt; a.Ci = ci; a.Co = co; a.KT = 9; a.w_img_stride = w_img_stride;
+    a.act = act; a.gain = gain; a.clamp = clamp; a.isy = a.isx = 1; a.OH = h; a.OW = wdt; a.osy = a.osx = 1; a.ncls = 1; a.ksplit = 1;
+    a.cls[0].SH = h; a.cls[0].SW = wdt; a.cls[0].ntaps = 9;
+    for (int t = 0; t < 9; ++t) a.cls[0].taps[t] = ConvTap{t / 3 - 1, t % 3 - 1, t};
+    a.rgb_w = rgb_w; a.rgb_bias = rgb_bias; a.rgb_out = rgb_out; a.rgb_co = rgb_co; a.rgb_clamp = rgb_clamp;
+    dim3 grid(((h + QH - 1) / QH) * ((wdt + QW - 1) / QW), 1, n_img);
+    hipLaunchKernelGGL(conv3x3_h2_f16_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    count_launch(FAM_CONV);
+    return check_launch("conv3x3_torgb_f16");
 }
 
 extern "C" int p3d_conv2d_nhwc_scaled(const void* x, const void* w, void* y, int dtype, const float* out_scale, const float* bias, const float* noise,

@@ -43,6 +43,7 @@ _lib.register('p3d_conv2d_nhwc', ctypes.c_int, [_vp] * 3 + [ctypes.c_int] + [_vp
 _lib.register('p3d_conv2d_nhwc_ws', ctypes.c_int, [_vp] * 3 + [ctypes.c_int] + [_vp] * 4 + [_i32] * 5 + [_i64, _i32, _i32, _i32, _f32, _f32, _vp, _i64, _vp])
 _lib.register('p3d_conv2d_nhwc_workspace', _i64, [ctypes.c_int] + [_i32] * 5 + [_i64, _i32, _i32])
 
+_lib.register('p3d_conv3x3_torgb_f16', ctypes.c_int, [_vp] * 8 + [_i32, _f32] + [_i32] * 5 + [ctypes.c_int64, _i32, _f32, _f32, _vp])
 _lib.register('p3d_conv2d_nhwc_scaled', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp] + [_i32] * 5 + [ctypes.c_int64] + [_i32] * 3 + [_f32, _f32, _vp, ctypes.c_int64, _vp])
 _lib.register('p3d_demod_coefs', ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp])
 _lib.register('p3d_up2_fir_f16', ctypes.c_int, [_vp] * 8 + [_i32] * 5 + [ctypes.c_int64, _f32, _i32, _f32, _f32, _vp])
@@ -433,7 +434,7 @@ def premodulate(weight, styles, up, in_pixels, dtype):
     return modulate_weights(weight, styles, demodulate=True, dtype=dtype), ('mfma', up, dtype)
 
 
-def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=None, noise_strength=None, act='lrelu', act_gain=1.0, clamp=None, pre=None):
+def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=None, noise_strength=None, act='lrelu', act_gain=1.0, clamp=None, pre=None, rgb=None):
     """Whole SynthesisLayer body after the style affine: modulated 3x3 conv (x2 up when ``up == 2``) + noise + bias + act.
     ``pre`` = (modulated weights, route tag) from ``premodulate`` — used when the tag matches the route taken here."""
     small = is_small(x, up)
@@ -467,6 +468,10 @@ def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=No
             y = y.add_((noise_const * noise_strength).to(y.dtype))
         return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
     wmod = wpre if wpre is not None else modulate_weights(weight, styles, demodulate=True, dtype=wtag)
+    if rgb is not None:                                    # (rgb_weight, rgb_styles, rgb_bias, rgb_clamp, img): checked by torgb_fusable
+        rgb_w, rgb_s, rgb_b, rgb_c, img = rgb
+        rgb_wmod = modulate_weights(rgb_w, rgb_s, demodulate=False, dtype=torch.float32)
+        return conv3x3_torgb(x, wmod, bias, act_idx, act_gain, clampv, rgb_wmod, rgb_b, rgb_c, img)
     if up == 1 and act_idx is not None:
         return conv2d(x, wmod, bias=bias, noise=noise_const, noise_strength=noise_strength, act=act_idx, gain=act_gain, clamp=clampv, split=split)
     if up == 1:
@@ -538,6 +543,45 @@ def fir4_bias_act(y, f, bias, noise, noise_strength, act, act_gain, clamp):
                                              _lib.stream_of(y))
     _lib.check(code, 'fir4_bias_act_nhwc')
     return out
+
+
+fused_torgb_calls = 0        # launches of the fused conv1 + ToRGB kernel (tests)
+fuse_torgb = os.environ.get('P3D_FUSE_TORGB', '1') != '0'      # SynthesisBlock.conv1 + ToRGB + skip-image sum in one launch where the kernel allows (Co = 128, fp16)
+
+
+def torgb_fusable(x, conv_weight, rgb_weight, img, up, noise_const, act):
+    """Can the block's last 3x3 layer also produce its ToRGB contribution (csrc/conv2d.hip: p3d_conv3x3_torgb_f16)?  x is that layer's INPUT."""
+    if not (fuse_torgb and enabled and up == 1 and noise_const is None and act in ('linear', 'lrelu') and img is not None and _is_nhwc_f16(x)):
+        return False
+    n, ci, h, w = x.shape
+    if n * ((h + 15) // 16) * ((w + 15) // 16) < 192:         # too few 16 x 16 patches to fill the chip: the dispatcher would take the split-K kernel
+        return False
+    return (conv_weight.shape[0] == 128 and tuple(conv_weight.shape[2:]) == (3, 3) and ci % 64 == 0 and h >= 32 and w >= 32 and rgb_weight.shape[0] <= 8
+            and tuple(rgb_weight.shape[1:]) == (128, 1, 1) and img.dtype == torch.float32 and img.is_contiguous() and tuple(img.shape) == (n, rgb_weight.shape[0], h, w)
+            and not img.requires_grad and _no_grad_needed(x, conv_weight, rgb_weight))
+
+
+def conv3x3_torgb(x, wmod, bias, act, gain, clamp, rgb_wmod, rgb_bias, rgb_clamp, img):
+    """3x3 'same' modulated conv (fp16 NHWC, Co = 128) + epilogue, and img += clamp(ToRGB(y) + rgb_bias) from the same launch."""
+    n, ci, h, w = x.shape
+    co = wmod.shape[1]
+    y = torch.empty([n, co, h, w], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    stride = 0 if wmod.shape[0] == 1 else co * 9 * ci
+    b32 = None if bias is None else bias.detach().float().contiguous()
+    rb32 = None if rgb_bias is None else rgb_bias.detach().float().contiguous()
+    rw = rgb_wmod.reshape(n, -1, co)
+    assert rw.dtype == torch.float32 and rw.is_contiguous() and wmod.dtype == torch.float16 and wmod.is_contiguous()
+    with _lib.kernel_timer('conv_f16', x):
+        code = _lib.lib().p3d_conv3x3_torgb_f16(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), _lib.ptr(b32), _lib.ptr(_zeros_page(x.device)), _lib.ptr(rw), _lib.ptr(rb32),
+                                                _lib.ptr(img), rw.shape[1], -1.0 if rgb_clamp is None else float(rgb_clamp), n, h, w, ci, co, stride,
+                                                int(act), float(gain), float(clamp), _lib.stream_of(x))
+    _lib.check(code, 'conv3x3_torgb_f16')
+    global fused_torgb_calls
+    fused_torgb_calls += 1
+    log = _lib.kernel_events.get('conv_flops')
+    if log is not None:
+        log.append((str(x.dtype), 2.0 * n * ci * co * 9 * h * w))
+    return y
 
 
 def torgb_accumulates(x, weight, out):

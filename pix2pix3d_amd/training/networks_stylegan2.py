@@ -248,7 +248,9 @@ class SynthesisLayer(torch.nn.Module):
             self.noise_strength = torch.nn.Parameter(torch.zeros([]))
             self.register_buffer('noise_const', torch.randn([resolution, resolution]))
 
-    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1):
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, rgb=None):
+        """``rgb`` (device inference, from SynthesisBlock): (torgb layer, its latent, skip image) — when the native kernel can, this layer
+        also adds the block's ToRGB output into the skip image from its own launch and returns (x, True); otherwise (x, False)."""
         if noise_mode not in ('random', 'const', 'none'):
             raise AssertionError(f'unknown noise_mode {noise_mode!r}')
         in_res = self.resolution // self.up
@@ -265,15 +267,24 @@ class SynthesisLayer(torch.nn.Module):
         if modconv.layer_supported(x, self.weight, styles, noise_mode, fused_modconv, self.up):
             # fp16 channels-last inference: weight modulation, MFMA conv, noise, bias, activation in native kernels
             const_noise = self.use_noise and noise_mode == 'const'
-            return modconv.synthesis_layer(x, self.weight, styles, self.bias, self.up, self.resample_filter,
-                                           noise_const=self.noise_const if const_noise else None,
-                                           noise_strength=self.noise_strength if const_noise else None,
-                                           act=self.activation, act_gain=self.act_gain * gain, clamp=clamp, pre=pre)
+            fused_rgb = None
+            if rgb is not None:
+                torgb, w_rgb, img = rgb
+                if modconv.torgb_fusable(x, self.weight, torgb.weight, img, self.up, self.noise_const if const_noise else None, self.activation):
+                    planned_rgb = modconv.take_plan(torgb) if modconv._plan else None
+                    s_rgb = planned_rgb[0] if planned_rgb is not None else torgb.affine(w_rgb, out_scale=torgb.weight_gain)
+                    fused_rgb = (torgb.weight, s_rgb, torgb.bias, torgb.conv_clamp, img)
+            y = modconv.synthesis_layer(x, self.weight, styles, self.bias, self.up, self.resample_filter,
+                                        noise_const=self.noise_const if const_noise else None,
+                                        noise_strength=self.noise_strength if const_noise else None,
+                                        act=self.activation, act_gain=self.act_gain * gain, clamp=clamp, pre=pre, rgb=fused_rgb)
+            return y if rgb is None else (y, fused_rgb is not None)
         if self.use_noise and noise_mode == 'const':
             noise = self.noise_const * self.noise_strength
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
                              resample_filter=self.resample_filter, flip_weight=(self.up == 1), fused_modconv=fused_modconv)
-        return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+        y = bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+        return y if rgb is None else (y, False)
 
     def extra_repr(self):
         return (f'in_channels={self.in_channels:d}, out_channels={self.out_channels:d}, w_dim={self.w_dim:d}, '
@@ -385,20 +396,37 @@ class SynthesisBlock(torch.nn.Module):
             x = self.conv0(x, per_layer[0], **conv_kwargs)
             x = self.conv1(x, per_layer[1], gain=np.sqrt(0.5), **conv_kwargs)
             x = shortcut.add_(x)
+        rgb_done = False
+        wants_rgb = self.is_last or self.architecture == 'skip'
+        if self.in_channels != 0 and self.architecture != 'resnet':
+            x = self.conv0(x, per_layer[0], **conv_kwargs)
+            if wants_rgb and img is not None and x.is_cuda and not torch.is_grad_enabled():
+                img = self._carry_image(img)                     # (independent of the convolutions: done first so that conv1 can add into it)
+                x, rgb_done = self.conv1(x, per_layer[1], rgb=(self.torgb, per_layer[self.num_conv], img), **conv_kwargs)
+                img_carried = True
+            else:
+                x = self.conv1(x, per_layer[1], **conv_kwargs)
+                img_carried = False
         else:
-            x = self.conv1(self.conv0(x, per_layer[0], **conv_kwargs), per_layer[1], **conv_kwargs)
+            img_carried = False
 
-        if img is not None and self._in_div == 2:                # carry the running image to this block's resolution
-            misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
-            if img.shape[1] <= 8 and img.is_cuda and not img.is_contiguous():
-                img = img.contiguous()                       # a narrow image stays NCHW: the layout the streaming ToRGB kernel accumulates into
-            img = upfirdn2d.upsample2d(img, self.resample_filter)
-        if self.is_last or self.architecture == 'skip':
+        if img is not None and not img_carried:
+            img = self._carry_image(img)
+        if wants_rgb and not rgb_done:
             y = self.torgb(x, per_layer[self.num_conv], fused_modconv=fused_modconv, accumulate_into=img)
             img = img if y is img else self._accumulate_image(img, y, fmt)
 
         assert x.dtype == dtype and (img is None or img.dtype == torch.float32)
         return x, img
+
+    def _carry_image(self, img):
+        """The running skip image at this block's resolution (:453-456)."""
+        if self._in_div != 2:
+            return img
+        misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
+        if img.shape[1] <= 8 and img.is_cuda and not img.is_contiguous():
+            img = img.contiguous()                               # a narrow image stays NCHW: the layout the ToRGB kernels accumulate into
+        return upfirdn2d.upsample2d(img, self.resample_filter)
 
     def _entry_features(self, x, batch, dtype, fmt):
         """The block's input activations in its working dtype / layout: the learned constant for b4, else the previous block's x."""

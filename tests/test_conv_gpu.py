@@ -364,3 +364,36 @@ def test_shared_weight_form_of_the_low_resolution_layers(hip_lib, n, ci, co, res
     e1, e0, e01 = rel_err(y1.double().cpu().numpy(), yr.numpy()), rel_err(y0.double().cpu().numpy(), yr.numpy()), rel_err(y1.cpu().numpy(), y0.cpu().numpy())
     print(n, ci, co, res, up, 'shared', e1, 'per-image', e0, 'between', e01)
     assert y1.shape == y0.shape and e1 < 1e-5 and e0 < 1e-5
+
+
+@pytest.mark.parametrize('img_channels,in_ch,res', [(3, 256, 256), (6, 128, 176), (1, 64, 160)])
+def test_last_conv_and_torgb_in_one_launch(hip_lib, img_channels, in_ch, res):
+    """SynthesisBlock.conv1 + ToRGB + skip-image sum from one launch (p3d_conv3x3_torgb_f16) against the three-launch form: the same x
+    (bit-identical: the convolution is untouched) and the same skip image up to the ToRGB weights' precision."""
+    from pix2pix3d_amd import _lib
+    from pix2pix3d_amd.training.networks_stylegan2 import SynthesisBlock
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    torch.manual_seed(img_channels)
+    blk = SynthesisBlock(in_ch, 128, w_dim=64, resolution=res, img_channels=img_channels, is_last=True, use_fp16=True, conv_clamp=256,
+                         fp16_channels_last=True).cuda().eval().requires_grad_(False)
+    blk.torgb.bias.normal_(); blk.conv1.bias.normal_()
+    n = 2
+    x = torch.randn(n, in_ch, res // 2, res // 2, device='cuda')
+    img = torch.randn(n, img_channels, res // 2, res // 2, device='cuda')
+    ws = torch.randn(n, 3, 64, device='cuda')
+    outs = {}
+    prev = modconv.fuse_torgb
+    try:
+        for flag in (True, False):
+            modconv.fuse_torgb = flag
+            c0 = modconv.fused_torgb_calls
+            with torch.no_grad():
+                outs[flag] = blk(x, img.clone(), ws, noise_mode='none')
+            outs[flag] += (modconv.fused_torgb_calls - c0,)
+    finally:
+        modconv.fuse_torgb = prev
+    (x1, i1, l1), (x0, i0, l0) = outs[True], outs[False]
+    assert (l1, l0) == (1, 0)                                                  # the fused kernel ran / did not run
+    assert torch.equal(x1, x0)                                                 # same kernel, same K order
+    # the streaming ToRGB kernel holds its modulated weights in fp16 (as the reference's fp16 layer does), the fused one in fp32
+    assert rel_err(i1.cpu().numpy(), i0.cpu().numpy()) < 1e-3
