@@ -778,31 +778,52 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
             *(f32x4*)(yout + ((int64_t)oy * a.W + ox) * a.Co + co) = *(const f32x4*)(ot + p * OP + ch * 8);
     }
     if (a.rgb_out) {                                                             // (host: Co == 128, one channel block, no noise)
-        const int p = tid, oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
-        if (oy < a.H && ox < a.W) {
-            float sum[8];
+        // ToRGB of the finished tile on the matrix cores, as torgb_nhwc_kernel does it: A = the tile's pixels (rows of `ot`), B = the image's
+        // modulated 1x1 weights rounded to fp16 (what the reference's fp16 layer multiplies by), 32 padded output columns.
+        const int col = lane & 31, kg = lane >> 5;
+        h8 bw[8];
 #pragma unroll
-            for (int o = 0; o < 8; ++o) sum[o] = 0.f;
-            const float* const wn = a.rgb_w + (int64_t)n * a.rgb_co * 128;
+        for (int sidx = 0; sidx < 8; ++sidx) {
 #pragma unroll
-            for (int c8 = 0; c8 < 16; ++c8) {
-                const h8 v = *(const h8*)(ot + p * OP + c8 * 8);
+            for (int e = 0; e < 8; ++e) bw[sidx][e] = (_Float16)0.f;
+            if (col < a.rgb_co) {
+                const float* wp = a.rgb_w + ((int64_t)n * a.rgb_co + col) * 128 + sidx * 16 + kg * 8;
+                const f32x4 w0 = *(const f32x4*)wp, w1 = *(const f32x4*)(wp + 4);
 #pragma unroll
-                for (int o = 0; o < 8; ++o)
-                    if (o < a.rgb_co) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) sum[o] = fmaf((float)v[e], wn[o * 128 + c8 * 8 + e], sum[o]);
-                    }
+                for (int e = 0; e < 4; ++e) { bw[sidx][e] = (_Float16)w0[e]; bw[sidx][4 + e] = (_Float16)w1[e]; }
             }
+        }
+        f32x16 rr[2];
 #pragma unroll
-            for (int o = 0; o < 8; ++o)
-                if (o < a.rgb_co) {
-                    float v = sum[o] + (a.rgb_bias ? a.rgb_bias[o] : 0.f);
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) rr[i][e] = 0.f;
+#pragma unroll
+            for (int sidx = 0; sidx < 8; ++sidx) {
+                const h8 av = *(const h8*)(ot + (wave * 64 + i * 32 + col) * OP + sidx * 16 + kg * 8);
+                rr[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bw[sidx], rr[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                                        // every wave has read its rows of the tile: it becomes the hand-over buffer
+        float* const ro = (float*)lds_b;                                        // [rgb_co][256 pixels]
+        if (col < a.rgb_co) {
+            const float b = a.rgb_bias ? a.rgb_bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = rr[i][e] + b;
                     if (a.rgb_clamp >= 0.f) v = fminf(fmaxf(v, -a.rgb_clamp), a.rgb_clamp);
-                    float* dst = a.rgb_out + (((int64_t)n * a.rgb_co + o) * a.H + oy) * a.W + ox;
-                    *dst += v;
+                    ro[col * 256 + wave * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg] = v;
                 }
         }
+        __syncthreads();
+        const int p = tid, oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
+        if (oy < a.H && ox < a.W)
+            for (int o = 0; o < a.rgb_co; ++o) {
+                float* dst = a.rgb_out + (((int64_t)n * a.rgb_co + o) * a.H + oy) * a.W + ox;
+                *dst += ro[o * 256 + p];
+            }
     }
 }
 

@@ -395,5 +395,5 @@ def test_last_conv_and_torgb_in_one_launch(hip_lib, img_channels, in_ch, res):
     (x1, i1, l1), (x0, i0, l0) = outs[True], outs[False]
     assert (l1, l0) == (1, 0)                                                  # the fused kernel ran / did not run
     assert torch.equal(x1, x0)                                                 # same kernel, same K order
-    # the streaming ToRGB kernel holds its modulated weights in fp16 (as the reference's fp16 layer does), the fused one in fp32
-    assert rel_err(i1.cpu().numpy(), i0.cpu().numpy()) < 1e-3
+    # both contract fp16 activations with the modulated weights rounded to fp16 (as the reference's fp16 layer does); fp32 summation order differs
+    assert rel_err(i1.cpu().numpy(), i0.cpu().numpy()) < 1e-5
