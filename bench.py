@@ -393,7 +393,7 @@ def main():
 
     if rank == 0:
         from pix2pix3d_amd.torch_utils.ops import modconv as _mc
-        bb = ('f32 tensors + f32 accumulation; the 3x3 backbone layers form each product as 3 bf16 MFMAs of (hi, lo) splits ("bf16x3", <= 5e-6 of the '
+        bb = ('f32 tensors + f32 accumulation; the backbone convolutions (3x3 and the 1x1 ToRGB) form each product as 3 bf16 MFMAs of (hi, lo) splits ("bf16x3", <= 5e-6 of the '
               'output range vs fp64 per layer; P3D_BF16X3=0 = exact f32 MFMA)') if _mc.split_bf16 else 'f32 (exact f32 MFMA)'
         rm = 'f32 gather / sampling / compositing, decoder MLPs as bf16x3 (P3D_MLP_BF16X3=0 = exact f32 MFMA)' if rmod.mlp_bf16x3 else 'f32'
         dtype_desc = f'backbone: {bb}; ray-marcher: {rm}; super-resolution: ' + ('f32' if args.force_fp32 else 'f16 storage / f32 accumulation (the reference GPU config)')
