@@ -73,6 +73,15 @@ int p3d_upfirdn2d(const void* x, const float* f, void* y, int dtype,
                   const int32_t out_size[4], const int64_t out_stride[4],
                   int32_t up_x, int32_t up_y, int32_t down_x, int32_t down_y,
                   int32_t pad_x0, int32_t pad_y0, int32_t flip, float gain, p3d_stream_t stream);
+/* p3d_upfirdn2d that ADDS its result into y (y += upfirdn2d(x)): the skip-image sum of SynthesisBlock (training/networks_stylegan2.py:453-459:
+ * img = upsample2d(img) + torgb) from the upsampling launch.  Channels-last tensors, 4-tap filters, C a multiple of 16 bytes; anything else
+ * P3D_ERR_UNSUPPORTED.                                                                                                          */
+int p3d_upfirdn2d_acc(const void* x, const float* f, void* y, int dtype,
+                  const int32_t in_size[4], const int64_t in_stride[4],
+                  const int32_t f_size[2], const int64_t f_stride[2],
+                  const int32_t out_size[4], const int64_t out_stride[4],
+                  int32_t up_x, int32_t up_y, int32_t down_x, int32_t down_y,
+                  int32_t pad_x0, int32_t pad_y0, int32_t flip, float gain, p3d_stream_t stream);
 
 /* ---- filtered_lrelu ----------------------------------------------------------------------------
  * Replaces filtered_lrelu_plugin.filtered_lrelu (torch_utils/ops/filtered_lrelu.cpp:20-213; kernel parameters filtered_lrelu.h:18-72,

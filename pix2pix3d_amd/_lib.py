@@ -35,6 +35,11 @@ _SIGNATURES = {
                                ctypes.POINTER(_c_i32), ctypes.POINTER(_c_i64),
                                ctypes.POINTER(_c_i32), ctypes.POINTER(_c_i64),
                                _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_float, _c_void_p]),
+    'p3d_upfirdn2d_acc': (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int,
+                                   ctypes.POINTER(_c_i32), ctypes.POINTER(_c_i64),
+                                   ctypes.POINTER(_c_i32), ctypes.POINTER(_c_i64),
+                                   ctypes.POINTER(_c_i32), ctypes.POINTER(_c_i64),
+                                   _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_i32, _c_float, _c_void_p]),
 }
 
 _lib = None

@@ -24,6 +24,7 @@ struct UpfirArgs {
     int up_x, up_y, down_x, down_y, pad_x0, pad_y0, flip;
     float gain;
     int lanes_on_c;            // 1: fastest thread axis walks channels (channels_last)
+    int accumulate;            // channels-last kernel only: y += result (the skip-image sum of SynthesisBlock in the upsampling launch)
     int64_t total;             // out_w * out_h * C * N
 };
 
@@ -216,9 +217,15 @@ __global__ void __launch_bounds__(256) upfirdn2d_cl_kernel(UpfirArgs a)
             }
         }
         P o;
+        P* const dst = (P*)((T*)a.y + (int64_t)n * a.osn + (int64_t)oy * a.osy + (int64_t)ox * a.osx + cv * VEC);
+        if (a.accumulate) {
+            const P old = *dst;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] += (float)ld(&old.v[e]);
+        }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) st(&o.v[e], (typename Acc<T>::type)acc[e]);
-        *(P*)((T*)a.y + (int64_t)n * a.osn + (int64_t)oy * a.osy + (int64_t)ox * a.osx + cv * VEC) = o;
+        *dst = o;
     }
 }
 
@@ -372,6 +379,10 @@ static int launch_upfirdn2d(const UpfirArgs& a, hipStream_t s)
     const int64_t cap = (int64_t)kNumCU * 32;
     int blocks = (int)(blocks64 > cap ? cap : blocks64);
     if (blocks < 1) blocks = 1;
+    if (a.accumulate) {
+        if (try_channels_last<T>(a, s)) { count_launch(FAM_UPFIRDN); return check_launch("upfirdn2d(channels_last, accumulate)"); }
+        return fail(P3D_ERR_UNSUPPORTED, "upfirdn2d_acc: only the channels-last 4-tap kernels accumulate");
+    }
     if (try_tiled<T>(a, s)) { count_launch(FAM_UPFIRDN); return check_launch("upfirdn2d(tiled)"); }
     if (try_channels_last<T>(a, s)) { count_launch(FAM_UPFIRDN); return check_launch("upfirdn2d(channels_last)"); }
 #define P3D_UPFIR_CASE(ux, uy, dx, dy, w, h) \
@@ -392,12 +403,12 @@ static int launch_upfirdn2d(const UpfirArgs& a, hipStream_t s)
 
 } // namespace p3d
 
-extern "C" int p3d_upfirdn2d(const void* x, const float* f, void* y, int dtype,
-                             const int32_t in_size[4], const int64_t in_stride[4],
-                             const int32_t f_size[2], const int64_t f_stride[2],
-                             const int32_t out_size[4], const int64_t out_stride[4],
-                             int32_t up_x, int32_t up_y, int32_t down_x, int32_t down_y,
-                             int32_t pad_x0, int32_t pad_y0, int32_t flip, float gain, p3d_stream_t stream)
+static int upfirdn2d_run(const void* x, const float* f, void* y, int dtype,
+                         const int32_t in_size[4], const int64_t in_stride[4],
+                         const int32_t f_size[2], const int64_t f_stride[2],
+                         const int32_t out_size[4], const int64_t out_stride[4],
+                         int32_t up_x, int32_t up_y, int32_t down_x, int32_t down_y,
+                         int32_t pad_x0, int32_t pad_y0, int32_t flip, float gain, int accumulate, p3d_stream_t stream)
 {
     using namespace p3d;
     P3D_REQUIRE(x && f && y, "upfirdn2d: x, f and y must be non-null");
@@ -414,6 +425,7 @@ extern "C" int p3d_upfirdn2d(const void* x, const float* f, void* y, int dtype,
     a.up_x = up_x; a.up_y = up_y; a.down_x = down_x; a.down_y = down_y;
     a.pad_x0 = pad_x0; a.pad_y0 = pad_y0; a.flip = flip ? 1 : 0; a.gain = gain;
     a.lanes_on_c = (a.osc == 1 && a.C > 1 && a.osx != 1) ? 1 : 0;
+    a.accumulate = accumulate;
     a.total = (int64_t)a.out_w * a.out_h * a.C * a.N;
     if (a.total <= 0) return P3D_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -423,6 +435,26 @@ extern "C" int p3d_upfirdn2d(const void* x, const float* f, void* y, int dtype,
         case P3D_F64: return launch_upfirdn2d<double>(a, s);
     }
     return fail(P3D_ERR_ARGUMENT, "upfirdn2d: unknown dtype %d", dtype);
+}
+
+extern "C" int p3d_upfirdn2d(const void* x, const float* f, void* y, int dtype,
+                             const int32_t in_size[4], const int64_t in_stride[4],
+                             const int32_t f_size[2], const int64_t f_stride[2],
+                             const int32_t out_size[4], const int64_t out_stride[4],
+                             int32_t up_x, int32_t up_y, int32_t down_x, int32_t down_y,
+                             int32_t pad_x0, int32_t pad_y0, int32_t flip, float gain, p3d_stream_t stream)
+{
+    return upfirdn2d_run(x, f, y, dtype, in_size, in_stride, f_size, f_stride, out_size, out_stride, up_x, up_y, down_x, down_y, pad_x0, pad_y0, flip, gain, 0, stream);
+}
+
+extern "C" int p3d_upfirdn2d_acc(const void* x, const float* f, void* y, int dtype,
+                                 const int32_t in_size[4], const int64_t in_stride[4],
+                                 const int32_t f_size[2], const int64_t f_stride[2],
+                                 const int32_t out_size[4], const int64_t out_stride[4],
+                                 int32_t up_x, int32_t up_y, int32_t down_x, int32_t down_y,
+                                 int32_t pad_x0, int32_t pad_y0, int32_t flip, float gain, p3d_stream_t stream)
+{
+    return upfirdn2d_run(x, f, y, dtype, in_size, in_stride, f_size, f_stride, out_size, out_stride, up_x, up_y, down_x, down_y, pad_x0, pad_y0, flip, gain, 1, stream);
 }
 
 extern "C" int p3d_fir4_bias_act_nhwc(const void* x, const float* f, void* y, int dtype, int32_t n_img, int32_t c, int32_t in_h, int32_t in_w,

@@ -158,6 +158,26 @@ class _Plugin:
         return y
 
 
+def upsample2d_add_(y, x, f):
+    """y += upsample2d(x, f, up=2) in one launch where the native kernel can (channels-last fp32 / fp16, 4 x 4 filter: the skip image of the
+    synthesis blocks, networks_stylegan2.py:453-459); the two-step form otherwise.  Returns y."""
+    n, c, h, w = x.shape
+    ok = (x.is_cuda and f is not None and f.ndim == 2 and tuple(f.shape) == (4, 4) and f.dtype == torch.float32 and x.dtype == y.dtype and x.dtype in (torch.float16, torch.float32)
+          and tuple(y.shape) == (n, c, 2 * h, 2 * w) and c > 1 and c % (16 // x.element_size()) == 0 and x.stride(1) == 1 and y.stride(1) == 1
+          and x.is_contiguous(memory_format=torch.channels_last) and y.is_contiguous(memory_format=torch.channels_last)
+          and not (x.requires_grad or y.requires_grad))
+    if not ok:
+        return y.add_(upsample2d(x, f))
+    code = _lib.lib().p3d_upfirdn2d_acc(
+        _lib.ptr(x), _lib.ptr(f), _lib.ptr(y), _lib.DTYPE_CODE[x.dtype],
+        _lib.i32x4(w, h, c, n), _lib.i64x4(x.stride(3), x.stride(2), x.stride(1), x.stride(0)),
+        _lib.i32x2(4, 4), _lib.i64x2(f.stride(1), f.stride(0)),
+        _lib.i32x4(2 * w, 2 * h, c, n), _lib.i64x4(y.stride(3), y.stride(2), y.stride(1), y.stride(0)),
+        2, 2, 1, 1, 2, 2, 0, 4.0, _lib.stream_of(x))                             # upsample2d: padding (fw + up - 1) // 2 = 2 in front, gain up^2
+    _lib.check(code, 'upfirdn2d_acc')
+    return y
+
+
 def _plugin():
     from .. import custom_ops
     return custom_ops.get_plugin('upfirdn2d_plugin')

@@ -400,7 +400,7 @@ class SynthesisBlock(torch.nn.Module):
         wants_rgb = self.is_last or self.architecture == 'skip'
         if self.in_channels != 0 and self.architecture != 'resnet':
             x = self.conv0(x, per_layer[0], **conv_kwargs)
-            if wants_rgb and img is not None and x.is_cuda and not torch.is_grad_enabled():
+            if wants_rgb and img is not None and self.img_channels <= 8 and x.is_cuda and not torch.is_grad_enabled():
                 img = self._carry_image(img)                     # (independent of the convolutions: done first so that conv1 can add into it)
                 x, rgb_done = self.conv1(x, per_layer[1], rgb=(self.torgb, per_layer[self.num_conv], img), **conv_kwargs)
                 img_carried = True
@@ -410,6 +410,18 @@ class SynthesisBlock(torch.nn.Module):
         else:
             img_carried = False
 
+        if (wants_rgb and not rgb_done and img is not None and not img_carried and self._in_div == 2 and self.img_channels > 8 and self.img_channels % 4 == 0
+                and img.is_cuda and not torch.is_grad_enabled() and fmt == torch.channels_last and img.is_contiguous(memory_format=torch.channels_last)):
+            # wide skip image (the 96 tri-plane channels), device inference: ToRGB first, then its upsampled predecessor is added INTO it by the
+            # upsampling launch — one pass over the image instead of three (upsample, ToRGB, add)
+            misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
+            y = self.torgb(x, per_layer[self.num_conv], fused_modconv=fused_modconv)
+            if y.dtype == torch.float32 and y.is_contiguous(memory_format=torch.channels_last):
+                img = upfirdn2d.upsample2d_add_(y, img, self.resample_filter)
+            else:
+                img = self._accumulate_image(self._carry_image(img), y, fmt)
+            assert x.dtype == dtype and img.dtype == torch.float32
+            return x, img
         if img is not None and not img_carried:
             img = self._carry_image(img)
         if wants_rgb and not rgb_done:
