@@ -346,6 +346,11 @@ int p3d_pixel_sum(const void* p, float* out, int dtype, int32_t channels_last, i
 int p3d_up2_fir_f16(const void* x, const void* w, void* y, const void* zeros128, const float* bias, const float* noise,
                     const float* noise_strength, const float* fir_yx_host, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co,
                     int64_t w_img_stride, float conv_gain, int32_t act, float act_gain, float clamp, p3d_stream_t stream);
+/* The same layer for fp32 tensors in the bf16x3 formulation (P3D_F32_BF16X3): w = p3d_modulate_weights(..., dtype P3D_F32_BF16X3)
+ * [N or 1][Co][9][Ci] in its [32 x hi | 32 x lo] K rows, x / y fp32.  Arguments as p3d_up2_fir_f16.                        */
+int p3d_up2_fir_bf16x3(const void* x, const void* w, void* y, const void* zeros128, const float* bias, const float* noise,
+                       const float* noise_strength, const float* fir_yx_host, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co,
+                       int64_t w_img_stride, float conv_gain, int32_t act, float act_gain, float clamp, p3d_stream_t stream);
 
 /* ---- 4x4 FIR + layer epilogue, channels-last --------------------------------------------------
  * The tail of every x2 synthesis layer in one pass: upfirdn2d(up = down = 1, 4x4 filter f [4][4] fp32 contiguous,

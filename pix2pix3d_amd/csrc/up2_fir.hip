@@ -339,3 +339,217 @@ extern "C" int p3d_up2_fir_f16(const void* x, const void* w, void* y, const void
     count_launch(FAM_CONV);
     return check_launch("up2_fir_f16");
 }
+
+// ---- the same layer for the fp32 backbone (bf16x3) ---------------------------------------------------------------------------------------
+// fp32 tensors, every product as three bf16 MFMAs of (hi, lo) splits (csrc/conv2d.hip, "bf16x3"): activations are split in registers,
+// the weights arrive pre-split from p3d_modulate_weights (dtype P3D_F32_BF16X3: K rows of [32 x hi | 32 x lo] per 32 input channels).
+// Same decomposition as above — a 28 x 28 tile of final pixels x 32 output channels per block, four parity classes accumulated at once
+// from one 17 x 17 halo slab per 32-channel chunk — in the simpler two-buffer form of conv3x3_halo_kernel: a chunk's slab (39 KB of fp32)
+// and its nine weight tiles (36 KB) stream in under the previous chunk's 108 MFMAs per wave, one rendezvous per chunk.  The
+// transposed-conv tile stays fp32 in LDS (131 KB) for the FIR, so there is ONE block per CU; the fp32 (2H+1)^2 intermediate of the
+// two-kernel form (135 MB each way at 256^2 x 128 channels, batch 4) never exists.
+namespace p3d {
+
+typedef __bf16 ubf8 __attribute__((ext_vector_type(8)));
+constexpr int UB_SW = 18;                                       // slab pixels per slab row (17 used)
+constexpr int UB_SLAB_PIECES = (17 * UB_SW + 7) / 8;            // 39 DMA pieces of 8 pixels x 128 B
+constexpr int UB_SLAB_SLOTS = UB_SLAB_PIECES * 64;              // 16-byte slots per slab buffer (39936 B)
+constexpr int UB_WT_SLOTS = 9 * UF_BN * 8;                      // 16-byte slots of a chunk's nine weight tiles (36864 B)
+constexpr int UB_CT_FLOATS = 32 * 32 * UF_BN;                   // 131072 B
+constexpr int UB_LDS = (2 * (UB_SLAB_SLOTS + UB_WT_SLOTS) * 16 > UB_CT_FLOATS * 4 + UF_TILE * UF_TILE * 4) ? 2 * (UB_SLAB_SLOTS + UB_WT_SLOTS) * 16
+                                                                                                           : UB_CT_FLOATS * 4 + UF_TILE * UF_TILE * 4;
+
+__device__ __forceinline__ void ub_split(const uf4& a0, const uf4& a1, ubf8& hi, ubf8& lo)
+{
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = a0[e], y = a1[e];
+        const __bf16 hx = (__bf16)x, hy = (__bf16)y;
+        hi[e] = hx; hi[4 + e] = hy;
+        lo[e] = (__bf16)(x - (float)hx); lo[4 + e] = (__bf16)(y - (float)hy);
+    }
+    asm volatile("s_nop 0" : "+v"(hi), "+v"(lo));              // conversion -> MFMA operand hazard: see split8 in render_device.h
+}
+
+__global__ void __launch_bounds__(256, 1) up2_fir_bf16x3_kernel(Up2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) char ub_lds[];
+    uf4* const slab = (uf4*)ub_lds;                                              // [2][UB_SLAB_SLOTS]
+    uf4* const wt = slab + 2 * UB_SLAB_SLOTS;                                    // [2][UB_WT_SLOTS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.z;
+    const int ncb = a.Co / UF_BN;
+    int mt, cb;
+    { const int L = blockIdx.x, q = L >> 3, r = L & 7; cb = q % ncb; mt = (q / ncb) * 8 + r; }
+    if (mt >= a.tiles) return;
+    const int ty = mt / a.tiles_x, tx = mt - ty * a.tiles_x;
+    const int cy0 = 14 * ty - 1, cx0 = 14 * tx - 1, co0 = cb * UF_BN;
+    const float* const xin = (const float*)a.x + (int64_t)n * a.H * a.W * a.Ci;
+    const float* const wgt = (const float*)a.w + (int64_t)n * a.w_img_stride;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const int pos = tid & 7, grow = tid >> 3;                                     // DMA lane: 16-byte position / row within a 32-row pass
+    const int kchunks = a.Ci / 32;
+
+    auto stage = [&](int cc, int buf) {
+#pragma unroll
+        for (int p = 0; p < (UB_SLAB_PIECES * 8 + 31) / 32; ++p) {               // slab: 10 passes of 32 pixel rows
+            const int row = grow + 32 * p;
+            if (row >= UB_SLAB_PIECES * 8) break;                                // wave-uniform (a wave's rows are whole groups of 8)
+            const int sy = row / UB_SW, sx = row - sy * UB_SW;
+            const int iy = cy0 - 1 + sy, ix = cx0 - 1 + sx;
+            const bool ok = (sy < 17) & (sx < 17) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
+            const float* src = ok ? xin + ((int64_t)iy * a.W + ix) * a.Ci + cc * 32 + (pos ^ ((row >> 1) & 7)) * 4 : (const float*)a.zeros;
+            __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)&slab[buf * UB_SLAB_SLOTS + (row - (grow & 7)) * 8], 16, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {                                            // weights: tap p, 32 rows (co) of 128 B
+            const int row = grow, co = co0 + row;
+            const float* src = wgt + ((int64_t)co * 9 + kTapW[p]) * a.Ci + cc * 32 + (pos ^ ((row >> 1) & 7)) * 4;
+            __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)&wt[buf * UB_WT_SLOTS + (p * UF_BN + wave * 8) * 8], 16, 0, 0);
+        }
+    };
+
+    uf16 acc[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][i][r] = 0.f;
+    const int frow = lane & 31, fk = lane >> 5;
+    int apix[2];                                                                 // slab pixel of this lane's positions under offset (0, 0)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) apix[i] = (wave * 4 + 2 * i + (frow >> 4) + 1) * UB_SW + (frow & 15) + 1;
+
+    stage(0, 0);
+    __syncthreads();
+    for (int cc = 0; cc < kchunks; ++cc) {
+        const int buf = cc & 1;
+        if (cc + 1 < kchunks) stage(cc + 1, buf ^ 1);
+        const uf4* const sl = slab + buf * UB_SLAB_SLOTS;
+        const uf4* const wl = wt + buf * UB_WT_SLOTS;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {                                            // two 16-channel K steps per chunk
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                ubf8 ah[2][2], al[2][2];                                         // [A offset of the phase][i]
+#pragma unroll
+                for (int ao = 0; ao < kPhaseNA[p]; ++ao)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int q = apix[i] + kPhaseDy[p][ao] * UB_SW + kPhaseDx[p][ao], key = (q >> 1) & 7;
+                        ub_split(sl[q * 8 + ((4 * m + 2 * fk) ^ key)], sl[q * 8 + ((4 * m + 2 * fk + 1) ^ key)], ah[ao][i], al[ao][i]);
+                    }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int slot = p * 3 + j, ao = kTapA[slot], cls = kTapCls[slot];
+                    const int rb = slot * UF_BN + frow;
+                    const ubf8 bh = __builtin_bit_cast(ubf8, wl[rb * 8 + ((2 * m + fk) ^ ((frow >> 1) & 7))]);
+                    const ubf8 bl = __builtin_bit_cast(ubf8, wl[rb * 8 + ((4 + 2 * m + fk) ^ ((frow >> 1) & 7))]);
+#pragma unroll
+                    for (int term = 0; term < 3; ++term)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            acc[cls][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(term >= 2 ? al[ao][i] : ah[ao][i], (term & 1) ? bl : bh, acc[cls][i], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                                         // drains the DMA of chunk cc + 1 and fences the buffer swap
+    }
+
+    // ---- the four class tiles -> one fp32 image [32][32][32 ch] ---------------------------------------------------------------
+    float* const ct = (float*)ub_lds;
+    float* const nz = ct + UB_CT_FLOATS;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int py = c >> 1, px = c & 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pp = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                const int row = 2 * (pp >> 4) + py, col = 2 * (pp & 15) + px;
+                ct[(row * 32 + col) * UF_BN + frow] = acc[c][i][r] * a.conv_gain;
+            }
+    }
+    const int OH = 2 * a.H, OW = 2 * a.W;
+    const int oy0 = UF_TILE * ty, ox0 = UF_TILE * tx;
+    {
+        const float ns = a.noise ? a.noise_strength[0] : 0.f;
+        for (int e = tid; e < UF_TILE * UF_TILE; e += 256) {
+            const int oy = oy0 + e / UF_TILE, ox = ox0 + e % UF_TILE;
+            nz[e] = (a.noise && oy < OH && ox < OW) ? a.noise[(int64_t)oy * OW + ox] * ns : 0.f;
+        }
+    }
+    __syncthreads();
+
+    // ---- separable 4-tap FIR down the 28 rows of a column, 4 channels per thread -------------------------------------------------
+    const int chunk = tid & 7, xo = tid >> 3;
+    if (xo >= UF_TILE) return;
+    const int ox = ox0 + xo;
+    if (ox >= OW) return;
+    uf4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bias = *(const uf4*)(a.bias + co0 + chunk * 4);
+    float* const yout = (float*)a.y + (int64_t)n * OH * OW * a.Co + co0 + chunk * 4;
+    uf4 out[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[q] = uf4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < UF_TILE + 3; ++j) {                                      // transposed-conv row 1 + j of the tile
+        uf4 h = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) h += *(const uf4*)(ct + (((1 + j) * 32 + xo + 1 + kx) * UF_BN + chunk * 4)) * a.fx[kx];
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            const int m = j - ky;
+            if (m >= 0 && m < UF_TILE) out[m & 3] += h * a.fy[ky];
+        }
+        const int m = j - 3;
+        if (m >= 0) {
+            const int oy = oy0 + m;
+            uf4 v = out[m & 3] + nz[m * UF_TILE + xo] + bias;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = v[e];
+                if (a.act == 1) t = t > 0.f ? t : 0.2f * t;
+                t *= a.act_gain;
+                if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
+                v[e] = t;
+            }
+            out[m & 3] = uf4{0.f, 0.f, 0.f, 0.f};
+            if (oy < OH) *(uf4*)(yout + ((int64_t)oy * OW + ox) * a.Co) = v;
+        }
+    }
+}
+
+} // namespace p3d
+
+extern "C" int p3d_up2_fir_bf16x3(const void* x, const void* w, void* y, const void* zeros128, const float* bias, const float* noise,
+                                  const float* noise_strength, const float* fir_yx_host, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co,
+                                  int64_t w_img_stride, float conv_gain, int32_t act, float act_gain, float clamp, p3d_stream_t stream)
+{
+    using namespace p3d;
+    P3D_REQUIRE(x && w && y && zeros128 && fir_yx_host, "up2_fir_bf16x3: null pointer");
+    P3D_REQUIRE(n_img >= 1 && h >= 1 && wdt >= 1, "up2_fir_bf16x3: bad sizes");
+    P3D_REQUIRE(act == 0 || act == 1, "up2_fir_bf16x3: act must be 0 (linear) or 1 (lrelu)");
+    if (ci % 32 != 0 || co % UF_BN != 0) return fail(P3D_ERR_UNSUPPORTED, "up2_fir_bf16x3: Ci=%d and Co=%d must be multiples of 32", ci, co);
+    P3D_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)zeros128 | (uintptr_t)bias) & 15u) == 0, "up2_fir_bf16x3: pointers must be 16-byte aligned");
+    P3D_REQUIRE((int64_t)h * wdt * ci * 4 < (1ll << 31), "up2_fir_bf16x3: image beyond 32-bit offsets");
+    Up2Args a{};
+    a.x = x; a.w = w; a.y = y; a.zeros = zeros128; a.bias = bias; a.noise = noise; a.noise_strength = noise_strength;
+    a.N = n_img; a.H = h; a.W = wdt; a.Ci = ci; a.Co = co; a.w_img_stride = w_img_stride; a.conv_gain = conv_gain;
+    for (int k = 0; k < 4; ++k) { a.fy[k] = fir_yx_host[k]; a.fx[k] = fir_yx_host[4 + k]; }
+    a.act = act; a.act_gain = act_gain; a.clamp = clamp;
+    const int tiles_y = (2 * h + UF_TILE - 1) / UF_TILE;
+    a.tiles_x = (2 * wdt + UF_TILE - 1) / UF_TILE;
+    a.tiles = a.tiles_x * tiles_y;
+    const int64_t blocks = (int64_t)((a.tiles + 7) / 8 * 8) * (co / UF_BN);
+    P3D_REQUIRE(blocks < (1ll << 31) && n_img < 65536, "up2_fir_bf16x3: bad launch size");
+    static std::atomic<uint64_t> once_devs{0};
+    const hipError_t e = reserve_lds_once((const void*)up2_fir_bf16x3_kernel, UB_LDS, once_devs);
+    if (e != hipSuccess) return fail(P3D_ERR_LAUNCH, "up2_fir_bf16x3: cannot reserve %d B of LDS: %s", UB_LDS, hipGetErrorString(e));
+    hipLaunchKernelGGL(up2_fir_bf16x3_kernel, dim3((unsigned)blocks, 1, n_img), dim3(256), UB_LDS, (hipStream_t)stream, a);
+    count_launch(FAM_CONV);
+    return check_launch("up2_fir_bf16x3");
+}

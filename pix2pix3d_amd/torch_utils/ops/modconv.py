@@ -46,6 +46,7 @@ _lib.register('p3d_conv2d_nhwc_workspace', _i64, [ctypes.c_int] + [_i32] * 5 + [
 _lib.register('p3d_conv3x3_torgb_f16', ctypes.c_int, [_vp] * 8 + [_i32, _f32] + [_i32] * 5 + [ctypes.c_int64, _i32, _f32, _f32, _vp])
 _lib.register('p3d_conv2d_nhwc_scaled', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp] + [_i32] * 5 + [ctypes.c_int64] + [_i32] * 3 + [_f32, _f32, _vp, ctypes.c_int64, _vp])
 _lib.register('p3d_demod_coefs', ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp])
+_lib.register('p3d_up2_fir_bf16x3', ctypes.c_int, [_vp] * 8 + [_i32] * 5 + [ctypes.c_int64, _f32, _i32, _f32, _f32, _vp])
 _lib.register('p3d_up2_fir_f16', ctypes.c_int, [_vp] * 8 + [_i32] * 5 + [ctypes.c_int64, _f32, _i32, _f32, _f32, _vp])
 _lib.register('p3d_fir4_bias_act_nhwc', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int] + [_i32] * 9 + [_f32, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _vp])
 _lib.register('p3d_fc_forward', ctypes.c_int, [_vp] * 4 + [_i32] * 3 + [_i64, _f32, _f32, _i32, _f32, _f32, _f32, _vp])
@@ -116,6 +117,9 @@ def torgb_supported(x, weight, styles, fused_modconv):
 
 BF16X3 = 'bf16x3'            # dtype tag: fp32 tensors whose products run as three bf16 MFMAs of (hi, lo) splits (csrc/conv2d.hip)
 DTYPE_F32_BF16X3 = 3         # p3d_dtype code of that formulation (include/p3d_hip.h)
+fuse_up2_f32_min_res = int(os.environ.get('P3D_FUSE_UP2_F32_MIN_RES', 1 << 30))      # fp32 (bf16x3) x2 layers from this input resolution up take the one-kernel form.
+                             # OFF by default: measured SLOWER than transposed conv + FIR (256->128 @128^2: 331 vs 302 us, 512->256 @64^2: 313 vs 234 us, batch 4) — its fp32
+                             # tile needs 131 KB of LDS, i.e. one 4-wave block per CU with nothing to hide the staging behind; kept, with its parity test, as the starting point
 fuse_up2 = os.environ.get('P3D_FUSE_UP2', '1') != '0'       # fp16 x2 layers: transposed conv + FIR + epilogue in one kernel (csrc/up2_fir.hip); 0 = the two-kernel form
 split_bf16 = os.environ.get('P3D_BF16X3', '1') != '0'      # use it for the fp32 layers that are bound by the fp32 matrix rate
 split_bf16_min_pixels = int(os.environ.get('P3D_BF16X3_MIN_PIXELS', 16))       # every fp32 3x3 layer (measured: 4096 -> 462, 1024 -> 472, 256 -> 474, 16 -> 476 img/s)
@@ -477,7 +481,8 @@ def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=No
     if up == 1:
         y = conv2d(x, wmod, noise=noise_const, noise_strength=noise_strength, split=split)
         return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
-    if fuse_up2 and act_idx is not None and x.dtype == torch.float16 and x.shape[1] % 32 == 0 and wmod.shape[1] % 32 == 0:
+    if fuse_up2 and act_idx is not None and x.shape[1] % 32 == 0 and wmod.shape[1] % 32 == 0 and (
+            x.dtype == torch.float16 or (split and min(x.shape[2], x.shape[3]) >= fuse_up2_f32_min_res)):
         taps = _separable_fir(resample_filter)
         if taps is not None:
             return up2_fir(x, wmod, taps, bias, noise_const, noise_strength, act_idx, act_gain, clampv)
@@ -510,8 +515,10 @@ def _separable_fir(f):
 
 def up2_fir(x, wmod, taps, bias, noise, noise_strength, act, act_gain, clamp):
     """The whole x2 layer in one launch: x NHWC fp16 [N,Ci,H,W], wmod [N or 1][Co][9][Ci] -> NHWC fp16 [N,Co,2H,2W]
-    (csrc/up2_fir.hip: transposed conv, 4x4 FIR, noise, bias, activation, clamp; the (2H+1)^2 intermediate stays in LDS)."""
-    assert _is_nhwc_f16(x) and wmod.dtype == torch.float16 and wmod.is_contiguous() and wmod.shape[2] == 9
+    (csrc/up2_fir.hip: transposed conv, 4x4 FIR, noise, bias, activation, clamp; the (2H+1)^2 intermediate stays in LDS).
+    fp32 x with bf16x3-layout weights (modulate_weights(dtype=BF16X3)) takes the bf16x3 build of the same kernel."""
+    split = x.dtype == torch.float32
+    assert _is_nhwc(x) and wmod.dtype == x.dtype and wmod.is_contiguous() and wmod.shape[2] == 9
     n, ci, h, w = x.shape
     co = wmod.shape[1]
     assert wmod.shape[0] in (1, n) and wmod.shape[3] == ci
@@ -520,13 +527,14 @@ def up2_fir(x, wmod, taps, bias, noise, noise_strength, act, act_gain, clamp):
     b32 = None if bias is None else bias.detach().float().contiguous()
     nz = None if noise is None else noise.detach().float().contiguous()
     ns = None if noise is None else noise_strength.detach().float().reshape(1).contiguous()
-    with _lib.kernel_timer('conv_f16', x):
-        code = _lib.lib().p3d_up2_fir_f16(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), _lib.ptr(_zeros_page(x.device)), _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns),
-                                          ctypes.cast(taps, ctypes.c_void_p), n, h, w, ci, co, stride, 1.0, int(act), float(act_gain), float(clamp), _lib.stream_of(x))
-    _lib.check(code, 'up2_fir_f16')
+    with _lib.kernel_timer('conv_bf16x3' if split else 'conv_f16', x):
+        fn = _lib.lib().p3d_up2_fir_bf16x3 if split else _lib.lib().p3d_up2_fir_f16
+        code = fn(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), _lib.ptr(_zeros_page(x.device)), _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns),
+                  ctypes.cast(taps, ctypes.c_void_p), n, h, w, ci, co, stride, 1.0, int(act), float(act_gain), float(clamp), _lib.stream_of(x))
+    _lib.check(code, 'up2_fir')
     log = _lib.kernel_events.get('conv_flops')
     if log is not None:
-        log.append((str(x.dtype), 2.0 * n * ci * co * 9 * h * w))
+        log.append(('bf16x3' if split else str(x.dtype), 2.0 * n * ci * co * 9 * h * w))
     return y
 
 

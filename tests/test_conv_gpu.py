@@ -397,3 +397,56 @@ def test_last_conv_and_torgb_in_one_launch(hip_lib, img_channels, in_ch, res):
     assert torch.equal(x1, x0)                                                 # same kernel, same K order
     # both contract fp16 activations with the modulated weights rounded to fp16 (as the reference's fp16 layer does); fp32 summation order differs
     assert rel_err(i1.cpu().numpy(), i0.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('ci,co,h,w,n,noise,act,clamp', [
+    (256, 128, 128, 128, 2, True, 'lrelu', None),      # backbone b256.conv0
+    (512, 256, 64, 64, 2, True, 'lrelu', None),        # backbone b128.conv0 (sixteen chunks)
+    (64, 32, 14, 14, 1, False, 'linear', None),        # exactly one tile
+    (96, 96, 33, 20, 3, True, 'lrelu', 0.5),           # ragged tiles, three chunks, clamp active
+    (32, 64, 6, 4, 2, True, 'lrelu', None),            # image smaller than a tile
+])
+def test_x2_layer_in_one_kernel_fp32_as_bf16x3(hip_lib, ci, co, h, w, n, noise, act, clamp):
+    """The bf16x3 build of csrc/up2_fir.hip (fp32 tensors) against the same chain in fp64 torch and against the two-kernel form:
+    the accuracy class of every other bf16x3 layer (1e-5 of the range)."""
+    from pix2pix3d_amd import _lib
+    from pix2pix3d_amd.torch_utils.ops import modconv, upfirdn2d
+    torch.manual_seed(ci + co + h)
+    x = _nhwc(torch.randn(n, ci, h, w, device='cuda'))
+    weight = torch.randn(co, ci, 3, 3, device='cuda')
+    styles = torch.randn(n, ci, device='cuda') + 1
+    bias = torch.randn(co, device='cuda')
+    nz = torch.randn(2 * h, 2 * w, device='cuda') if noise else None
+    ns = torch.tensor(0.3, device='cuda') if noise else None
+    f = upfirdn2d.setup_filter([1, 3, 3, 1], device=torch.device('cuda'))
+    gain = float(np.sqrt(2)) if act == 'lrelu' else 1.0
+    prev = (modconv.fuse_up2_f32_min_res, modconv.shared_weight_max_pixels)
+    try:
+        modconv.shared_weight_max_pixels = 0
+        modconv.fuse_up2_f32_min_res = 1
+        u0 = _lib.launch_count('upfirdn2d')
+        y1 = modconv.synthesis_layer(x, weight, styles, bias, 2, f, noise_const=nz, noise_strength=ns, act=act, act_gain=gain, clamp=clamp)
+        assert _lib.launch_count('upfirdn2d') == u0                              # no separate FIR
+        modconv.fuse_up2_f32_min_res = 1 << 30
+        y0 = modconv.synthesis_layer(x, weight, styles, bias, 2, f, noise_const=nz, noise_strength=ns, act=act, act_gain=gain, clamp=clamp)
+    finally:
+        modconv.fuse_up2_f32_min_res, modconv.shared_weight_max_pixels = prev
+    assert y1.shape == (n, co, 2 * h, 2 * w) and y1.dtype == torch.float32 and y1.is_contiguous(memory_format=torch.channels_last)
+    wq = weight.double().cpu()[None] * styles.double().cpu()[:, None, :, None, None]
+    wq = wq * (wq.square().sum(dim=[2, 3, 4], keepdim=True) + 1e-8).rsqrt()
+    xd = x.double().cpu()
+    ct = torch.stack([F.conv_transpose2d(xd[i:i + 1], wq[i].transpose(0, 1), stride=2)[0] for i in range(n)])
+    fd = (f.double().cpu() * 4).flip([0, 1])
+    yr = F.conv2d(F.pad(ct, [1, 1, 1, 1]).reshape(n * co, 1, 2 * h + 3, 2 * w + 3), fd[None, None]).reshape(n, co, 2 * h, 2 * w)
+    if noise:
+        yr = yr + (nz.double().cpu() * 0.3)
+    yr = yr + bias.double().cpu().view(1, -1, 1, 1)
+    if act == 'lrelu':
+        yr = F.leaky_relu(yr, 0.2)
+    yr = yr * gain
+    if clamp is not None:
+        yr = yr.clamp(-clamp, clamp)
+    e1, e0 = rel_err(y1.double().cpu().numpy(), yr.numpy()), rel_err(y0.double().cpu().numpy(), yr.numpy())
+    print(ci, co, h, w, 'fused', e1, 'two-kernel', e0)
+    tol = 1e-5 if clamp is None else 1e-4                                        # (a clamp at 0.5 shrinks the range the error is measured against)
+    assert e1 < tol and e0 < tol
