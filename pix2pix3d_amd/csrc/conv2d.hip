@@ -56,7 +56,7 @@ __device__ __forceinline__ void split_bf16x8(const f32x4& a0, const f32x4& a1, b
     }
     // every converted register complete before the first MFMA reads any of them: see the hazard note at split8 in render_device.h
     // (v_cvt_pk_bf16_f32 -> MFMA operand at the compiler's two wait states returned stale 16-lane groups in the ray-marcher)
-    asm volatile("s_nop 0" : "+v"(hi), "+v"(lo));
+    asm volatile("s_nop 4" : "+v"(hi), "+v"(lo));
 }
 
 struct ConvTap { int dy, dx, widx; };

@@ -413,8 +413,9 @@ typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 // HAZARD (measured on gfx950, ROCm 7.2 hipcc): an MFMA that reads, as SrcB, a register written by v_cvt_pk_bf16_f32 two wait states
 // earlier — the distance the compiler's own hazard nops give — now and then sees the OLD value of one 16-lane group: 5 % of the rays of a
 // render off by 1e-3, and whether a build shows it depends on how the scheduler happened to interleave conversions and MFMAs (one
-// version of this kernel was clean, the next two were not, with identical decoder code).  The empty asm below makes every converted
-// register complete before the first MFMA that uses any of them (>= 5 wait states in the code that results), which is clean.
+// version of this kernel was clean, the next two were not, with identical decoder code).  The asm below ties every converted register to
+// one point after the conversions and holds the wave there for five wait states before any MFMA can read them (a build with >= 5 wait
+// states between conversion and MFMA measured clean; 2 did not; the threshold in between was not searched).
 __device__ __forceinline__ void split8(const float* v, bf8& hi, bf8& lo)
 {
 #pragma unroll
@@ -424,7 +425,7 @@ __device__ __forceinline__ void split8(const float* v, bf8& hi, bf8& lo)
         hi[e] = hx;
         lo[e] = (__bf16)(x - (float)hx);
     }
-    asm volatile("s_nop 0" : "+v"(hi), "+v"(lo));
+    asm volatile("s_nop 4" : "+v"(hi), "+v"(lo));
 }
 __device__ __forceinline__ f32x16 mfma3(const bf8& ah, const bf8& al, const bf8& bh, const bf8& bl, f32x16 c)
 {

@@ -368,7 +368,7 @@ __device__ __forceinline__ void ub_split(const uf4& a0, const uf4& a1, ubf8& hi,
         hi[e] = hx; hi[4 + e] = hy;
         lo[e] = (__bf16)(x - (float)hx); lo[4 + e] = (__bf16)(y - (float)hy);
     }
-    asm volatile("s_nop 0" : "+v"(hi), "+v"(lo));              // conversion -> MFMA operand hazard: see split8 in render_device.h
+    asm volatile("s_nop 4" : "+v"(hi), "+v"(lo));              // conversion -> MFMA operand hazard: see split8 in render_device.h
 }
 
 __global__ void __launch_bounds__(256, 1) up2_fir_bf16x3_kernel(Up2Args a)
