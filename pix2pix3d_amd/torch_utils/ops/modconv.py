@@ -308,22 +308,24 @@ def plain_layer(x, weight, bias, weight_gain, resample_filter, down, padding, ac
     co, ci, k, _ = weight.shape
     if x.shape[2] * x.shape[3] <= gemm_max_pixels:
         return _plain_small(x, weight, bias, weight_gain, resample_filter, down, padding, act, act_gain, clamp)
-    wmod = _cached_weight(weight, ('mfma', x.dtype, float(weight_gain)),
+    split = use_split_bf16(x, ci)                          # fp32 layers (the label-map Encoder of G.mapping, fp32 discriminator blocks) as bf16x3 too
+    wdt = BF16X3 if split else x.dtype
+    wmod = _cached_weight(weight, ('mfma', wdt, float(weight_gain)),
                           lambda: modulate_weights(weight, torch.ones([1, ci], dtype=torch.float32, device=weight.device), demodulate=False,
-                                                   pre_scale=float(weight_gain), dtype=x.dtype))
+                                                   pre_scale=float(weight_gain), dtype=wdt))
     x = x.contiguous(memory_format=torch.channels_last)
     act_idx = {'linear': 0, 'lrelu': 1}[act]
     clampv = -1.0 if clamp is None else float(clamp)
     if down == 1:
         assert padding == k // 2
-        return conv2d(x, wmod, bias=bias, act=act_idx, gain=act_gain, clamp=clampv)
+        return conv2d(x, wmod, bias=bias, act=act_idx, gain=act_gain, clamp=clampv, split=split)
     fw = resample_filter.shape[-1]
     p0, p1 = padding + (fw - down + 1) // 2, padding + (fw - down) // 2
     if k == 1:
         x = upfirdn2d.upfirdn2d(x, resample_filter, down=down, padding=[p0, p1, p0, p1])
-        return conv2d(x, wmod, bias=bias, act=act_idx, gain=act_gain, clamp=clampv)
+        return conv2d(x, wmod, bias=bias, act=act_idx, gain=act_gain, clamp=clampv, split=split)
     x = upfirdn2d.upfirdn2d(x, resample_filter, padding=[p0, p1, p0, p1])
-    return conv2d(x, wmod, bias=bias, act=act_idx, gain=act_gain, clamp=clampv, down=2)
+    return conv2d(x, wmod, bias=bias, act=act_idx, gain=act_gain, clamp=clampv, down=2, split=split)
 
 
 def fc_supported(x, weight, bias, activation):
