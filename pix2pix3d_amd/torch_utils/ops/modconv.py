@@ -308,7 +308,8 @@ def plain_layer(x, weight, bias, weight_gain, resample_filter, down, padding, ac
     co, ci, k, _ = weight.shape
     if x.shape[2] * x.shape[3] <= gemm_max_pixels:
         return _plain_small(x, weight, bias, weight_gain, resample_filter, down, padding, act, act_gain, clamp)
-    split = use_split_bf16(x, ci)                          # fp32 layers (the label-map Encoder of G.mapping, fp32 discriminator blocks) as bf16x3 too
+    split = use_split_bf16(x, ci)                          # fp32 layers (the label-map Encoder of G.mapping, fp32 discriminator blocks) as bf16x3 too;
+                                                           # narrow inputs (the 6-channel label map: K = 6 products, no averaging) stay exact fp32
     wdt = BF16X3 if split else x.dtype
     wmod = _cached_weight(weight, ('mfma', wdt, float(weight_gain)),
                           lambda: modulate_weights(weight, torch.ones([1, ci], dtype=torch.float32, device=weight.device), demodulate=False,
@@ -330,22 +331,29 @@ def plain_layer(x, weight, bias, weight_gain, resample_filter, down, padding, ac
 
 def fc_supported(x, weight, bias, activation):
     """FullyConnectedLayer calls the one-launch kernel covers: a few fp32 rows on the device, inference."""
-    return (enabled and x.is_cuda and x.ndim == 2 and x.dtype == torch.float32 and 1 <= x.shape[0] <= 16 and x.shape[1] % 4 == 0
-            and x.shape[0] * x.shape[1] <= 16384 and activation in ('linear', 'lrelu') and weight.dtype == torch.float32
-            and _no_grad_needed(x, weight, bias))
+    return (enabled and x.is_cuda and x.ndim == 2 and x.dtype == torch.float32 and 1 <= x.shape[0] <= 16
+            and x.shape[0] * ((x.shape[1] + 3) // 4 * 4) <= 16384 and activation in ('linear', 'lrelu') and weight.dtype == torch.float32
+            and _no_grad_needed(x, weight, bias))          # (in_features that are not a multiple of 4 — the 25 camera parameters — are zero-padded in fc())
 
 
 def fc(x, weight, bias, weight_gain, bias_gain, activation='linear', out_scale=1.0):
     """act((x @ weight.T) * weight_gain + bias * bias_gain) * def_gain * out_scale in one launch (networks_stylegan2.py:113-127)."""
     n, out_f = x.shape[0], weight.shape[0]
     x32 = x.detach()
+    in_f = x.shape[1]
+    if in_f % 4 != 0:                                      # whole float4 rows for the kernel: zero columns change nothing
+        pad = 4 - in_f % 4
+        x32 = torch.nn.functional.pad(x32, [0, pad])
+        w32 = _cached_weight(weight, ('fc_pad', pad), lambda: torch.nn.functional.pad(weight.detach().float(), [0, pad]).contiguous())
+        in_f += pad
+    else:
+        w32 = weight.detach().contiguous()
     if x32.stride(1) != 1 or x32.stride(0) % 4 != 0 or x32.data_ptr() % 16 != 0:
         x32 = x32.contiguous()
-    w32 = weight.detach().contiguous()
     b32 = None if bias is None else bias.detach().float().contiguous()
     y = torch.empty([n, out_f], dtype=torch.float32, device=x.device)
     act_gain = bias_act.activation_funcs[activation].def_gain
-    code = _lib.lib().p3d_fc_forward(_lib.ptr(x32), _lib.ptr(w32), _lib.ptr(b32), _lib.ptr(y), n, x.shape[1], out_f, x32.stride(0) if n > 1 else x.shape[1], float(weight_gain), float(bias_gain),
+    code = _lib.lib().p3d_fc_forward(_lib.ptr(x32), _lib.ptr(w32), _lib.ptr(b32), _lib.ptr(y), n, in_f, out_f, x32.stride(0) if n > 1 else in_f, float(weight_gain), float(bias_gain),
                                      {'linear': 1, 'lrelu': 3}[activation], 0.2, float(act_gain), float(out_scale), _lib.stream_of(x))
     _lib.check(code, 'fc_forward')
     return y
@@ -365,6 +373,7 @@ def fc_multi(jobs):
     """Several FullyConnectedLayer evaluations in one launch.  ``jobs``: list of (x [n, in], layer, out_scale) with ``layer`` a
     FullyConnectedLayer every one of which passes fc_supported and all x with the same row count; returns the list of outputs."""
     n = jobs[0][0].shape[0]
+    assert all(x.shape[1] % 4 == 0 for x, _, _ in jobs)
     outs, keep = [], []
     arr = (_FcJob * len(jobs))()
     for k, (x, layer, out_scale) in enumerate(jobs):
