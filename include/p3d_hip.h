@@ -165,7 +165,10 @@ int p3d_pack_decoder_bf16x3(const float* w1_a, const float* b1_a, const float* w
  * Outputs: feat [N*M][32*n_nets] (already *2-1), depth [N*M] (clamped to the global sample-depth
  * range, ray_marcher.py:49-50), wsum [N*M].  minmax_ws: 2 x uint32 device scratch.
  * dbg_fine [N*M][S_f] (sorted importance depths) and dbg_wcoarse [N*M][S_c-1] are optional.
- * Returns P3D_ERR_UNSUPPORTED when S_c or S_f exceed 64 (or S_f == 0).                        */
+ * Returns P3D_ERR_UNSUPPORTED when S_c or S_f exceed 64 (or S_f == 0).
+ * Envelope: at most 64 coarse and 1..64 fine samples per ray; clamp_mode 'softplus' (the only mode ray_marcher.py:35 accepts); no
+ * density_noise term (renderer.py:116-117: training-time regulariser, 0 in every shipped configuration); the OSG 32-64-33 decoders.
+ * Outside it the Python mirror takes the tensor-op formulation and says so with a RuntimeWarning (or raises under fused_policy 'require'). */
 int p3d_render_forward(const float* planes_cl, const float* decoder, const float* ray_o, const float* ray_d,
                        const float* u_coarse, const float* u_fine, const float* t_start, const float* t_end,
                        const p3d_render_desc* desc, float* feat, float* depth, float* wsum, uint32_t* minmax_ws,

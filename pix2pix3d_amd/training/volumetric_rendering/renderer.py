@@ -21,6 +21,18 @@ from . import math_utils
 from .ray_marcher import MipRayMarcher2
 
 fused_policy = 'auto'          # 'auto' | 'require' | 'never'
+_warned_routes = set()
+
+
+def _warn_tensor_op_route(who, reason):
+    """A device tensor is about to take the tensor-op formulation instead of the fused kernel: say so, once per reason — a silent
+    fallback would look like the native path in every output but the profile.  (Expected cases: autograd through an entry point without
+    a fused backward, density_noise > 0, more than 64 coarse / fine samples per ray, a decoder that is not the OSG 32-64-33 MLP.)"""
+    key = (who, reason)
+    if key not in _warned_routes:
+        _warned_routes.add(key)
+        import warnings
+        warnings.warn(f'{who}: device tensors on the tensor-op renderer, not the fused HIP kernel: {reason}', RuntimeWarning, stacklevel=3)
 fused_training = True          # graphs that need gradients: fused forward + recompute-in-backward (see _FusedRenderFn)
 fused_backward = True          # ... with the backward on the device kernels of csrc/render_bwd.hip (False: replay the tensor-op renderer)
 mlp_bf16x3 = os.environ.get('P3D_MLP_BF16X3', '1') != '0'      # inference: the decoder MLPs as three bf16 MFMAs per fp32 product (csrc/render_device.h)
@@ -188,8 +200,11 @@ class ImportanceRenderer(torch.nn.Module):
         return None
 
     def _tensor_op_guard(self, planes, reason):
-        if planes.device.type == 'cuda' and fused_policy == 'require':
+        if planes.device.type != 'cuda' or fused_policy == 'never':
+            return
+        if fused_policy == 'require':
             raise RuntimeError(f'ImportanceRenderer: fused HIP path required but unavailable: {reason}')
+        _warn_tensor_op_route(type(self).__name__, reason)
 
     def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options):
         self.plane_axes = self.plane_axes.to(ray_origins.device)
