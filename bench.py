@@ -10,11 +10,16 @@ real architecture, N(0,1) latents, orbit cameras).  Inference shards by image: e
 no data-path collective ("weak" scaling); the only collectives are the barriers bracketing the timed region and a
 MAX-reduce of the elapsed time.  Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
 ``roofline`` for the dominant hand-written kernel (the fused ray-marcher; HIP-event timed inside the timed region, on the
-stream it is launched on; ``frac`` against the HBM roofline on the survey's tap-bytes convention and ``mfma_frac`` against the
-fp32 matrix-core floor of its decoder, which is what actually bounds it), ``cpu_baseline`` (the REFERENCE itself in a child
+stream it is launched on): ``bound`` / ``achieved`` / ``peak`` / ``frac`` name the resource that the committed counter passes of THIS kernel
+(profiles/render_pmc.json, hash-checked against the kernel sources) show closest to its peak, busy units per launch / the LIVE launch
+duration / the resource's peak at 2.4 GHz; ``tap_bytes`` keeps the survey's convention (1 543 algorithmic bytes per sample vs the 8 TB/s
+HBM peak — the taps are served by L1 / L2, so that figure can exceed 1 and is not a bound); ``traffic`` = memory-side bytes per launch from
+the PMC passes; ``exact_fp32`` = the same timed loop with every bf16x3 switch off (exact fp32 MFMA in the backbone and the decoder — the
+reference's own arithmetic class, training_loop.py:278-280); ``cpu_baseline`` (the REFERENCE itself in a child
 process when its checkout is reachable — ``kind: "reference"`` — else the CPU oracle, a port of the reference's force_fp32 CPU
 path — ``kind: "port"``; a bounded sample: batch 1, same resolution and sample counts) and ``train_step`` (one training
-iteration of BASELINE config 3 on the same GPUs: G pass, D pass with R1, flat gradient all-reduce over RCCL).
+iteration of BASELINE config 3 on the same GPUs: the four phases of training_loop.py — Gmain, Greg (density regularisation), Dmain, Dreg (R1)
+— each with its flat gradient all-reduce over RCCL and its Adam step, then the G_ema update).
 """
 import argparse
 import json
@@ -49,9 +54,10 @@ def parse():
     p.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a captured hipGraph')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--miopen-find', action='store_true', help='let MIOpen benchmark its solvers for the vendor-library convs (slow warm-up)')
-    p.add_argument('--cpu-reps', type=int, default=2)
+    p.add_argument('--cpu-reps', type=int, default=4, help='CPU baseline runs per thread count: 1 warm-up + (n - 1) timed (median reported)')
     p.add_argument('--train-step', action='store_true', help='time training iterations of BASELINE config 3 (G pass + D pass with R1 + gradient all-reduce) instead of inference')
     p.add_argument('--no-train-step', action='store_true', help='skip the short train_step extra of the default run')
+    p.add_argument('--no-exact-fp32', action='store_true', help='skip the second timed loop with the bf16x3 switches off')
     p.add_argument('--train-nrr', type=int, default=128, help='neural rendering resolution of the training passes (train.py: 128 for the 512^2 configs)')
     return p.parse_args()
 
@@ -127,32 +133,50 @@ def cpu_baseline(args, G_cpu, kw, info, ws, c):
                       f'faster of {all_threads} / {min(all_threads, 32)} threads ({t:.2f} s/img; host has {os.cpu_count()} logical cores)'}
 
 
-def render_traffic(args, nrr):
-    """Memory-side bytes per launch of the ray-marcher from the committed PMC passes (profiles/render_pmc.json, written by
-    tests/gpu_pmc_traffic.py) — only for the workload it was taken on and only while the kernel sources are the ones it was taken from."""
+def _kernel_source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ('pix2pix3d_amd/csrc/render.hip', 'pix2pix3d_amd/csrc/render_device.h'):
+        h.update(open(os.path.join(ROOT, rel), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def pmc_record(args, nrr, exact=False):
+    """The committed counter passes of the ray-marcher (profiles/render_pmc.json / render_pmc_exact_fp32.json, written by tests/gpu_pmc_render.py)
+    — only for the workload they were taken on and only while the kernel sources are the ones they were taken from (else None: a stale
+    PMC is not quoted)."""
     try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'render_pmc.json')))
-        sys.path.insert(0, os.path.join(ROOT, 'tests'))
-        from gpu_pmc_traffic import kernel_source_hash
-        if args.batch == 4 and args.depth == 128 and nrr == 128 and pmc.get('kernel_src_sha16') == kernel_source_hash():
-            return pmc['traffic_bytes_per_launch']
-    except (OSError, KeyError, ValueError, ImportError):
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'render_pmc_exact_fp32.json' if exact else 'render_pmc.json')))
+        if args.batch == 4 and args.depth == 128 and nrr == 128 and args.dataset == 'seg2cat' and pmc.get('kernel_src_sha16') == _kernel_source_hash():
+            return pmc
+    except (OSError, KeyError, ValueError):
         pass
     return None
 
 
+G_REG_INTERVAL, D_REG_INTERVAL = 4, 16        # train.py:239, 466 (--density_reg_every) and training_loop.py:249: the lazy-regularisation schedule
+R1_GAMMA = 10.0                               # the --gamma of the shipped afhq script (train_scripts/afhq_seg.sh)
+
+
 def train_setup(args, device, world):
     """BASELINE config 3 per GPU: seg2cat generator in training mode (unfused modulation, fp16 SR heads) and the dual discriminator
-    (fp16 top blocks, conv_clamp 256, train.py:289-318, 381-387, 509-512), batch 4, 128^2 rays x 48+48 samples."""
+    (fp16 top blocks, conv_clamp 256, train.py:289-318, 381-387, 509-512), batch 4, 128^2 rays x 48+48 samples; G_ema; one Adam per
+    network with the lazy-regularisation correction of training_loop.py:360-373."""
+    import copy
     from pix2pix3d_amd import configs, dnnlib
     kw = configs.generator_kwargs(args.dataset, depth=(48, 48))
     rk = kw['rendering_kwargs']
     info = configs.dataset_info(args.dataset)
     torch.manual_seed(0)
-    G = dnnlib.util.construct_class_by_name(**kw).to(device).train().requires_grad_(True)
+    G = dnnlib.util.construct_class_by_name(**kw).to(device).train().requires_grad_(False)
     D = dnnlib.util.construct_class_by_name(class_name='training.dual_discriminator.DualDiscriminator', c_dim=25, img_resolution=info['res'], img_channels=3,
                                             channel_base=32768, channel_max=512, num_fp16_res=4, conv_clamp=256, disc_c_noise=0,
-                                            block_kwargs=dict(freeze_layers=0), mapping_kwargs={}, epilogue_kwargs=dict(mbstd_group_size=4)).to(device).train().requires_grad_(True)
+                                            block_kwargs=dict(freeze_layers=0), mapping_kwargs={}, epilogue_kwargs=dict(mbstd_group_size=4)).to(device).train().requires_grad_(False)
+    G_ema = copy.deepcopy(G).eval()
+    opts = {}
+    for name, module, lr, interval in (('G', G, 0.0025, G_REG_INTERVAL), ('D', D, 0.002, D_REG_INTERVAL)):
+        mb = interval / (interval + 1)
+        opts[name] = torch.optim.Adam(module.parameters(), lr=lr * mb, betas=[0 ** mb, 0.99 ** mb], eps=1e-8)
     n = args.batch
     g = torch.Generator().manual_seed(99 + int(os.environ.get('RANK', 0)))
     z = torch.randn(n, 512, generator=g).to(device)
@@ -160,68 +184,122 @@ def train_setup(args, device, world):
         (torch.rand([n, 1, info['res'], info['res']], generator=g) * 2 - 1).to(device)
     c = torch.tensor(np.stack([configs.orbit_camera(7 * k + 3, radius=rk['avg_camera_radius'], pivot=rk['avg_camera_pivot']) for k in range(n)]), dtype=torch.float32).to(device)
     real = {'image': torch.randn(n, 3, info['res'], info['res'], generator=g).to(device), 'image_raw': torch.randn(n, 3, args.train_nrr, args.train_nrr, generator=g).to(device)}
-    return G, D, (z, mask), c, real
+    return dict(G=G, D=D, G_ema=G_ema, opts=opts, z=z, mask=mask, c=c, real=real, rk=rk, seg=info['data_type'] == 'seg', nrr=args.train_nrr, world=world)
 
 
-def train_iteration(G, D, zm, c, real, nrr, world, timers):
-    """One iteration: G pass (mapping + synthesis forward + backward of an image loss; loss.py:440-470 without the loss networks), flat
-    all-reduce of G's gradients (training_loop.py:531-542), D pass on real images with the R1 penalty (loss.py:849-891), flat
-    all-reduce of D's gradients.  ``timers``: dict of lists of (start, end) event pairs per stage."""
+def _finish_phase(module, opt, world):
+    """training_loop.py:528-543: flat gradient all-reduce of the phase's module, then its optimizer step."""
     from pix2pix3d_amd import dp
+    flat = dp.allreduce_gradients(module, world_size=world)
+    opt.step()
+    return flat.numel() * 4 if flat is not None else 0
+
+
+def train_iteration(st, timers, phases=('Gmain', 'Greg', 'Dmain', 'Dreg')):
+    """One iteration with EVERY phase of training_loop.py:487-543 (i.e. what the loop does on an iteration where both lazy regularisers
+    fire): Gmain (loss.py:557-656: mapping + synthesis at 128^2 rays, D on the generated pair, adversarial + image / label-map
+    reconstruction terms; the LPIPS network is not part of this path and is left out), Greg (loss.py:681-706: density regularisation through
+    G.sample_mixed on 2 x 1000 points), Dmain (loss.py:827-869: D on generated and on real images), Dreg (loss.py:871-887: R1 with the
+    double backward), each followed by its flat gradient all-reduce + Adam step; then the G_ema update (training_loop.py:545-557).
+    ``timers``: dict of lists of events, one mark after every phase."""
     from pix2pix3d_amd.torch_utils.ops import conv2d_gradfix
+    F = torch.nn.functional
+    G, D, c, real, rk, world = st['G'], st['D'], st['c'], st['real'], st['rk'], st['world']
+    batch = {'mask': st['mask'], 'pose': c}
+    sizes = {}
 
     def mark(key):
         e = torch.cuda.Event(enable_timing=True); e.record()
         timers.setdefault(key, []).append(e)
     mark('t0')
-    ws = G.mapping(zm[0], c, {'mask': zm[1], 'pose': c}, update_emas=False)     # label-map Encoder + MLP: every run_G of the loop starts here (loss.py:440)
-    out = G.synthesis(ws, c, neural_rendering_resolution=nrr, noise_mode='random')
-    loss = out['image'].float().square().mean() + out['semantic'].float().square().mean() + out['image_raw'].square().mean()
-    loss.backward()
-    mark('g_done')
-    flat_g = dp.allreduce_gradients(G, world_size=world)
-    mark('g_sync')
-    img = {k: v.detach().requires_grad_(True) for k, v in real.items()}
-    logits = D(img, c)
-    with conv2d_gradfix.no_weight_gradients():
-        grads = torch.autograd.grad(outputs=[logits.sum()], inputs=list(img.values()), create_graph=True, only_inputs=True)
-    r1 = sum(gr.square().sum([1, 2, 3]) for gr in grads)
-    (torch.nn.functional.softplus(-logits) + r1 * 5).mean().backward()
-    mark('d_done')
-    flat_d = dp.allreduce_gradients(D, world_size=world)
-    mark('d_sync')
-    sizes = (flat_g.numel() * 4, flat_d.numel() * 4)
-    for m in (G, D):
-        for p in m.parameters():
-            p.grad = None
+    if 'Gmain' in phases:
+        G.requires_grad_(True); st['opts']['G'].zero_grad(set_to_none=True)
+        ws = G.mapping(st['z'], c, batch, update_emas=False)           # label-map Encoder + MLP: every run_G of the loop starts here (loss.py:440)
+        out = G.synthesis(ws, c, neural_rendering_resolution=st['nrr'])      # noise_mode defaults to 'random', as run_G leaves it
+        logits = D({'image': out['image'], 'image_raw': out['image_raw']}, c)
+        loss = F.softplus(-logits).mean()
+        loss = loss + F.smooth_l1_loss(out['image'].float(), real['image']) + F.smooth_l1_loss(out['image_raw'], real['image_raw'])
+        if st['seg']:                                                      # cross_entropy2d on the label map and its raw rendering (loss.py:609-617)
+            tgt = st['mask'].squeeze(1).long()
+            loss = loss + F.cross_entropy(out['semantic'].float(), tgt) + F.cross_entropy(out['semantic_raw'], F.interpolate(st['mask'].float(), size=st['nrr'], mode='nearest').squeeze(1).long())
+        else:
+            loss = loss + F.smooth_l1_loss(out['semantic'].float(), st['mask']) + F.smooth_l1_loss(out['semantic_raw'], F.interpolate(st['mask'], size=st['nrr'], mode='nearest'))
+        loss.backward()
+        sizes['G'] = _finish_phase(G, st['opts']['G'], world)
+        G.requires_grad_(False)
+        del out, logits, loss
+    mark('Gmain')
+    if 'Greg' in phases:
+        G.requires_grad_(True); st['opts']['G'].zero_grad(set_to_none=True)
+        ws = G.mapping(st['z'], c, batch, update_emas=False)
+        initial = torch.rand((ws.shape[0], 1000, 3), device=ws.device) * 2 - 1
+        coords = torch.cat([initial, initial + torch.randn_like(initial) * rk['density_reg_p_dist']], dim=1)
+        sigma = G.sample_mixed(coords, torch.randn_like(coords), ws, update_emas=False)['sigma']
+        half = sigma.shape[1] // 2
+        (F.l1_loss(sigma[:, :half], sigma[:, half:]) * rk['density_reg'] * G_REG_INTERVAL).backward()      # gain = the phase interval (training_loop.py:519)
+        sizes['Greg'] = _finish_phase(G, st['opts']['G'], world)
+        G.requires_grad_(False)
+        del sigma
+    mark('Greg')
+    if 'Dmain' in phases:
+        D.requires_grad_(True); st['opts']['D'].zero_grad(set_to_none=True)
+        with torch.no_grad():                                              # G.requires_grad_(False) in the loop: no graph through the generator
+            ws = G.mapping(st['z'], c, batch, update_emas=True)
+            gen = G.synthesis(ws, c, neural_rendering_resolution=st['nrr'], update_emas=True)
+        F.softplus(D({'image': gen['image'].float(), 'image_raw': gen['image_raw']}, c)).mean().backward()
+        F.softplus(-D({k: v.detach() for k, v in real.items()}, c)).mean().backward()
+        sizes['D'] = _finish_phase(D, st['opts']['D'], world)
+        D.requires_grad_(False)
+        del gen
+    mark('Dmain')
+    if 'Dreg' in phases:
+        D.requires_grad_(True); st['opts']['D'].zero_grad(set_to_none=True)
+        img = {k: v.detach().requires_grad_(True) for k, v in real.items()}
+        logits = D(img, c)
+        with conv2d_gradfix.no_weight_gradients():
+            grads = torch.autograd.grad(outputs=[logits.sum()], inputs=list(img.values()), create_graph=True, only_inputs=True)
+        r1 = sum(gr.square().sum([1, 2, 3]) for gr in grads)
+        (logits * 0 + r1 * (R1_GAMMA / 2)).mean().mul(D_REG_INTERVAL).backward()
+        sizes['Dreg'] = _finish_phase(D, st['opts']['D'], world)
+        D.requires_grad_(False)
+        del logits, grads, r1
+    mark('Dreg')
+    with torch.no_grad():                                                  # G_ema (training_loop.py:545-557), beta for batch 32 / ema_kimg 10
+        beta = 0.5 ** (4 * world / (10 * 1000))
+        torch._foreach_lerp_(list(st['G_ema'].parameters()), list(G.parameters()), 1.0 - beta)
+        for b_ema, b in zip(st['G_ema'].buffers(), G.buffers()):
+            b_ema.copy_(b)
+    mark('ema')
     return sizes
 
 
 def train_summary(timers, sizes, world, batch, wall_ms):
     def avg(a, b):
         return float(np.mean([x.elapsed_time(y) for x, y in zip(timers[a], timers[b])]))
-    g_ms, gs_ms, d_ms, ds_ms = avg('t0', 'g_done'), avg('g_done', 'g_sync'), avg('g_sync', 'd_done'), avg('d_done', 'd_sync')
-    bus = lambda nbytes, ms: round(2 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 1) if world > 1 and ms > 0 else None
-    return {'what': 'BASELINE config 3 per GPU: G pass (mapping incl. the label-map Encoder + synthesis, fwd + bwd, training mode) + flat gradient all-reduce + D pass on real images with R1 + all-reduce; '
-                    f'batch {batch}/GPU; every convolution forward / data gradient / weight gradient on libp3d_hip.so',
+    ph = {'Gmain': avg('t0', 'Gmain'), 'Greg': avg('Gmain', 'Greg'), 'Dmain': avg('Greg', 'Dmain'), 'Dreg': avg('Dmain', 'Dreg'), 'ema': avg('Dreg', 'ema')}
+    lazy = ph['Gmain'] + ph['Greg'] / G_REG_INTERVAL + ph['Dmain'] + ph['Dreg'] / D_REG_INTERVAL + ph['ema']
+    return {'what': 'BASELINE config 3 per GPU, every phase of training_loop.py in one iteration: Gmain (mapping incl. the label-map Encoder + synthesis + D on the generated pair, fwd + bwd) '
+                    '+ Greg (density regularisation: G.sample_mixed under autograd on the fused point kernels) + Dmain (generated + real) + Dreg (R1 double backward), each with its flat gradient '
+                    f'all-reduce and Adam step, then G_ema; batch {batch}/GPU; every convolution forward / data gradient / weight gradient on libp3d_hip.so; LPIPS and augmentation are not part of this path',
             'ms_per_iteration': round(wall_ms, 2), 'img_per_s': round(batch * world / (wall_ms * 1e-3), 2),
-            'g_pass_ms': round(g_ms, 2), 'd_pass_ms': round(d_ms, 2),
-            'allreduce': {'g_bytes': sizes[0], 'd_bytes': sizes[1], 'g_ms': round(gs_ms, 3), 'd_ms': round(ds_ms, 3), 'g_bus_GBps': bus(sizes[0], gs_ms), 'd_bus_GBps': bus(sizes[1], ds_ms),
-                          'note': 'world 1: concatenate + nan_to_num + scatter only' if world == 1 else 'RCCL ring over xGMI; bus GB/s = 2(p-1)/p x bytes / time'}}
+            'phase_ms': {k: round(v, 2) for k, v in ph.items()},
+            'lazy_schedule': {'G_reg_interval': G_REG_INTERVAL, 'D_reg_interval': D_REG_INTERVAL, 'ms_per_iteration': round(lazy, 2), 'img_per_s': round(batch * world / (lazy * 1e-3), 2),
+                              'note': 'amortised as the loop runs it: Gmain + Greg / 4 + Dmain + Dreg / 16 + ema'},
+            'allreduce': {'bytes_per_phase': sizes, 'note': ('world 1: concatenate + nan_to_num + scatter only' if world == 1 else 'RCCL ring over xGMI') + '; inside the phase times'}}
 
 
 def run_train(args, device, world, dist, iters, warm):
-    G, D, zm, c, real = train_setup(args, device, world)
+    st = train_setup(args, device, world)
     timers = {}
     for _ in range(warm):
-        sizes = train_iteration(G, D, zm, c, real, args.train_nrr, world, {})
+        sizes = train_iteration(st, {})
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
-        sizes = train_iteration(G, D, zm, c, real, args.train_nrr, world, timers)
+        sizes = train_iteration(st, timers)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -232,7 +310,21 @@ def run_train(args, device, world, dist, iters, warm):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     summary = train_summary(timers, sizes, world, args.batch, elapsed / iters * 1e3)
-    del G, D
+    if world > 1:                                                        # the exchange alone: one more all-reduce of each flat vector, timed
+        from pix2pix3d_amd import dp
+        bus = {}
+        for name, mod in (('G', st['G']), ('D', st['D'])):
+            mod.requires_grad_(True)
+            for p_ in mod.parameters():
+                p_.grad = torch.zeros_like(p_)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            dp.allreduce_gradients(mod, world_size=world)
+            e0.record(); flat = dp.allreduce_gradients(mod, world_size=world); e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            bus[name] = {'bytes': flat.numel() * 4, 'ms': round(ms, 3), 'bus_GBps': round(2 * (world - 1) / world * flat.numel() * 4 / (ms * 1e-3) / 1e9, 1)}
+        summary['allreduce']['timed_alone'] = bus
+    del st
     torch.cuda.empty_cache()
     return summary, elapsed
 
@@ -263,7 +355,7 @@ def main():
     if args.train_step:                                              # BASELINE config 3 as the timed workload
         summary, elapsed = run_train(args, device, world, dist, args.steps, max(args.warmup, 1))
         if rank == 0:
-            line = {'metric': 'training img/s (seg2cat 512^2, batch 4/GPU, 128^2 rays x 48+48 samples; G pass + D/R1 pass + gradient all-reduce)',
+            line = {'metric': 'training img/s (seg2cat 512^2, batch 4/GPU, 128^2 rays x 48+48 samples; Gmain + Greg + Dmain + Dreg, all-reduce + Adam per phase)',
                     'value': summary['img_per_s'], 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                     'ms_per_step': summary['ms_per_iteration'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                     'dtype': 'f32 (backbone, ray-marcher) + f16/f32-acc (super-resolution, discriminator top blocks), as train.py configures', 'data': 'synthetic',
@@ -282,108 +374,161 @@ def main():
     ws, c = ws_cpu.to(device), c_cpu.to(device)
     nrr = info['nrr']
     syn_kw = dict(noise_mode='const', neural_rendering_resolution=nrr, force_fp32=args.force_fp32)
+    from pix2pix3d_amd.torch_utils.ops import modconv as _mc
 
     def step():
         with torch.no_grad():
             return G.synthesis(ws, c, **syn_kw)
 
-    # stage timers (HIP events on torch's current stream == the stream every kernel of the step is launched on)
-    stage_events = {'backbone': [], 'render': [], 'sr': []}
-
-    def hook(mod, key):
-        def pre(m, a):
-            e = torch.cuda.Event(enable_timing=True); e.record(); m._p3d_e0 = e
-
-        def post(m, a, o):
-            e = torch.cuda.Event(enable_timing=True); e.record(); stage_events[key].append((m._p3d_e0, e))
-        return mod.register_forward_pre_hook(pre), mod.register_forward_hook(post)
-
-    for _ in range(max(args.warmup, 1)):
-        out = step()
-    torch.cuda.synchronize()
-    # a fresh box may still be loading code objects / growing the allocator's pools: keep warming (untimed) until three
-    # consecutive steps agree within 5 %, at most 40 extra steps
-    hist = []
-    for _ in range(40):
-        t0 = time.perf_counter(); step(); torch.cuda.synchronize(); hist.append(time.perf_counter() - t0)
-        if len(hist) >= 3 and max(hist[-3:]) < 1.05 * min(hist[-3:]):
-            break
-    assert out['image'].shape == (args.batch, 3, info['res'], info['res'])
-
-    launch = 'eager'
-    graph = None
-    if not args.no_graph:
-        try:                                                         # replay the whole step as one hipGraph
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                step()
-            torch.cuda.current_stream().wait_stream(s)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = step()
-            graph.replay()
+    def measure(settle_s):
+        """Warm up, capture the step as one hipGraph, settle, time K steps (barrier + synchronize on both sides, MAX over ranks); then an
+        eager pass of the same steps with HIP events around the stages and the instrumented kernels."""
+        for _ in range(max(args.warmup, 1)):
+            out = step()
+        torch.cuda.synchronize()
+        # a fresh box may still be loading code objects / growing the allocator's pools: keep warming (untimed) until three
+        # consecutive steps agree within 5 %, at most 40 extra steps
+        hist = []
+        for _ in range(40):
+            t0 = time.perf_counter(); step(); torch.cuda.synchronize(); hist.append(time.perf_counter() - t0)
+            if len(hist) >= 3 and max(hist[-3:]) < 1.05 * min(hist[-3:]):
+                break
+        assert out['image'].shape == (args.batch, 3, info['res'], info['res'])
+        launch, graph = 'eager', None
+        if not args.no_graph:
+            try:                                                         # replay the whole step as one hipGraph
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    step()
+                torch.cuda.current_stream().wait_stream(s)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = step()
+                graph.replay()
+                torch.cuda.synchronize()
+                launch = 'hipgraph'
+            except Exception as e:                                       # noqa: BLE001 - report and fall back to eager launches
+                graph = None
+                launch = f'eager (graph capture failed: {type(e).__name__})'
+                torch.cuda.synchronize()
+        run = graph.replay if graph is not None else step
+        # untimed settling: a box that has just booted (or idled) needs a moment of sustained load before its clocks / power state level
+        # out.  Replay in chunks of 10 until at least 1.5 s have passed and three consecutive chunks agree within 1.5 % (at most settle_s).
+        chunks, t_start = [], time.perf_counter()
+        while True:
+            t0 = time.perf_counter()
+            for _ in range(10):
+                run()
             torch.cuda.synchronize()
-            launch = 'hipgraph'
-        except Exception as e:                                       # noqa: BLE001 - report and fall back to eager launches
-            graph = None
-            launch = f'eager (graph capture failed: {type(e).__name__})'
-            torch.cuda.synchronize()
-
-    run = graph.replay if graph is not None else step
-    # untimed settling: a box that has just booted (or idled) needs a moment of sustained load before its clocks / power state level
-    # out.  Replay in chunks of 10 until at least 1.5 s have passed and three consecutive chunks agree within 1.5 % (at most 8 s).
-    # (Run-to-run spread on one box stays about +-3 % either way: 359-379 img/s over six back-to-back runs.)
-    chunks, t_start = [], time.perf_counter()
-    while True:
+            chunks.append(time.perf_counter() - t0)
+            spent = time.perf_counter() - t_start
+            if spent > settle_s or (spent > min(1.5, settle_s) and len(chunks) >= 3 and max(chunks[-3:]) < 1.015 * min(chunks[-3:])):
+                break
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(10):
+        for _ in range(args.steps):
             run()
         torch.cuda.synchronize()
-        chunks.append(time.perf_counter() - t0)
-        spent = time.perf_counter() - t_start
-        if spent > 8.0 or (spent > 1.5 and len(chunks) >= 3 and max(chunks[-3:]) < 1.015 * min(chunks[-3:])):
-            break
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        del graph
+        # per-kernel / per-stage HIP-event timing: a second, eager pass over the same steps (events cannot be read back from inside a
+        # captured graph); the ray-marcher is one launch per step, so its event pair IS its launch duration.  Events are recorded on
+        # torch's current stream == the stream every kernel of the step is launched on.
+        stage_events = {'backbone': [], 'render': [], 'sr': []}
 
-    # per-kernel / per-stage HIP-event timing: a second, eager pass over the same K steps (events cannot be read back
-    # from inside a captured graph); the ray-marcher is one launch per step, so its event pair IS its launch duration
-    handles = []
-    handles += hook(G.backbone.synthesis, 'backbone') + hook(G.renderer, 'render')
-    handles += hook(G.superresolution, 'sr') + hook(G.superresolution_semantic, 'sr')
-    n_prof = min(args.steps, 10)
-    for k in ('render_forward', 'conv_f16', 'conv_f32', 'conv_bf16x3', 'conv_flops'):
-        _lib.kernel_events[k] = []
-    for _ in range(n_prof):
-        step()
-    torch.cuda.synchronize()
-    kern = _lib.kernel_events.pop('render_forward')
-    render_kernel_ms = sum(a.elapsed_time(b) for a, b in kern) / max(len(kern), 1)
-    conv_ms = {k: sum(a.elapsed_time(b) for a, b in _lib.kernel_events.pop(k)) / n_prof for k in ('conv_f16', 'conv_f32', 'conv_bf16x3')}
-    flops = _lib.kernel_events.pop('conv_flops')
-    conv_fl = {'conv_f16': sum(f for d, f in flops if 'float16' in d) / n_prof, 'conv_f32': sum(f for d, f in flops if 'float32' in d) / n_prof,
-               'conv_bf16x3': sum(f for d, f in flops if d == 'bf16x3') / n_prof}
-    for h in handles:
-        h.remove()
-    stage_ms = {k: (sum(a.elapsed_time(b) for a, b in v) / n_prof if v else 0.0) for k, v in stage_events.items()}
+        def hook(mod, key):
+            def pre(m, a):
+                e = torch.cuda.Event(enable_timing=True); e.record(); m._p3d_e0 = e
+
+            def post(m, a, o):
+                e = torch.cuda.Event(enable_timing=True); e.record(); stage_events[key].append((m._p3d_e0, e))
+            return mod.register_forward_pre_hook(pre), mod.register_forward_hook(post)
+        handles = []
+        handles += hook(G.backbone.synthesis, 'backbone') + hook(G.renderer, 'render')
+        handles += hook(G.superresolution, 'sr') + hook(G.superresolution_semantic, 'sr')
+        n_prof = min(args.steps, 10)
+        for k in ('render_forward', 'conv_f16', 'conv_f32', 'conv_bf16x3', 'conv_flops'):
+            _lib.kernel_events[k] = []
+        for _ in range(n_prof):
+            step()
+        torch.cuda.synchronize()
+        kern = _lib.kernel_events.pop('render_forward')
+        render_kernel_ms = sum(a.elapsed_time(b) for a, b in kern) / max(len(kern), 1)
+        conv_ms = {k: sum(a.elapsed_time(b) for a, b in _lib.kernel_events.pop(k)) / n_prof for k in ('conv_f16', 'conv_f32', 'conv_bf16x3')}
+        flops = _lib.kernel_events.pop('conv_flops')
+        conv_fl = {'conv_f16': sum(f for d, f in flops if 'float16' in d) / n_prof, 'conv_f32': sum(f for d, f in flops if 'float32' in d) / n_prof,
+                   'conv_bf16x3': sum(f for d, f in flops if d == 'bf16x3') / n_prof}
+        for h in handles:
+            h.remove()
+        stage_ms = {k: (sum(a.elapsed_time(b) for a, b in v) / n_prof if v else 0.0) for k, v in stage_events.items()}
+        # conv_f32: exact fp32 MFMA kernels vs the 157.3 TF fp32 matrix peak.  conv_bf16x3: the fp32 layers computed as three bf16 MFMAs per
+        # product: 'tflops' counts each fp32 multiply-add once (fp32-equivalent), 'frac_of_peak' the 3x bf16 MFMA work it executes vs 2.5 PF
+        mfma_conv = {k: {'ms_per_step': round(conv_ms[k], 3), 'tflops': round(conv_fl[k] / (conv_ms[k] * 1e-3) / 1e12, 1) if conv_ms[k] > 0 else None,
+                         'frac_of_peak': round(conv_fl[k] * (3.0 if k == 'conv_bf16x3' else 1.0) / (conv_ms[k] * 1e-3) / 1e12 / (157.3 if k == 'conv_f32' else 2500.0), 3) if conv_ms[k] > 0 else None}
+                     for k in ('conv_f16', 'conv_f32', 'conv_bf16x3')}
+        return dict(elapsed=elapsed, launch=launch, render_kernel_ms=render_kernel_ms, n_render=len(kern), stage_ms=stage_ms, mfma_conv=mfma_conv)
+
+    def roofline(m, mlp_bf3):
+        """The ray-marcher's roofline object from its live launch duration + the committed counter passes of this kernel build."""
+        samples_per_launch = args.batch * nrr * nrr * args.depth
+        render_s = m['render_kernel_ms'] * 1e-3
+        tap_gbs = samples_per_launch * BYTES_PER_SAMPLE / render_s / 1e9 if render_s > 0 else 0.0
+        pmc = pmc_record(args, nrr, exact=not mlp_bf3)
+        mfma_floor_ms = samples_per_launch * MLP_FLOP_PER_SAMPLE * COARSE_FACTOR * (3.0 / (2500.0e12) if mlp_bf3 else 1.0 / (F32_MFMA_PEAK_TF * 1e12)) * 1e3
+        r = {'kernel': 'render_forward_kernel (fused tri-plane ray-marcher), decoder MLPs as ' + ('bf16x3 (3 bf16 MFMAs per fp32 product)' if mlp_bf3 else 'exact f32-input MFMA')}
+        bind = pmc.get('binding') if pmc else None
+        if bind and bind.get('busy_units_per_launch') and render_s > 0:
+            ach = bind['busy_units_per_launch'] / render_s
+            r.update({'bound': bind['resource'], 'achieved': round(ach / 1e9, 2), 'peak': round(bind['peak_units_per_s'] / 1e9, 2), 'unit': 'G ' + bind['unit'],
+                      'frac': round(ach / bind['peak_units_per_s'], 4),
+                      'binding': {'source': 'profiles/' + ('render_pmc.json' if mlp_bf3 else 'render_pmc_exact_fp32.json') + f" (kernel sources sha16 {pmc['kernel_src_sha16']} == this tree)",
+                                  'counter': bind['counter'], 'busy_units_per_launch': bind['busy_units_per_launch'],
+                                  'utilisation_in_pmc_pass': round(bind['utilisation_in_pmc_pass'], 4),
+                                  'all_resources_in_pmc_pass': {k: round(v, 4) for k, v in pmc['derived'].get('utilisation', {}).items()},
+                                  'wave_time_split': {k: round(v, 3) for k, v in pmc['derived'].get('wave_time_split', {}).items()},
+                                  'note': 'the resource of this kernel closest to its peak in the counter passes; frac = its busy units per launch / the LIVE launch duration / its peak at the 2.4 GHz '
+                                          'maximum clock (a lower bound on the utilisation at the clock the run actually held)'}})
+        else:
+            r.update({'bound': 'hbm', 'achieved': round(tap_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(tap_gbs / HBM_PEAK_GBS, 4), 'binding': None,
+                      'bound_note': 'no counter passes of THIS kernel build under profiles/ (hash mismatch): only the tap-bytes convention is available, which the taps being served by L1 / L2 lets exceed 1'})
+        r.update({'traffic': pmc.get('traffic_bytes_per_launch') if pmc else None,
+                  'tap_bytes': {'achieved': round(tap_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(tap_gbs / HBM_PEAK_GBS, 4), 'bytes_per_unit': BYTES_PER_SAMPLE,
+                                'note': "SURVEY 8(d)'s convention: 12 taps x 128 B + ray I/O per ray-sample vs the HBM peak; the taps are served by L1 / L2 (traffic << these bytes), so this is a "
+                                        'throughput figure, not a bound'},
+                  'mfma_frac': round(mfma_floor_ms / m['render_kernel_ms'], 4) if m['render_kernel_ms'] > 0 else None, 'mfma_floor_ms': round(mfma_floor_ms, 4),
+                  'ms_per_launch': round(m['render_kernel_ms'], 4), 'launches_timed': m['n_render'], 'units_per_launch': samples_per_launch})
+        return r
+
+    main_m = measure(8.0)
+    exact = None
+    if not args.no_exact_fp32:                                       # the same loop with every bf16x3 switch off: exact fp32 MFMA in the backbone and the decoder
+        prev = (_mc.split_bf16, rmod.mlp_bf16x3)
+        _mc.split_bf16, rmod.mlp_bf16x3 = False, False
+        try:
+            torch.cuda.empty_cache()
+            exact_m = measure(3.0)
+            exact = {'value': round(args.batch * world * args.steps / exact_m['elapsed'], 3), 'unit': 'img/s', 'ms_per_step': round(exact_m['elapsed'] / args.steps * 1e3, 3),
+                     'launch': exact_m['launch'], 'stage_ms': {k: round(v, 3) for k, v in exact_m['stage_ms'].items()}, 'mfma_conv': exact_m['mfma_conv'],
+                     'roofline': roofline(exact_m, False),
+                     'what': 'P3D_BF16X3=0 P3D_MLP_BF16X3=0: every fp32 convolution and the decoder MLPs on the f32-input MFMA (exact fp32 products, the arithmetic class the reference '
+                             'insists on, training_loop.py:278-280); super-resolution heads unchanged'}
+        except Exception as e:                                       # noqa: BLE001 - the headline line must still be printed
+            exact = {'error': f'{type(e).__name__}: {e}'[:300]}
+        finally:
+            _mc.split_bf16, rmod.mlp_bf16x3 = prev
 
     train = None
     if not args.no_train_step:                                       # short: 2 warm-up + 3 timed iterations
-        del graph
         G = G.cpu()
         torch.cuda.empty_cache()
         try:
@@ -392,19 +537,15 @@ def main():
             train = {'error': f'{type(e).__name__}: {e}'[:300]}
 
     if rank == 0:
-        from pix2pix3d_amd.torch_utils.ops import modconv as _mc
         bb = ('f32 tensors + f32 accumulation; the backbone convolutions (3x3 and the 1x1 ToRGB) form each product as 3 bf16 MFMAs of (hi, lo) splits ("bf16x3", <= 5e-6 of the '
-              'output range vs fp64 per layer; P3D_BF16X3=0 = exact f32 MFMA)') if _mc.split_bf16 else 'f32 (exact f32 MFMA)'
+              'output range vs fp64 per layer; P3D_BF16X3=0 = exact f32 MFMA, timed as `exact_fp32`)') if _mc.split_bf16 else 'f32 (exact f32 MFMA)'
         rm = 'f32 gather / sampling / compositing, decoder MLPs as bf16x3 (P3D_MLP_BF16X3=0 = exact f32 MFMA)' if rmod.mlp_bf16x3 else 'f32'
         dtype_desc = f'backbone: {bb}; ray-marcher: {rm}; super-resolution: ' + ('f32' if args.force_fp32 else 'f16 storage / f32 accumulation (the reference GPU config)')
+        elapsed, stage_ms = main_m['elapsed'], main_m['stage_ms']
         ms_per_step = elapsed / args.steps * 1e3
         imgs = args.batch * world * args.steps
         samples_per_launch = args.batch * nrr * nrr * args.depth
-        render_s = render_kernel_ms * 1e-3
-        achieved = samples_per_launch * BYTES_PER_SAMPLE / render_s / 1e9 if render_s > 0 else 0.0
-        traffic = render_traffic(args, nrr)                         # memory-side bytes per launch (committed PMC passes of THIS kernel, else null)
-        mlp_bf3 = bool(rmod.mlp_bf16x3)                          # decoder MLPs as three bf16 MFMAs per fp32 product (csrc/render_device.h)
-        mfma_floor_ms = samples_per_launch * MLP_FLOP_PER_SAMPLE * COARSE_FACTOR * (3.0 / (2500.0e12) if mlp_bf3 else 1.0 / (F32_MFMA_PEAK_TF * 1e12)) * 1e3
+        render_s = main_m['render_kernel_ms'] * 1e-3
         line = {
             'metric': f'rendered img/s ({info["res"]}^2, {args.depth} depth)',
             'value': round(imgs / elapsed, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -412,23 +553,13 @@ def main():
             'dtype': dtype_desc,
             'data': 'synthetic',
             'config': {'workload': f'{args.dataset} G.synthesis: batch {args.batch}/GPU, 256^2x96 tri-planes, {nrr}^2 rays x {args.depth // 2}+{args.depth // 2} samples, '
-                                   f'two {info["sr"]} SR heads -> {info["res"]}^2 image + label map', 'launch': launch, 'parallelism': f'replicas x{world} (images sharded, no collective)'},
+                                   f'two {info["sr"]} SR heads -> {info["res"]}^2 image + label map', 'launch': main_m['launch'], 'parallelism': f'replicas x{world} (images sharded, no collective)'},
             'ray_samples_per_s': round(samples_per_launch / render_s, 1) if render_s > 0 else None,
             'stage_ms': {k: round(v, 3) for k, v in stage_ms.items()},
             'conv_tflops': round(FLOP_PER_IMG * args.batch / ((stage_ms['backbone'] + stage_ms['sr']) * 1e-3) / 1e12, 2) if stage_ms['backbone'] + stage_ms['sr'] > 0 else None,
-            'roofline': {'kernel': 'render_forward_kernel (fused tri-plane ray-marcher)', 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                         'mfma_frac': round(mfma_floor_ms / render_kernel_ms, 4) if render_kernel_ms > 0 else None, 'mfma_floor_ms': round(mfma_floor_ms, 4),
-                         'decoder_mfma': 'bf16x3 (3 bf16 MFMAs per fp32 product, vs 2.5 PF)' if mlp_bf3 else 'f32-input MFMA (vs 157.3 TF)',
-                         'bound_note': 'taps are served by L1/L2 (traffic << algorithmic bytes), whole 128-byte lines per load instruction, so frac (algorithmic tap bytes / '
-                                       'time vs the HBM peak) can exceed 1; the decoder is off the fp32 matrix rate (mfma_frac); the kernel is VALU-bound (DESIGN.md 2.1)'
-                                       if mlp_bf3 else 'taps are served by L1/L2 (traffic << algorithmic bytes): the decoder on the fp32 matrix cores (mfma_frac) is the binding floor',
-                         'ms_per_launch': round(render_kernel_ms, 4), 'launches_timed': len(kern), 'units_per_launch': samples_per_launch, 'bytes_per_unit': BYTES_PER_SAMPLE},
-            # conv_f32: exact fp32 MFMA kernels vs the 157.3 TF fp32 matrix peak.  conv_bf16x3: the fp32 layers computed as three bf16 MFMAs per
-            # product: 'tflops' counts each fp32 multiply-add once (fp32-equivalent), 'frac_of_peak' the 3x bf16 MFMA work it executes vs 2.5 PF
-            'mfma_conv': {k: {'ms_per_step': round(conv_ms[k], 3), 'tflops': round(conv_fl[k] / (conv_ms[k] * 1e-3) / 1e12, 1) if conv_ms[k] > 0 else None,
-                              'frac_of_peak': round(conv_fl[k] * (3.0 if k == 'conv_bf16x3' else 1.0) / (conv_ms[k] * 1e-3) / 1e12 / (157.3 if k == 'conv_f32' else 2500.0), 3) if conv_ms[k] > 0 else None}
-                          for k in ('conv_f16', 'conv_f32', 'conv_bf16x3')},
+            'roofline': roofline(main_m, bool(rmod.mlp_bf16x3)),
+            'mfma_conv': main_m['mfma_conv'],
+            'exact_fp32': exact,
             'cpu_baseline': cpu,
             'train_step': train,
         }

@@ -1,0 +1,105 @@
+// Regression probe for a gfx950 hazard the bf16x3 kernels work around (render_device.h split8, conv2d.hip split_bf16x8):
+// an MFMA that reads, as SrcB, VGPRs written by v_cvt_pk_bf16_f32 a few wait states earlier can see stale contents of a 16-lane group.
+// hipcc (ROCm 7.2) leaves 2 wait states there; the kernels hold the wave for 5 (`s_nop 4`) after their conversions.
+//
+// The probe pins that distance in hand-written asm, where neither the compiler nor the assembler moves or pads anything: per iteration
+// a wave converts eight fresh fp32 values per lane into four VGPRs, waits WAIT states, and issues v_mfma_f32_32x32x16_bf16 with those
+// VGPRs as SrcB — once at the distance under test and once behind 16 wait states (the reference), into two accumulators that must end
+// up bit-identical.  A lane whose accumulators differ saw stale SrcB data.  Launch shape = the ray-marcher's: 8 waves per block, two
+// waves per SIMD, every CU busy.
+#include "p3d_common.h"
+
+namespace p3d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+
+#define P3D_CVT4 \
+    "v_cvt_pk_bf16_f32 v100, %[x0], %[x1]\n" \
+    "v_cvt_pk_bf16_f32 v101, %[x2], %[x3]\n" \
+    "v_cvt_pk_bf16_f32 v102, %[x4], %[x5]\n" \
+    "v_cvt_pk_bf16_f32 v103, %[x6], %[x7]\n"
+
+#define P3D_MFMA_B "v_mfma_f32_32x32x16_bf16 %[acc], %[a], v[100:103], %[acc]\n"      /* converted registers as SrcB (the ray-marcher's decoder) */
+#define P3D_MFMA_A "v_mfma_f32_32x32x16_bf16 %[acc], v[100:103], %[a], %[acc]\n"      /* ... as SrcA (the convolutions' activations)              */
+#define P3D_OPERANDS : [acc] "+v"(acc) : [a] "v"(a), [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]), [x6] "v"(x[6]), [x7] "v"(x[7])
+
+template <int WAIT, bool SRCA>           // wait states between the last conversion and the MFMA (0..8)
+__device__ __forceinline__ void cvt_then_mfma(f32x16& acc, const bf8& a, const float (&x)[8])
+{
+    static_assert(WAIT >= 0 && WAIT <= 8, "one s_nop covers 1..8 wait states");
+    if constexpr (WAIT == 0) {
+        if constexpr (SRCA) asm volatile(P3D_CVT4 P3D_MFMA_A P3D_OPERANDS : "v100", "v101", "v102", "v103");
+        else                asm volatile(P3D_CVT4 P3D_MFMA_B P3D_OPERANDS : "v100", "v101", "v102", "v103");
+    } else {
+        if constexpr (SRCA) asm volatile(P3D_CVT4 "s_nop %[n]\n" P3D_MFMA_A P3D_OPERANDS, [n] "n"(WAIT - 1) : "v100", "v101", "v102", "v103");
+        else                asm volatile(P3D_CVT4 "s_nop %[n]\n" P3D_MFMA_B P3D_OPERANDS, [n] "n"(WAIT - 1) : "v100", "v101", "v102", "v103");
+    }
+}
+// (the leading s_nop keeps the rewrite of v[100:103] well clear of the previous MFMA's operand reads)
+template <bool SRCA>
+__device__ __forceinline__ void cvt_then_mfma_safe(f32x16& acc, const bf8& a, const float (&x)[8])
+{
+    if constexpr (SRCA) asm volatile("s_nop 7\n" P3D_CVT4 "s_nop 7\n" "s_nop 7\n" P3D_MFMA_A P3D_OPERANDS : "v100", "v101", "v102", "v103");
+    else                asm volatile("s_nop 7\n" P3D_CVT4 "s_nop 7\n" "s_nop 7\n" P3D_MFMA_B P3D_OPERANDS : "v100", "v101", "v102", "v103");
+}
+
+template <int WAIT, bool SRCA>
+__global__ void __launch_bounds__(512, 2) cvt_mfma_hazard_kernel(int iters, unsigned* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+    bf8 a;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = (__bf16)(1.f + 0.125f * (float)((lane + e) & 7));        // exact in bf16
+    f32x16 fast, safe;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { fast[r] = 0.f; safe[r] = 0.f; }
+    unsigned s = gid * 2654435761u + 12345u;
+    for (int it = 0; it < iters; ++it) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {                                   // fresh values every iteration: what the conversion leaves differs from the registers' old contents
+            s = s * 1664525u + 1013904223u;
+            x[e] = (float)(int)(s >> 8) * (1.f / 8388608.f) - 1.f;
+        }
+        cvt_then_mfma<WAIT, SRCA>(fast, a, x);
+        cvt_then_mfma_safe<SRCA>(safe, a, x);
+    }
+    unsigned bad = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bad += (__float_as_uint(fast[r]) != __float_as_uint(safe[r])) ? 1u : 0u;
+    if (bad) { atomicAdd(out, 1u); atomicAdd(out + 1, bad); }
+}
+
+template <int WAIT>
+static void launch_probe(int blocks, int iters, unsigned* out, hipStream_t s, int src_a)
+{
+    if (src_a) hipLaunchKernelGGL((cvt_mfma_hazard_kernel<WAIT, true>), dim3(blocks), dim3(512), 0, s, iters, out);
+    else       hipLaunchKernelGGL((cvt_mfma_hazard_kernel<WAIT, false>), dim3(blocks), dim3(512), 0, s, iters, out);
+}
+
+} // namespace p3d
+
+using namespace p3d;
+
+extern "C" int p3d_probe_cvt_mfma_hazard(int32_t wait_states, int32_t src_a, int32_t iters, uint32_t* counts, p3d_stream_t stream)
+{
+    P3D_REQUIRE(counts && iters >= 1 && wait_states >= 0 && wait_states <= 8, "probe_cvt_mfma_hazard: bad arguments (wait_states 0..8)");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(counts, 0, 2 * sizeof(uint32_t), s) != hipSuccess) return fail(P3D_ERR_LAUNCH, "probe_cvt_mfma_hazard: memset failed");
+    const int blocks = kNumCU * 2;
+    switch (wait_states) {
+        case 0: launch_probe<0>(blocks, iters, counts, s, src_a); break;
+        case 1: launch_probe<1>(blocks, iters, counts, s, src_a); break;
+        case 2: launch_probe<2>(blocks, iters, counts, s, src_a); break;
+        case 3: launch_probe<3>(blocks, iters, counts, s, src_a); break;
+        case 4: launch_probe<4>(blocks, iters, counts, s, src_a); break;
+        case 5: launch_probe<5>(blocks, iters, counts, s, src_a); break;
+        case 6: launch_probe<6>(blocks, iters, counts, s, src_a); break;
+        case 7: launch_probe<7>(blocks, iters, counts, s, src_a); break;
+        default: launch_probe<8>(blocks, iters, counts, s, src_a); break;
+    }
+    count_launch(FAM_AUX);
+    return check_launch("probe_cvt_mfma_hazard");
+}

@@ -129,9 +129,14 @@ __device__ __forceinline__ void scatter_features(const RenderArgs& a, float* __r
     }
 }
 
-template <int NNETS>
+// POINTS = true: the same point-wise pass for free-standing point queries (renderer.py:142-148 run_model, G.sample_mixed — the density
+// regularisation of loss.py:681-706): a wave walks tiles of 32 POINTS instead of the samples of 32 rays, the upstream gradients are
+// dL/drgb [P][NNETS*32] (post-squash outputs, natural channel order) and dL/dsigma [P] instead of the tape's (colour weight, dL/dsigma).
+struct PointArgs { const float* coords; const float* g_rgb; const float* g_sigma; int pts_per_img, total_pts; };
+
+template <int NNETS, bool POINTS = false>
 __global__ void __launch_bounds__(kBwdWaves * 64, 1)
-render_backward_kernel(RenderArgs a, const float* __restrict__ bwd_stream, float* __restrict__ d_planes, float* __restrict__ d_dec)
+render_backward_kernel(RenderArgs a, const float* __restrict__ bwd_stream, float* __restrict__ d_planes, float* __restrict__ d_dec, PointArgs pa)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -153,25 +158,28 @@ render_backward_kernel(RenderArgs a, const float* __restrict__ bwd_stream, float
     const int SN = NNETS - 1;
     const int S = a.Sc + a.Sf;
 
-    const int ray0 = (blockIdx.x * kBwdWaves + wave) * 32;
-    if (ray0 >= a.total_rays) return;
-    const int g = min(ray0 + j, a.total_rays - 1);
-    const bool live = (ray0 + j) < a.total_rays;
-    const int n_img = g / a.rays_per_img;
+    const int ray0 = POINTS ? 0 : (blockIdx.x * kBwdWaves + wave) * 32;
+    if (!POINTS && ray0 >= a.total_rays) return;
+    int g = POINTS ? 0 : min(ray0 + j, a.total_rays - 1);
+    bool live = POINTS ? false : (ray0 + j) < a.total_rays;
+    int n_img = POINTS ? 0 : g / a.rays_per_img;
     const rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.planes, 0, a.planes_total_bytes, 0x00020000);
-    const unsigned img = (unsigned)n_img * a.img_bytes;
-    const unsigned dimg = (unsigned)n_img * 3u * (unsigned)(a.H * a.W) * 32u;    // d_planes is always the compact [N][3][H][W][32] (< 2^29 floats, checked on the host)
-    const float ox = a.ray_o[g * 3 + 0], oy = a.ray_o[g * 3 + 1], oz = a.ray_o[g * 3 + 2];
-    const float dx = a.ray_d[g * 3 + 0], dy = a.ray_d[g * 3 + 1], dz = a.ray_d[g * 3 + 2];
+    unsigned img = (unsigned)n_img * a.img_bytes;
+    unsigned dimg = (unsigned)n_img * 3u * (unsigned)(a.H * a.W) * 32u;    // d_planes is always the compact [N][3][H][W][32] (< 2^29 floats, checked on the host)
+    float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+    if (!POINTS) {
+        ox = a.ray_o[g * 3 + 0]; oy = a.ray_o[g * 3 + 1]; oz = a.ray_o[g * 3 + 2];
+        dx = a.ray_d[g * 3 + 0]; dy = a.ray_d[g * 3 + 1]; dz = a.ray_d[g * 3 + 2];
+    }
     const float cs = a.coord_scale;
-    const float4* const tape = (const float4*)a.tape_s + (size_t)g * S;
+    const float4* const tape = POINTS ? nullptr : (const float4*)a.tape_s + (size_t)g * S;
     static_assert(TP == kFeatPitch, "T_f is the cooperative gather's tile");
 
-    float dC[NNETS][16];                                          // dL/dC (= 2 dL/dfeat) of this lane's channels
+    float dC[NNETS][16];                                          // rays: dL/dC (= 2 dL/dfeat) of this lane's channels; points: dL/drgb of the tile's point
 #pragma unroll
     for (int n = 0; n < NNETS; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dC[n][r] = live ? 2.f * a.g_feat[(size_t)g * (NNETS * 32) + n * 32 + acc_row(r, h)] : 0.f;
+        for (int r = 0; r < 16; ++r) dC[n][r] = (!POINTS && live) ? 2.f * a.g_feat[(size_t)g * (NNETS * 32) + n * 32 + acc_row(r, h)] : 0.f;
 
     f32x16 aW2[NNETS][2], aW1[NNETS][2];                          // weight-gradient tiles (accumulate over all samples of the wave)
     float ab2[NNETS], ab1[NNETS][2], aW2s[2] = {0.f, 0.f}, ab2s = 0.f;
@@ -185,12 +193,31 @@ render_backward_kernel(RenderArgs a, const float* __restrict__ bwd_stream, float
     }
 
     // the pass is order-free over samples: small launches split every ray's samples over gridDim.y blocks so that all CUs get work
+    // (points: the "samples" are the tiles of 32 points this wave takes, grid-stride)
     const int k_per = (S + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int k_begin = (int)blockIdx.y * k_per, k_end = min(S, k_begin + k_per);
-    for (int k = k_begin; k < k_end; ++k) {
-        const float4 rec = tape[k];                               // z, colour weight, dL/dsigma
-        const float z = rec.x, wgt = live ? rec.y : 0.f, dsig = live ? rec.z : 0.f;
-        const float px = cs * fmaf(z, dx, ox), py = cs * fmaf(z, dy, oy), pz = cs * fmaf(z, dz, oz);
+    const int k_begin = POINTS ? (int)blockIdx.x * kBwdWaves + wave : (int)blockIdx.y * k_per;
+    const int k_end = POINTS ? (pa.total_pts + 31) / 32 : min(S, k_begin + k_per);
+    const int k_step = POINTS ? (int)gridDim.x * kBwdWaves : 1;
+    for (int k = k_begin; k < k_end; k += k_step) {
+        float wgt = 1.f, dsig = 0.f, px, py, pz;
+        if constexpr (POINTS) {
+            g = min(k * 32 + j, pa.total_pts - 1);
+            live = (k * 32 + j) < pa.total_pts;
+            n_img = g / pa.pts_per_img;
+            img = (unsigned)n_img * a.img_bytes;
+            dimg = (unsigned)n_img * 3u * (unsigned)(a.H * a.W) * 32u;
+            px = cs * pa.coords[(size_t)g * 3]; py = cs * pa.coords[(size_t)g * 3 + 1]; pz = cs * pa.coords[(size_t)g * 3 + 2];
+            dsig = (live && pa.g_sigma) ? pa.g_sigma[g] : 0.f;
+#pragma unroll
+            for (int n = 0; n < NNETS; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dC[n][r] = (live && pa.g_rgb) ? pa.g_rgb[(size_t)g * (NNETS * 32) + n * 32 + acc_row(r, h)] : 0.f;
+        } else {
+            const float4 rec = tape[k];                           // z, colour weight, dL/dsigma
+            const float z = rec.x;
+            wgt = live ? rec.y : 0.f; dsig = live ? rec.z : 0.f;
+            px = cs * fmaf(z, dx, ox); py = cs * fmaf(z, dy, oy); pz = cs * fmaf(z, dz, oz);
+        }
         float feat[16];
         wave_sync();                                              // the previous sample's readers of T_f are done
         gather_features_coop<true>(a, rsrc, img, lane, px, py, pz, Tf, Tt, feat);      // eight lanes to a texel; lands in T_f as [channel][ray] and in the lane's registers
@@ -428,13 +455,59 @@ extern "C" int p3d_render_backward(const float* planes_cl, const float* decoder,
         if (d->n_nets == 1) {
             static std::atomic<uint64_t> once1_devs{0}; const hipError_t once1 = reserve_lds_once((const void*)render_backward_kernel<1>, (int)lds_bytes, once1_devs);
             if (once1 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_backward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(once1));
-            hipLaunchKernelGGL(render_backward_kernel<1>, dim3(blocks, splits), dim3(kBwdWaves * 64), lds_bytes, s, a, decoder_bwd, d_planes_cl, d_decoder);
+            hipLaunchKernelGGL(render_backward_kernel<1>, dim3(blocks, splits), dim3(kBwdWaves * 64), lds_bytes, s, a, decoder_bwd, d_planes_cl, d_decoder, PointArgs{});
         } else {
             static std::atomic<uint64_t> once2_devs{0}; const hipError_t once2 = reserve_lds_once((const void*)render_backward_kernel<2>, (int)lds_bytes, once2_devs);
             if (once2 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_backward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(once2));
-            hipLaunchKernelGGL(render_backward_kernel<2>, dim3(blocks, splits), dim3(kBwdWaves * 64), lds_bytes, s, a, decoder_bwd, d_planes_cl, d_decoder);
+            hipLaunchKernelGGL(render_backward_kernel<2>, dim3(blocks, splits), dim3(kBwdWaves * 64), lds_bytes, s, a, decoder_bwd, d_planes_cl, d_decoder, PointArgs{});
         }
     }
     count_launch(FAM_RENDER);
     return check_launch("render_backward");
+}
+
+// Backward of the point queries (p3d_sample_points): dL/dplanes (compact channels-last [N][3][H][W][32], zeroed here) and the
+// effective-weight decoder gradients (the layout of p3d_render_backward's d_decoder) from dL/drgb [N*P][n_nets*32] and dL/dsigma [N*P]
+// (either may be null = zero).  Reference: autograd through ImportanceRenderer.run_model (renderer.py:142-148), i.e. grid_sample's
+// backward + the decoder's — what the density regularisation differentiates (loss.py:681-706).  Coordinates get no gradient.
+extern "C" int p3d_sample_points_backward(const float* planes_cl, const float* decoder, const float* decoder_bwd, const float* coords,
+                                          const p3d_render_desc* d, int32_t pts_per_img, const float* g_rgb, const float* g_sigma,
+                                          float* d_planes_cl, float* d_decoder, p3d_stream_t stream)
+{
+    P3D_REQUIRE(d, "sample_points_backward: null descriptor");
+    P3D_REQUIRE(d->n_nets == 1 || d->n_nets == 2, "sample_points_backward: n_nets must be 1 or 2");
+    P3D_REQUIRE(planes_cl && decoder && decoder_bwd && coords && d_planes_cl && d_decoder, "sample_points_backward: null pointer");
+    P3D_REQUIRE(d->plane_h >= 1 && d->plane_w >= 1 && d->box_warp != 0.f && pts_per_img >= 1 && d->n_img >= 0, "sample_points_backward: bad sizes");
+    const int64_t total = (int64_t)d->n_img * pts_per_img;
+    P3D_REQUIRE(total <= INT32_MAX / 64, "sample_points_backward: too many points");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t plane_floats = (size_t)d->n_img * 3 * d->plane_h * d->plane_w * 32;
+    if (hipMemsetAsync(d_planes_cl, 0, plane_floats * sizeof(float), s) != hipSuccess || hipMemsetAsync(d_decoder, 0, 2 * kGradNetStride * sizeof(float), s) != hipSuccess)
+        return fail(P3D_ERR_LAUNCH, "sample_points_backward: memset failed");
+    if (total == 0 || (!g_rgb && !g_sigma)) return P3D_OK;
+    RenderArgs a{};
+    a.H = d->plane_h; a.W = d->plane_w; a.coord_scale = 2.f / d->box_warp; a.sem_sigmoid = d->semantic_sigmoid;
+    if (d->pixel_stride > 0) { a.plane_stride = d->plane_stride; a.pix_stride = d->pixel_stride; a.img_stride = d->image_stride; }
+    else { a.plane_stride = (int64_t)a.H * a.W * 32; a.pix_stride = 32; a.img_stride = 3 * a.plane_stride; }
+    a.plane_bytes = (unsigned)(a.plane_stride * 4); a.pix_bytes = (unsigned)(a.pix_stride * 4); a.img_bytes = (unsigned)(a.img_stride * 4);
+    if ((int64_t)d->n_img * a.img_stride * 4 >= ((int64_t)1 << 31) || (int64_t)d->plane_h * d->plane_w >= (1 << 24) || d->pixel_stride * 4 >= (1 << 16))
+        return fail(P3D_ERR_UNSUPPORTED, "sample_points_backward: plane tensor too large for 32-bit buffer addressing");
+    a.planes_total_bytes = (unsigned)((int64_t)d->n_img * a.img_stride * 4);
+    a.planes = planes_cl; a.decoder = decoder;
+    PointArgs pa{coords, g_rgb, g_sigma, pts_per_img, (int)total};
+    const size_t lds_bytes = (size_t)(kDecoderFloats + kBwdFloats + kBwdWaves * kBwdWaveLds) * sizeof(float);
+    const int64_t tiles = (total + 31) / 32;
+    int blocks = (int)((tiles + kBwdWaves - 1) / kBwdWaves);
+    if (blocks > kNumCU) blocks = kNumCU;                                 // one block per CU (LDS); waves take further tiles grid-stride
+    if (d->n_nets == 1) {
+        static std::atomic<uint64_t> once1_devs{0}; const hipError_t once1 = reserve_lds_once((const void*)render_backward_kernel<1, true>, (int)lds_bytes, once1_devs);
+        if (once1 != hipSuccess) return fail(P3D_ERR_LAUNCH, "sample_points_backward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(once1));
+        hipLaunchKernelGGL((render_backward_kernel<1, true>), dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, a, decoder_bwd, d_planes_cl, d_decoder, pa);
+    } else {
+        static std::atomic<uint64_t> once2_devs{0}; const hipError_t once2 = reserve_lds_once((const void*)render_backward_kernel<2, true>, (int)lds_bytes, once2_devs);
+        if (once2 != hipSuccess) return fail(P3D_ERR_LAUNCH, "sample_points_backward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(once2));
+        hipLaunchKernelGGL((render_backward_kernel<2, true>), dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, a, decoder_bwd, d_planes_cl, d_decoder, pa);
+    }
+    count_launch(FAM_RENDER);
+    return check_launch("sample_points_backward");
 }

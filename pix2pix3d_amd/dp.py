@@ -45,6 +45,8 @@ def broadcast_module(module, src=0, group=None):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data if t.is_leaf else t, src=src, group=group)
+    from .torch_utils.ops import modconv                  # writes through .data do not bump the version counter the weight caches watch
+    modconv.invalidate_caches()
 
 
 def shard_indices(n_items, rank, world_size):

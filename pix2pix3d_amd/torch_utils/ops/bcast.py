@@ -33,7 +33,18 @@ def layout(x):
         geo = (1, n, h * w, c)
     else:
         return None
+    if not cl_ok(geo):                                          # csrc/bcast_ops.hip: the NCHW kernels index (n, c) rows with 16 bits
+        return None
     return geo if geo[3] % vec == 0 and x.data_ptr() % 16 == 0 else None
+
+
+def cl_ok(geo):
+    return bool(geo[0]) or geo[1] * geo[2] < 65536
+
+
+def _aligned(*ts):
+    """Every operand the C side takes by 16-byte vectors (p3d_bcast_fma / p3d_channel_dot check it and refuse otherwise)."""
+    return all(t is None or t.data_ptr() % 16 == 0 for t in ts)
 
 
 def _scale_fma(x, geo, s, z):
@@ -98,6 +109,9 @@ class _ScaleChannels(torch.autograd.Function):
             return (gy * s_x.reshape(n, c, 1, 1) if need_x else None, (gy * x).sum([2, 3]).to(ctx.s_dtype) if need_s else None)
         gy = _same_layout(gy.to(x.dtype), x)
         geo = layout(x)
+        if not _aligned(gy):                                                  # (a view into a larger buffer): the tensor-op formulation
+            n, c = s_x.shape
+            return (gy * s_x.reshape(n, c, 1, 1) if need_x else None, (gy.float() * x.float()).sum([2, 3]).to(ctx.s_dtype) if need_s else None)
         gx = _scale_fma(gy, geo, s_x.float().contiguous(), None) if need_x else None
         gs = _channel_dot(gy, x, geo).to(ctx.s_dtype) if need_s else None
         return gx, gs
@@ -132,6 +146,9 @@ class _FmaNative(torch.autograd.Function):
                     dout.sum([0, 1] if ctx.c_shape[0] == 1 else [1], keepdim=True).to(ctx.c_dtype) if need_c else None)
         dout = _same_layout(dout.to(a.dtype), a)
         geo = layout(a)
+        if not _aligned(dout):
+            return (dout * b if need_a else None, (dout.float() * a.float()).sum([2, 3], keepdim=True).to(b.dtype) if need_b else None,
+                    dout.sum([0, 1] if ctx.c_shape[0] == 1 else [1], keepdim=True).to(ctx.c_dtype) if need_c else None)
         da = _scale_fma(dout, geo, b.reshape(b.shape[0], b.shape[1]).float().contiguous(), None) if need_a else None
         db = _channel_dot(dout, a, geo).to(b.dtype).reshape(b.shape) if need_b else None
         dc = None
@@ -147,7 +164,11 @@ def fma_supported(a, b, c):
     if layout(a) is None or not (isinstance(b, torch.Tensor) and isinstance(c, torch.Tensor)) or b.dtype != a.dtype:
         return False
     n, ch, h, w = a.shape
-    return tuple(b.shape) == (n, ch, 1, 1) and tuple(c.shape) in ((n, 1, h, w), (1, 1, h, w)) and b.is_cuda and c.is_cuda
+    if not (tuple(b.shape) == (n, ch, 1, 1) and tuple(c.shape) in ((n, 1, h, w), (1, 1, h, w)) and b.is_cuda and c.is_cuda):
+        return False
+    # the addend is passed as a dense [Nz,1,H,W] tensor of a's dtype: a contiguous() / to() copy is freshly allocated (aligned); an operand
+    # used as is must be aligned itself
+    return c.dtype != a.dtype or not c.is_contiguous() or c.data_ptr() % 16 == 0
 
 
 def fma(a, b, c):

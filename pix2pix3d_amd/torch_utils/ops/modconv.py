@@ -264,6 +264,13 @@ def _cached_weight(weight, tag, make):
     return value
 
 
+def invalidate_caches():
+    """Drop every derived weight form.  The cache notices in-place updates of a parameter through its autograd version counter; writes that
+    bypass it (``param.data.copy_()``, ``dist.broadcast(param.data)``) do not bump it — code that overwrites parameters that way (dp.broadcast_module,
+    misc.copy_params_and_buffers, the checkpoint loader) calls this afterwards."""
+    _plain_weights.clear()
+
+
 def plain_layer_supported(x, weight, up, down, activation):
     """Conv2dLayer calls (networks_stylegan2.py:135-188) the native kernels cover: inference on the device, 1x1 / 3x3, down in {1, 2}."""
     if not enabled or up != 1 or down not in (1, 2) or not _dense_dev(x) or activation not in ('linear', 'lrelu'):

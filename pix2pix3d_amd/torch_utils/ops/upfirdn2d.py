@@ -165,7 +165,7 @@ def upsample2d_add_(y, x, f):
     ok = (x.is_cuda and f is not None and f.ndim == 2 and tuple(f.shape) == (4, 4) and f.dtype == torch.float32 and x.dtype == y.dtype and x.dtype in (torch.float16, torch.float32)
           and tuple(y.shape) == (n, c, 2 * h, 2 * w) and c > 1 and c % (16 // x.element_size()) == 0 and x.stride(1) == 1 and y.stride(1) == 1
           and x.is_contiguous(memory_format=torch.channels_last) and y.is_contiguous(memory_format=torch.channels_last)
-          and not (x.requires_grad or y.requires_grad))
+          and x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0 and not (x.requires_grad or y.requires_grad))
     if not ok:
         return y.add_(upsample2d(x, f))
     code = _lib.lib().p3d_upfirdn2d_acc(
@@ -174,6 +174,8 @@ def upsample2d_add_(y, x, f):
         _lib.i32x2(4, 4), _lib.i64x2(f.stride(1), f.stride(0)),
         _lib.i32x4(2 * w, 2 * h, c, n), _lib.i64x4(y.stride(3), y.stride(2), y.stride(1), y.stride(0)),
         2, 2, 1, 1, 2, 2, 0, 4.0, _lib.stream_of(x))                             # upsample2d: padding (fw + up - 1) // 2 = 2 in front, gain up^2
+    if code == _lib.P3D_ERR_UNSUPPORTED:                                         # the channels-last kernel declined this geometry: two-step form
+        return y.add_(upsample2d(x, f))
     _lib.check(code, 'upfirdn2d_acc')
     return y
 

@@ -243,10 +243,10 @@ class SynthesisLayer(torch.nn.Module):
         self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
         fmt = torch.channels_last if channels_last else torch.contiguous_format
         self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=fmt))
+        if use_noise:                                # fixed noise image for noise_mode='const' + its learned strength (starts at 0); registration
+            self.register_buffer('noise_const', torch.randn([resolution, resolution]))      # order = the reference's (:307-310): parameters() /
+            self.noise_strength = torch.nn.Parameter(torch.zeros([]))                       # state_dict / optimizer indices line up with its runs
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
-        if use_noise:                                # fixed noise image for noise_mode='const' + its learned strength (starts at 0)
-            self.noise_strength = torch.nn.Parameter(torch.zeros([]))
-            self.register_buffer('noise_const', torch.randn([resolution, resolution]))
 
     def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, rgb=None):
         """``rgb`` (device inference, from SynthesisBlock): (torgb layer, its latent, skip image) — when the native kernel can, this layer
@@ -494,7 +494,7 @@ def prefetch_styles(blocks, block_ws, block_kwargs):
             if block.is_last or block.architecture == 'skip':
                 todo.append((block.torgb, next(ws_iter), block.torgb.weight_gain, None, dtype))
         # every style affine of the network in one launch (they are ~6 us of launch latency each on their own)
-        batched = (0 < len(todo) <= modconv.FC_MAX_JOBS and len({t[1].shape[0] for t in todo}) == 1
+        batched = (0 < len(todo) <= modconv.FC_MAX_JOBS and len({t[1].shape[0] for t in todo}) == 1 and all(t[1].shape[1] % 4 == 0 for t in todo)   # (fc_multi takes whole float4 rows; fc() pads)
                    and all(modconv.fc_supported(w, l.affine.weight, l.affine.bias, l.affine.activation) for l, w, *_ in todo))
         all_styles = (modconv.fc_multi([(w, l.affine, sc) for l, w, sc, _, _ in todo]) if batched
                       else [l.affine(w) if sc == 1 else l.affine(w, out_scale=sc) for l, w, sc, _, _ in todo])

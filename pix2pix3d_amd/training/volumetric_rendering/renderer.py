@@ -26,8 +26,7 @@ _warned_routes = set()
 
 def _warn_tensor_op_route(who, reason):
     """A device tensor is about to take the tensor-op formulation instead of the fused kernel: say so, once per reason — a silent
-    fallback would look like the native path in every output but the profile.  (Expected cases: autograd through an entry point without
-    a fused backward, density_noise > 0, more than 64 coarse / fine samples per ray, a decoder that is not the OSG 32-64-33 MLP.)"""
+    fallback would look like the native path in every output but the profile.  (Expected cases: a gradient w.r.t. rays, depth or point coordinates, density_noise > 0, more than 64 coarse / fine samples per ray, a decoder that is not the OSG 32-64-33 MLP.)"""
     key = (who, reason)
     if key not in _warned_routes:
         _warned_routes.add(key)
@@ -58,6 +57,7 @@ _lib.register('p3d_pack_decoder_bwd', ctypes.c_int, [_vp] * 4 + [ctypes.c_int32,
 _lib.register('p3d_render_backward', ctypes.c_int, [_vp] * 9 + [ctypes.POINTER(_RenderDesc)] + [_vp] * 6 + [_vp])
 _lib.register('p3d_render_forward', ctypes.c_int, [_vp] * 8 + [ctypes.POINTER(_RenderDesc)] + [_vp] * 6 + [_vp])
 _lib.register('p3d_sample_points', ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(_RenderDesc), _i32, _vp, _vp, _vp])
+_lib.register('p3d_sample_points_backward', ctypes.c_int, [_vp] * 4 + [ctypes.POINTER(_RenderDesc), _i32] + [_vp] * 4 + [_vp])
 _lib.register('p3d_importance_sample', ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp])
 _lib.register('p3d_render_decoder_floats_dual', ctypes.c_int, [])
 _lib.register('p3d_pack_decoder_dual', ctypes.c_int, [_vp] * 8 + [_f32, _vp, _vp])
@@ -284,17 +284,14 @@ class ImportanceRenderer(torch.nn.Module):
         self.plane_axes = self.plane_axes.to(sample_coordinates.device)
         needs_grad = torch.is_grad_enabled() and (planes.requires_grad or sample_coordinates.requires_grad
                                                   or any(p.requires_grad for p in decoder.parameters()))
-        reason = self._fused_reason(planes, decoder, options, needs_grad, trainable=False)
+        # a graph that needs gradients (the density regularisation, loss.py:681-706) takes the fused forward + p3d_sample_points_backward;
+        # only a gradient w.r.t. the coordinates themselves has no fused form
+        reason = self._fused_reason(planes, decoder, options, needs_grad, trainable=not (torch.is_grad_enabled() and sample_coordinates.requires_grad))
         if reason is None:
-            n, p, _ = sample_coordinates.shape
-            ctx = _FusedContext(planes, _decoder_nets(decoder))
-            xyz = _f32c(sample_coordinates)
-            rgb = torch.empty([n, p, 32 * ctx.n_nets], device=planes.device, dtype=torch.float32)
-            sigma = torch.empty([n, p, 1], device=planes.device, dtype=torch.float32)
-            d = ctx.desc(options)
-            code = _lib.lib().p3d_sample_points(_lib.ptr(ctx.planes_cl), _lib.ptr(ctx.packed), _lib.ptr(xyz), ctypes.byref(d), p,
-                                                _lib.ptr(rgb), _lib.ptr(sigma), _lib.stream_of(rgb))
-            _lib.check(code, 'sample_points')
+            if needs_grad:
+                rgb, sigma = _FusedPointsFn.apply(decoder, options, sample_coordinates, planes, *decoder.parameters())
+            else:
+                rgb, sigma = fused_sample_points(planes, decoder, sample_coordinates, options)
             return {'rgb': rgb, 'sigma': sigma}
         self._tensor_op_guard(planes, reason)
         feats = sample_from_planes(self.plane_axes, planes, sample_coordinates, padding_mode='zeros', box_warp=options['box_warp'])
@@ -534,7 +531,7 @@ class _replay_draws:
         torch.rand_like, torch.rand = self._rl, self._r
 
 
-backward_calls = {'fused': 0, 'replay': 0}      # which backward _FusedRenderFn took (tests: the training step must take 'fused')
+backward_calls = {'fused': 0, 'replay': 0, 'points': 0}      # which backward _FusedRenderFn took (tests: the training step must take 'fused'); 'points': _FusedPointsFn
 
 
 class _FusedRenderFn(torch.autograd.Function):
@@ -585,6 +582,91 @@ class _FusedRenderFn(torch.autograd.Function):
         return (None,) * 7 + tuple(res)
 
 
+def fused_sample_points(planes, decoder, coordinates, opt):
+    """One launch of p3d_sample_points: (rgb [N,P,32*n_nets], sigma [N,P,1]) at coordinates [N,P,3] (exact fp32 MFMA decoder)."""
+    n, p, _ = coordinates.shape
+    ctx = _FusedContext(planes, _decoder_nets(decoder))
+    xyz = _f32c(coordinates)
+    rgb = torch.empty([n, p, 32 * ctx.n_nets], device=planes.device, dtype=torch.float32)
+    sigma = torch.empty([n, p, 1], device=planes.device, dtype=torch.float32)
+    d = ctx.desc(opt)
+    code = _lib.lib().p3d_sample_points(_lib.ptr(ctx.planes_cl), _lib.ptr(ctx.packed), _lib.ptr(xyz), ctypes.byref(d), p,
+                                        _lib.ptr(rgb), _lib.ptr(sigma), _lib.stream_of(rgb))
+    _lib.check(code, 'sample_points')
+    return rgb, sigma
+
+
+def _decoder_param_grads(decoder, nets, d_dec):
+    """Effective-weight gradient record of the device kernels -> gradients of the raw FullyConnectedLayer parameters, in ``decoder.parameters()`` order."""
+    stride = _lib.lib().p3d_render_grad_decoder_floats() // 2
+    by_param = {}
+    for i, (fc1, fc2) in enumerate(nets):
+        g = d_dec[i * stride:(i + 1) * stride]
+        by_param[id(fc1.weight)] = g[0:2048].reshape(64, 32) * fc1.weight_gain
+        by_param[id(fc1.bias)] = g[2048:2112] * fc1.bias_gain
+        by_param[id(fc2.weight)] = g[2112:4224].reshape(33, 64) * fc2.weight_gain
+        by_param[id(fc2.bias)] = g[4224:4257] * fc2.bias_gain
+    return [by_param.get(id(p)) if p.requires_grad else None for p in decoder.parameters()]
+
+
+def _pack_decoder_bwd(nets, lr_mul, dev):
+    lib = _lib.lib()
+    packed_bwd = torch.empty([lib.p3d_render_bwd_decoder_floats()], dtype=torch.float32, device=dev)
+    w1s = [_f32c(fc1.weight) for fc1, _ in nets] + [None]
+    w2s = [_f32c(fc2.weight) for _, fc2 in nets] + [None]
+    _lib.check(lib.p3d_pack_decoder_bwd(_lib.ptr(w1s[0]), _lib.ptr(w2s[0]), _lib.ptr(w1s[1]), _lib.ptr(w2s[1]), len(nets), lr_mul, _lib.ptr(packed_bwd),
+                                        _lib.stream_of(packed_bwd)), 'pack_decoder_bwd')
+    return packed_bwd
+
+
+def fused_sample_points_backward(planes, decoder, coordinates, opt, g_rgb, g_sigma):
+    """dL/dplanes and dL/d(decoder parameters) of ``fused_sample_points`` from dL/drgb [N,P,32*n_nets] and dL/dsigma [N,P,1] (either may be
+    None), by one launch of p3d_sample_points_backward (csrc/render_bwd.hip)."""
+    info = _decoder_nets(decoder)
+    nets, lr_mul, _ = info
+    lib = _lib.lib()
+    n, p, _ = coordinates.shape
+    dev = planes.device
+    ctx = _FusedContext(planes, info)
+    packed_bwd = _pack_decoder_bwd(nets, lr_mul, dev)
+    xyz = _f32c(coordinates)
+    gr = None if g_rgb is None else _f32c(g_rgb)
+    gs = None if g_sigma is None else _f32c(g_sigma).reshape(-1)
+    d_planes = torch.empty([n, 3, ctx.h, ctx.w, 32], dtype=torch.float32, device=dev)
+    d_dec = torch.empty([lib.p3d_render_grad_decoder_floats()], dtype=torch.float32, device=dev)
+    d = ctx.desc(opt)
+    code = lib.p3d_sample_points_backward(_lib.ptr(ctx.planes_cl), _lib.ptr(ctx.packed), _lib.ptr(packed_bwd), _lib.ptr(xyz), ctypes.byref(d), p,
+                                          _lib.ptr(gr), _lib.ptr(gs), _lib.ptr(d_planes), _lib.ptr(d_dec), _lib.stream_of(d_planes))
+    _lib.check(code, 'sample_points_backward')
+    g_planes = d_planes.permute(0, 1, 4, 2, 3)                    # [N, 3, 32, H, W] view of the channels-last gradient
+    if planes.dim() == 5 and planes.is_contiguous():
+        g_planes = g_planes.contiguous()
+    return g_planes, _decoder_param_grads(decoder, nets, d_dec)
+
+
+class _FusedPointsFn(torch.autograd.Function):
+    """Point queries under autograd (G.sample_mixed in the density regularisation, loss.py:681-706): fused forward, nothing per-point
+    kept; the backward recomputes gather + decoder on the device (``p3d_sample_points_backward``) and returns gradients for the
+    planes and the decoder parameters."""
+
+    @staticmethod
+    def forward(ctx, decoder, opt, coordinates, planes, *params):
+        rgb, sigma = fused_sample_points(planes, decoder, coordinates, opt)
+        ctx.decoder, ctx.opt = decoder, opt
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(planes, coordinates)
+        return rgb, sigma
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_sigma):
+        planes, coordinates = ctx.saved_tensors
+        backward_calls['points'] += 1
+        if g_rgb is None and g_sigma is None:
+            return (None,) * (4 + len(list(ctx.decoder.parameters())))
+        g_planes, g_params = fused_sample_points_backward(planes, ctx.decoder, coordinates, ctx.opt, g_rgb, g_sigma)
+        return (None, None, None, g_planes if ctx.needs_input_grad[3] else None) + tuple(g_params)
+
+
 def fused_render_backward(planes, decoder, ray_origins, ray_directions, opt, u_coarse, u_fine, t_start, t_end, g_feat, g_wsum=None, debug=False):
     """dL/dplanes (same shape and layout class as ``planes``) and dL/d(decoder parameters) (in ``decoder.parameters()`` order) of the
     fused render, by the two recomputing launches of csrc/render_bwd.hip.  Decoder parameters must require grad to get an entry."""
@@ -596,11 +678,7 @@ def fused_render_backward(planes, decoder, ray_origins, ray_directions, opt, u_c
     s_all = sc + sf
     dev = planes.device
     ctx = _FusedContext(planes, info)
-    packed_bwd = torch.empty([lib.p3d_render_bwd_decoder_floats()], dtype=torch.float32, device=dev)
-    w1s = [_f32c(fc1.weight) for fc1, _ in nets] + [None]
-    w2s = [_f32c(fc2.weight) for _, fc2 in nets] + [None]
-    _lib.check(lib.p3d_pack_decoder_bwd(_lib.ptr(w1s[0]), _lib.ptr(w2s[0]), _lib.ptr(w1s[1]), _lib.ptr(w2s[1]), len(nets), lr_mul, _lib.ptr(packed_bwd),
-                                        _lib.stream_of(packed_bwd)), 'pack_decoder_bwd')
+    packed_bwd = _pack_decoder_bwd(nets, lr_mul, dev)
     auto = t_start is not None
     t0 = _f32c(t_start).reshape(-1) if auto else None
     t1 = _f32c(t_end).reshape(-1) if auto else None
@@ -619,15 +697,7 @@ def fused_render_backward(planes, decoder, ray_origins, ray_directions, opt, u_c
     g_planes = d_planes.permute(0, 1, 4, 2, 3)                    # [N, 3, 32, H, W] view of the channels-last gradient
     if planes.dim() == 5 and planes.is_contiguous():
         g_planes = g_planes.contiguous()
-    stride = lib.p3d_render_grad_decoder_floats() // 2
-    by_param = {}
-    for i, (fc1, fc2) in enumerate(nets):
-        g = d_dec[i * stride:(i + 1) * stride]
-        by_param[id(fc1.weight)] = g[0:2048].reshape(64, 32) * fc1.weight_gain
-        by_param[id(fc1.bias)] = g[2048:2112] * fc1.bias_gain
-        by_param[id(fc2.weight)] = g[2112:4224].reshape(33, 64) * fc2.weight_gain
-        by_param[id(fc2.bias)] = g[4224:4257] * fc2.bias_gain
-    g_params = [by_param.get(id(p)) if p.requires_grad else None for p in decoder.parameters()]
+    g_params = _decoder_param_grads(decoder, nets, d_dec)
     if debug:                                                     # the per-sample tape: z, colour weight, dL/dsigma (tests)
         return g_planes, g_params, tape_s
     return g_planes, g_params

@@ -3,7 +3,7 @@
 Run in the authoring container only (it needs the read-only checkout at /root/reference, which does
 not exist on the GPU box):
 
-    python tests/golden/make_golden.py [group ...]      # groups: ops renderer semrenderer model flrelu train checkpoint variants discriminator api srheads architectures helpers
+    python tests/golden/make_golden.py [group ...]      # groups: ops renderer semrenderer model model_full flrelu train train_full greg checkpoint variants discriminator api srheads architectures helpers
 
 The reference and this repo own the same top-level module names, so this script must never import
 ``pix2pix3d_amd``; it puts /root/reference first on sys.path and imports the reference's modules
@@ -447,6 +447,108 @@ def group_train():
 
 
 GROUPS['train'] = group_train
+
+
+def _grad_record(G, heads):
+    """Norm of EVERY parameter gradient (name-ordered) + the first 64 entries of the named ones."""
+    names = [n for n, _ in G.named_parameters()]
+    params = dict(G.named_parameters())
+    norms = np.array([float(params[n].grad.double().norm()) if params[n].grad is not None else -1.0 for n in names], dtype=np.float64)
+    arrays = {'grad_names': np.array(names), 'grad_norms': norms, 'head_names': np.array(heads)}
+    for i, nme in enumerate(heads):
+        arrays[f'h{i}'] = params[nme].grad.reshape(-1)[:64].clone()
+    return arrays
+
+
+def group_train_full():
+    """BASELINE config 3 at its real size, one Gmain-style pass of the reference on the CPU: seg2cat, batch 2, 128^2 rays x 48+48,
+    G.mapping (label map -> Encoder -> ws, loss.py:440) + G.synthesis in training mode (unfused modulation, tensor-op renderer under
+    autograd), a scalar loss over image / semantic / image_raw, backward through everything.  Records the loss, the gradient norm of
+    every parameter and heads of a dozen gradients (backbone, Encoder of G.mapping, decoder, both SR heads)."""
+    import dnnlib
+    configs = _load_by_path('p3d_configs', os.path.join(os.path.dirname(os.path.dirname(HERE)), 'pix2pix3d_amd', 'configs.py'))
+    weights = _load_by_path('p3d_weights', os.path.join(HERE, 'weights.py'))
+    kw = configs.generator_kwargs('seg2cat', depth=(48, 48))
+    info = configs.dataset_info('seg2cat')
+    torch.manual_seed(0)
+    G = dnnlib.util.construct_class_by_name(**kw).train().requires_grad_(True)
+    weights.seed_module(G, seed=1)
+    n, nrr = 2, 128
+    gz = torch.Generator().manual_seed(15)
+    z = torch.randn(n, 512, generator=gz)
+    mask = torch.randint(0, info['sem'], [n, 1, info['res'], info['res']], generator=gz)
+    rk = kw['rendering_kwargs']
+    c = torch.tensor(np.stack([configs.orbit_camera(k, radius=rk['avg_camera_radius'], pivot=rk['avg_camera_pivot']) for k in (3, 24)]))
+    ws = G.mapping(z, c, {'mask': mask, 'pose': c}, update_emas=False)
+    torch.manual_seed(4321)
+    with _RandTape() as tape:
+        out = G.synthesis(ws, c, neural_rendering_resolution=nrr, noise_mode='const')
+    assert len(tape.draws) == 2
+    loss = out['image'].square().mean() + out['semantic'].square().mean() * 0.1 + out['image_raw'].square().mean()
+    loss.backward()
+    heads = ['backbone.synthesis.b4.const', 'backbone.synthesis.b256.conv1.weight', 'backbone.synthesis.b64.conv0.affine.bias',
+             'backbone.synthesis.b256.torgb.weight', 'decoder.net.0.weight', 'decoder.net_semantic.2.bias', 'decoder.net_semantic.0.weight',
+             'superresolution.block1.conv1.weight', 'superresolution.block0.conv0.bias', 'superresolution_semantic.block1.torgb.bias']
+    enc = [nm for nm, p in G.named_parameters() if nm.startswith('backbone.mapping') and p.grad is not None and p.ndim >= 2]
+    heads += [enc[0], enc[len(enc) // 2], enc[-1]]
+    arrays = dict(z=z, c=c, mask=mask.to(torch.int16), nrr=np.int64(nrr), depth=np.array([48, 48]), render_seed=np.int64(4321), loss=loss.detach(), ws=ws.detach(),
+                  u_coarse_head=tape.draws[0].reshape(-1)[:16], u_fine_head=tape.draws[1].reshape(-1)[:16])
+    for k in ('image_raw', 'semantic_raw', 'image', 'semantic'):
+        arrays[k + '_mean'] = out[k].detach().double().mean(dim=[2, 3])
+    arrays.update(_grad_record(G, heads))
+    save('train_full_seg2cat', **arrays)
+
+
+GROUPS['train_full'] = group_train_full
+
+
+def group_greg():
+    """The density-regularisation phase ('Greg', loss.py:681-706, reg_type 'l1') of the reference on the CPU: ws = G.mapping(...),
+    1000 uniform points per image + their perturbed copies, sigma = G.sample_mixed(...)['sigma'], L1 between the halves x density_reg,
+    backward.  The points and the perturbation are recorded (the loss draws them with the global generator)."""
+    import dnnlib
+    configs = _load_by_path('p3d_configs', os.path.join(os.path.dirname(os.path.dirname(HERE)), 'pix2pix3d_amd', 'configs.py'))
+    weights = _load_by_path('p3d_weights', os.path.join(HERE, 'weights.py'))
+    kw = configs.generator_kwargs('seg2cat', depth=(48, 48))
+    info = configs.dataset_info('seg2cat')
+    torch.manual_seed(0)
+    G = dnnlib.util.construct_class_by_name(**kw).train().requires_grad_(True)
+    weights.seed_module(G, seed=1)
+    n = 2
+    gz = torch.Generator().manual_seed(25)
+    z = torch.randn(n, 512, generator=gz)
+    mask = torch.randint(0, info['sem'], [n, 1, info['res'], info['res']], generator=gz)
+    rk = kw['rendering_kwargs']
+    c = torch.tensor(np.stack([configs.orbit_camera(k, radius=rk['avg_camera_radius'], pivot=rk['avg_camera_pivot']) for k in (5, 50)]))
+    ws = G.mapping(z, c, {'mask': mask, 'pose': c}, update_emas=False)
+    torch.manual_seed(777)
+    initial = torch.rand((n, 1000, 3)) * 2 - 1
+    perturbed = initial + torch.randn_like(initial) * rk['density_reg_p_dist']
+    coords = torch.cat([initial, perturbed], dim=1)
+    res = G.sample_mixed(coords, torch.randn_like(coords), ws, update_emas=False, noise_mode='const')
+    sigma = res['sigma']
+    s_i, s_p = sigma[:, :sigma.shape[1] // 2], sigma[:, sigma.shape[1] // 2:]
+    loss = torch.nn.functional.l1_loss(s_i, s_p) * rk['density_reg']
+    loss.backward()
+    heads = ['backbone.synthesis.b4.const', 'backbone.synthesis.b256.conv1.weight', 'backbone.synthesis.b256.torgb.weight', 'backbone.synthesis.b256.torgb.bias',
+             'decoder.net_semantic.0.weight', 'decoder.net_semantic.0.bias', 'decoder.net_semantic.2.weight', 'decoder.net_semantic.2.bias']
+    enc = [nm for nm, p in G.named_parameters() if nm.startswith('backbone.mapping') and p.grad is not None and p.ndim >= 2]
+    heads += [enc[0], enc[-1]]
+    arrays = dict(z=z, c=c, mask=mask.to(torch.int16), coords=coords, loss=loss.detach(), sigma=sigma.detach(), rgb_head=res['rgb'].detach()[:, :8], ws=ws.detach())
+    arrays.update(_grad_record(G, heads))
+    # second record: a loss that also uses the colours (the general autograd contract of run_model)
+    for p in G.parameters():
+        p.grad = None
+    ws2 = G.mapping(z, c, {'mask': mask, 'pose': c}, update_emas=False)
+    res2 = G.sample_mixed(coords, None, ws2, update_emas=False, noise_mode='const')
+    loss2 = res2['rgb'].square().mean() + res2['sigma'].square().mean() * 1e-3
+    loss2.backward()
+    rec2 = _grad_record(G, heads)
+    arrays.update({'rgbloss': loss2.detach(), 'rgbloss_grad_norms': rec2['grad_norms'], **{f'rgbloss_h{i}': rec2[f'h{i}'] for i in range(len(heads))}})
+    save('greg_seg2cat', **arrays)
+
+
+GROUPS['greg'] = group_greg
 
 
 def _tile_large(module, period=512, limit=1024):

@@ -8,5 +8,5 @@ cp $(find /tmp/prof_bench -name '*kernel_stats.csv' | head -1) gpurun_out/${tag}
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_train -o t -- python $GRAFT_REPO_ROOT/tests/gpu_train_census.py 4 128 --no-census > $GRAFT_REPO_ROOT/gpurun_out/${tag}_train_passes.log 2> /tmp/prof_train.err)
 cp $(find /tmp/prof_train -name '*kernel_stats.csv' | head -1) gpurun_out/${tag}_train_kernel_stats.csv
 python tests/gpu_train_census.py 4 128 --json gpurun_out/${tag}_train_census.json > gpurun_out/${tag}_train_census.log 2>&1
-python bench.py > gpurun_out/${tag}_bench_line_hipgraph.json 2> /dev/null
+python bench.py --no-train-step --no-cpu-baseline > gpurun_out/${tag}_bench_line_hipgraph.json 2> /dev/null
 head -c 600 gpurun_out/${tag}_bench_line_hipgraph.json; echo; grep pass gpurun_out/${tag}_train_census.log | cut -c1-200; head -12 gpurun_out/${tag}_bench_kernel_stats.csv | cut -c1-160

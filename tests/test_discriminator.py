@@ -17,7 +17,18 @@ CASES = dict(dual=dict(class_name='training.dual_discriminator.DualDiscriminator
                          channel_max=16, num_fp16_res=0, conv_clamp=None))
 
 
-def _dboth(name, device, tol, grad_tol=None):
+def _field_close(a, ref, tol, robust):
+    """max-norm parity of a gradient field; ``robust``: relative L2 error <= tol and at most 0.1 % of the elements off by more than tol of the
+    field's maximum (see test_discriminator_dboth_phase_on_the_native_convolutions for why the bf16x3 leg needs that form)."""
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    if not robust:
+        return rel_err(a, ref) < tol, rel_err(a, ref)
+    l2 = float(np.linalg.norm(a - ref) / max(np.linalg.norm(ref), 1e-30))
+    frac = float((np.abs(a - ref) > tol * np.abs(ref).max()).mean())
+    return (l2 < tol and frac <= 1e-3), (l2, frac, rel_err(a, ref))
+
+
+def _dboth(name, device, tol, grad_tol=None, robust=False):
     gt = tol if grad_tol is None else grad_tol
     from pix2pix3d_amd import dnnlib
     from pix2pix3d_amd.torch_utils.ops import conv2d_gradfix
@@ -36,9 +47,11 @@ def _dboth(name, device, tol, grad_tol=None):
         grads = torch.autograd.grad(outputs=[logits.sum()], inputs=list(img.values()), create_graph=True, only_inputs=True)
     r1 = sum(gr.square().sum([1, 2, 3]) for gr in grads)
     (torch.nn.functional.softplus(-logits) + r1 * 5).mean().backward()
-    assert rel_err(grads[0].detach().cpu().numpy(), g['g_img']) < gt
+    ok, stat = _field_close(grads[0].detach().cpu().numpy(), g['g_img'], gt, robust)
+    assert ok, ('g_img', stat)
     if name != 'single':
-        assert rel_err(grads[1].detach().cpu().numpy(), g['g_raw']) < gt
+        ok, stat = _field_close(grads[1].detach().cpu().numpy(), g['g_raw'], gt, robust)
+        assert ok, ('g_raw', stat)
     assert rel_err(r1.detach().cpu().numpy(), g['r1']) < gt
     params = dict(D.named_parameters())
     names = [n for n, p in params.items() if p.grad is not None]
@@ -66,16 +79,20 @@ def test_discriminator_dboth_phase_on_the_native_convolutions(hip_lib, name):
     """The same phase as the training loop runs it (conv2d_gradfix.enabled = True, training_loop.py:281): every convolution, its
     data gradient, the R1 double-backward and the weight gradients go through libp3d_hip.so — none through torch's operators.
 
-    Two legs.  Exact fp32 (conv2d_gradfix.split_bf16 off): everything within 2e-3 of the reference records.  Default (fp32 layers as
-    bf16x3): every convolution is within 1e-5 of fp32 (tests/gpu_probe_split_d.py compares them call by call), logits within 2e-3;
-    but the 'dual' record holds one pre-activation at -9e-8 of a range of 1.5 which that rounding carries across zero, leaky-ReLU's
-    slope jumps 0.2 -> 1 there and the gradients downstream of that one unit move by 3-6 % of their maximum — a property of the
-    function at that point, not of the kernels — so the gradient quantities of this leg are held to 0.1."""
+    Two legs.  Exact fp32 (conv2d_gradfix.split_bf16 off): everything within 2e-3 of the reference records, max-norm.  Default (fp32 layers as
+    bf16x3): every convolution is within 1e-5 of fp32 (tests/gpu_probe_split_d.py compares them call by call), logits within 2e-3, and every
+    gradient quantity within 1e-2 (round 2 allowed 0.1): r1, all parameter-gradient norms, the gradient head, and the two R1 gradient
+    FIELDS in the robust form of ``_field_close``.  Why a field is not held in max-norm on this leg: a leaky-ReLU layer of these networks
+    has up to 262 144 pre-activations of range ~1.5, the closest to zero sits at 4e-8 .. 5e-7 of the range for EVERY input seed
+    (tests/golden/seed_search_discriminator.py lists seeds 31..45: there is no seed without such units), and a 5e-6 perturbation carries a
+    handful of them across zero; the slope then jumps 0.2 -> 1 and the input-gradient of the 3x3 neighbourhood behind that unit moves by a few
+    per cent of the field's maximum — a property of the function at those points, not of the kernels.  Such a flip touches ~30 of the field's
+    49 152 elements, so "relative L2 <= 1e-2 and <= 0.1 % of the elements off by more than 1e-2 of the maximum" pins everything else."""
     from pix2pix3d_amd.torch_utils.ops import conv2d_gradfix
     prev, conv2d_gradfix.enabled = conv2d_gradfix.enabled, True
     c0 = dict(conv2d_gradfix.native_calls)
     try:
-        _dboth(name, 'cuda', 2e-3, grad_tol=0.1)
+        _dboth(name, 'cuda', 2e-3, grad_tol=1e-2, robust=True)
         prev_split, conv2d_gradfix.split_bf16 = conv2d_gradfix.split_bf16, False
         try:
             _dboth(name, 'cuda', 2e-3)

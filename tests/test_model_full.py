@@ -107,7 +107,8 @@ def test_ray_marcher_at_bench_size_matches_oracle_on_every_ray(hip_lib, tag):
     e_depth = float((depth.cpu().reshape(do.shape) - do).abs().max())
     e_w = rel_err(wsum.cpu().numpy().reshape(wo.shape), wo.numpy())
     print(tag, dict(feat=e_feat, depth=e_depth, wsum=e_w))
-    assert e_feat < 1e-3 and e_depth < 1e-4 and e_w < 1e-3
+    # measured ~1e-5 (bf16x3 decoder) / ~2e-6 (exact): 1e-4 also catches the v_cvt_pk_bf16_f32 -> MFMA hazard (5 % of the rays off by 1e-3) at a tenth of its amplitude
+    assert e_feat < 1e-4 and e_depth < 1e-4 and e_w < 1e-4
     # a flipped importance bin moves a sample by >= 1e-3 of the ray: count rays whose depth differs visibly
     bad = ((depth.cpu().reshape(do.shape) - do).abs() > 2e-5).float().mean().item()
     assert bad < 1e-3, bad
