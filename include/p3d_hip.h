@@ -96,7 +96,7 @@ int p3d_upfirdn2d_acc(const void* x, const float* f, void* y, int dtype,
  *   code & 1 -> times slope, code & 2 -> 0, elements outside the tensor pass unchanged; clamp is not applied.
  * sw_limit: valid bytes per sign row ((active width + 3) >> 2).  clamp = +inf disables clamping.
  * Returns P3D_ERR_UNSUPPORTED (-1, the plugin's "no specialised kernel" code, filtered_lrelu.cpp:56-60) when the tiles of this geometry
- * do not fit 64 KB of LDS or s_ofs_x is not a multiple of 4 in write mode: the caller then takes the generic route
+ * do not fit gfx950's 160 KB of LDS or s_ofs_x is not a multiple of 4 in write mode: the caller then takes the generic route
  * (upfirdn2d -> p3d_filtered_lrelu_act -> upfirdn2d), as the reference does.                                                        */
 int p3d_filtered_lrelu(const void* x, const float* fu, const float* fd, const void* b, uint8_t* s, void* y, int dtype,
                        const int32_t x_size[4], const int64_t x_stride[4], const int32_t y_size[4], const int64_t y_stride[4], int64_t b_stride,
@@ -420,7 +420,8 @@ int p3d_ray_sample(const float* cam2world, const float* intrinsics, float* origi
  * Not part of the reference's interface.  gfx950 hazard behind the `s_nop 4` of the bf16x3 kernels (csrc/render_device.h split8,
  * csrc/conv2d.hip split_bf16x8): v_mfma_f32_32x32x16_bf16 reading, as SrcB (src_a = 0: the ray-marcher's decoder) or SrcA (src_a = 1: the
  * convolutions' activations), VGPRs written by v_cvt_pk_bf16_f32 `wait_states` (0..8) wait states earlier, against the same MFMA 16
- * wait states later, on every CU, `iters` iterations per wave.
+ * wait states later, on every CU, `iters` iterations per wave.  src_a = 2 probes the opposite order (write-after-read): the MFMA reads the
+ * registers as SrcB and a v_cvt_pk_bf16_f32 overwrites them `wait_states` later, against the same overwrite 64 wait states later.
  * counts[0] <- lanes whose results differ, counts[1] <- differing accumulator registers (both 0 = no stale read observed).            */
 int p3d_probe_cvt_mfma_hazard(int32_t wait_states, int32_t src_a, int32_t iters, uint32_t* counts, p3d_stream_t stream);
 

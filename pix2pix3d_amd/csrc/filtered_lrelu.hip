@@ -218,11 +218,19 @@ extern "C" int p3d_filtered_lrelu(const void* x, const float* fu, const float* f
     a.IW = (((a.UW + 3) & ~3) + fu_w - 2) / up + 2; a.IH = (a.UH + fu_h - 2) / up + 2;      // (width: whole sign bytes, see the kernel)
     const size_t lds = (size_t)(fu_w * fu_h + fd_w * fd_h + a.IW * a.IH + a.UW * a.UH) * sizeof(float);
     // "no specialised kernel": same meaning as the plugin's return code -1 (filtered_lrelu.cpp:56-60) — the caller takes the generic route
-    if (lds > 64 * 1024) return fail(P3D_ERR_UNSUPPORTED, "filtered_lrelu: tiles of %zu B do not fit (filters %dx%d / %dx%d, up %d, down %d)", lds, fu_w, fu_h, fd_w, fd_h, up, down);
+    // (gfx950 has 160 KB of LDS per CU; more than 64 KB per block is an opt-in per kernel and device, taken once below)
+    constexpr size_t kLdsMax = 160 * 1024;
+    if (lds > kLdsMax) return fail(P3D_ERR_UNSUPPORTED, "filtered_lrelu: tiles of %zu B do not fit %zu B of LDS (filters %dx%d / %dx%d, up %d, down %d)", lds, kLdsMax, fu_w, fu_h, fd_w, fd_h, up, down);
     if (sign_mode == 1 && (s_ofs_x & 3)) return fail(P3D_ERR_UNSUPPORTED, "filtered_lrelu: sign offset x = %d is not byte aligned in write mode", s_ofs_x);
     const int64_t blocks = (int64_t)a.C * a.N * a.tiles_x * a.tiles_y;
     P3D_REQUIRE(blocks < (1ll << 31), "filtered_lrelu: too many tiles");
     hipStream_t st_ = (hipStream_t)stream;
+    if (lds > 64 * 1024) {
+        static std::atomic<uint64_t> once_h{0}, once_f{0};
+        const hipError_t e = dtype == P3D_F16 ? reserve_lds_once((const void*)filtered_lrelu_kernel<__half>, (int)kLdsMax, once_h)
+                                              : reserve_lds_once((const void*)filtered_lrelu_kernel<float>, (int)kLdsMax, once_f);
+        if (e != hipSuccess) return fail(P3D_ERR_LAUNCH, "filtered_lrelu: cannot reserve %zu B of LDS: %s", kLdsMax, hipGetErrorString(e));
+    }
     if (dtype == P3D_F16) hipLaunchKernelGGL(filtered_lrelu_kernel<__half>, dim3((unsigned)blocks), dim3(256), lds, st_, a);
     else                  hipLaunchKernelGGL(filtered_lrelu_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, st_, a);
     count_launch(FAM_FLRELU);

@@ -44,7 +44,27 @@ __device__ __forceinline__ void cvt_then_mfma_safe(f32x16& acc, const bf8& a, co
     else                asm volatile("s_nop 7\n" P3D_CVT4 "s_nop 7\n" "s_nop 7\n" P3D_MFMA_B P3D_OPERANDS : "v100", "v101", "v102", "v103");
 }
 
-template <int WAIT, bool SRCA>
+// WAR flavour: the MFMA reads v[100:103] as SrcB over several passes; how soon may a following v_cvt_pk_bf16_f32 overwrite them?  The
+// fast variant overwrites WAIT wait states after the MFMA issues, the reference 64 wait states later; the accumulators must agree.
+#define P3D_CVT4Y \
+    "v_cvt_pk_bf16_f32 v100, %[y0], %[y1]\n" \
+    "v_cvt_pk_bf16_f32 v101, %[y2], %[y3]\n" \
+    "v_cvt_pk_bf16_f32 v102, %[y4], %[y5]\n" \
+    "v_cvt_pk_bf16_f32 v103, %[y6], %[y7]\n"
+#define P3D_OPERANDS_Y P3D_OPERANDS, [y0] "v"(y[0]), [y1] "v"(y[1]), [y2] "v"(y[2]), [y3] "v"(y[3]), [y4] "v"(y[4]), [y5] "v"(y[5]), [y6] "v"(y[6]), [y7] "v"(y[7])
+template <int WAIT>
+__device__ __forceinline__ void mfma_then_cvt(f32x16& acc, const bf8& a, const float (&x)[8], const float (&y)[8])
+{
+    if constexpr (WAIT == 0) asm volatile("s_nop 7\n" P3D_CVT4 "s_nop 7\ns_nop 7\n" P3D_MFMA_B P3D_CVT4Y P3D_OPERANDS_Y : "v100", "v101", "v102", "v103");
+    else asm volatile("s_nop 7\n" P3D_CVT4 "s_nop 7\ns_nop 7\n" P3D_MFMA_B "s_nop %[n]\n" P3D_CVT4Y P3D_OPERANDS_Y, [n] "n"(WAIT - 1) : "v100", "v101", "v102", "v103");
+}
+__device__ __forceinline__ void mfma_then_cvt_safe(f32x16& acc, const bf8& a, const float (&x)[8], const float (&y)[8])
+{
+    asm volatile("s_nop 7\n" P3D_CVT4 "s_nop 7\ns_nop 7\n" P3D_MFMA_B "s_nop 7\ns_nop 7\ns_nop 7\ns_nop 7\ns_nop 7\ns_nop 7\ns_nop 7\ns_nop 7\n" P3D_CVT4Y P3D_OPERANDS_Y
+                 : "v100", "v101", "v102", "v103");
+}
+
+template <int WAIT, int MODE>            // MODE 0: RAW into SrcB, 1: RAW into SrcA, 2: WAR on SrcB
 __global__ void __launch_bounds__(512, 2) cvt_mfma_hazard_kernel(int iters, unsigned* __restrict__ out)
 {
     const int lane = threadIdx.x & 63;
@@ -57,14 +77,20 @@ __global__ void __launch_bounds__(512, 2) cvt_mfma_hazard_kernel(int iters, unsi
     for (int r = 0; r < 16; ++r) { fast[r] = 0.f; safe[r] = 0.f; }
     unsigned s = gid * 2654435761u + 12345u;
     for (int it = 0; it < iters; ++it) {
-        float x[8];
+        float x[8], y[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {                                   // fresh values every iteration: what the conversion leaves differs from the registers' old contents
             s = s * 1664525u + 1013904223u;
             x[e] = (float)(int)(s >> 8) * (1.f / 8388608.f) - 1.f;
+            y[e] = x[e] * 3.f + 5.f;
         }
-        cvt_then_mfma<WAIT, SRCA>(fast, a, x);
-        cvt_then_mfma_safe<SRCA>(safe, a, x);
+        if constexpr (MODE == 2) {
+            mfma_then_cvt<WAIT>(fast, a, x, y);
+            mfma_then_cvt_safe(safe, a, x, y);
+        } else {
+            cvt_then_mfma<WAIT, MODE == 1>(fast, a, x);
+            cvt_then_mfma_safe<MODE == 1>(safe, a, x);
+        }
     }
     unsigned bad = 0;
 #pragma unroll
@@ -73,10 +99,11 @@ __global__ void __launch_bounds__(512, 2) cvt_mfma_hazard_kernel(int iters, unsi
 }
 
 template <int WAIT>
-static void launch_probe(int blocks, int iters, unsigned* out, hipStream_t s, int src_a)
+static void launch_probe(int blocks, int iters, unsigned* out, hipStream_t s, int mode)
 {
-    if (src_a) hipLaunchKernelGGL((cvt_mfma_hazard_kernel<WAIT, true>), dim3(blocks), dim3(512), 0, s, iters, out);
-    else       hipLaunchKernelGGL((cvt_mfma_hazard_kernel<WAIT, false>), dim3(blocks), dim3(512), 0, s, iters, out);
+    if (mode == 2)      hipLaunchKernelGGL((cvt_mfma_hazard_kernel<WAIT, 2>), dim3(blocks), dim3(512), 0, s, iters, out);
+    else if (mode == 1) hipLaunchKernelGGL((cvt_mfma_hazard_kernel<WAIT, 1>), dim3(blocks), dim3(512), 0, s, iters, out);
+    else                hipLaunchKernelGGL((cvt_mfma_hazard_kernel<WAIT, 0>), dim3(blocks), dim3(512), 0, s, iters, out);
 }
 
 } // namespace p3d
@@ -86,6 +113,7 @@ using namespace p3d;
 extern "C" int p3d_probe_cvt_mfma_hazard(int32_t wait_states, int32_t src_a, int32_t iters, uint32_t* counts, p3d_stream_t stream)
 {
     P3D_REQUIRE(counts && iters >= 1 && wait_states >= 0 && wait_states <= 8, "probe_cvt_mfma_hazard: bad arguments (wait_states 0..8)");
+    P3D_REQUIRE(src_a >= 0 && src_a <= 2, "probe_cvt_mfma_hazard: mode (src_a) must be 0, 1 or 2");
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(counts, 0, 2 * sizeof(uint32_t), s) != hipSuccess) return fail(P3D_ERR_LAUNCH, "probe_cvt_mfma_hazard: memset failed");
     const int blocks = kNumCU * 2;

@@ -86,8 +86,12 @@ class _Cfg:
 
 
 native = True              # device tensors of the covered family go to libp3d_hip.so; False = torch's operators everywhere
-split_bf16 = os.environ.get('P3D_TRAIN_BF16X3', '1') != '0'      # fp32 forward / data-gradient convolutions as three bf16 MFMAs per product (csrc/conv2d.hip,
-                                                                 # "bf16x3": ~5e-6 of the output range, 2.5x the fp32 matrix rate); weight gradients stay exact fp32
+split_bf16 = os.environ.get('P3D_TRAIN_BF16X3', '0') == '1'      # opt-in: fp32 forward / data-gradient convolutions as three bf16 MFMAs per product (csrc/conv2d.hip,
+                                                                 # "bf16x3": ~5e-6 of the output range, 2.5x the fp32 matrix rate; weight gradients stay exact fp32 either
+                                                                 # way).  Training defaults to EXACT fp32 products — the reference's stance (training_loop.py:278-280 turns
+                                                                 # TF32 off): a 5e-6 perturbation carries a handful of leaky-ReLU pre-activations across zero per pass,
+                                                                 # which moves R1 gradient fields by ~1 % in L2 (tests/test_discriminator.py) — fine for inference, not a
+                                                                 # default for a training run that is meant to reproduce the reference's
 native_calls = {'forward': 0, 'weight_grad': 0, 'aten': 0}      # which route the dense arithmetic took (tests)
 
 _vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64

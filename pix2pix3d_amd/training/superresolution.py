@@ -133,3 +133,19 @@ class SuperresolutionHybrid2X_semantic(_SuperresolutionBase):
         _two_blocks(self, SynthesisBlockNoUp, SynthesisBlock, channels, 128, 64, 64, 128, semantic_channels, sr_num_fp16_res > 0, block_kwargs)
         from ..torch_utils.ops import upfirdn2d
         self.register_buffer('resample_filter', upfirdn2d.setup_filter([1, 3, 3, 1]))
+
+
+@persistence.persistent_class
+class SuperresolutionHybridDeepfp32(_SuperresolutionBase):
+    """128^2 -> 256^2 head of the old 256x256 EG3D models (:160-188, "here for backwards compatibility"): a no-upsampling block then a x2
+    block like 4X, but without the ``sr_antialias`` argument — inputs smaller than 128^2 are enlarged with plain bilinear interpolation.
+    No generator of this repository's configurations selects it; it is reachable by name from old checkpoints."""
+    _resize_only_up = True
+
+    def __init__(self, channels, img_resolution, sr_num_fp16_res, num_fp16_res=4, conv_clamp=None, channel_base=None, channel_max=None, **block_kwargs):
+        super().__init__()
+        assert img_resolution == 256
+        self.input_resolution, self.sr_antialias = 128, False
+        _two_blocks(self, SynthesisBlockNoUp, SynthesisBlock, channels, 128, 64, 128, 256, 3, sr_num_fp16_res > 0, block_kwargs)
+        from ..torch_utils.ops import upfirdn2d
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter([1, 3, 3, 1]))

@@ -316,6 +316,32 @@ class OSGDecoder_semantic(torch.nn.Module):
         return {'rgb': labels, 'sigma': y[..., 0:1]}
 
 
+class OSGDecoder_semantic_entangle(torch.nn.Module):
+    """ONE 32-64-(1 + decoder_output_dim) MLP whose outputs are split by position (:891-924): density, 3 colour channels (clamped sigmoid),
+    ``semantic_channels`` raw label logits, and the remaining feature channels (clamped sigmoid) — or clamped sigmoid on everything when
+    ``options['sigmoid']``.  No shipped configuration selects it (train.py builds the lateSeparate decoder); kept for checkpoints that name it.
+    The fused ray-marcher does not implement this split, so renders with it take the tensor-op formulation."""
+
+    def __init__(self, n_features, options):
+        super().__init__()
+        self.hidden_dim = 64
+        self.net = _osg_mlp(n_features, self.hidden_dim, 1 + options['decoder_output_dim'], options['decoder_lr_mul'])
+        self.feature_sigmoid = options['sigmoid']
+        self.semantic_channels = options['semantic_channels']
+
+    def forward(self, sampled_features, ray_directions):
+        x = sampled_features.mean(1)
+        n, m, c = x.shape
+        y = self.net(x.reshape(n * m, c)).reshape(n, m, -1)
+        squash = lambda t: torch.sigmoid(t) * (1 + 2 * 0.001) - 0.001
+        if self.feature_sigmoid:
+            feature = squash(y[..., 1:])
+        else:
+            k = 4 + self.semantic_channels
+            feature = torch.cat((squash(y[..., 1:4]), y[..., 4:k], squash(y[..., k:])), dim=-1)
+        return {'rgb': feature, 'sigma': y[..., 0:1]}
+
+
 class OSGDecoder_semantic_lateSeparate(torch.nn.Module):
     """Two independent 32-64-33 MLPs on the plane-averaged feature: a colour net and a label net; the density is
     channel 0 of the LABEL net (:926-970).  Output 'rgb' = cat(32 colour channels, 32 label channels)."""

@@ -264,7 +264,12 @@ class ImportanceRenderer(torch.nn.Module):
             s = z.shape[2]
             pts = (ray_origins.unsqueeze(-2) + z * ray_directions.unsqueeze(-2)).reshape(n, -1, 3)
             dirs = ray_directions.unsqueeze(-2).expand(-1, -1, s, -1).reshape(n, -1, 3)
-            out = point_fn(pts, dirs) if point_fn is not None else self.run_model(planes, decoder, pts, dirs, opt)
+            if point_fn is not None:
+                out = point_fn(pts, dirs)
+            elif torch.is_grad_enabled():                    # this method IS the tensor-op formulation: under autograd its point queries are tensor ops too
+                out = self._points_tensor_ops(planes, decoder, pts, dirs, opt)      # (the replay backward and the tests' reference runs rely on that)
+            else:
+                out = self.run_model(planes, decoder, pts, dirs, opt)
             return out['rgb'].reshape(n, m, s, -1), out['sigma'].reshape(n, m, s, 1)
 
         c_c, s_c = decode(z_c)
@@ -294,6 +299,11 @@ class ImportanceRenderer(torch.nn.Module):
                 rgb, sigma = fused_sample_points(planes, decoder, sample_coordinates, options)
             return {'rgb': rgb, 'sigma': sigma}
         self._tensor_op_guard(planes, reason)
+        return self._points_tensor_ops(planes, decoder, sample_coordinates, sample_directions, options)
+
+    def _points_tensor_ops(self, planes, decoder, sample_coordinates, sample_directions, options):
+        """run_model as the reference writes it (renderer.py:142-148): grid_sample + decoder, differentiable in everything."""
+        self.plane_axes = self.plane_axes.to(sample_coordinates.device)
         feats = sample_from_planes(self.plane_axes, planes, sample_coordinates, padding_mode='zeros', box_warp=options['box_warp'])
         out = decoder(feats, sample_directions)
         if options.get('density_noise', 0) > 0:
@@ -664,6 +674,11 @@ class _FusedPointsFn(torch.autograd.Function):
         if g_rgb is None and g_sigma is None:
             return (None,) * (4 + len(list(ctx.decoder.parameters())))
         g_planes, g_params = fused_sample_points_backward(planes, ctx.decoder, coordinates, ctx.opt, g_rgb, g_sigma)
+        if g_rgb is None:                                    # only the density carries a gradient (the density regularisation): with two nets the
+            nets = _decoder_nets(ctx.decoder)[0]             # colour net is not part of the graph — None for its parameters, as autograd reports it
+            if len(nets) == 2:
+                skip = {id(p) for fc in nets[0] for p in fc.parameters()}
+                g_params = [None if id(p) in skip else g for p, g in zip(ctx.decoder.parameters(), g_params)]
         return (None, None, None, g_planes if ctx.needs_input_grad[3] else None) + tuple(g_params)
 
 

@@ -551,6 +551,38 @@ def group_greg():
 GROUPS['greg'] = group_greg
 
 
+def group_legacy_classes():
+    """Two reference classes no shipped configuration reaches but checkpoints can name: OSGDecoder_semantic_entangle
+    (triplane_cond.py:891-924) and SuperresolutionHybridDeepfp32 (superresolution.py:160-188)."""
+    import dnnlib
+    from training.triplane_cond import OSGDecoder_semantic_entangle
+    weights = _load_by_path('p3d_weights', os.path.join(HERE, 'weights.py'))
+    arrays = {}
+    gz = torch.Generator().manual_seed(91)
+    feats = torch.randn(2, 3, 50, 32, generator=gz)
+    for tag, sig in (('raw', False), ('sigmoid', True)):
+        dec = OSGDecoder_semantic_entangle(32, {'decoder_lr_mul': 1.0, 'decoder_output_dim': 32, 'sigmoid': sig, 'semantic_channels': 6}).requires_grad_(False)
+        weights.seed_module(dec, seed=71)
+        out = dec(feats, None)
+        arrays[f'dec.{tag}.rgb'], arrays[f'dec.{tag}.sigma'] = out['rgb'], out['sigma']
+    arrays['dec.feats_head'] = feats.reshape(-1)[:16].clone()
+    torch.manual_seed(0)
+    sr = dnnlib.util.construct_class_by_name(class_name='training.superresolution.SuperresolutionHybridDeepfp32', channels=32, img_resolution=256, sr_num_fp16_res=4,
+                                             channel_base=32768, channel_max=512, fused_modconv_default='inference_only').eval().requires_grad_(False)
+    weights.seed_module(sr, seed=72)
+    for tag, side in (('same', 128), ('small', 96)):
+        x = torch.randn(1, 32, side, side, generator=gz)
+        ws = torch.randn(1, 14, 512, generator=gz)
+        with torch.no_grad():
+            y = sr(x[:, :3].clone(), x, ws, noise_mode='const')
+        arrays[f'sr.{tag}.x_head'], arrays[f'sr.{tag}.ws_head'] = x.reshape(-1)[:16].clone(), ws.reshape(-1)[:16].clone()      # inputs are re-drawn from the seed by the tests
+        arrays[f'sr.{tag}.thumb'], arrays[f'sr.{tag}.crop'] = _thumb(y, 8)
+    save('legacy_classes', **arrays)
+
+
+GROUPS['legacy_classes'] = group_legacy_classes
+
+
 def _tile_large(module, period=512, limit=1024):
     """Replace every tensor above ``limit`` elements by a tiling of its first ``period`` values: the checkpoint then xz-compresses
     to a few hundred KiB (the label-map Encoder alone is 204 MB of fixed 512-channel layers) while every value stays name-seeded."""

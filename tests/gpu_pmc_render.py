@@ -29,16 +29,18 @@ PEAK_CLOCK_HZ = 2.4e9                       # MI355X_MICROARCH.md: max clock
 L2_PEAK_GBS, HBM_PEAK_GBS = 34500.0, 8000.0
 LINE = 128                                  # bytes per L1 / L2 line on gfx950
 
-GROUPS = [
-    ['SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_LDS', 'SQ_ACTIVE_INST_VMEM'],
-    ['SQ_INSTS_VALU', 'SQ_INSTS_MFMA', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM_RD', 'SQ_INSTS_SALU', 'SQ_ACTIVE_INST_SCA', 'SQ_INSTS_VALU_TRANS_F32'],
+GROUPS = [          # the SQ / GRBM and the two traffic passes first (known to run in seconds); the texture-path blocks last, few counters per pass, each pass
+    ['SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_LDS', 'SQ_ACTIVE_INST_VMEM'],   # under its own
+    ['SQ_INSTS_VALU', 'SQ_INSTS_MFMA', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM_RD', 'SQ_INSTS_SALU', 'SQ_ACTIVE_INST_SCA', 'SQ_INSTS_VALU_TRANS_F32'],   # timeout
     ['SQ_LDS_IDX_ACTIVE', 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_ADDR_CONFLICT', 'SQ_WAIT_INST_LDS', 'SQ_INST_LEVEL_VMEM', 'SQ_INST_LEVEL_LDS', 'SQ_WAVES', 'GRBM_GUI_ACTIVE'],
-    ['TA_TA_BUSY_sum', 'TA_BUFFER_READ_WAVEFRONTS_sum', 'TA_BUFFER_TOTAL_CYCLES_sum', 'TA_ADDR_STALLED_BY_TC_CYCLES_sum'],
-    ['TCP_TOTAL_CACHE_ACCESSES_sum', 'TCP_TCC_READ_REQ_sum', 'TCP_PENDING_STALL_CYCLES_sum', 'TCP_TCP_TA_DATA_STALL_CYCLES_sum'],
-    ['TCC_HIT_sum', 'TCC_MISS_sum', 'TCC_REQ_sum', 'TCC_READ_sum'],
     ['FETCH_SIZE'],
     ['WRITE_SIZE'],
+    ['TCC_HIT_sum', 'TCC_MISS_sum'],
+    ['TCC_REQ_sum', 'TCC_READ_sum'],
+    ['TCP_TOTAL_CACHE_ACCESSES_sum', 'TCP_TCC_READ_REQ_sum'],
+    ['TA_TA_BUSY_sum', 'TA_BUFFER_READ_WAVEFRONTS_sum'],
 ]
+PASS_TIMEOUT_S = int(os.environ.get('PMC_PASS_TIMEOUT', 75))       # (round 3: a four-counter TA pass never returned and cost its whole 600 s)
 
 
 def kernel_source_hash(root=ROOT):
@@ -54,7 +56,14 @@ def one_pass(idx, counters, out_root):
     env = dict(os.environ, REPS='1', TMPDIR='/tmp')
     cmd = ['rocprofv3', '--kernel-trace', '--pmc'] + counters + ['--output-format', 'csv', '-d', out_dir, '-o', 'r', '--',
                                                                    sys.executable, os.path.join(ROOT, 'tests', 'gpu_profile_render.py')]
-    r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    import signal
+    proc = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=PASS_TIMEOUT_S)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)                      # the pass's own process group (rocprofv3 + the python child), nothing else
+        proc.communicate()
+        return None, None, f'pass timed out after {PASS_TIMEOUT_S} s'
     vals, dur = {}, []
     for f in glob.glob(os.path.join(out_dir, '**', '*counter_collection.csv'), recursive=True):
         with open(f) as fh:
@@ -67,7 +76,7 @@ def one_pass(idx, counters, out_root):
                 if KERNEL in row.get('Kernel_Name', ''):
                     dur.append((float(row['End_Timestamp']) - float(row['Start_Timestamp'])) * 1e-6)
     if not vals:
-        return None, None, r.stdout[-1500:]
+        return None, None, out[-1500:]
     return {k: sum(v) / len(v) for k, v in vals.items()}, (sum(dur) / len(dur) if dur else None), None
 
 
@@ -118,7 +127,7 @@ BUSY_OF = {   # resource -> (counter, busy-cycle scale, peak units per second, u
 
 
 def main():
-    out_root = os.path.join(ROOT, 'gpurun_out', 'rpmc')
+    out_root = os.path.join(ROOT, 'gpurun_out', 'rpmc' + ('_exact' if os.environ.get('P3D_MLP_BF16X3', '1') == '0' else ''))
     counters, ms, errors = {}, {}, {}
     for i, grp in enumerate(GROUPS):
         vals, dur, err = one_pass(i, grp, out_root)

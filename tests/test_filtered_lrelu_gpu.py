@@ -130,6 +130,15 @@ def test_act_kernel_and_unsupported_geometry(hip_lib):
         gref = torch.where((cd & 2) > 0, torch.zeros_like(gref), gref)
         ret = F._Plugin.filtered_lrelu_act_(gsrc, so, 2, 1, 0.7, 0.1, float('inf'), False)
         assert ret.numel() == 0 and torch.allclose(gsrc.double(), gref, atol=2e-3 if dtype == torch.float16 else 1e-6)
-    big = torch.ones(64, device='cuda')
-    y, so, rc = F._Plugin.filtered_lrelu(torch.randn(1, 1, 32, 32, device='cuda'), big, big, None, None, 4, 4, 30, 30, 30, 30, 0, 0, 1.0, 0.2, float('inf'), False, False)
+    # 64-tap filters at up = down = 4 need 103 KB of tiles: above the 64 KB default, inside gfx950's 160 KB (opt-in taken by the entry point)
+    xb = torch.randn(1, 2, 32, 32, device='cuda')
+    f64 = torch.randn(64, device='cuda').abs() + 0.1
+    f64 = f64 / f64.sum()
+    y, so, rc = F._Plugin.filtered_lrelu(xb, f64, f64, None, None, 4, 4, 30, 30, 30, 30, 0, 0, 1.0, 0.2, float('inf'), False, False)
+    assert rc == 0 and y.numel() > 0
+    want = F.filtered_lrelu(xb, fu=f64, fd=f64, up=4, down=4, padding=30, gain=1.0, slope=0.2, clamp=None, impl='ref')
+    assert y.shape == want.shape and (y - want).abs().max().item() < 2e-5 * max(want.abs().max().item(), 1e-3)
+    # ... and 96 taps (187 KB) do not fit: the plugin's -1 protocol
+    big = torch.ones(96, device='cuda')
+    y, so, rc = F._Plugin.filtered_lrelu(torch.randn(1, 1, 32, 32, device='cuda'), big, big, None, None, 4, 4, 46, 46, 46, 46, 0, 0, 1.0, 0.2, float('inf'), False, False)
     assert rc == -1 and y.numel() == 0 and so.numel() == 0
