@@ -61,8 +61,6 @@ __device__ __forceinline__ void split_bf16x8(const f32x4& a0, const f32x4& a1, b
 
 struct ConvTap { int dy, dx, widx; };
 
-static inline bool h2_regw() { static const bool v = [] { const char* e = getenv("P3D_H2_REGW"); return e ? atoi(e) != 0 : false; }(); return v; }      // conv3x3_h2_f16_kernel<REGW>
-
 struct ConvArgs {
     const void* x;         // [N][H][W][Ci]           fp16 or fp32 (kernel template)
     const void* w;         // [N or 1][Co][KT][Ci]    (KT = taps in the weight tensor: 9 for 3x3, 1 for 1x1)
@@ -92,7 +90,6 @@ struct ConvArgs {
     float* rgb_out;        // [N][rgb_co][H][W] fp32, accumulated into
     int rgb_co;            // <= 8
     float rgb_clamp;       // on (sum + bias) before the accumulation; < 0: off
-    int stagger;           // conv3x3_h2_f16_kernel: stagger_first_round (p3d_common.h); 0 = off
     const float* oscale;   // [N][Co] or null (generic kernel, fp32 tensors): the accumulator is multiplied by oscale[image][channel] before the
                            // rest of the epilogue — the demodulation coefficient of the SHARED-weight form of the modulated convolution
 };
@@ -601,10 +598,6 @@ constexpr int H2_WT_BYTES = BN * 64;                            // 8192
 constexpr int H2_WT_BASE = 2 * H2_SLAB_BUF;                     // 47104
 constexpr int H2_LDS = H2_WT_BASE + 3 * H2_WT_BYTES;            // 71680 (>= the 69632-byte epilogue stage)
 
-// REGW: a step's 8 KB weight tile goes global -> VGPR -> LDS (two global_load_dwordx4 + two ds_write_b128 per thread) instead of by LDS-DMA
-// (see up2_fir_f16_kernel in up2_fir.hip for why); the slab stays on DMA.  Same timeline as the DMA ring: tile ks+3 is requested right after
-// the rendezvous of step ks and must be in LDS at the rendezvous of step ks+2 — it is written there from registers, just before the barrier.
-template <bool REGW>
 __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
 {
     // ONE __shared__ object on purpose: with two, hipcc drains vmcnt to 0 before the first ds_read of every step and the counted
@@ -618,7 +611,6 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
         const int nmt = gridDim.x, ncb = gridDim.y, L = blockIdx.x + blockIdx.y * nmt;
         if ((nmt & 7) == 0) { const int q = L >> 3, r = L & 7; cb = q % ncb; mt = (q / ncb) * 8 + r; }
     }
-    stagger_first_round(a.stagger, blockIdx.z == 0 && (int)(blockIdx.x + blockIdx.y * gridDim.x) < 2 * kNumCU, (volatile int*)lds_b);
     const int ty0 = mt / tiles_x, tx0 = mt - ty0 * tiles_x;
     const int oy0 = ty0 * QH, ox0 = tx0 * QW, co0 = cb * BN;
     const char* const xin_b = (const char*)((const __half*)a.x + (int64_t)n * a.H * a.W * a.Ci);
@@ -660,18 +652,6 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
             __builtin_amdgcn_global_load_lds((glb_ptr)(base + woff[p2]), (lds_ptr)(lds_b + H2_WT_BASE + slot * H2_WT_BYTES + (wave * 2 + p2) * 1024), 16, 0, 0);
     };
 
-    f32x4 G[2][2];                                                             // REGW: two tiles in flight, tile ks in set ks & 1
-    auto gload_w = [&](int cc, int t, int set) {
-        const char* const base = wgt_b + (t * a.Ci + cc * 32) * 2;
-#pragma unroll
-        for (int p2 = 0; p2 < 2; ++p2)
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(G[set][p2]) : "v"(woff[p2]), "s"(base) : "memory");
-    };
-    auto put_w = [&](int set, int slot) {
-#pragma unroll
-        for (int p2 = 0; p2 < 2; ++p2)
-            asm volatile("ds_write_b128 %0, %1" :: "v"(H2_WT_BASE + slot * H2_WT_BYTES + (wave * 2 + p2) * 1024 + lane * 16), "v"(G[set][p2]) : "memory");
-    };
     f32x16 acc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -712,22 +692,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
     // TWO steps earlier, while the group issued one step earlier (tile ks+2, plus a slab after tap 0) stays in flight under a counted
     // vmcnt.  Two full steps of flight out of three slots (PMC on a one-step version: 46 % of the wave cycles waiting at vmcnt(0) +
     // barrier).  Nine taps and three slots: the slot index is t % 3, a compile-time constant of the unrolled body.
-    if constexpr (REGW) {
-        stage_slab(0, 0);
-        gload_w(0, 0, 0);
-        gload_w(0, 1, 1);
-        wait_vmcnt<0>();
-        put_w(0, 0);
-        put_w(1, 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        gload_w(0, 2, 0);                                                       // tile 2 stays in flight (written at the rendezvous of step 1)
-    } else {
-        stage_slab(0, 0);
-        stage_w(0, 0, 0);
-        stage_w(0, 1, 1);
-        stage_w(0, 2, 2);
-        wait_vmcnt<2>();                                                        // slab 0, tiles 0 and 1 (tile 2 stays in flight)
-    }
+    stage_slab(0, 0);
+    stage_w(0, 0, 0);
+    stage_w(0, 1, 1);
+    stage_w(0, 2, 2);
+    wait_vmcnt<2>();                                                            // slab 0, tiles 0 and 1 (tile 2 stays in flight)
     __builtin_amdgcn_s_barrier();
     load_frags(0, 0, 0, fa[0], fb[0]);
     for (int cp = 0; cp < kpairs; ++cp) {
@@ -749,18 +718,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
                         if (t == 1 && next_chunk) { if (nslab == 6) wait_vmcnt<8>(); else wait_vmcnt<7>(); }
                         else if (t2) wait_vmcnt<2>();
                         else wait_vmcnt<0>();
-                        if constexpr (REGW) {                                   // tile ks+1 (requested two steps ago) from its registers into its slot
-                            const bool t1 = (t < 8) || next_chunk;
-                            if (t1 && !(t == 0 && h == 0 && cp == 0)) {         // (the prologue wrote tile 1 itself)
-                                put_w((h + t + 1) & 1, (t + 1) % 3);
-                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            }
-                        }
                         __builtin_amdgcn_s_barrier();
-                        if constexpr (REGW) {
-                            if (t < 6) gload_w(cc, t + 3, (h + t + 1) & 1);     // tile ks+3 -> the register set tile ks+1 just left
-                            else if (next_chunk) gload_w(cc + 1, t - 6, (h + t + 1) & 1);
-                        } else
                         if (t < 6) stage_w(cc, t + 3, t % 3);                   // tile ks+3 -> the slot tile ks just left
                         else if (next_chunk) stage_w(cc + 1, t - 6, t % 3);
                         if (t == 0 && next_chunk) stage_slab(cc + 1, h ^ 1);
@@ -1300,9 +1258,7 @@ extern "C" int p3d_conv3x3_torgb_f16(const void* x, const void* w, void* y, cons
     for (int t = 0; t < 9; ++t) a.cls[0].taps[t] = ConvTap{t / 3 - 1, t % 3 - 1, t};
     a.rgb_w = rgb_w; a.rgb_bias = rgb_bias; a.rgb_out = rgb_out; a.rgb_co = rgb_co; a.rgb_clamp = rgb_clamp;
     dim3 grid(((h + QH - 1) / QH) * ((wdt + QW - 1) / QW), 1, n_img);
-    a.stagger = stagger_sleeps_from_env();
-    if (h2_regw()) hipLaunchKernelGGL(conv3x3_h2_f16_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else           hipLaunchKernelGGL(conv3x3_h2_f16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(conv3x3_h2_f16_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     count_launch(FAM_CONV);
     return check_launch("conv3x3_torgb_f16");
 }
@@ -1378,9 +1334,7 @@ int p3d::conv2d_nhwc_run(const void* x, const void* w, void* y, int dtype, const
         if (h2_ok && !prefer_split) {
             if (dry) return P3D_OK;
             dim3 grid(((h + QH - 1) / QH) * ((wdt + QW - 1) / QW), co / BN, n_img);
-            a.stagger = stagger_sleeps_from_env();
-            if (h2_regw()) hipLaunchKernelGGL(conv3x3_h2_f16_kernel<true>, grid, dim3(256), 0, s, a);
-            else           hipLaunchKernelGGL(conv3x3_h2_f16_kernel<false>, grid, dim3(256), 0, s, a);
+            hipLaunchKernelGGL(conv3x3_h2_f16_kernel, grid, dim3(256), 0, s, a);
             count_launch(FAM_CONV);
             return check_launch("conv3x3_h2_f16");
         }

@@ -5,7 +5,6 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
-#include <stdlib.h>
 #include <atomic>
 #include "../../include/p3d_hip.h"
 
@@ -48,31 +47,6 @@ int conv2d_nhwc_run(const void* x, const void* w, void* y, int dtype, const floa
                     void* workspace, int64_t workspace_bytes, int64_t* query, const float* out_scale, p3d_stream_t stream);
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
-
-// Two blocks that share a CU and start together run their phases (prologue / K loop on the matrix cores / epilogue on VALU + stores) in
-// lockstep, so one's epilogue never hides under the other's K loop.  In the FIRST round of a launch (one block per hardware slot) the block
-// whose first wave sits in an odd wave slot of its SIMD sleeps `sleeps` x ~3.4 us (s_sleep 127 = 8128 cycles) before it starts; every later
-// block inherits the shift because its slot frees that much later.  `flag`: 4 bytes of the block's LDS, not yet in use.
-// (P3D_STAGGER_SLEEPS, default 0 = off; a measurement switch until a launch shape has been shown to gain from it.)
-__device__ __forceinline__ void stagger_first_round(int sleeps, bool first_round, volatile int* flag)
-{
-    if (sleeps <= 0 || !first_round) return;                     // uniform over the block
-    if (threadIdx.x == 0) {
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        *flag = (int)(hw & 1u);                                   // wave_id[0] of the block's first wave
-    }
-    __syncthreads();
-    const int odd = *flag;
-    __syncthreads();
-    if (odd)
-        for (int i = 0; i < sleeps; ++i) __builtin_amdgcn_s_sleep(127);
-}
-inline int stagger_sleeps_from_env()
-{
-    static const int v = [] { const char* e = getenv("P3D_STAGGER_SLEEPS"); return e ? atoi(e) : 0; }();
-    return v;
-}
 
 } // namespace p3d
 

@@ -633,8 +633,11 @@ render_forward_kernel(RenderArgs a)
     // ------------------------------ phase A: coarse densities -> weights ------------------------------
     {
         float T = 1.f, z_prev = 0.f, s_prev = 0.f;
-        for (int i = 0; i < Sc; ++i) {
-            const float z = coarse_depth(a, g, i, uc[i]);
+        float u_next = uc[0];                                    // the uniform of sample i + 1 is requested a whole step before it is needed:
+        for (int i = 0; i < Sc; ++i) {                           // read in place it put one global-load round trip on every step's critical path
+            const float u_i = u_next;
+            if (i + 1 < Sc) u_next = uc[i + 1];
+            const float z = coarse_depth(a, g, i, u_i);
             float feat[16];
             if constexpr (COOP) gather_features_coop(a, rsrc_sem, img, lane, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), ftile, ttile, feat);
             else gather_features<true>(a, rsrc_sem, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
@@ -689,12 +692,21 @@ render_forward_kernel(RenderArgs a)
     int ic = 0, jf = 0;
     float zc = coarse_depth(a, g, 0, uc[0]);
     float zf = (Sf > 0) ? tile[j] : INFINITY;
+    float uc_ahead = (Sc > 1) ? uc[1] : 0.f;                     // both merge streams are read one element ahead (a global load and an LDS read
+    float zf_ahead = (Sf > 1) ? tile[kPitch + j] : INFINITY;     // that used to sit, with their waits, at the top of every step)
     const int S = Sc + Sf;
     for (int k = 0; k < S; ++k) {
         const bool take_c = (zc <= zf);
         const float z = take_c ? zc : zf;
-        if (take_c) { ++ic; zc = (ic < Sc) ? coarse_depth(a, g, ic, uc[ic]) : INFINITY; }
-        else        { ++jf; zf = (jf < Sf) ? tile[jf * kPitch + j] : INFINITY; }
+        if (take_c) {
+            ++ic;
+            zc = (ic < Sc) ? coarse_depth(a, g, ic, uc_ahead) : INFINITY;
+            if (ic + 1 < Sc) uc_ahead = uc[ic + 1];
+        } else {
+            ++jf;
+            zf = zf_ahead;
+            zf_ahead = (jf + 1 < Sf) ? tile[(jf + 1) * kPitch + j] : INFINITY;
+        }
 
         float feat[16], feat_tex[16];
         if constexpr (COOP) gather_features_coop(a, rsrc_sem, img, lane, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), ftile, ttile, feat);
@@ -731,12 +743,27 @@ render_forward_kernel(RenderArgs a)
             if constexpr (BF3) mlp_layer2_bf3(lds, n, lane, h, h0, h1, o);
             else               mlp_layer2(lds, n, lane, h, h0, h1, o);
             const bool squash = (n == 0) || (NNETS == 1) || a.sem_sigmoid;     // raw logits for the label net (triplane_cond.py:960-964)
+            if constexpr (TAPE) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float c = squash ? sigmoid_clamped(o[r]) : o[r];
-                if (TAPE) t_A = fmaf(acc[n][r], prev[n][r] + c, t_A);          // dL/dw of interval k-1, colour part: sum_ch dC (c[k-1] + c[k]) / 2
-                else      acc[n][r] = fmaf(hw, prev[n][r] + c, acc[n][r]);     // hw == 0 for the first sample
-                prev[n][r] = c;
+                for (int r = 0; r < 16; ++r) {
+                    const float c = squash ? sigmoid_clamped(o[r]) : o[r];
+                    t_A = fmaf(acc[n][r], prev[n][r] + c, t_A);                // dL/dw of interval k-1, colour part: sum_ch dC (c[k-1] + c[k]) / 2
+                    prev[n][r] = c;
+                }
+            } else {
+                // hw (c[k-1] + c[k]) as two FMAs, the new colour written straight over the old one (no add, no move); hw == 0 for the first sample.
+                // The label net's squash flag is wave-uniform: a scalar branch, not sixteen sigmoids and sixteen selects that are thrown away.
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[n][r] = fmaf(hw, prev[n][r], acc[n][r]);
+                if (squash) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) prev[n][r] = sigmoid_clamped(o[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) prev[n][r] = o[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[n][r] = fmaf(hw, prev[n][r], acc[n][r]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }

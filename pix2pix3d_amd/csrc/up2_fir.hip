@@ -60,7 +60,6 @@ struct Up2Args {
     int act;               // 0 linear, 1 lrelu(0.2)
     float act_gain, clamp; // clamp < 0: off
     int tiles_x, tiles;    // 28 x 28 tiles per row / per image
-    int stagger;           // stagger_first_round (p3d_common.h); 0 = off
     int debug;             // measurement only (P3D_UP2_DEBUG): 1 stop after the K loop, 2 skip the K loop, 4 no stores, 8 no FIR, 16 no tile writes
 };
 
@@ -76,11 +75,6 @@ __device__ constexpr int kPhaseDy[3][2] = {{0, 0}, {0, -1}, {0, -1}};
 __device__ constexpr int kPhaseDx[3][2] = {{0, 0}, {0, 0}, {-1, -1}};
 __device__ constexpr int kPhaseNA[3] = {1, 2, 2};
 
-// REGW: the nine weight tiles of a chunk (18 KB per block) go global -> VGPR -> LDS (global_load_dwordx4 + ds_write_b128) instead of by LDS-DMA.
-// The K loop moved 1.85 GB per launch through global_load_lds at ~8 TB/s — the rate LDS-DMA saturates at on this chip (MI355X_MICROARCH.md,
-// `ldsdma-fill`: ~25 GB/s per CU and loader wave, 6.4-6.8 TB/s chip) — while the vector-memory path into registers has several times that.
-// The slab (the other 22 KB per chunk) stays on DMA.  Same LDS image either way (a lane's 16 bytes land at piece base + lane * 16).
-template <bool REGW>
 __global__ void __launch_bounds__(256, 2) up2_fir_f16_kernel(Up2Args a)
 {
     __shared__ __attribute__((aligned(16))) char lds_b[UF_LDS];
@@ -94,7 +88,6 @@ __global__ void __launch_bounds__(256, 2) up2_fir_f16_kernel(Up2Args a)
         cb = q % ncb; mt = (q / ncb) * 8 + r;
     }
     if (mt >= a.tiles) return;
-    stagger_first_round(a.stagger, blockIdx.z == 0 && blockIdx.x < 2 * kNumCU, (volatile int*)lds_b);
     const int ty = mt / a.tiles_x, tx = mt - ty * a.tiles_x;
     const int cy0 = 14 * ty - 1, cx0 = 14 * tx - 1, co0 = cb * UF_BN;           // class-grid origin of the 16 x 16 patch
     const char* const xin_b = (const char*)((const __half*)a.x + (int64_t)n * a.H * a.W * a.Ci);
@@ -129,23 +122,6 @@ __global__ void __launch_bounds__(256, 2) up2_fir_f16_kernel(Up2Args a)
                 __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(lds_b + buf + (wave + 4 * g) * 1024), 16, 0, 0);
             }
         }
-    };
-    // register-staged weights: group p (the phase's tiles) of the NEXT chunk is loaded at rendezvous p and written to LDS two rendezvous later
-    // (the slots were freed at rendezvous p), one register set per phase
-    uf4 G[3][2];
-    auto gload_w = [&](int cc, int p) {                                          // p is a compile-time constant at every call
-        const int j0 = wave >> 1;
-        const char* const b0 = wgt_b + ((j0 ? kTapW[p * 3 + 1] : kTapW[p * 3]) * a.Ci + cc * 32) * 2;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(G[p][0]) : "v"(woff), "s"(b0) : "memory");
-        if (two) {
-            const char* const b1 = wgt_b + (kTapW[p * 3 + 2] * a.Ci + cc * 32) * 2;
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(G[p][1]) : "v"(woff), "s"(b1) : "memory");
-        }
-    };
-    auto put_w = [&](int p) {
-        const int half = (wave & 1) * 1024, j0 = wave >> 1;
-        asm volatile("ds_write_b128 %0, %1" :: "v"(UF_WT_BASE + (p * 3 + j0) * UF_TAP + half + lane * 16), "v"(G[p][0]) : "memory");
-        if (two) asm volatile("ds_write_b128 %0, %1" :: "v"(UF_WT_BASE + (p * 3 + 2) * UF_TAP + half + lane * 16), "v"(G[p][1]) : "memory");
     };
     auto stage_w = [&](int cc, int p) {                                         // p is a compile-time constant at every call
         const int half = (wave & 1) * 1024;
@@ -203,105 +179,49 @@ __global__ void __launch_bounds__(256, 2) up2_fir_f16_kernel(Up2Args a)
     // DMA groups of a wave: W = 2 (waves 0, 1) or 1 pieces, S = 6 or 5.  At the rendezvous that ends phase p of chunk c everything
     // but the NEWEST group must have landed: after phase 0 that is W(c, 2) [-> W(c, 1) is in], after phase 1 W(c+1, 0) + slab(c+1)
     // [-> W(c, 2) is in], after phase 2 W(c+1, 1) [-> W(c+1, 0) and the slab are in]; then the phase's slots take chunk c+1's taps.
-    if constexpr (REGW) {
-        // Waits (per wave, nW = 2 / 1 weight loads per group, S = 6 / 5 slab pieces; loads return in order).  Before rendezvous 0 of chunk c
-        // group 1 of c (issued at rendezvous 1 of c-1) must be in registers and only group 2 may be outstanding; before rendezvous 1 group 2,
-        // with group 0 of c+1 and its slab (issued at rendezvous 0) outstanding; before rendezvous 2 group 0 AND the slab, with group 1 of
-        // c+1 outstanding.  The ds_writes sit between the first half of the phase's MFMAs and the lgkmcnt(0) that was there anyway.
-        stage_slab(0);
-        gload_w(0, 0); gload_w(0, 1); gload_w(0, 2);
-        uf_wait_vmcnt<0>();
-        put_w(0); put_w(1); put_w(2);
+    stage_slab(0);
+    stage_w(0, 0);
+    stage_w(0, 1);
+    stage_w(0, 2);
+    if (two) uf_wait_vmcnt<4>(); else uf_wait_vmcnt<2>();                        // slab 0 and phase 0's taps
+    __builtin_amdgcn_s_barrier();
+    UF_LOAD(0, 0, 0, 0);
+    for (int cc = 0; cc < ((a.debug & 2) ? 0 : kchunks); ++cc) {
+        const bool more = cc + 1 < kchunks;
+        const int sb = (cc & 1) * UF_SLAB_BUF, sn = UF_SLAB_BUF - sb;
+        // phase 0
+        UF_LOAD(0, 1, 1, sb);
+        asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+        UF_MFMA(0, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (two) uf_wait_vmcnt<2>(); else uf_wait_vmcnt<1>();
         __builtin_amdgcn_s_barrier();
-        UF_LOAD(0, 0, 0, 0);
-        for (int cc = 0; cc < ((a.debug & 2) ? 0 : kchunks); ++cc) {
-            const bool more = cc + 1 < kchunks;
-            const int sb = (cc & 1) * UF_SLAB_BUF, sn = UF_SLAB_BUF - sb;
-            // phase 0
-            UF_LOAD(0, 1, 1, sb);
-            asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
-            UF_MFMA(0, 0);
-            if (cc > 0) { if (two) uf_wait_vmcnt<2>(); else uf_wait_vmcnt<1>(); put_w(1); }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (more) { gload_w(cc + 1, 0); stage_slab(cc + 1); }
-            UF_LOAD(1, 0, 0, sb);
-            UF_MFMA(0, 1);
-            // phase 1
-            UF_LOAD(1, 1, 1, sb);
-            asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
-            UF_MFMA(1, 0);
-            if (cc > 0) {
-                if (more) { if (two) uf_wait_vmcnt<8>(); else uf_wait_vmcnt<6>(); }
-                else uf_wait_vmcnt<0>();
-                put_w(2);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (more) gload_w(cc + 1, 1);
-            UF_LOAD(2, 0, 0, sb);
-            UF_MFMA(1, 1);
-            // phase 2
-            UF_LOAD(2, 1, 1, sb);
-            asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
-            UF_MFMA(2, 0);
-            if (more) {
-                if (two) uf_wait_vmcnt<2>(); else uf_wait_vmcnt<1>();
-                put_w(0);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                gload_w(cc + 1, 2);
-                UF_LOAD(0, 0, 0, sn);
-            } else
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            UF_MFMA(2, 1);
-        }
-    } else {
-        stage_slab(0);
-        stage_w(0, 0);
-        stage_w(0, 1);
-        stage_w(0, 2);
-        if (two) uf_wait_vmcnt<4>(); else uf_wait_vmcnt<2>();                        // slab 0 and phase 0's taps
+        if (more) { stage_w(cc + 1, 0); stage_slab(cc + 1); }
+        UF_LOAD(1, 0, 0, sb);
+        UF_MFMA(0, 1);
+        // phase 1
+        UF_LOAD(1, 1, 1, sb);
+        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+        UF_MFMA(1, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (more) { if (two) uf_wait_vmcnt<8>(); else uf_wait_vmcnt<6>(); }
+        else uf_wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        UF_LOAD(0, 0, 0, 0);
-        for (int cc = 0; cc < ((a.debug & 2) ? 0 : kchunks); ++cc) {
-            const bool more = cc + 1 < kchunks;
-            const int sb = (cc & 1) * UF_SLAB_BUF, sn = UF_SLAB_BUF - sb;
-            // phase 0
-            UF_LOAD(0, 1, 1, sb);
-            asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
-            UF_MFMA(0, 0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (more) stage_w(cc + 1, 1);
+        UF_LOAD(2, 0, 0, sb);
+        UF_MFMA(1, 1);
+        // phase 2
+        UF_LOAD(2, 1, 1, sb);
+        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+        UF_MFMA(2, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (more) {
             if (two) uf_wait_vmcnt<2>(); else uf_wait_vmcnt<1>();
             __builtin_amdgcn_s_barrier();
-            if (more) { stage_w(cc + 1, 0); stage_slab(cc + 1); }
-            UF_LOAD(1, 0, 0, sb);
-            UF_MFMA(0, 1);
-            // phase 1
-            UF_LOAD(1, 1, 1, sb);
-            asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
-            UF_MFMA(1, 0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (more) { if (two) uf_wait_vmcnt<8>(); else uf_wait_vmcnt<6>(); }
-            else uf_wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            if (more) stage_w(cc + 1, 1);
-            UF_LOAD(2, 0, 0, sb);
-            UF_MFMA(1, 1);
-            // phase 2
-            UF_LOAD(2, 1, 1, sb);
-            asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
-            UF_MFMA(2, 0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (more) {
-                if (two) uf_wait_vmcnt<2>(); else uf_wait_vmcnt<1>();
-                __builtin_amdgcn_s_barrier();
-                stage_w(cc + 1, 2);
-                UF_LOAD(0, 0, 0, sn);
-            }
-            UF_MFMA(2, 1);
+            stage_w(cc + 1, 2);
+            UF_LOAD(0, 0, 0, sn);
         }
+        UF_MFMA(2, 1);
     }
 #undef UF_LOAD
 #undef UF_MFMA
@@ -412,13 +332,10 @@ extern "C" int p3d_up2_fir_f16(const void* x, const void* w, void* y, const void
     const int tiles_y = (2 * h + UF_TILE - 1) / UF_TILE;
     a.tiles_x = (2 * wdt + UF_TILE - 1) / UF_TILE;
     a.tiles = a.tiles_x * tiles_y;
-    a.stagger = stagger_sleeps_from_env();
     { static const int dbg = [] { const char* d = getenv("P3D_UP2_DEBUG"); return d ? atoi(d) : 0; }(); a.debug = dbg; }      // phase switches of tests/gpu_probe_up2.py (0 = the layer)
     const int64_t blocks = (int64_t)((a.tiles + 7) / 8 * 8) * (co / UF_BN);
     P3D_REQUIRE(blocks < (1ll << 31) && n_img < 65536, "up2_fir_f16: bad launch size");
-    static const bool regw = [] { const char* e = getenv("P3D_UP2_REGW"); return e ? atoi(e) != 0 : true; }();      // weights through registers (0: LDS-DMA, the round-2 form)
-    if (regw) hipLaunchKernelGGL(up2_fir_f16_kernel<true>, dim3((unsigned)blocks, 1, n_img), dim3(256), 0, (hipStream_t)stream, a);
-    else      hipLaunchKernelGGL(up2_fir_f16_kernel<false>, dim3((unsigned)blocks, 1, n_img), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(up2_fir_f16_kernel, dim3((unsigned)blocks, 1, n_img), dim3(256), 0, (hipStream_t)stream, a);
     count_launch(FAM_CONV);
     return check_launch("up2_fir_f16");
 }

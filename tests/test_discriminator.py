@@ -25,7 +25,8 @@ def _field_close(a, ref, tol, robust):
         return rel_err(a, ref) < tol, rel_err(a, ref)
     l2 = float(np.linalg.norm(a - ref) / max(np.linalg.norm(ref), 1e-30))
     frac = float((np.abs(a - ref) > tol * np.abs(ref).max()).mean())
-    return (l2 < 2 * tol and frac <= 1e-2), (l2, frac, rel_err(a, ref))
+    frac_max = 1e-2 if a.size >= 20000 else 5e-2            # one flipped unit's neighbourhood is ~150 elements: 5 % of the 3 072-element raw-image field
+    return (l2 < 2 * tol and frac <= frac_max and rel_err(a, ref) < 10 * tol), (l2, frac, rel_err(a, ref))
 
 
 def _dboth(name, device, tol, grad_tol=None, robust=False):
@@ -82,8 +83,9 @@ def test_discriminator_dboth_phase_on_the_native_convolutions(hip_lib, name):
     Two legs.  The default (exact fp32 products): everything within 2e-3 of the reference records, max-norm.  The bf16x3 opt-in
     (P3D_TRAIN_BF16X3=1): every convolution is within 1e-5 of fp32 (tests/gpu_probe_split_d.py compares them call by call), logits within
     2e-3, r1 / every parameter-gradient norm / the gradient head within 1e-2 (round 2 allowed 0.1), and the two R1 gradient FIELDS in the
-    robust form of ``_field_close``: relative L2 <= 2e-2 and at most 1 % of the elements off by more than 1e-2 of the field's maximum
-    (measured on 'dual': L2 1.1e-2, 0.6 % of the elements, max-norm 3e-2; 'dual_clamp' and 'single' pass the same statistic at 1e-2).
+    robust form of ``_field_close``: relative L2 <= 2e-2, max-norm <= 0.1 and at most 1 % of the elements (5 % for the 3 072-element raw-image
+    field) off by more than 1e-2 of the field's maximum (measured on 'dual': image field L2 1.1e-2, 0.6 % of the elements, max-norm 3e-2; raw
+    field L2 1.2e-2, 1.3 %, 4.4e-2; 'dual_clamp' and 'single' pass the same statistic at 1e-2).
     Why a field is not held in max-norm on that leg: a leaky-ReLU layer of these networks has up to 262 144 pre-activations of range ~1.5,
     the closest to zero sits at 4e-8 .. 5e-7 of the range for EVERY input seed (tests/golden/seed_search_discriminator.py lists seeds
     31..45: there is no seed without such units), so a 5e-6 perturbation carries ~10 of the ~800 000 units of the high-resolution layers

@@ -46,7 +46,8 @@ def _check_grads(G, g, tol, prefix='', head_tol=None):
         head = params[nme].grad.reshape(-1)[:64].float().cpu().numpy()
         want = g[f'{prefix}h{i}']
         ref_norm = float(ref[names.index(nme)])
-        assert np.abs(head - want).max() < head_tol * max(np.abs(want).max(), ref_norm / np.sqrt(params[nme].numel()) * 3, 1e-12), (nme, np.abs(head - want).max(), np.abs(want).max())
+        floor = 1e-5 * float(ref[live].max()) / np.sqrt(params[nme].numel())       # a gradient that cancels analytically (d sigma_i - d sigma_p w.r.t. a bias) is 1e-10 of noise either way
+        assert np.abs(head - want).max() < head_tol * max(np.abs(want).max(), ref_norm / np.sqrt(params[nme].numel()) * 3, 1e-12) + floor, (nme, np.abs(head - want).max(), np.abs(want).max())
     return float(err[live].max())
 
 
@@ -185,9 +186,9 @@ def test_config3_gradients_bf16x3_opt_in(hip_lib):
 def test_config3_gradients_fp16_sr_heads(hip_lib):
     """BASELINE config 3 as train.py configures it on a GPU: fp16 super-resolution heads (sr_num_fp16_res = 4, conv_clamp 256).  The
     reference record is fp32 (its CPU path), so this leg is held to the fp16 class.  The record's loss is a MEAN over 3 x 512^2 pixels, i.e.
-    1e-6-sized image gradients, which fp16 tensors cannot carry (6e-5 is the smallest normal): the backward runs on loss x 2^14 and the
+    1e-6-sized image gradients, which fp16 tensors cannot carry (6e-5 is the smallest normal): the backward runs on loss x 256 and the
     gradients are divided back — linear, and what any fp16 training setup does when its gradients are that small (the training losses of
     loss.py put ~1e-3..1e-5 on the image through D and do not need it)."""
     with _native_training(bf16x3=False):
-        worst = _train_full('cuda', 3e-2, force_fp32=False, loss_scale=16384.0)
+        worst = _train_full('cuda', 3e-2, force_fp32=False, loss_scale=256.0)
     print('worst gradient-norm error (fp16 SR heads)', worst)
