@@ -455,16 +455,7 @@ def main():
             return mod.register_forward_pre_hook(pre), mod.register_forward_hook(post)
         handles = []
         handles += hook(G.backbone.synthesis, 'backbone') + hook(G.renderer, 'render')
-        # the two SR heads run on two streams: time them as ONE stage, fork to join, on the stream the step is launched on
-        plain_heads = G._sr_heads
-
-        def timed_heads(*a, **k):
-            e0 = torch.cuda.Event(enable_timing=True); e0.record()
-            out = plain_heads(*a, **k)
-            e1 = torch.cuda.Event(enable_timing=True); e1.record()
-            stage_events['sr'].append((e0, e1))
-            return out
-        G._sr_heads = timed_heads
+        handles += hook(G.superresolution, 'sr') + hook(G.superresolution_semantic, 'sr')
         n_prof = min(args.steps, 10)
         for k in ('render_forward', 'conv_f16', 'conv_f32', 'conv_bf16x3', 'conv_flops'):
             _lib.kernel_events[k] = []
@@ -479,7 +470,6 @@ def main():
                    'conv_bf16x3': sum(f for d, f in flops if d == 'bf16x3') / n_prof}
         for h in handles:
             h.remove()
-        del G._sr_heads                                              # (the instance attribute: the class's method is back)
         stage_ms = {k: (sum(a.elapsed_time(b) for a, b in v) / n_prof if v else 0.0) for k, v in stage_events.items()}
         # conv_f32: exact fp32 MFMA kernels vs the 157.3 TF fp32 matrix peak.  conv_bf16x3: the fp32 layers computed as three bf16 MFMAs per
         # product: 'tflops' counts each fp32 multiply-add once (fp32-equivalent), 'frac_of_peak' the 3x bf16 MFMA work it executes vs 2.5 PF

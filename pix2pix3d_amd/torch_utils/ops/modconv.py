@@ -28,22 +28,6 @@ def side_stream(device):
     return st
 
 
-# Skip-image stream (device inference): a block's ToRGB and the upsample-and-add of the running skip image depend on the block's x only, and
-# nothing but the NEXT block's ToRGB depends on them — the whole image chain of the backbone (7 ToRGB + 6 upsampling launches, ~0.4 ms of
-# memory-bound work per step) runs beside the convolutions of the following blocks instead of between them.  Captured as a branch of the hipGraph.
-image_stream_enabled = os.environ.get('P3D_IMG_STREAM', '1') != '0'
-sr_streams_enabled = os.environ.get('P3D_SR_STREAMS', '1') != '0'      # the two super-resolution heads (image / label map) on two streams
-_image_streams = {}
-
-
-def image_stream(device, which=0):
-    key = (device, which)
-    st = _image_streams.get(key)
-    if st is None:
-        st = _image_streams[key] = torch.cuda.Stream(device=device)
-    return st
-
-
 def take_plan(layer):
     """Pop this layer's prefetched (styles, premodulated weights) and make the current stream wait for them."""
     hit = _plan.pop(id(layer), None)

@@ -415,20 +415,6 @@ class SynthesisBlock(torch.nn.Module):
             # wide skip image (the 96 tri-plane channels), device inference: ToRGB first, then its upsampled predecessor is added INTO it by the
             # upsampling launch — one pass over the image instead of three (upsample, ToRGB, add)
             misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
-            side = modconv.image_stream(x.device) if modconv.image_stream_enabled else None
-            if side is not None:                                 # the image chain on its own stream (modconv.image_stream); SynthesisNetwork.forward joins it
-                main = torch.cuda.current_stream(x.device)
-                side.wait_stream(main)                           # x is ready; the previous block's image work already sits on `side`
-                x.record_stream(side)
-                with torch.cuda.stream(side):
-                    y = self.torgb(x, per_layer[self.num_conv], fused_modconv=fused_modconv)
-                    if y.dtype == torch.float32 and y.is_contiguous(memory_format=torch.channels_last):
-                        img = upfirdn2d.upsample2d_add_(y, img, self.resample_filter)
-                    else:
-                        img = self._accumulate_image(self._carry_image(img), y, fmt)
-                self._image_on_side = True
-                assert x.dtype == dtype and img.dtype == torch.float32
-                return x, img
             y = self.torgb(x, per_layer[self.num_conv], fused_modconv=fused_modconv)
             if y.dtype == torch.float32 and y.is_contiguous(memory_format=torch.channels_last):
                 img = upfirdn2d.upsample2d_add_(y, img, self.resample_filter)
@@ -557,21 +543,12 @@ class SynthesisNetwork(torch.nn.Module):
                 idx += block.num_conv
         planned = self._prefetch(block_ws, block_kwargs)
         x = img = None
-        on_side = False
         try:
             for res, cur in zip(self.block_resolutions, block_ws):
-                block = getattr(self, f'b{res}')
-                block._image_on_side = False
-                x, img = block(x, img, cur, **block_kwargs)
-                on_side = on_side or block._image_on_side
+                x, img = getattr(self, f'b{res}')(x, img, cur, **block_kwargs)
         finally:
             if planned:
                 finish_prefetch(ws.device)
-            if on_side:                                          # join the skip-image stream: the caller reads img on the current stream
-                main = torch.cuda.current_stream(ws.device)
-                main.wait_stream(modconv.image_stream(ws.device))
-                if img is not None:
-                    img.record_stream(main)
         return img
 
     def _prefetch(self, block_ws, block_kwargs):

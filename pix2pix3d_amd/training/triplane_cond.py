@@ -369,26 +369,6 @@ class _TriPlaneBase(_TriPlaneCore):
     """The conditional generators' entry points: ``mapping`` / ``sample`` / ``forward`` take the data batch (label map + pose)."""
     _backbone_class = None      # Generator_cond, set below the class
 
-
-    def _sr_heads(self, rgb_image, rgb_feat, semantic_image, sem_feat, ws_image, ws_semantic, sr_kw):
-        """Both super-resolution heads (superresolution.py:297-354).  They share nothing but their inputs, so device inference runs the
-        label-map head on a second stream (modconv.image_stream(device, 1)) beside the image head — a branch of the captured hipGraph: one
-        head's store-bound x2 layers and prologues run under the other's matrix-core layers.  Anything else: one after the other."""
-        from ..torch_utils.ops import modconv
-        if not (modconv.sr_streams_enabled and rgb_feat.is_cuda and not torch.is_grad_enabled()):
-            return (self.superresolution(rgb_image, rgb_feat, ws_image, **sr_kw),
-                    self.superresolution_semantic(semantic_image, sem_feat, ws_semantic, **sr_kw))
-        dev = rgb_feat.device
-        main, side = torch.cuda.current_stream(dev), modconv.image_stream(dev, 1)
-        side.wait_stream(main)
-        for t in (semantic_image, sem_feat, ws_semantic):
-            t.record_stream(side)
-        with torch.cuda.stream(side):
-            sr_semantic = self.superresolution_semantic(semantic_image, sem_feat, ws_semantic, **sr_kw)
-        sr_image = self.superresolution(rgb_image, rgb_feat, ws_image, **sr_kw)
-        main.wait_stream(side)
-        sr_semantic.record_stream(main)
-        return sr_image, sr_semantic
     def mapping(self, z, c, batch, truncation_psi=1, truncation_cutoff=None, update_emas=False):
         if self.rendering_kwargs['c_gen_conditioning_zero']:
             c = torch.zeros_like(c)
@@ -454,8 +434,9 @@ class TriPlaneSemanticEntangleGenerator(_TriPlaneBase):
         rgb_feat, sem_feat = feature_image[:, :half], feature_image[:, half:]
         sr_kw = self._sr_kwargs(synthesis_kwargs)
         rgb_image = rgb_feat[:, :3]
+        sr_image = self.superresolution(rgb_image, rgb_feat, ws, **sr_kw)
         semantic_image = sem_feat[:, :self.semantic_channels]
-        sr_image, sr_semantic = self._sr_heads(rgb_image, rgb_feat, semantic_image, sem_feat, ws, ws, sr_kw)
+        sr_semantic = self.superresolution_semantic(semantic_image, sem_feat, ws, **sr_kw)
         return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image, 'semantic': sr_semantic, 'semantic_raw': semantic_image}
 
 
@@ -566,8 +547,9 @@ class TriPlaneSemanticEntangleGenerator_withBG(TriPlaneSemanticEntangleGenerator
         rgb_feat, sem_feat = feature_image[:, :half], feature_image[:, half:]
         sr_kw = self._sr_kwargs(synthesis_kwargs)
         rgb_image = rgb_feat[:, :3]
+        sr_image = self.superresolution(rgb_image, rgb_feat, ws, **sr_kw)
         semantic_image = sem_feat[:, :self.semantic_channels]
-        sr_image, sr_semantic = self._sr_heads(rgb_image, rgb_feat, semantic_image, sem_feat, ws, ws, sr_kw)
+        sr_semantic = self.superresolution_semantic(semantic_image, sem_feat, ws, **sr_kw)
         return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image, 'semantic': sr_semantic, 'semantic_raw': semantic_image,
                 'weight': weight_image}
 

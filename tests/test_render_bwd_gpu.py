@@ -113,7 +113,7 @@ def test_bench_sized_backward_properties(hip_lib):
     with torch.no_grad():
         dirs = {i: torch.randn_like(params[i]) for i in colour}
         an_w = sum(float((gd1[i].double() * dirs[i].double()).sum()) for i in colour)
-        epsw = 2e-3
+        epsw = 8e-3                                   # (2e-3 left the quotient at the mercy of the forward's fp32 rounding: ~1e-4 of noise on L / 4e-3)
         for i in colour:
             params[i].add_(epsw * dirs[i])
         lp = loss(planes)
