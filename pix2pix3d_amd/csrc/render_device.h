@@ -484,8 +484,12 @@ __device__ __forceinline__ void mlp_layer2_bf3(const float* lds, int n, int lane
 
 // ---- importance sampling for one ray, wave-cooperative (renderer.py:194-253) ----------------------
 // lane i holds coarse weight w_i (i < Sc-1) and coarse depth z_i (i < Sc); lane j returns fine depth j
-// (unsorted), +inf for j >= Sf.  sA / sB: two 64-float LDS scratch rows of this wave.
-__device__ __forceinline__ float importance_depth(int Sc, int Sf, int lane, float w_i, float z_i, float u, float* sA, float* sB)
+// (unsorted), +inf for j >= Sf.  Everything stays in registers: lane k keeps pdf entry k, bin midpoint k and (after the scan) cdf entry k;
+// the two sequential fp32 sums (normaliser, cdf — sequential so that the searchsorted indices are reproducible bit for bit) broadcast
+// lane k's value with v_readlane instead of going through LDS (round 2 read two LDS words and waited for them in each of the 2 x 61
+// iterations: ~10 % of the kernel's wave time for 2 % of its arithmetic).  sA / sB are no longer used.
+__device__ __forceinline__ float lane_bcast(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+__device__ __forceinline__ float importance_depth(int Sc, int Sf, int lane, float w_i, float z_i, float u, float* /*sA*/, float* /*sB*/)
 {
 #pragma clang fp contract(off)
     const float ninf = -INFINITY;
@@ -496,27 +500,23 @@ __device__ __forceinline__ float importance_depth(int Sc, int Sf, int lane, floa
     const float ap = (mp + mpn) / 2.f;                     // avg_pool1d(k=2, s=1): Sc-1 values
     const float wk = (ap + 0.01f) + 1e-5f;                 // "+ 0.01" then sample_pdf's "+ eps"
     const float zn = __shfl_down(z_i, 1, 64);
-    const float zmid = 0.5f * (z_i + zn);                  // bins: Sc-1 midpoints
+    const float zmid = 0.5f * (z_i + zn);                  // bins: Sc-1 midpoints, lane k holds bin k
     const int nw = Sc - 3;                                 // pdf entries = smoothed[1:-1]
-    wave_sync();
-    if (lane >= 1 && lane <= nw) sA[lane - 1] = wk;
-    if (lane <= Sc - 2) sB[lane] = zmid;
-    wave_sync();
+    const float pnum = __shfl_down(wk, 1, 64);             // lane k: pdf numerator k = smoothed[k + 1]
     float total = 0.f;
-    for (int k = 0; k < nw; ++k) total = total + sA[k];
-    wave_sync();
-    if (lane < nw) sA[lane] = sA[lane] / total;
-    wave_sync();
-    // cdf_0 = 0, cdf_{k+1} = cdf_k + pdf_k (Sc-2 entries); inds = #{cdf <= u} (searchsorted right=True)
-    float cdf = 0.f, cb = 0.f, zb = sB[0], ca = 0.f, za = 0.f;
-    bool found = false;
-    for (int k = 0; k <= nw; ++k) {
-        if (k > 0) cdf = cdf + sA[k - 1];
-        const float zk = sB[k];
-        if (cdf <= u) { cb = cdf; zb = zk; }
-        else if (!found) { ca = cdf; za = zk; found = true; }
+    for (int k = 0; k < nw; ++k) total = total + lane_bcast(pnum, k);
+    const float pdf = pnum / total;                        // lane k < nw
+    // cdf_0 = 0, cdf_{k+1} = cdf_k + pdf_k (Sc-2 entries); inds = #{cdf <= u} (searchsorted right=True; the cdf is non-decreasing)
+    float cdf = 0.f, mycdf = 0.f;
+    int inds = (0.f <= u) ? 1 : 0;
+    for (int k = 0; k < nw; ++k) {
+        cdf = cdf + lane_bcast(pdf, k);
+        inds += (cdf <= u) ? 1 : 0;
+        mycdf = (lane == k + 1) ? cdf : mycdf;             // lane k keeps cdf entry k
     }
-    if (!found) { ca = cb; za = zb; }                      // above clamps to the last bin
+    const int below = max(inds - 1, 0), above = min(inds, nw);
+    const float cb = __shfl(mycdf, below, 64), ca = __shfl(mycdf, above, 64);
+    const float zb = __shfl(zmid, below, 64), za = __shfl(zmid, above, 64);
     float denom = ca - cb;
     if (denom < 1e-5f) denom = 1.f;
     const float t = (u - cb) / denom;
