@@ -12,7 +12,7 @@ import threading
 import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, 'libp3d_hip.so')
+LIB_PATH = os.environ.get('P3D_LIB_PATH') or os.path.join(_PKG_DIR, 'libp3d_hip.so')      # (P3D_LIB_PATH: A/B runs of two builds on one box)
 
 P3D_OK = 0
 P3D_ERR_UNSUPPORTED = -1

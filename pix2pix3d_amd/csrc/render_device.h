@@ -484,12 +484,8 @@ __device__ __forceinline__ void mlp_layer2_bf3(const float* lds, int n, int lane
 
 // ---- importance sampling for one ray, wave-cooperative (renderer.py:194-253) ----------------------
 // lane i holds coarse weight w_i (i < Sc-1) and coarse depth z_i (i < Sc); lane j returns fine depth j
-// (unsorted), +inf for j >= Sf.  Everything stays in registers: lane k keeps pdf entry k, bin midpoint k and (after the scan) cdf entry k;
-// the two sequential fp32 sums (normaliser, cdf — sequential so that the searchsorted indices are reproducible bit for bit) broadcast
-// lane k's value with v_readlane instead of going through LDS (round 2 read two LDS words and waited for them in each of the 2 x 61
-// iterations: ~10 % of the kernel's wave time for 2 % of its arithmetic).  sA / sB are no longer used.
-__device__ __forceinline__ float lane_bcast(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
-__device__ __forceinline__ float importance_depth(int Sc, int Sf, int lane, float w_i, float z_i, float u, float* /*sA*/, float* /*sB*/)
+// (unsorted), +inf for j >= Sf.  sA / sB: two 64-float LDS scratch rows of this wave.
+__device__ __forceinline__ float importance_depth(int Sc, int Sf, int lane, float w_i, float z_i, float u, float* sA, float* sB)
 {
 #pragma clang fp contract(off)
     const float ninf = -INFINITY;
@@ -500,23 +496,27 @@ __device__ __forceinline__ float importance_depth(int Sc, int Sf, int lane, floa
     const float ap = (mp + mpn) / 2.f;                     // avg_pool1d(k=2, s=1): Sc-1 values
     const float wk = (ap + 0.01f) + 1e-5f;                 // "+ 0.01" then sample_pdf's "+ eps"
     const float zn = __shfl_down(z_i, 1, 64);
-    const float zmid = 0.5f * (z_i + zn);                  // bins: Sc-1 midpoints, lane k holds bin k
+    const float zmid = 0.5f * (z_i + zn);                  // bins: Sc-1 midpoints
     const int nw = Sc - 3;                                 // pdf entries = smoothed[1:-1]
-    const float pnum = __shfl_down(wk, 1, 64);             // lane k: pdf numerator k = smoothed[k + 1]
+    wave_sync();
+    if (lane >= 1 && lane <= nw) sA[lane - 1] = wk;
+    if (lane <= Sc - 2) sB[lane] = zmid;
+    wave_sync();
     float total = 0.f;
-    for (int k = 0; k < nw; ++k) total = total + lane_bcast(pnum, k);
-    const float pdf = pnum / total;                        // lane k < nw
-    // cdf_0 = 0, cdf_{k+1} = cdf_k + pdf_k (Sc-2 entries); inds = #{cdf <= u} (searchsorted right=True; the cdf is non-decreasing)
-    float cdf = 0.f, mycdf = 0.f;
-    int inds = (0.f <= u) ? 1 : 0;
-    for (int k = 0; k < nw; ++k) {
-        cdf = cdf + lane_bcast(pdf, k);
-        inds += (cdf <= u) ? 1 : 0;
-        mycdf = (lane == k + 1) ? cdf : mycdf;             // lane k keeps cdf entry k
+    for (int k = 0; k < nw; ++k) total = total + sA[k];
+    wave_sync();
+    if (lane < nw) sA[lane] = sA[lane] / total;
+    wave_sync();
+    // cdf_0 = 0, cdf_{k+1} = cdf_k + pdf_k (Sc-2 entries); inds = #{cdf <= u} (searchsorted right=True)
+    float cdf = 0.f, cb = 0.f, zb = sB[0], ca = 0.f, za = 0.f;
+    bool found = false;
+    for (int k = 0; k <= nw; ++k) {
+        if (k > 0) cdf = cdf + sA[k - 1];
+        const float zk = sB[k];
+        if (cdf <= u) { cb = cdf; zb = zk; }
+        else if (!found) { ca = cdf; za = zk; found = true; }
     }
-    const int below = max(inds - 1, 0), above = min(inds, nw);
-    const float cb = __shfl(mycdf, below, 64), ca = __shfl(mycdf, above, 64);
-    const float zb = __shfl(zmid, below, 64), za = __shfl(zmid, above, 64);
+    if (!found) { ca = cb; za = zb; }                      // above clamps to the last bin
     float denom = ca - cb;
     if (denom < 1e-5f) denom = 1.f;
     const float t = (u - cb) / denom;
@@ -633,11 +633,8 @@ render_forward_kernel(RenderArgs a)
     // ------------------------------ phase A: coarse densities -> weights ------------------------------
     {
         float T = 1.f, z_prev = 0.f, s_prev = 0.f;
-        float u_next = uc[0];                                    // the uniform of sample i + 1 is requested a whole step before it is needed:
-        for (int i = 0; i < Sc; ++i) {                           // read in place it put one global-load round trip on every step's critical path
-            const float u_i = u_next;
-            if (i + 1 < Sc) u_next = uc[i + 1];
-            const float z = coarse_depth(a, g, i, u_i);
+        for (int i = 0; i < Sc; ++i) {
+            const float z = coarse_depth(a, g, i, uc[i]);
             float feat[16];
             if constexpr (COOP) gather_features_coop(a, rsrc_sem, img, lane, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), ftile, ttile, feat);
             else gather_features<true>(a, rsrc_sem, img, h, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), feat);
@@ -692,21 +689,12 @@ render_forward_kernel(RenderArgs a)
     int ic = 0, jf = 0;
     float zc = coarse_depth(a, g, 0, uc[0]);
     float zf = (Sf > 0) ? tile[j] : INFINITY;
-    float uc_ahead = (Sc > 1) ? uc[1] : 0.f;                     // both merge streams are read one element ahead (a global load and an LDS read
-    float zf_ahead = (Sf > 1) ? tile[kPitch + j] : INFINITY;     // that used to sit, with their waits, at the top of every step)
     const int S = Sc + Sf;
     for (int k = 0; k < S; ++k) {
         const bool take_c = (zc <= zf);
         const float z = take_c ? zc : zf;
-        if (take_c) {
-            ++ic;
-            zc = (ic < Sc) ? coarse_depth(a, g, ic, uc_ahead) : INFINITY;
-            if (ic + 1 < Sc) uc_ahead = uc[ic + 1];
-        } else {
-            ++jf;
-            zf = zf_ahead;
-            zf_ahead = (jf + 1 < Sf) ? tile[(jf + 1) * kPitch + j] : INFINITY;
-        }
+        if (take_c) { ++ic; zc = (ic < Sc) ? coarse_depth(a, g, ic, uc[ic]) : INFINITY; }
+        else        { ++jf; zf = (jf < Sf) ? tile[jf * kPitch + j] : INFINITY; }
 
         float feat[16], feat_tex[16];
         if constexpr (COOP) gather_features_coop(a, rsrc_sem, img, lane, cs * fmaf(z, dx, ox), cs * fmaf(z, dy, oy), cs * fmaf(z, dz, oz), ftile, ttile, feat);
@@ -743,27 +731,12 @@ render_forward_kernel(RenderArgs a)
             if constexpr (BF3) mlp_layer2_bf3(lds, n, lane, h, h0, h1, o);
             else               mlp_layer2(lds, n, lane, h, h0, h1, o);
             const bool squash = (n == 0) || (NNETS == 1) || a.sem_sigmoid;     // raw logits for the label net (triplane_cond.py:960-964)
-            if constexpr (TAPE) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float c = squash ? sigmoid_clamped(o[r]) : o[r];
-                    t_A = fmaf(acc[n][r], prev[n][r] + c, t_A);                // dL/dw of interval k-1, colour part: sum_ch dC (c[k-1] + c[k]) / 2
-                    prev[n][r] = c;
-                }
-            } else {
-                // hw (c[k-1] + c[k]) as two FMAs, the new colour written straight over the old one (no add, no move); hw == 0 for the first sample.
-                // The label net's squash flag is wave-uniform: a scalar branch, not sixteen sigmoids and sixteen selects that are thrown away.
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[n][r] = fmaf(hw, prev[n][r], acc[n][r]);
-                if (squash) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) prev[n][r] = sigmoid_clamped(o[r]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) prev[n][r] = o[r];
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[n][r] = fmaf(hw, prev[n][r], acc[n][r]);
+            for (int r = 0; r < 16; ++r) {
+                const float c = squash ? sigmoid_clamped(o[r]) : o[r];
+                if (TAPE) t_A = fmaf(acc[n][r], prev[n][r] + c, t_A);          // dL/dw of interval k-1, colour part: sum_ch dC (c[k-1] + c[k]) / 2
+                else      acc[n][r] = fmaf(hw, prev[n][r] + c, acc[n][r]);     // hw == 0 for the first sample
+                prev[n][r] = c;
             }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -41,7 +41,8 @@ for _ in range(int(os.environ.get('REPS', 3))):
     out = rmod.fused_render(planes, dec, o, d, opt, uc, uf)
 torch.cuda.synchronize()
 s = torch.cuda.Event(True); e = torch.cuda.Event(True); s.record()
-for _ in range(5):
+ITERS = int(os.environ.get("ITERS", 5))
+for _ in range(ITERS):
     rmod.fused_render(planes, dec, o, d, opt, uc, uf)
 e.record(); torch.cuda.synchronize()
-print(f'render {s.elapsed_time(e) / 5:.3f} ms per launch (incl. pack + clamp)')
+print(f"render {s.elapsed_time(e) / ITERS:.4f} ms per launch (incl. pack + clamp; {os.environ.get('P3D_LIB_PATH', 'default build')})")
