@@ -23,6 +23,13 @@
 #include "render_device.h"
 
 namespace p3d {
+// Ablation builds (measurement only, never the shipped library: tests/gpu_probe_rbwd.sh compiles this file with -DP3D_RBWD_DEBUG=<bits>):
+// 1 no plane atomics (the compiler then drops the whole scatter walk), 2 no weight-gradient products, 4 no gather, 8 no data-gradient MFMAs,
+// 16 the scatter walk with its atomics replaced by a register sink (walk kept, no memory-side work).  Compile-time so that the product build is untouched.
+#ifndef P3D_RBWD_DEBUG
+#define P3D_RBWD_DEBUG 0
+#endif
+constexpr int kRbwdDbg = P3D_RBWD_DEBUG;
 
 constexpr int kBwdNetStride = 4096;              // per net: 64 MFMA steps x 64 lanes (steps 0..31: dh, 32..63: df)
 constexpr int kBwdFloats = 2 * kBwdNetStride;
@@ -107,32 +114,57 @@ __device__ __forceinline__ void scatter_features(const RenderArgs& a, float* __r
         }
     }
     wave_sync();
-    // ray-major walk: per (ray pair) one read of the lane's channel value and six 16-byte reads of the ray's 12 weights / offsets, all
-    // independent, then up to 12 atomics.  (A tap-major walk with three dependent LDS reads per atomic spent more time in LDS latency
-    // than in the atomics themselves: at one wave per SIMD nothing hides it.)
+    // Entry-major walk with lane = CHANNEL: half-wave `half` takes entries 16 half .. 16 half + 15 in order — per entry one read of the lane's channel
+    // value and six 16-byte reads of its 12 weights / offsets, all independent (a tap-major walk with three dependent LDS reads per atomic spent
+    // more time in LDS latency than in the atomics: at one wave per SIMD nothing hides it).
+    // RUN COMBINING (round 3).  The atomics were half of this kernel (profiles/round3_i_render_bwd_ablation.log: 10.6 ms, 5.4 without them): 2 x 1 536 B
+    // of read-modify-write per sample at the memory side.  In ray mode a wave's 32 entries are 32 CONSECUTIVE SAMPLES OF ONE RAY, and consecutive
+    // samples keep hitting the same texels — always on the plane that faces the camera (a ray barely moves across it), and wherever the importance
+    // samples bunch up on the other two.  So each tap slot keeps a pending (texel, value): a sample whose tap is the pending texel adds to it in a
+    // register, anything else sends the pending sum as ONE atomic and starts a new run; 12 flushes close the walk.
+    // (one plane at a time: 4 pending slots + 4 weights + 4 offsets live instead of 12 + 12 + 12 — the kernel has no register to spare)
     const int c = lane & 31, half = lane >> 5;
+    [[maybe_unused]] float sink = 0.f;
+#pragma unroll 1
+    for (int p = 0; p < 3; ++p) {
+        unsigned p_off[4]; float p_val[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { p_off[t] = 0xffffffffu; p_val[t] = 0.f; }
 #pragma unroll 2
-    for (int pr = 0; pr < 16; ++pr) {
-        const int ray = 2 * pr + half;
-        const float v = Tdf[ray * TP + c];
-        float w[12]; unsigned off[12];
+        for (int pr = 0; pr < 16; ++pr) {
+            const int e = half * 16 + pr;
+            const float v = Tdf[e * TP + c];
+            const f32x4 w = *(const f32x4*)(Tw + e * 12 + 4 * p);
+            const u32x4 off = *(const u32x4*)(Toff + e * 12 + 4 * p);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const f32x4 wv = *(const f32x4*)(Tw + ray * 12 + 4 * q);
-            const u32x4 ov = *(const u32x4*)(Toff + ray * 12 + 4 * q);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { w[4 * q + e] = wv[e]; off[4 * q + e] = ov[e]; }
+            for (int t = 0; t < 4; ++t) {
+                if (w[t] == 0.f) continue;                        // dead lane / out-of-image tap: never contributed (uniform over the half-wave)
+                const float contrib = w[t] * v;
+                if (off[t] == p_off[t]) p_val[t] += contrib;
+                else {
+                    if (p_off[t] != 0xffffffffu && !(kRbwdDbg & 1)) {
+                        if constexpr ((kRbwdDbg & 16) != 0) sink += p_val[t] * (float)p_off[t];
+                        else unsafeAtomicAdd(d_planes + p_off[t] + c, p_val[t]);
+                    }
+                    p_off[t] = off[t]; p_val[t] = contrib;
+                }
+            }
         }
 #pragma unroll
-        for (int t = 0; t < 12; ++t)
-            if (w[t] != 0.f) unsafeAtomicAdd(d_planes + off[t] + c, w[t] * v);
+        for (int t = 0; t < 4; ++t)
+            if (p_off[t] != 0xffffffffu && !(kRbwdDbg & 1)) {
+                if constexpr ((kRbwdDbg & 16) != 0) sink += p_val[t] * (float)p_off[t];
+                else unsafeAtomicAdd(d_planes + p_off[t] + c, p_val[t]);
+            }
     }
+    if constexpr ((kRbwdDbg & 16) != 0) { if (sink == 12345.678f) d_planes[0] = sink; }
 }
 
 // POINTS = true: the same point-wise pass for free-standing point queries (renderer.py:142-148 run_model, G.sample_mixed — the density
 // regularisation of loss.py:681-706): a wave walks tiles of 32 POINTS instead of the samples of 32 rays, the upstream gradients are
 // dL/drgb [P][NNETS*32] (post-squash outputs, natural channel order) and dL/dsigma [P] instead of the tape's (colour weight, dL/dsigma).
-struct PointArgs { const float* coords; const float* g_rgb; const float* g_sigma; int pts_per_img, total_pts; };
+struct PointArgs { const float* coords; const float* g_rgb; const float* g_sigma; int pts_per_img, total_pts;
+                   int tiles_per_wave; };      // ray mode: consecutive (ray, 32-sample chunk) tiles one wave takes
 
 template <int NNETS, bool POINTS = false>
 __global__ void __launch_bounds__(kBwdWaves * 64, 1)
@@ -158,28 +190,24 @@ render_backward_kernel(RenderArgs a, const float* __restrict__ bwd_stream, float
     const int SN = NNETS - 1;
     const int S = a.Sc + a.Sf;
 
-    const int ray0 = POINTS ? 0 : (blockIdx.x * kBwdWaves + wave) * 32;
-    if (!POINTS && ray0 >= a.total_rays) return;
-    int g = POINTS ? 0 : min(ray0 + j, a.total_rays - 1);
-    bool live = POINTS ? false : (ray0 + j) < a.total_rays;
-    int n_img = POINTS ? 0 : g / a.rays_per_img;
+    // Work units ("tiles" of 32 lanes j).  Points: 32 consecutive points, tiles dealt grid-stride.  Rays: 32 consecutive SAMPLES OF ONE RAY — tile
+    // t = ray t / tiles_per_ray, samples 32 (t % tiles_per_ray) + j — a wave takes pa.tiles_per_wave consecutive tiles.  (Round 2 gave a wave 32 rays
+    // and walked their samples; the pass is order-free, and one ray per tile is what lets the scatter combine runs of equal texels.)
+    const int tiles_per_ray = (S + 31) >> 5;
+    const int n_tiles = POINTS ? (pa.total_pts + 31) / 32 : a.total_rays * tiles_per_ray;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int k_begin = POINTS ? (int)blockIdx.x * kBwdWaves + wave_u : ((int)blockIdx.x * kBwdWaves + wave_u) * pa.tiles_per_wave;
+    const int k_end = POINTS ? n_tiles : min(n_tiles, k_begin + pa.tiles_per_wave);
+    const int k_step = POINTS ? (int)gridDim.x * kBwdWaves : 1;
+    if (k_begin >= k_end) return;
+    int g = 0, n_img = 0;
+    bool live = false;
     const rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.planes, 0, a.planes_total_bytes, 0x00020000);
-    unsigned img = (unsigned)n_img * a.img_bytes;
-    unsigned dimg = (unsigned)n_img * 3u * (unsigned)(a.H * a.W) * 32u;    // d_planes is always the compact [N][3][H][W][32] (< 2^29 floats, checked on the host)
-    float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
-    if (!POINTS) {
-        ox = a.ray_o[g * 3 + 0]; oy = a.ray_o[g * 3 + 1]; oz = a.ray_o[g * 3 + 2];
-        dx = a.ray_d[g * 3 + 0]; dy = a.ray_d[g * 3 + 1]; dz = a.ray_d[g * 3 + 2];
-    }
+    unsigned img = 0, dimg = 0;                                   // d_planes is always the compact [N][3][H][W][32] (< 2^29 floats, checked on the host)
     const float cs = a.coord_scale;
-    const float4* const tape = POINTS ? nullptr : (const float4*)a.tape_s + (size_t)g * S;
     static_assert(TP == kFeatPitch, "T_f is the cooperative gather's tile");
 
     float dC[NNETS][16];                                          // rays: dL/dC (= 2 dL/dfeat) of this lane's channels; points: dL/drgb of the tile's point
-#pragma unroll
-    for (int n = 0; n < NNETS; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dC[n][r] = (!POINTS && live) ? 2.f * a.g_feat[(size_t)g * (NNETS * 32) + n * 32 + acc_row(r, h)] : 0.f;
 
     f32x16 aW2[NNETS][2], aW1[NNETS][2];                          // weight-gradient tiles (accumulate over all samples of the wave)
     float ab2[NNETS], ab1[NNETS][2], aW2s[2] = {0.f, 0.f}, ab2s = 0.f;
@@ -192,12 +220,6 @@ render_backward_kernel(RenderArgs a, const float* __restrict__ bwd_stream, float
             for (int r = 0; r < 16; ++r) { aW2[n][t][r] = 0.f; aW1[n][t][r] = 0.f; }
     }
 
-    // the pass is order-free over samples: small launches split every ray's samples over gridDim.y blocks so that all CUs get work
-    // (points: the "samples" are the tiles of 32 points this wave takes, grid-stride)
-    const int k_per = (S + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int k_begin = POINTS ? (int)blockIdx.x * kBwdWaves + wave : (int)blockIdx.y * k_per;
-    const int k_end = POINTS ? (pa.total_pts + 31) / 32 : min(S, k_begin + k_per);
-    const int k_step = POINTS ? (int)gridDim.x * kBwdWaves : 1;
     for (int k = k_begin; k < k_end; k += k_step) {
         float wgt = 1.f, dsig = 0.f, px, py, pz;
         if constexpr (POINTS) {
@@ -213,13 +235,29 @@ render_backward_kernel(RenderArgs a, const float* __restrict__ bwd_stream, float
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dC[n][r] = (live && pa.g_rgb) ? pa.g_rgb[(size_t)g * (NNETS * 32) + n * 32 + acc_row(r, h)] : 0.f;
         } else {
-            const float4 rec = tape[k];                           // z, colour weight, dL/dsigma
+            g = k / tiles_per_ray;                                // wave-uniform
+            const int ks = (k - g * tiles_per_ray) * 32 + j;      // this lane's sample
+            live = ks < S;
+            n_img = g / a.rays_per_img;
+            img = (unsigned)n_img * a.img_bytes;
+            dimg = (unsigned)n_img * 3u * (unsigned)(a.H * a.W) * 32u;
+            const float ox = a.ray_o[g * 3 + 0], oy = a.ray_o[g * 3 + 1], oz = a.ray_o[g * 3 + 2];
+            const float dx = a.ray_d[g * 3 + 0], dy = a.ray_d[g * 3 + 1], dz = a.ray_d[g * 3 + 2];
+#pragma unroll
+            for (int n = 0; n < NNETS; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dC[n][r] = 2.f * a.g_feat[(size_t)g * (NNETS * 32) + n * 32 + acc_row(r, h)];
+            const float4 rec = ((const float4*)a.tape_s)[(size_t)g * S + min(ks, S - 1)];      // z, colour weight, dL/dsigma
             const float z = rec.x;
             wgt = live ? rec.y : 0.f; dsig = live ? rec.z : 0.f;
             px = cs * fmaf(z, dx, ox); py = cs * fmaf(z, dy, oy); pz = cs * fmaf(z, dz, oz);
         }
         float feat[16];
         wave_sync();                                              // the previous sample's readers of T_f are done
+        if constexpr ((kRbwdDbg & 4) != 0) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) feat[c] = 0.1f * (float)(c + h);
+        } else
         gather_features_coop<true>(a, rsrc, img, lane, px, py, pz, Tf, Tt, feat);      // eight lanes to a texel; lands in T_f as [channel][ray] and in the lane's registers
         f32x16 df;
 #pragma unroll
@@ -251,7 +289,7 @@ render_backward_kernel(RenderArgs a, const float* __restrict__ bwd_stream, float
             if (n == SN && h == 0) Tds[j] = ds_n;
             wave_sync();
             // ---- dW2 (colour rows) += do h^T ; db2 ; density row
-            {
+            if constexpr (!(kRbwdDbg & 2)) {
                 float fa[16], dsv[16];
                 read_row16(Tdo + ti * TP + 16 * tk, fa);
                 if (n == SN) read_row16(Tds + 16 * tk, dsv);
@@ -278,7 +316,7 @@ render_backward_kernel(RenderArgs a, const float* __restrict__ bwd_stream, float
             f32x16 dh0, dh1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dh0[r] = 0.f; dh1[r] = 0.f; }
-            {
+            if constexpr (!(kRbwdDbg & 8)) {
                 const f32x4* wv = (const f32x4*)(bwd + n * kBwdNetStride) + lane;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -310,7 +348,7 @@ render_backward_kernel(RenderArgs a, const float* __restrict__ bwd_stream, float
             }
             wave_sync();
             // ---- dW1 += da f^T ; db1
-            {
+            if constexpr (!(kRbwdDbg & 2)) {
                 float fbf[16];
                 read_row16(Tf + ti * TP + 16 * tk, fbf);
 #pragma unroll
@@ -326,7 +364,7 @@ render_backward_kernel(RenderArgs a, const float* __restrict__ bwd_stream, float
                 }
             }
             // ---- df += W1^T da
-            {
+            if constexpr (!(kRbwdDbg & 8)) {
                 const f32x4* wv = (const f32x4*)(bwd + n * kBwdNetStride) + 8 * 64 + lane;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -449,17 +487,22 @@ extern "C" int p3d_render_backward(const float* planes_cl, const float* decoder,
     // 2. point-wise backward
     {
         const size_t lds_bytes = (size_t)(kDecoderFloats + kBwdFloats + kBwdWaves * kBwdWaveLds) * sizeof(float);
-        const int blocks = (int)((total + kBwdWaves * 32 - 1) / (kBwdWaves * 32));
-        int splits = 1;                                                  // one block per CU at a time: aim for >= 2 rounds of blocks
-        while (blocks * splits < 2 * kNumCU && splits < 8) splits *= 2;
+        // one block per CU at a time (LDS); a wave takes `tpw` consecutive (ray, 32-sample chunk) tiles: as many as keeps >= 2 rounds of blocks on
+        // the chip, at most 96 (the weight-gradient tiles leave through atomics once per wave)
+        const int S_all = a.Sc + a.Sf;
+        const int64_t n_tiles = total * ((S_all + 31) / 32);
+        int tpw = (int)(n_tiles / ((int64_t)kBwdWaves * 2 * kNumCU));
+        tpw = tpw < 1 ? 1 : (tpw > 96 ? 96 : tpw);
+        const int blocks = (int)((n_tiles + (int64_t)kBwdWaves * tpw - 1) / ((int64_t)kBwdWaves * tpw));
+        PointArgs pa{}; pa.tiles_per_wave = tpw;
         if (d->n_nets == 1) {
             static std::atomic<uint64_t> once1_devs{0}; const hipError_t once1 = reserve_lds_once((const void*)render_backward_kernel<1>, (int)lds_bytes, once1_devs);
             if (once1 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_backward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(once1));
-            hipLaunchKernelGGL(render_backward_kernel<1>, dim3(blocks, splits), dim3(kBwdWaves * 64), lds_bytes, s, a, decoder_bwd, d_planes_cl, d_decoder, PointArgs{});
+            hipLaunchKernelGGL(render_backward_kernel<1>, dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, a, decoder_bwd, d_planes_cl, d_decoder, pa);
         } else {
             static std::atomic<uint64_t> once2_devs{0}; const hipError_t once2 = reserve_lds_once((const void*)render_backward_kernel<2>, (int)lds_bytes, once2_devs);
             if (once2 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_backward: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(once2));
-            hipLaunchKernelGGL(render_backward_kernel<2>, dim3(blocks, splits), dim3(kBwdWaves * 64), lds_bytes, s, a, decoder_bwd, d_planes_cl, d_decoder, PointArgs{});
+            hipLaunchKernelGGL(render_backward_kernel<2>, dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, a, decoder_bwd, d_planes_cl, d_decoder, pa);
         }
     }
     count_launch(FAM_RENDER);
@@ -494,7 +537,7 @@ extern "C" int p3d_sample_points_backward(const float* planes_cl, const float* d
         return fail(P3D_ERR_UNSUPPORTED, "sample_points_backward: plane tensor too large for 32-bit buffer addressing");
     a.planes_total_bytes = (unsigned)((int64_t)d->n_img * a.img_stride * 4);
     a.planes = planes_cl; a.decoder = decoder;
-    PointArgs pa{coords, g_rgb, g_sigma, pts_per_img, (int)total};
+    PointArgs pa{coords, g_rgb, g_sigma, pts_per_img, (int)total, 0};
     const size_t lds_bytes = (size_t)(kDecoderFloats + kBwdFloats + kBwdWaves * kBwdWaveLds) * sizeof(float);
     const int64_t tiles = (total + 31) / 32;
     int blocks = (int)((tiles + kBwdWaves - 1) / kBwdWaves);
