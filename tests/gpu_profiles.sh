@@ -3,7 +3,7 @@
 # usage: bash tests/gpu_profiles.sh <tag>     -> gpurun_out/<tag>_*
 tag=${1:-round2}
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-graph --no-train-step > $GRAFT_REPO_ROOT/gpurun_out/${tag}_bench_line_eager.json 2> /tmp/prof_bench.err)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-graph --no-train-step --no-exact-fp32 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_bench_line_eager.json 2> /tmp/prof_bench.err)
 cp $(find /tmp/prof_bench -name '*kernel_stats.csv' | head -1) gpurun_out/${tag}_bench_kernel_stats.csv
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_train -o t -- python $GRAFT_REPO_ROOT/tests/gpu_train_census.py 4 128 --no-census > $GRAFT_REPO_ROOT/gpurun_out/${tag}_train_passes.log 2> /tmp/prof_train.err)
 cp $(find /tmp/prof_train -name '*kernel_stats.csv' | head -1) gpurun_out/${tag}_train_kernel_stats.csv
