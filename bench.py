@@ -54,7 +54,7 @@ def parse():
     p.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a captured hipGraph')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--miopen-find', action='store_true', help='let MIOpen benchmark its solvers for the vendor-library convs (slow warm-up)')
-    p.add_argument('--cpu-reps', type=int, default=4, help='CPU baseline runs per thread count: 1 warm-up + (n - 1) timed (median reported)')
+    p.add_argument('--cpu-reps', type=int, default=6, help='CPU baseline runs per thread count: 1 warm-up + (n - 1) timed (median reported; SURVEY 8(d): >= 5)')
     p.add_argument('--train-step', action='store_true', help='time training iterations of BASELINE config 3 (G pass + D pass with R1 + gradient all-reduce) instead of inference')
     p.add_argument('--no-train-step', action='store_true', help='skip the short train_step extra of the default run')
     p.add_argument('--no-exact-fp32', action='store_true', help='skip the second timed loop with the bf16x3 switches off')

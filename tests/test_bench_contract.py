@@ -1,0 +1,54 @@
+"""The benchmark line's contract, checked on the line the final tree printed on an MI355X (profiles/round3_l_bench_line_default.json) and on
+bench.py's argument surface: the keys the driver parses, the roofline object backed by committed counter passes whose hash matches the
+kernel sources of this tree, the CPU baseline, the exact-fp32 leg and the four-phase training step."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def _line(name):
+    return json.load(open(os.path.join(ROOT, 'profiles', name)))
+
+
+def test_default_line_has_the_contract_keys():
+    d = _line('round3_l_bench_line_default.json')
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
+              'roofline', 'cpu_baseline', 'exact_fp32', 'train_step'):
+        assert k in d, k
+    assert d['unit'] == 'img/s' and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None and d['data'] == 'synthetic'
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    assert abs(d['value'] - 4 * d['n_gpus'] / (d['ms_per_step'] * 1e-3)) < 0.01 * d['value']           # value = images of all ranks / time
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'binding', 'tap_bytes', 'ms_per_launch', 'units_per_launch'):
+        assert k in r, k
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and 0 < r['frac'] <= 1.0                  # a bound: never above its peak
+    assert r['binding'] is not None and r['bound'] in r['binding']['all_resources_in_pmc_pass']
+    assert r['traffic'] < r['units_per_launch'] * r['tap_bytes']['bytes_per_unit']                       # memory-side bytes << tap bytes
+    c = d['cpu_baseline']
+    assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == 'img/s'
+    e = d['exact_fp32']
+    assert e['value'] < d['value'] and e['mfma_conv']['conv_f32']['tflops'] is not None and e['roofline']['bound'] == 'mfma_pipe'
+    t = d['train_step']
+    assert set(t['phase_ms']) == {'Gmain', 'Greg', 'Dmain', 'Dreg', 'ema'} and t['lazy_schedule']['ms_per_iteration'] < t['ms_per_iteration']
+
+
+def test_committed_counter_passes_belong_to_this_trees_kernel():
+    h = hashlib.sha256()
+    for rel in ('pix2pix3d_amd/csrc/render.hip', 'pix2pix3d_amd/csrc/render_device.h'):
+        h.update(open(os.path.join(ROOT, rel), 'rb').read())
+    for name in ('render_pmc.json', 'render_pmc_exact_fp32.json'):
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))
+        assert pmc['kernel_src_sha16'] == h.hexdigest()[:16], f'profiles/{name} was taken from other kernel sources: re-run tests/gpu_pmc_render.py'
+        b = pmc['binding']
+        assert b['resource'] == max(pmc['derived']['utilisation'].items(), key=lambda kv: kv[1])[0] and b['busy_units_per_launch'] > 0
+
+
+def test_bench_argument_surface():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--help'], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+    for flag in ('--gpus', '--steps', '--warmup', '--train-step', '--no-exact-fp32', '--no-cpu-baseline', '--cpu-reps'):
+        assert flag in r.stdout, flag
