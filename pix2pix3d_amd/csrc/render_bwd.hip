@@ -130,24 +130,36 @@ __device__ __forceinline__ void scatter_features(const RenderArgs& a, float* __r
         unsigned p_off[4]; float p_val[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) { p_off[t] = 0xffffffffu; p_val[t] = 0.f; }
-#pragma unroll 2
+        // entries one ahead in registers (the walk is a chain of LDS reads at one wave per SIMD) and select-based bookkeeping: the only
+        // control flow per tap is the exec-masked atomic of a flush (the first cut branched three levels deep per tap: 2.4 ms of walk
+        // beside 2.6 ms of atomics, profiles/round3_k_*)
+        const float* const tv = Tdf + half * 16 * TP + c;
+        const float* const tw = Tw + half * 16 * 12 + 4 * p;
+        const unsigned* const to = Toff + half * 16 * 12 + 4 * p;
+        float v_n = tv[0];
+        f32x4 w_n = *(const f32x4*)tw;
+        u32x4 o_n = *(const u32x4*)to;
+#pragma unroll
         for (int pr = 0; pr < 16; ++pr) {
-            const int e = half * 16 + pr;
-            const float v = Tdf[e * TP + c];
-            const f32x4 w = *(const f32x4*)(Tw + e * 12 + 4 * p);
-            const u32x4 off = *(const u32x4*)(Toff + e * 12 + 4 * p);
+            const float v = v_n;
+            const f32x4 w = w_n;
+            const u32x4 off = o_n;
+            if (pr + 1 < 16) {
+                v_n = tv[(pr + 1) * TP];
+                w_n = *(const f32x4*)(tw + (pr + 1) * 12);
+                o_n = *(const u32x4*)(to + (pr + 1) * 12);
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                if (w[t] == 0.f) continue;                        // dead lane / out-of-image tap: never contributed (uniform over the half-wave)
                 const float contrib = w[t] * v;
-                if (off[t] == p_off[t]) p_val[t] += contrib;
-                else {
-                    if (p_off[t] != 0xffffffffu && !(kRbwdDbg & 1)) {
-                        if constexpr ((kRbwdDbg & 16) != 0) sink += p_val[t] * (float)p_off[t];
-                        else unsafeAtomicAdd(d_planes + p_off[t] + c, p_val[t]);
-                    }
-                    p_off[t] = off[t]; p_val[t] = contrib;
+                const bool valid = w[t] != 0.f;                   // dead lane / out-of-image tap: never contributed (uniform over the half-wave)
+                const bool same = off[t] == p_off[t];
+                if (valid && !same && p_off[t] != 0xffffffffu && !(kRbwdDbg & 1)) {
+                    if constexpr ((kRbwdDbg & 16) != 0) sink += p_val[t] * (float)p_off[t];
+                    else unsafeAtomicAdd(d_planes + p_off[t] + c, p_val[t]);
                 }
+                p_val[t] = valid ? (same ? p_val[t] + contrib : contrib) : p_val[t];
+                p_off[t] = valid ? off[t] : p_off[t];
             }
         }
 #pragma unroll
