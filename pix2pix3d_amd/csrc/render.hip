@@ -93,15 +93,16 @@ sample_points_kernel(RenderArgs a, const float* coords, int pts_per_img, int tot
 __global__ void __launch_bounds__(64) importance_kernel(const float* z_coarse, const float* w_coarse, const float* u_fine,
                                                         float* z_fine, int rays, int Sc, int Sf, int sort)
 {
-    __shared__ float sA[64], sB[64];
     const int lane = threadIdx.x;
     for (int r = blockIdx.x; r < rays; r += gridDim.x) {
         const float w_i = (lane < Sc - 1) ? w_coarse[(size_t)r * (Sc - 1) + lane] : 0.f;
         const float z_i = (lane < Sc) ? z_coarse[(size_t)r * Sc + lane] : 0.f;
         const float u = (lane < Sf) ? u_fine[(size_t)r * Sf + lane] : 2.f;
-        float zf = importance_depth(Sc, Sf, lane, w_i, z_i, u, sA, sB);
-        if (sort) zf = bitonic_sort64(zf, lane);
-        if (lane < Sf) z_fine[(size_t)r * Sf + lane] = zf;
+        const float w1[1] = {w_i}, z1[1] = {z_i}, u1[1] = {u};
+        float zf[1];
+        importance_depth<1>(Sc, Sf, lane, w1, z1, u1, zf);
+        if (sort) bitonic_sort64<1>(zf, lane);
+        if (lane < Sf) z_fine[(size_t)r * Sf + lane] = zf[0];
         wave_sync();
     }
 }

@@ -22,7 +22,7 @@ constexpr int OFF_W1X  = kDecoderFloats;
 constexpr int kDecoderFloatsDual = kDecoderFloats + 2048;
 constexpr int kPitch = 33;                       // LDS pitch of the per-wave [sample][ray] tile
 constexpr int kMaxS = 64;                        // max coarse / fine samples per ray
-constexpr int kWaveTile = kMaxS * kPitch + 128;  // + two 64-float scratch rows
+constexpr int kWaveTile = kMaxS * kPitch + 128;  // + two 64-float scratch rows (unused since the importance sampler went to registers; kept: the tile bases are 16-byte aligned with it)
 constexpr int kWavesPerBlock = 8;
 constexpr int kFeatPitch = 36;                   // floats per ray in the cooperative gather's hand-over tile (144 B: 16 consecutive rays start on 16 different bank quads)
 constexpr int kFeatTile = 32 * kFeatPitch;       // per wave
@@ -482,61 +482,76 @@ __device__ __forceinline__ void mlp_layer2_bf3(const float* lds, int n, int lane
     }
 }
 
-// ---- importance sampling for one ray, wave-cooperative (renderer.py:194-253) ----------------------
-// lane i holds coarse weight w_i (i < Sc-1) and coarse depth z_i (i < Sc); lane j returns fine depth j
-// (unsorted), +inf for j >= Sf.  sA / sB: two 64-float LDS scratch rows of this wave.
-__device__ __forceinline__ float importance_depth(int Sc, int Sf, int lane, float w_i, float z_i, float u, float* sA, float* sB)
+// ---- importance sampling, wave-cooperative (renderer.py:194-253), NR rays at a time ------------------------------
+// Per ray: lane i holds coarse weight w_i (i < Sc-1) and coarse depth z_i (i < Sc); lane j returns fine depth j (unsorted), +inf for j >= Sf.
+// Everything stays in registers: lane k keeps pdf entry k, bin midpoint k and (after the scan) cdf entry k; the two sequential fp32 sums
+// (normaliser, cdf — sequential so that the searchsorted indices are reproducible bit for bit) broadcast lane k's value with v_readlane.
+// The whole phase is dependent-latency work (61-step scans, a 21-stage sort, divisions) with two waves per SIMD to hide it — 11 % of the
+// kernel (profiles/round3_n_render_ablation.log) — so NR = 2 rays go through it TOGETHER: two independent chains in every loop.
+__device__ __forceinline__ float lane_bcast(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+template <int NR>
+__device__ __forceinline__ void importance_depth(int Sc, int Sf, int lane, const float (&w_i)[NR], const float (&z_i)[NR], const float (&u)[NR], float (&z)[NR])
 {
 #pragma clang fp contract(off)
     const float ninf = -INFINITY;
-    const float wi  = (lane < Sc - 1) ? w_i : ninf;
-    float wl = __shfl_up(wi, 1, 64);  if (lane == 0) wl = ninf;
-    const float mp = fmaxf(wl, wi);                        // max_pool1d(k=2, s=1, pad=1): Sc values
-    const float mpn = __shfl_down(mp, 1, 64);
-    const float ap = (mp + mpn) / 2.f;                     // avg_pool1d(k=2, s=1): Sc-1 values
-    const float wk = (ap + 0.01f) + 1e-5f;                 // "+ 0.01" then sample_pdf's "+ eps"
-    const float zn = __shfl_down(z_i, 1, 64);
-    const float zmid = 0.5f * (z_i + zn);                  // bins: Sc-1 midpoints
     const int nw = Sc - 3;                                 // pdf entries = smoothed[1:-1]
-    wave_sync();
-    if (lane >= 1 && lane <= nw) sA[lane - 1] = wk;
-    if (lane <= Sc - 2) sB[lane] = zmid;
-    wave_sync();
-    float total = 0.f;
-    for (int k = 0; k < nw; ++k) total = total + sA[k];
-    wave_sync();
-    if (lane < nw) sA[lane] = sA[lane] / total;
-    wave_sync();
-    // cdf_0 = 0, cdf_{k+1} = cdf_k + pdf_k (Sc-2 entries); inds = #{cdf <= u} (searchsorted right=True)
-    float cdf = 0.f, cb = 0.f, zb = sB[0], ca = 0.f, za = 0.f;
-    bool found = false;
-    for (int k = 0; k <= nw; ++k) {
-        if (k > 0) cdf = cdf + sA[k - 1];
-        const float zk = sB[k];
-        if (cdf <= u) { cb = cdf; zb = zk; }
-        else if (!found) { ca = cdf; za = zk; found = true; }
+    float pnum[NR], zmid[NR], total[NR], pdf[NR], cdf[NR], mycdf[NR];
+    int inds[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        const float wi  = (lane < Sc - 1) ? w_i[q] : ninf;
+        float wl = __shfl_up(wi, 1, 64);  if (lane == 0) wl = ninf;
+        const float mp = fmaxf(wl, wi);                    // max_pool1d(k=2, s=1, pad=1): Sc values
+        const float mpn = __shfl_down(mp, 1, 64);
+        const float ap = (mp + mpn) / 2.f;                 // avg_pool1d(k=2, s=1): Sc-1 values
+        const float wk = (ap + 0.01f) + 1e-5f;             // "+ 0.01" then sample_pdf's "+ eps"
+        const float zn = __shfl_down(z_i[q], 1, 64);
+        zmid[q] = 0.5f * (z_i[q] + zn);                    // bins: Sc-1 midpoints, lane k holds bin k
+        pnum[q] = __shfl_down(wk, 1, 64);                  // lane k: pdf numerator k = smoothed[k + 1]
+        total[q] = 0.f;
     }
-    if (!found) { ca = cb; za = zb; }                      // above clamps to the last bin
-    float denom = ca - cb;
-    if (denom < 1e-5f) denom = 1.f;
-    const float t = (u - cb) / denom;
-    const float z = zb + t * (za - zb);
-    return (lane < Sf) ? z : INFINITY;
+    for (int k = 0; k < nw; ++k)
+#pragma unroll
+        for (int q = 0; q < NR; ++q) total[q] = total[q] + lane_bcast(pnum[q], k);
+    // cdf_0 = 0, cdf_{k+1} = cdf_k + pdf_k (Sc-2 entries); inds = #{cdf <= u} (searchsorted right=True; the cdf is non-decreasing)
+#pragma unroll
+    for (int q = 0; q < NR; ++q) { pdf[q] = pnum[q] / total[q]; cdf[q] = 0.f; mycdf[q] = 0.f; inds[q] = (0.f <= u[q]) ? 1 : 0; }
+    for (int k = 0; k < nw; ++k)
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            cdf[q] = cdf[q] + lane_bcast(pdf[q], k);
+            inds[q] += (cdf[q] <= u[q]) ? 1 : 0;
+            mycdf[q] = (lane == k + 1) ? cdf[q] : mycdf[q];    // lane k keeps cdf entry k
+        }
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        const int below = max(inds[q] - 1, 0), above = min(inds[q], nw);
+        const float cb = __shfl(mycdf[q], below, 64), ca = __shfl(mycdf[q], above, 64);
+        const float zb = __shfl(zmid[q], below, 64), za = __shfl(zmid[q], above, 64);
+        float denom = ca - cb;
+        if (denom < 1e-5f) denom = 1.f;
+        const float t = (u[q] - cb) / denom;
+        const float zz = zb + t * (za - zb);
+        z[q] = (lane < Sf) ? zz : INFINITY;
+    }
 }
 
-__device__ __forceinline__ float bitonic_sort64(float v, int lane)
+template <int NR>
+__device__ __forceinline__ void bitonic_sort64(float (&v)[NR], int lane)
 {
 #pragma unroll
     for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
-            const float o = __shfl_xor(v, j, 64);
             const bool up = ((lane & k) == 0);
             const bool lower = ((lane & j) == 0);
-            v = (lower == up) ? fminf(v, o) : fmaxf(v, o);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const float o = __shfl_xor(v[q], j, 64);
+                v[q] = (lower == up) ? fminf(v[q], o) : fmaxf(v[q], o);
+            }
         }
     }
-    return v;
 }
 
 // ---- the fused kernel -------------------------------------------------------------------------------
@@ -586,8 +601,6 @@ render_forward_kernel(RenderArgs a)
     __syncthreads();
 
     float* tile = lds + kDecFloats + wave * kWaveTile;          // [sample][kPitch] coarse weights, then fine depths
-    float* sA = tile + kMaxS * kPitch;
-    float* sB = sA + 64;
     const int SN = NNETS - 1;                                    // density comes from the last net (triplane_cond.py:958)
     const int Sc = a.Sc, Sf = a.Sf;
 
@@ -610,7 +623,11 @@ render_forward_kernel(RenderArgs a)
             const int blk = slot * per + sub;                                 // (image, row block) index within the strip
             const int nrb = R / rpb;                                          // row blocks per image
             const int n_i = blk / nrb, rb = blk - n_i * nrb;
-            const int row = rb * rpb + wave * 2 + (j >> 4), col = strip * 16 + (j & 15);
+            // a full block (8 waves, 16 x 16 pixels): wave w = 8 rows x 4 columns, ray j = (row j & 7, column j >> 3), so the eight rays of a gather
+            // group (8 i .. 8 i + 7) are ONE pixel column: their (x,z)- and (z,x)-plane taps are the same one or two texel lines per load
+            // instruction instead of eight (round 3, same box: 1.302 vs 1.338 ms).  Smaller blocks keep two 16-pixel rows per wave.
+            const int row = (wpb == 8) ? rb * rpb + (wave & 1) * 8 + (j & 7) : rb * rpb + wave * 2 + (j >> 4);
+            const int col = (wpb == 8) ? strip * 16 + (wave >> 1) * 4 + (j >> 3) : strip * 16 + (j & 15);
             g_lane = n_i * a.rays_per_img + row * R + col;
             ray0 = 0;                                                         // every lane is a real ray in this mode
         }
@@ -658,19 +675,27 @@ render_forward_kernel(RenderArgs a)
     }
     wave_sync();
 
-    // ------------------------------ phase B: importance depths, sorted --------------------------------
-    for (int r = 0; r < 32; ++r) {
-        const int gr = __shfl(g, r, 64);                                         // global index of the wave's r-th ray (wave-uniform)
-        const bool r_live = __shfl((int)live, r, 64) != 0;
-        const float w_i = (lane < Sc - 1) ? tile[lane * kPitch + r] : 0.f;
-        const float z_i = (lane < Sc) ? coarse_depth(a, gr, lane, a.u_coarse[(size_t)gr * Sc + lane]) : 0.f;
-        const float u   = (lane < Sf) ? a.u_fine[(size_t)gr * Sf + lane] : 2.f;
-        if (a.dbg_wcoarse && lane < Sc - 1 && r_live) a.dbg_wcoarse[(size_t)gr * (Sc - 1) + lane] = w_i;
-        float zf = importance_depth(Sc, Sf, lane, w_i, z_i, u, sA, sB);
-        zf = bitonic_sort64(zf, lane);
+    // ------------------------------ phase B: importance depths, sorted (two rays at a time) ------------
+    for (int r = 0; r < 32; r += 2) {
+        int gr[2]; bool r_live[2];
+        float w_i[2], z_i[2], u[2], zf[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            gr[q] = __shfl(g, r + q, 64);                                        // global index of the wave's ray (wave-uniform)
+            r_live[q] = __shfl((int)live, r + q, 64) != 0;
+            w_i[q] = (lane < Sc - 1) ? tile[lane * kPitch + r + q] : 0.f;
+            z_i[q] = (lane < Sc) ? coarse_depth(a, gr[q], lane, a.u_coarse[(size_t)gr[q] * Sc + lane]) : 0.f;
+            u[q]   = (lane < Sf) ? a.u_fine[(size_t)gr[q] * Sf + lane] : 2.f;
+            if (a.dbg_wcoarse && lane < Sc - 1 && r_live[q]) a.dbg_wcoarse[(size_t)gr[q] * (Sc - 1) + lane] = w_i[q];
+        }
+        importance_depth<2>(Sc, Sf, lane, w_i, z_i, u, zf);
+        bitonic_sort64<2>(zf, lane);
         wave_sync();
-        if (lane < Sf) tile[lane * kPitch + r] = zf;
-        if (a.dbg_fine && lane < Sf && r_live) a.dbg_fine[(size_t)gr * Sf + lane] = zf;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (lane < Sf) tile[lane * kPitch + r + q] = zf[q];
+            if (a.dbg_fine && lane < Sf && r_live[q]) a.dbg_fine[(size_t)gr[q] * Sf + lane] = zf[q];
+        }
     }
     wave_sync();
 
