@@ -225,6 +225,7 @@ __device__ __forceinline__ void gather_features(const RenderArgs& a, rsrc_t rsrc
 // the bytes of ftile rows 16..31, which the step does not write before groups 0 and 1 (the only readers of those entries) have issued.
 constexpr int kTapRow = 24;                      // floats per ray
 constexpr int kTapTile = 16 * kTapRow;           // per wave, beside ftile
+constexpr int kRaysB = 4;                        // rays that go through the importance sampler together (independent chains; 2 -> 4: -1.3 %, profiles/round3_q_*)
 __device__ __forceinline__ float* tap_entry(float* ftile, float* ttile, int ray)
 {
     return ray < 16 ? ftile + 16 * kFeatPitch + ray * kTapRow : ttile + (ray - 16) * kTapRow;
@@ -487,7 +488,7 @@ __device__ __forceinline__ void mlp_layer2_bf3(const float* lds, int n, int lane
 // Everything stays in registers: lane k keeps pdf entry k, bin midpoint k and (after the scan) cdf entry k; the two sequential fp32 sums
 // (normaliser, cdf — sequential so that the searchsorted indices are reproducible bit for bit) broadcast lane k's value with v_readlane.
 // The whole phase is dependent-latency work (61-step scans, a 21-stage sort, divisions) with two waves per SIMD to hide it — 11 % of the
-// kernel (profiles/round3_n_render_ablation.log) — so NR = 2 rays go through it TOGETHER: two independent chains in every loop.
+// kernel (profiles/round3_n_render_ablation.log) — so NR rays go through it TOGETHER: NR independent chains in every loop.
 __device__ __forceinline__ float lane_bcast(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
 template <int NR>
 __device__ __forceinline__ void importance_depth(int Sc, int Sf, int lane, const float (&w_i)[NR], const float (&z_i)[NR], const float (&u)[NR], float (&z)[NR])
@@ -675,12 +676,12 @@ render_forward_kernel(RenderArgs a)
     }
     wave_sync();
 
-    // ------------------------------ phase B: importance depths, sorted (two rays at a time) ------------
-    for (int r = 0; r < 32; r += 2) {
-        int gr[2]; bool r_live[2];
-        float w_i[2], z_i[2], u[2], zf[2];
+    // ------------------------------ phase B: importance depths, sorted (kRaysB rays at a time) ---------
+    for (int r = 0; r < 32; r += kRaysB) {
+        int gr[kRaysB]; bool r_live[kRaysB];
+        float w_i[kRaysB], z_i[kRaysB], u[kRaysB], zf[kRaysB];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < kRaysB; ++q) {
             gr[q] = __shfl(g, r + q, 64);                                        // global index of the wave's ray (wave-uniform)
             r_live[q] = __shfl((int)live, r + q, 64) != 0;
             w_i[q] = (lane < Sc - 1) ? tile[lane * kPitch + r + q] : 0.f;
@@ -688,11 +689,11 @@ render_forward_kernel(RenderArgs a)
             u[q]   = (lane < Sf) ? a.u_fine[(size_t)gr[q] * Sf + lane] : 2.f;
             if (a.dbg_wcoarse && lane < Sc - 1 && r_live[q]) a.dbg_wcoarse[(size_t)gr[q] * (Sc - 1) + lane] = w_i[q];
         }
-        importance_depth<2>(Sc, Sf, lane, w_i, z_i, u, zf);
-        bitonic_sort64<2>(zf, lane);
+        importance_depth<kRaysB>(Sc, Sf, lane, w_i, z_i, u, zf);
+        bitonic_sort64<kRaysB>(zf, lane);
         wave_sync();
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < kRaysB; ++q) {
             if (lane < Sf) tile[lane * kPitch + r + q] = zf[q];
             if (a.dbg_fine && lane < Sf && r_live[q]) a.dbg_fine[(size_t)gr[q] * Sf + lane] = zf[q];
         }
