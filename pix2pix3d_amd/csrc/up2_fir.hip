@@ -24,6 +24,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <math.h>
 #include "p3d_common.h"
 #include "../../include/p3d_hip.h"
 
@@ -42,8 +43,10 @@ constexpr int UF_BN = 32;                                       // output channe
 constexpr int UF_TAP = UF_BN * 64;                              // bytes of one tap's weight tile (32 rows x 32 channels)
 constexpr int UF_WT_BASE = 2 * UF_SLAB_BUF;                     // 45056
 constexpr int UF_TILE = 28;                                     // final pixels per tile side
-constexpr int UF_CT_BYTES = 32 * 32 * UF_BN * 2;                // 65536: the transposed-conv tile, fp16
-constexpr int UF_LDS = UF_CT_BYTES + UF_TILE * UF_TILE * 4;     // + the tile's noise = 68672 (>= 45056 + 9 * 2048)
+constexpr int UF_CP = 32 * 32 + 8;                              // halfs per channel of the channel-major tile image (2064 B: 16 channels = 16 bank quads)
+constexpr int UF_CT_BYTES = UF_BN * UF_CP * 2;                  // 66048: the transposed-conv tile, fp16 (the pixel-major image of the VALU epilogue needs 65536)
+constexpr int UF_NZ_FLOATS = UF_TILE * UF_TILE + 16;            // the tile's noise (+ slack: lanes 28..31 of a row read past their row)
+constexpr int UF_LDS = UF_CT_BYTES + (UF_NZ_FLOATS + UF_BN) * 4;  // + the bias row = 69376 (>= 45056 + 9 * 2048); two blocks per CU
 
 struct Up2Args {
     const void* x;         // [N][H][W][Ci] fp16
@@ -75,6 +78,9 @@ __device__ constexpr int kPhaseDy[3][2] = {{0, 0}, {0, -1}, {0, -1}};
 __device__ constexpr int kPhaseDx[3][2] = {{0, 0}, {0, 0}, {-1, -1}};
 __device__ constexpr int kPhaseNA[3] = {1, 2, 2};
 
+// MFMA_FIR: the 4 x 4 FIR of the epilogue on the matrix cores (below); false = the vector-ALU epilogue, for filters whose tap products are
+// not fp16 numbers.
+template <bool MFMA_FIR>
 __global__ void __launch_bounds__(256, 2) up2_fir_f16_kernel(Up2Args a)
 {
     __shared__ __attribute__((aligned(16))) char lds_b[UF_LDS];
@@ -175,6 +181,20 @@ __global__ void __launch_bounds__(256, 2) up2_fir_f16_kernel(Up2Args a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][i][r] = 0.f;
 
+    // the epilogue's noise tile and bias: loaded NOW, into five registers, so that their global-memory latency passes under the K loop (as part
+    // of the epilogue it was ~2 us of every block's life with nothing to hide it)
+    float nz_pre[4], bias_pre = 0.f;
+    if constexpr (MFMA_FIR) {
+        const int OH = 2 * a.H, OW = 2 * a.W;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q;
+            const int oy = UF_TILE * ty + e / UF_TILE, ox = UF_TILE * tx + e % UF_TILE;
+            nz_pre[q] = (a.noise && e < UF_TILE * UF_TILE && oy < OH && ox < OW) ? a.noise[(int64_t)oy * OW + ox] : 0.f;
+        }
+        if (a.bias && tid < UF_BN) bias_pre = a.bias[co0 + tid];
+    }
+
     // ---- K loop --------------------------------------------------------------------------------------------------------------
     // DMA groups of a wave: W = 2 (waves 0, 1) or 1 pieces, S = 6 or 5.  At the rendezvous that ends phase p of chunk c everything
     // but the NEWEST group must have landed: after phase 0 that is W(c, 2) [-> W(c, 1) is in], after phase 1 W(c+1, 0) + slab(c+1)
@@ -230,9 +250,145 @@ __global__ void __launch_bounds__(256, 2) up2_fir_f16_kernel(Up2Args a)
     if (a.debug & 1) { if (acc[0][0][0] == 123.f) ((float*)a.y)[0] = 1.f; return; }
     __syncthreads();                                                            // slabs and taps are dead: the LDS becomes the epilogue's
 
+    const int OH = 2 * a.H, OW = 2 * a.W;
+    const int oy0 = UF_TILE * ty, ox0 = UF_TILE * tx;
+    float* const nz = (float*)(lds_b + UF_CT_BYTES);
+    if constexpr (!MFMA_FIR) {
+        const float ns = a.noise ? a.noise_strength[0] : 0.f;
+        for (int e = tid; e < UF_NZ_FLOATS; e += 256) {
+            const int oy = oy0 + e / UF_TILE, ox = ox0 + e % UF_TILE;
+            nz[e] = (a.noise && e < UF_TILE * UF_TILE && oy < OH && ox < OW) ? a.noise[(int64_t)oy * OW + ox] * ns : 0.f;
+        }
+    }
+    if constexpr (MFMA_FIR) {
+        // everything a finished value still needs, folded: y = clamp(max(v, slope v)) with v = (acc + noise + bias) * act_gain
+        //   = fma(acc, act_gain, (noise * strength + bias) * act_gain); the LDS noise tile and bias row hold the second term's pieces pre-scaled
+        const float slope = (a.act == 1) ? 0.2f : 1.f, lim = (a.clamp >= 0.f) ? a.clamp : INFINITY;
+        float* const bs = nz + UF_NZ_FLOATS;                                    // [32] bias * act_gain
+        {
+            const float ns = a.noise ? a.noise_strength[0] * a.act_gain : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (tid + 256 * q < UF_NZ_FLOATS) nz[tid + 256 * q] = nz_pre[q] * ns;
+            if (tid < UF_BN) bs[tid] = bias_pre * a.act_gain;
+        }
+        // ---- the FIR on the matrix cores --------------------------------------------------------------------------------------
+        // out[m][xo] = sum_ky sum_kx fy[ky] fx[kx] ct[1 + m + ky][1 + xo + kx] is, for one output row m and one tap row ky, a product of the tile row
+        // ct[1 + m + ky][.] (M = 32 channels x K = 32 columns) with the BANDED constant matrix B_ky[xin][xo] = fy[ky] fx[xin - xo - 1]: eight
+        // 32x32x16 MFMAs per output row and 32 channels, fp16 inputs (the tile is fp16 anyway, the tap products are fp16 numbers — host check),
+        // fp32 accumulation.  The vector-ALU version of this epilogue was the kernel's busiest pipe (~2 800 VALU instructions per thread, 408
+        // conversions, 128 two-byte LDS stores: profiles/round3_g_kernel_pmc_infer_train.txt); here a thread issues 56 MFMAs and ~1 100 VALU.
+        // The tile image is CHANNEL-major [32 ch][32 rows][32 columns] (pitch 2064 B), so
+        //   * the accumulators leave as 16-byte LDS stores: a lane's 4 consecutive accumulator rows are 4 consecutive class columns of one
+        //     channel, and the two x-parity classes interleave them into 8 consecutive tile columns;
+        //   * an A fragment (channel = lane & 31, eight consecutive columns) is one ds_read_b128;
+        //   * 16 consecutive channels start on 16 different bank quads for both.
+        __half* const ct = (__half*)lds_b;
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uh8 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e]     = (_Float16)(acc[py * 2 + 0][i][q * 4 + e] * a.conv_gain);
+                        v[2 * e + 1] = (_Float16)(acc[py * 2 + 1][i][q * 4 + e] * a.conv_gain);
+                    }
+                    const int row = 2 * (wave * 4 + i * 2 + (q >> 1)) + py, col = 16 * (q & 1) + 8 * fk;
+                    *(uh8*)(ct + frow * UF_CP + row * 32 + col) = v;
+                }
+        // B fragments: lane (xo = lane & 31, K group fk) holds B_ky[xin = 16 kh + 8 fk + e][xo], e = 0 .. 7
+        uh8 bf[4][2];
+        {
+            float band[2][8];
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int kx = kh * 16 + fk * 8 + e - frow - 1;
+                    band[kh][e] = (frow < UF_TILE) ? (kx == 0 ? a.fx[0] : kx == 1 ? a.fx[1] : kx == 2 ? a.fx[2] : kx == 3 ? a.fx[3] : 0.f) : 0.f;
+                }
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bf[ky][kh][e] = (_Float16)(a.fy[ky] * band[kh][e]);
+        }
+        // what a lane finishes: pixel column xo = lane & 31 of an output row, channels (r & 3) + 8 (r >> 2) + 4 fk
+        const int ox = ox0 + frow;
+        const bool col_ok = frow < UF_TILE && ox < OW;
+        __half* const yout = (__half*)a.y + (int64_t)n * OH * OW * a.Co + co0 + 8 * fk;
+        __syncthreads();
+        if (a.debug & 8) return;
+        float bias[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uf4 b4 = *(const uf4*)(bs + 8 * q + 4 * fk);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias[q * 4 + e] = b4[e];
+        }
+        // wave w: output rows 7 w .. 7 w + 6 of the tile from tile rows 7 w + 1 .. 7 w + 10; four rows in flight, one accumulator each (a row's
+        // first MFMA starts from the constant 0)
+        uf16 o[4];
+        uf16 zero16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+        const __half* const arow = ct + frow * UF_CP + (wave * 7 + 1) * 32 + fk * 8;
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            const uh8 a0 = *(const uh8*)(arow + t * 32), a1 = *(const uh8*)(arow + t * 32 + 16);
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky)
+                if (t - ky >= 0 && t - ky < 7) o[(t - ky) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bf[ky][0], ky == 0 ? zero16 : o[(t - ky) & 3], 0, 0, 0);
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky)
+                if (t - ky >= 0 && t - ky < 7) o[(t - ky) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bf[ky][1], o[(t - ky) & 3], 0, 0, 0);
+            if (t >= 3) {                                                       // output row t - 3 is complete
+                const int m = wave * 7 + t - 3, oy = oy0 + m, s = (t - 3) & 3;
+                const float nzv = nz[m * UF_TILE + frow];
+                unsigned pk[8];                                                 // [q][2]: channels 8 q + 4 fk + 0 .. 3 as two half pairs
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        float v2[2];
+#pragma unroll
+                        for (int z = 0; z < 2; ++z) {
+                            float v = fmaf(o[s][q * 4 + e2 * 2 + z], a.act_gain, nzv + bias[q * 4 + e2 * 2 + z]);
+                            v = fmaxf(v, slope * v);
+                            v2[z] = __builtin_amdgcn_fmed3f(v, -lim, lim);
+                        }
+                        typedef _Float16 uh2 __attribute__((ext_vector_type(2)));
+                        uh2 hv; hv[0] = (_Float16)v2[0]; hv[1] = (_Float16)v2[1];
+                        pk[q * 2 + e2] = __builtin_bit_cast(unsigned, hv);
+                    }
+                // the fk = 0 half-wave holds channels {0-3, 8-11, 16-19, 24-27}, fk = 1 {4-7, ...}: trade q = 1, 3 of the lower half against
+                // q = 0, 2 of the upper one and every lane owns 8 consecutive channels twice: 16-byte stores, a pixel's 64 bytes from two lanes
+                uf4 st[2];
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        const unsigned mine_lo = pk[(2 * pr) * 2 + e2], mine_hi = pk[(2 * pr + 1) * 2 + e2];
+                        const unsigned send = fk ? mine_lo : mine_hi;
+                        const unsigned recv = (unsigned)__shfl_xor((int)send, 32, 64);
+                        st[pr][e2]     = __uint_as_float(fk ? recv : mine_lo);
+                        st[pr][2 + e2] = __uint_as_float(fk ? mine_hi : recv);
+                    }
+                if (col_ok && oy < OH && !(a.debug & 4)) {
+                    __half* dst = yout + ((int64_t)oy * OW + ox) * a.Co;
+                    *(uf4*)dst = st[0];
+                    *(uf4*)(dst + 16) = st[1];
+                }
+            }
+        }
+        return;
+    }
     // ---- the four class tiles -> one fp16 image [32][32][32 ch] --------------------------------------------------------------
     __half* const ct = (__half*)lds_b;
-    float* const nz = (float*)(lds_b + UF_CT_BYTES);
     if (!(a.debug & 16))
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -245,15 +401,6 @@ __global__ void __launch_bounds__(256, 2) up2_fir_f16_kernel(Up2Args a)
                 const int row = 2 * (p >> 4) + py, col = 2 * (p & 15) + px;
                 ct[(row * 32 + col) * UF_BN + frow] = __float2half(acc[c][i][r] * a.conv_gain);
             }
-    }
-    const int OH = 2 * a.H, OW = 2 * a.W;
-    const int oy0 = UF_TILE * ty, ox0 = UF_TILE * tx;
-    {
-        const float ns = a.noise ? a.noise_strength[0] : 0.f;
-        for (int e = tid; e < UF_TILE * UF_TILE; e += 256) {
-            const int oy = oy0 + e / UF_TILE, ox = ox0 + e % UF_TILE;
-            nz[e] = (a.noise && oy < OH && ox < OW) ? a.noise[(int64_t)oy * OW + ox] * ns : 0.f;
-        }
     }
     __syncthreads();
 
@@ -335,7 +482,17 @@ extern "C" int p3d_up2_fir_f16(const void* x, const void* w, void* y, const void
     { static const int dbg = [] { const char* d = getenv("P3D_UP2_DEBUG"); return d ? atoi(d) : 0; }(); a.debug = dbg; }      // phase switches of tests/gpu_probe_up2.py (0 = the layer)
     const int64_t blocks = (int64_t)((a.tiles + 7) / 8 * 8) * (co / UF_BN);
     P3D_REQUIRE(blocks < (1ll << 31) && n_img < 65536, "up2_fir_f16: bad launch size");
-    hipLaunchKernelGGL(up2_fir_f16_kernel, dim3((unsigned)blocks, 1, n_img), dim3(256), 0, (hipStream_t)stream, a);
+    // the matrix-core FIR multiplies the fp16 tile by fy[ky] * fx[kx] as fp16 numbers: exact for setup_filter([1, 3, 3, 1]) with gain 4 ({1, 3, 9} / 16) and
+    // for any filter whose 16 tap products are fp16 numbers; others take the vector-ALU epilogue (fp32 taps)
+    bool taps_fp16 = true;
+    for (int ky = 0; ky < 4; ++ky)
+        for (int kx = 0; kx < 4; ++kx) {
+            const float p = a.fy[ky] * a.fx[kx];
+            taps_fp16 = taps_fp16 && (float)(_Float16)p == p && (p == 0.f || fabsf(p) >= 6.2e-5f);
+        }
+    static const bool force_valu = [] { const char* d = getenv("P3D_UP2_VALU_FIR"); return d && atoi(d) != 0; }();      // A/B switch of tests/gpu_probe_up2.py
+    if (taps_fp16 && !force_valu) hipLaunchKernelGGL(up2_fir_f16_kernel<true>, dim3((unsigned)blocks, 1, n_img), dim3(256), 0, (hipStream_t)stream, a);
+    else                          hipLaunchKernelGGL(up2_fir_f16_kernel<false>, dim3((unsigned)blocks, 1, n_img), dim3(256), 0, (hipStream_t)stream, a);
     count_launch(FAM_CONV);
     return check_launch("up2_fir_f16");
 }
