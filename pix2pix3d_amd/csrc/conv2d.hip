@@ -1111,11 +1111,16 @@ __global__ void __launch_bounds__(256) torgb_nhwc_kernel(const __half* __restric
     const float b = (bias && col < Co) ? bias[col] : 0.f;
     const __half* xi = x + (int64_t)n * HW * Ci;
     const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-    for (int p0 = wave_global * 32; p0 < HW; p0 += nwaves * 32) {
+    // A wave takes several 32-pixel tiles (the launch is sized to the chip: two waves per SIMD), and the NEXT tile's 16 loads are in flight while
+    // this one is multiplied and stored — with one tile per wave, as first written, a wave's life was the weight set-up above plus one exposed
+    // round trip to memory (68 us for 134 MB on the 256-channel 256^2 layer of the SR heads).
+    const int stride = nwaves * 32;
+    auto load_tile = [&](h8 (&fa)[KSTEPS], int p0) {
         const int p = min(p0 + col, HW - 1);                           // fragment row = pixel
-        h8 fa[KSTEPS];
 #pragma unroll
         for (int k = 0; k < KSTEPS; ++k) fa[k] = *(const h8*)(xi + (int64_t)p * Ci + k * 16 + kg * 8);
+    };
+    auto finish_tile = [&](const h8 (&fa)[KSTEPS], int p0) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -1142,6 +1147,18 @@ __global__ void __launch_bounds__(256) torgb_nhwc_kernel(const __half* __restric
                 }
             }
         }
+    };
+    h8 fa0[KSTEPS], fa1[KSTEPS];
+    int p0 = wave_global * 32;
+    if (p0 < HW) load_tile(fa0, p0);
+    while (p0 < HW) {
+        if (p0 + stride < HW) load_tile(fa1, p0 + stride);
+        finish_tile(fa0, p0);
+        p0 += stride;
+        if (p0 >= HW) break;
+        if (p0 + stride < HW) load_tile(fa0, p0 + stride);
+        finish_tile(fa1, p0);
+        p0 += stride;
     }
 }
 
@@ -1385,7 +1402,7 @@ extern "C" int p3d_torgb_nhwc_f16(const void* x, const float* weight, const floa
         return fail(P3D_ERR_UNSUPPORTED, "torgb_nhwc_f16: needs Ci in {64,128,256}, Co <= 32, H*W a multiple of 4 (got %d, %d, %d)", ci, co, hw);
     hipStream_t s = (hipStream_t)stream;
     int blocks = (hw / 32 + 3) / 4;
-    const int cap = kNumCU * 8 / (n_img > 0 ? n_img : 1);
+    const int cap = kNumCU * 2 / (n_img > 0 ? n_img : 1);            // 2 blocks x 4 waves per CU over all images: two waves per SIMD (two tiles of fragments each)
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
 #define P3D_RGB(K) case K * 16: hipLaunchKernelGGL(torgb_nhwc_kernel<K>, dim3(blocks, n_img), dim3(256), 0, s, (const __half*)x, weight, styles, bias, y_nchw, hw, co, clamp, accumulate); break;
