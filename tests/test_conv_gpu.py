@@ -259,10 +259,13 @@ def test_bf16x3_formulation_of_the_fp32_convolution(hip_lib, ci, co, res, transp
     (96, 96, 33, 20, 2, True, 'lrelu', None),          # three chunks (odd): both slab buffers end a loop
     (32, 32, 3, 5, 2, True, 'lrelu', None),            # image smaller than a tile
 ])
-def test_x2_layer_in_one_kernel(hip_lib, ci, co, h, w, n, noise, act, clamp):
+@pytest.mark.parametrize('taps', [[1, 3, 3, 1], [0.1, 0.45, 0.35, 0.1]], ids=['fir_on_mfma', 'fir_on_valu'])
+def test_x2_layer_in_one_kernel(hip_lib, ci, co, h, w, n, noise, act, clamp, taps):
     """csrc/up2_fir.hip: conv_transpose2d(stride 2) + 4x4 FIR (pad 1, gain 4) + noise + bias + act + clamp against the same chain in
     fp64 torch on the fp16-rounded operands (with the fp16 rounding of the transposed conv's output the reference has), and
-    against the two-kernel form.  Tolerance: one fp16 rounding of the result + one of the intermediate (2e-3 of the range)."""
+    against the two-kernel form.  Tolerance: one fp16 rounding of the result + one of the intermediate (2e-3 of the range).
+    Two filters: setup_filter([1, 3, 3, 1]) — tap products {1, 3, 9} / 16 are fp16 numbers, the FIR runs as banded-matrix MFMAs — and an
+    asymmetric one whose products are not, which takes the kernel's vector-ALU epilogue (fp32 taps)."""
     from pix2pix3d_amd import _lib
     from pix2pix3d_amd.torch_utils.ops import modconv, upfirdn2d
     torch.manual_seed(ci + co + h)
@@ -272,7 +275,7 @@ def test_x2_layer_in_one_kernel(hip_lib, ci, co, h, w, n, noise, act, clamp):
     bias = torch.randn(co, device='cuda')
     nz = torch.randn(2 * h, 2 * w, device='cuda') if noise else None
     ns = torch.tensor(0.3, device='cuda') if noise else None
-    f = upfirdn2d.setup_filter([1, 3, 3, 1], device=torch.device('cuda'))
+    f = upfirdn2d.setup_filter(taps, device=torch.device('cuda'))
     gain = float(np.sqrt(2)) if act == 'lrelu' else 1.0
     prev = modconv.fuse_up2
     try:
