@@ -222,6 +222,30 @@ def test_lowres_512_channel_layers_take_the_split_k_schedule(hip_lib, dtype, res
     assert rel_err(yt.double().cpu().numpy(), ytr.cpu().numpy()) < tol
 
 
+@pytest.mark.parametrize('ci,co,h,w,n', [(256, 128, 64, 64, 4), (64, 96, 70, 52, 4), (32, 256, 33, 40, 3), (128, 128, 128, 128, 1)])
+@pytest.mark.parametrize('split', [True, False], ids=['bf16x3', 'exact_fp32'])
+def test_transposed_conv_at_layer_sizes(hip_lib, ci, co, h, w, n, split):
+    """The fp32 stride-2 transposed convolution (four parity classes in one launch) at the sizes of the backbone's x2 layers, against
+    conv_transpose2d in fp64: ragged class grids (odd sizes: the classes differ by a row / column), a channel count that is not a
+    multiple of the tile, exact fp32 and bf16x3.  (Written for a halo-slab build of this form, which measured no faster than the generic
+    kernel and was not kept — profiles/round3_ac_*; the cases stay.)"""
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    torch.manual_seed(ci + co + h)
+    x = _nhwc(torch.randn(n, ci, h, w, device='cuda'))
+    weight = torch.randn(co, ci, 3, 3, device='cuda')
+    styles = torch.randn(n, ci, device='cuda') + 1
+    w32 = modconv.modulate_weights(weight, styles, dtype=torch.float32)
+    wm = modconv.modulate_weights(weight, styles, dtype=modconv.BF16X3) if split else w32
+    y = modconv.conv2d(x, wm, transposed=True, split=split)
+    assert y.shape == (n, co, 2 * h + 1, 2 * w + 1)
+    wq = w32.double().reshape(n, co, 3, 3, ci).permute(0, 1, 4, 2, 3).cpu()
+    xd = x.double().cpu()
+    ref = torch.stack([F.conv_transpose2d(xd[i:i + 1], wq[i].transpose(0, 1), stride=2)[0] for i in range(n)])
+    e = rel_err(y.double().cpu().numpy(), ref.numpy())
+    print((ci, co, h, w, n, split), e)
+    assert e < (1e-5 if split else 3e-6), e
+
+
 @pytest.mark.parametrize('ci,co,res,transposed', [(256, 256, 64, False), (128, 128, 128, False), (256, 128, 64, True), (64, 96, 70, False)])
 def test_bf16x3_formulation_of_the_fp32_convolution(hip_lib, ci, co, res, transposed):
     """P3D_F32_BF16X3: every fp32 product as three bf16 MFMAs of (hi, lo) splits with fp32 accumulation.  Bar: <= 1e-5
