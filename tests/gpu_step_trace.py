@@ -1,0 +1,29 @@
+"""One benchmark step, launch by launch: rocprofv3 --kernel-trace over a short `bench.py` run (hipGraph replays), then the kernels of the LAST
+step with their start offsets and durations.   python tests/gpu_step_trace.py [--no-graph]   -> gpurun_out/step_trace.txt"""
+import csv, glob, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out_dir = '/tmp/step_trace'
+cmd = ['rocprofv3', '--kernel-trace', '--output-format', 'csv', '-d', out_dir, '-o', 't', '--', sys.executable, os.path.join(ROOT, 'bench.py'),
+       '--no-cpu-baseline', '--no-train-step', '--no-exact-fp32', '--steps', '4', '--warmup', '2'] + sys.argv[1:]
+subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=400)
+rows = []
+for f in glob.glob(os.path.join(out_dir, '**', '*kernel_trace.csv'), recursive=True):
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
+rows.sort()
+marks = [i for i, r in enumerate(rows) if 'render_forward_kernel' in r[2]]
+# the timed graph replays come before the eager profiling pass of bench.py; take the step between the 3rd- and 2nd-last ray-marcher of the
+# FIRST half (graph replays) — simplest robust choice: the densest step = smallest wall time between consecutive ray-marcher launches
+best = min(range(len(marks) - 1), key=lambda k: rows[marks[k + 1]][0] - rows[marks[k]][0])
+lo, hi = marks[best], marks[best + 1]
+t0 = rows[lo][0]
+os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+with open(os.path.join(ROOT, 'gpurun_out', 'step_trace.txt'), 'w') as f:
+    f.write(f'# one step (ray-marcher to ray-marcher), {hi - lo} kernels, {(rows[hi][0] - t0) / 1e3:.1f} us wall; columns: start us, duration us, gap to previous end us, kernel\n')
+    prev_end = rows[lo][0]
+    for s, e, name in rows[lo:hi]:
+        name = name.replace('void ', '').replace('p3d::', '')
+        f.write(f'{(s - t0) / 1e3:9.1f} {(e - s) / 1e3:8.1f} {(s - prev_end) / 1e3:7.1f}  {name[:110]}\n')
+        prev_end = max(prev_end, e)
+print(open(os.path.join(ROOT, 'gpurun_out', 'step_trace.txt')).read())
