@@ -317,6 +317,17 @@ int p3d_conv2d_nhwc_scaled(const void* x, const void* w, void* y, int dtype, con
                            const float* noise_strength, const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co,
                            int64_t w_img_stride, int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, void* workspace,
                            int64_t workspace_bytes, p3d_stream_t stream);
+/* Activations that stay split between the bf16x3 layers of an inference pass (training/networks_stylegan2.py:436-459: conv0 -> conv1 -> ToRGB /
+ * the next block, each a modulated_conv2d :26-105 whose fp32 products this library forms as three bf16 MFMAs).  x_split != 0: x is NOT fp32 but,
+ * per pixel and 32 channels, [32 x bf16 hi | 32 x bf16 lo] in the same 128 bytes (hi = bf16(v), lo = bf16(v - hi): exactly what the kernels
+ * otherwise compute in registers for every tap) — as written by a call with y_split != 0 or by p3d_fir4_bias_act_nhwc_split.  Results are
+ * bit-identical to the plain-tensor calls.  dtype is implied (P3D_F32_BF16X3: w from p3d_modulate_weights in that layout).  x_split is taken by
+ * every route (3x3, 1x1, transposed, stride 2); y_split only by the 3x3 'same' layers the halo-slab kernel runs (Co % 32 == 0, an image of at
+ * least 8 x 16 whose own grid fills the chip): otherwise P3D_ERR_UNSUPPORTED and nothing is launched — ask again with y_split = 0.           */
+int p3d_conv2d_nhwc_bf16x3_io(const void* x, const void* w, void* y, const float* bias, const float* noise, const float* noise_strength,
+                              const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
+                              int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, int32_t x_split, int32_t y_split,
+                              void* workspace, int64_t workspace_bytes, p3d_stream_t stream);
 /* d[n][o] = rsqrt(sum_i styles[n][i]^2 * w2[o][i] + 1e-8) with w2[o][i] = sum over the taps of weight[o][i][.]^2 (networks_stylegan2.py:57-63) */
 int p3d_demod_coefs(const float* styles, const float* w2, float* d, int32_t n_rows, int32_t ci, int32_t co, p3d_stream_t stream);
 
@@ -374,6 +385,12 @@ int p3d_fir4_bias_act_nhwc(const void* x, const float* f, void* y, int dtype, in
                            int32_t pad_x0, int32_t pad_y0, int32_t out_h, int32_t out_w, int32_t flip, float gain,
                            const float* bias, const float* noise, const float* noise_strength, int32_t act, float alpha, float act_gain,
                            float clamp, p3d_stream_t stream);
+/* The same pass on fp32 input with the result written in the split layout of p3d_conv2d_nhwc_bf16x3_io (C % 32 == 0): the x2 layer's output goes
+ * to the block's next bf16x3 convolution without an fp32 copy of it ever existing.                                                        */
+int p3d_fir4_bias_act_nhwc_split(const void* x, const float* f, void* y, int32_t n_img, int32_t c, int32_t in_h, int32_t in_w,
+                                 int32_t pad_x0, int32_t pad_y0, int32_t out_h, int32_t out_w, int32_t flip, float gain,
+                                 const float* bias, const float* noise, const float* noise_strength, int32_t act, float alpha, float act_gain,
+                                 float clamp, p3d_stream_t stream);
 
 /* ---- low-resolution layers and style affines: launch-count diet (csrc/small_ops.hip) -----------
  * p3d_fc_forward: FullyConnectedLayer.forward (training/networks_stylegan2.py:113-127) in one launch:

@@ -92,6 +92,8 @@ struct ConvArgs {
     float rgb_clamp;       // on (sum + bias) before the accumulation; < 0: off
     const float* oscale;   // [N][Co] or null (generic kernel, fp32 tensors): the accumulator is multiplied by oscale[image][channel] before the
                            // rest of the epilogue — the demodulation coefficient of the SHARED-weight form of the modulated convolution
+    int y_split;           // != 0 (conv3x3_halo_kernel<float, true, .>): y leaves in the bf16x3 K-row layout — per 32 channels [32 x bf16 hi | 32 x bf16 lo],
+                           // the same 128 bytes as 32 floats — which the next bf16x3 layer reads without splitting anything (XS below)
 };
 
 // 16-B slot of (row, chunk).  Two 128-byte tile rows share one 256-byte LDS bank row, so the XOR key is (row >> 1) & 7:
@@ -102,10 +104,15 @@ template <class T> struct ConvTraits;
 template <> struct ConvTraits<__half> { static constexpr int BK = 64; };      // elements per 128-byte K row
 template <> struct ConvTraits<float>  { static constexpr int BK = 32; };
 
-template <class T, bool BF3 = false>
+// XS (bf16x3 only): the activations arrive ALREADY split — K rows of [32 x bf16 hi | 32 x bf16 lo] written by the producing layer's epilogue
+// (ConvArgs::y_split, fir4_cl_fused_kernel) — so A fragments are two plain 16-byte LDS reads like the weights': the in-register split (8
+// conversions + 8 subtractions + the conversion -> MFMA guard per fragment, repeated by every tap and every wave that reads the pixel) cost
+// the bf16x3 kernels 13-21 % (profiles/round3_ae_*).  Staging is unchanged: the rows have the same bytes either way.
+template <class T, bool BF3 = false, bool XS = false>
 __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
 {
     static_assert(!BF3 || sizeof(T) == 4, "bf16x3 is a formulation of the fp32 convolution");
+    static_assert(!XS || BF3, "pre-split activations are the bf16x3 kernels' input format");
     constexpr int BK = ConvTraits<T>::BK;
     constexpr int EPC = 16 / sizeof(T);                                        // elements per 16-byte chunk
     __shared__ __attribute__((aligned(16))) f32x4 lds[2][2][BM * 8];          // [buffer][A|B][row*8 + chunk], 16-byte slots
@@ -216,6 +223,10 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const int ra = wm * 64 + i * 32 + frow, rb = wn * 64 + i * 32 + frow;
+                        if constexpr (XS) {
+                            ah[i] = __builtin_bit_cast(bf8, lds[buf][0][swz(ra, 2 * m + fk)]);
+                            al[i] = __builtin_bit_cast(bf8, lds[buf][0][swz(ra, 4 + 2 * m + fk)]);
+                        } else
                         split_bf16x8(lds[buf][0][swz(ra, 4 * m + 2 * fk)], lds[buf][0][swz(ra, 4 * m + 2 * fk + 1)], ah[i], al[i]);
                         bh[i] = __builtin_bit_cast(bf8, lds[buf][1][swz(rb, 2 * m + fk)]);          // weight row = [32 hi | 32 lo] bf16
                         bl[i] = __builtin_bit_cast(bf8, lds[buf][1][swz(rb, 4 + 2 * m + fk)]);
@@ -426,10 +437,11 @@ constexpr int PH = 8, PW = 16;                      // pixel patch of a block (P
 constexpr int SLAB_W = PW + 2, SLAB_ROWS = (PH + 2) * (PW + 2);          // 18, 180 slab pixels
 constexpr int SLAB_SLOTS = ((SLAB_ROWS + 7) / 8) * 8 * 8;                // padded to whole 8-row DMA groups, 16-byte slots
 
-template <class T, bool BF3 = false>
+template <class T, bool BF3 = false, bool XS = false>
 __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(ConvArgs a)
 {
     static_assert(!BF3 || sizeof(T) == 4, "bf16x3 is a formulation of the fp32 convolution");
+    static_assert(!XS || BF3, "pre-split activations are the bf16x3 kernels' input format");
     constexpr int BK = ConvTraits<T>::BK;
     constexpr int EPC = 16 / sizeof(T);
     __shared__ __attribute__((aligned(16))) f32x4 slab[2][SLAB_SLOTS];       // [buffer][slab pixel * 8 + chunk]
@@ -509,6 +521,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(ConvArgs a)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int sr = arow[i] + toff, key = (sr >> 1) & 7, rb = wn * 64 + i * 32 + frow;
+                    if constexpr (XS) {
+                        ah[i] = __builtin_bit_cast(bf8, slab[sb][sr * 8 + ((2 * m + fk) ^ key)]);
+                        al[i] = __builtin_bit_cast(bf8, slab[sb][sr * 8 + ((4 + 2 * m + fk) ^ key)]);
+                    } else
                     split_bf16x8(slab[sb][sr * 8 + ((4 * m + 2 * fk) ^ key)], slab[sb][sr * 8 + ((4 * m + 2 * fk + 1) ^ key)], ah[i], al[i]);
                     bh[i] = __builtin_bit_cast(bf8, wt[wb][swz(rb, 2 * m + fk)]);
                     bl[i] = __builtin_bit_cast(bf8, wt[wb][swz(rb, 4 + 2 * m + fk)]);
@@ -566,6 +582,15 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(ConvArgs a)
                 if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
                 v *= a.gain;
                 if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
+                if constexpr (BF3) {
+                    if (a.y_split) {                                            // this lane's channel inside its 32-channel K row: hi at [frow], lo at [32 + frow]
+                        __bf16* row = (__bf16*)((float*)a.y + (((int64_t)n * a.H + oy) * a.W + ox) * a.Co + (co - frow));
+                        const __bf16 hv = (__bf16)v;
+                        row[frow] = hv;
+                        row[32 + frow] = (__bf16)(v - (float)hv);
+                        continue;
+                    }
+                }
                 st((T*)a.y + (((int64_t)n * a.H + oy) * a.W + ox) * a.Co + co, v);
             }
     }
@@ -1212,7 +1237,7 @@ static void conv_launch_shape(const ConvArgs& a, int* M, int* z, int* nsteps)
     *nsteps = taps;
 }
 
-static int launch_conv(ConvArgs& a, int dtype, hipStream_t s, void* workspace, int64_t workspace_bytes, int64_t* query)
+static int launch_conv(ConvArgs& a, int dtype, hipStream_t s, void* workspace, int64_t workspace_bytes, int64_t* query, bool x_split = false)
 {
     int M, z, taps;
     conv_launch_shape(a, &M, &z, &taps);
@@ -1226,6 +1251,7 @@ static int launch_conv(ConvArgs& a, int dtype, hipStream_t s, void* workspace, i
     if (want > 1 && workspace && workspace_bytes >= need && (((uintptr_t)workspace) & 15u) == 0) { a.ksplit = want; a.partial = (float*)workspace; }
     dim3 grid(gx, gy, z * a.ksplit);
     if (dtype == P3D_F16)             hipLaunchKernelGGL(conv2d_nhwc_kernel<__half>, grid, dim3(256), 0, s, a);
+    else if (dtype == P3D_F32_BF16X3 && x_split) hipLaunchKernelGGL((conv2d_nhwc_kernel<float, true, true>), grid, dim3(256), 0, s, a);
     else if (dtype == P3D_F32_BF16X3) hipLaunchKernelGGL((conv2d_nhwc_kernel<float, true>), grid, dim3(256), 0, s, a);
     else                              hipLaunchKernelGGL(conv2d_nhwc_kernel<float>, grid, dim3(256), 0, s, a);
     count_launch(FAM_CONV);
@@ -1280,6 +1306,15 @@ extern "C" int p3d_conv3x3_torgb_f16(const void* x, const void* w, void* y, cons
     return check_launch("conv3x3_torgb_f16");
 }
 
+extern "C" int p3d_conv2d_nhwc_bf16x3_io(const void* x, const void* w, void* y, const float* bias, const float* noise, const float* noise_strength,
+                                         const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
+                                         int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, int32_t x_split, int32_t y_split,
+                                         void* workspace, int64_t workspace_bytes, p3d_stream_t stream)
+{
+    return p3d::conv2d_nhwc_run_io(x, w, y, P3D_F32_BF16X3, bias, noise, noise_strength, zeros128, n_img, h, wdt, ci, co, w_img_stride, kernel_size, resample, act, gain,
+                                   clamp, 0, 0, workspace, workspace_bytes, nullptr, nullptr, x_split, y_split, stream);
+}
+
 extern "C" int p3d_conv2d_nhwc_scaled(const void* x, const void* w, void* y, int dtype, const float* out_scale, const float* bias, const float* noise,
                                       const float* noise_strength, const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co,
                                       int64_t w_img_stride, int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, void* workspace,
@@ -1305,6 +1340,21 @@ int p3d::conv2d_nhwc_run(const void* x, const void* w, void* y, int dtype, const
                          int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, int32_t out_h, int32_t out_w,
                          void* workspace, int64_t workspace_bytes, int64_t* query, const float* out_scale, p3d_stream_t stream)
 {
+    return conv2d_nhwc_run_io(x, w, y, dtype, bias, noise, noise_strength, zeros128, n_img, h, wdt, ci, co, w_img_stride, kernel_size, resample, act, gain, clamp,
+                              out_h, out_w, workspace, workspace_bytes, query, out_scale, 0, 0, stream);
+}
+
+// x_split / y_split (dtype P3D_F32_BF16X3 only): the activations are / the result is to be in the bf16x3 K-row layout — per pixel and 32 channels
+// [32 x bf16 hi | 32 x bf16 lo] in the 128 bytes of 32 floats.  Every route takes x_split; y_split needs the halo-slab 3x3 kernel (anything else:
+// P3D_ERR_UNSUPPORTED before a launch, the caller asks again for a plain result).
+int p3d::conv2d_nhwc_run_io(const void* x, const void* w, void* y, int dtype, const float* bias, const float* noise, const float* noise_strength,
+                            const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
+                            int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, int32_t out_h, int32_t out_w,
+                            void* workspace, int64_t workspace_bytes, int64_t* query, const float* out_scale, int32_t x_split, int32_t y_split,
+                            p3d_stream_t stream)
+{
+    P3D_REQUIRE(!(x_split || y_split) || dtype == P3D_F32_BF16X3, "conv2d_nhwc: pre-split activations are a bf16x3 format");
+    P3D_REQUIRE(!y_split || co % 32 == 0, "conv2d_nhwc: a split result needs whole 32-channel rows");
     // query != null: dry run — *query = bytes of split-K scratch this call would like (0: none); nothing is launched
     const bool dry = query != nullptr;
     if (dry) { *query = 0; x = w = zeros128 = (const void*)(uintptr_t)16; y = (void*)(uintptr_t)16; }
@@ -1330,8 +1380,9 @@ int p3d::conv2d_nhwc_run(const void* x, const void* w, void* y, int dtype, const
         a.OH = (h - kernel_size) / 2 + 1; a.OW = (wdt - kernel_size) / 2 + 1; a.osy = a.osx = 1; a.isy = a.isx = 2; a.ncls = 1;
         a.cls[0].SH = a.OH; a.cls[0].SW = a.OW; a.cls[0].ooy = a.cls[0].oox = 0; a.cls[0].ntaps = a.KT;
         for (int t = 0; t < a.KT; ++t) a.cls[0].taps[t] = ConvTap{t / kernel_size, t % kernel_size, t};
+        if (y_split) return fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc: a split result is produced by the 3x3 halo kernel only");
         a.fold = fold_batch(a, dtype);
-        return launch_conv(a, dtype, s, workspace, workspace_bytes, query);
+        return launch_conv(a, dtype, s, workspace, workspace_bytes, query, x_split != 0);
     }
     if (!transposed_stride2) {                                       // correlation, "same" padding: input offset = tap - k/2
         a.OH = h; a.OW = wdt; a.osy = a.osx = 1; a.ncls = 1;
@@ -1358,14 +1409,17 @@ int p3d::conv2d_nhwc_run(const void* x, const void* w, void* y, int dtype, const
         if (halo_ok && !prefer_split) {                                   // halo-reuse kernel for the plain 3x3 layers
             if (dry) return P3D_OK;
             dim3 grid(((h + PH - 1) / PH) * ((wdt + PW - 1) / PW), (co + BN - 1) / BN, n_img);
+            a.y_split = y_split;
             if (dtype == P3D_F16)             hipLaunchKernelGGL(conv3x3_halo_kernel<__half>, grid, dim3(256), 0, s, a);
+            else if (dtype == P3D_F32_BF16X3 && x_split) hipLaunchKernelGGL((conv3x3_halo_kernel<float, true, true>), grid, dim3(256), 0, s, a);
             else if (dtype == P3D_F32_BF16X3) hipLaunchKernelGGL((conv3x3_halo_kernel<float, true>), grid, dim3(256), 0, s, a);
             else                              hipLaunchKernelGGL(conv3x3_halo_kernel<float>, grid, dim3(256), 0, s, a);
             count_launch(FAM_CONV);
             return check_launch("conv3x3_halo");
         }
+        if (y_split) return fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc: a split result is produced by the 3x3 halo kernel only");
         a.fold = fold_batch(a, dtype);
-        return launch_conv(a, dtype, s, workspace, workspace_bytes, query);
+        return launch_conv(a, dtype, s, workspace, workspace_bytes, query, x_split != 0);
     }
     // conv_transpose2d(stride 2, no padding): out[(2i+py), (2j+px)] = sum_{ky = py (mod 2), kx = px (mod 2)} x[i - (ky-py)/2, j - (kx-px)/2] w[ky, kx]
     // -> four dense sub-problems (4 / 2 / 2 / 1 taps), all in ONE launch so the grid fills the chip
@@ -1391,7 +1445,8 @@ int p3d::conv2d_nhwc_run(const void* x, const void* w, void* y, int dtype, const
             return check_launch("convT_h2_f16");
         }
     }
-    return launch_conv(a, dtype, s, workspace, workspace_bytes, query);
+    if (y_split) return fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc: a split result is produced by the 3x3 halo kernel only");
+    return launch_conv(a, dtype, s, workspace, workspace_bytes, query, x_split != 0);
 }
 
 extern "C" int p3d_torgb_nhwc_f16(const void* x, const float* weight, const float* styles, const float* bias, float* y_nchw,

@@ -45,6 +45,11 @@ int conv2d_nhwc_run(const void* x, const void* w, void* y, int dtype, const floa
                     const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
                     int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, int32_t out_h, int32_t out_w,
                     void* workspace, int64_t workspace_bytes, int64_t* query, const float* out_scale, p3d_stream_t stream);
+int conv2d_nhwc_run_io(const void* x, const void* w, void* y, int dtype, const float* bias, const float* noise, const float* noise_strength,
+                       const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
+                       int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, int32_t out_h, int32_t out_w,
+                       void* workspace, int64_t workspace_bytes, int64_t* query, const float* out_scale, int32_t x_split, int32_t y_split,
+                       p3d_stream_t stream);
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -236,7 +236,8 @@ __global__ void __launch_bounds__(256) upfirdn2d_cl_kernel(UpfirArgs a)
 // down 8 rows for one 16-byte channel chunk (44 LDS reads for 8 outputs instead of 128), then applies
 // v = fir + noise*strength + bias -> lrelu -> * act_gain -> clamp and stores — the activation never makes a second trip
 // through HBM.
-struct FirEpilogue { const float* bias; const float* noise; const float* noise_strength; int act; float alpha, act_gain, clamp; };
+struct FirEpilogue { const float* bias; const float* noise; const float* noise_strength; int act; float alpha, act_gain, clamp;
+                     int y_split; };   // fp32 only: the result leaves as bf16x3 K rows — per 32 channels [32 x bf16 hi | 32 x bf16 lo] — for the next bf16x3 convolution (csrc/conv2d.hip, XS)
 
 template <class T>
 __global__ void __launch_bounds__(256) fir4_cl_fused_kernel(UpfirArgs a, FirEpilogue ep)
@@ -334,6 +335,22 @@ __global__ void __launch_bounds__(256) fir4_cl_fused_kernel(UpfirArgs a, FirEpil
             v *= ep.act_gain;
             if (ep.clamp >= 0.f) v = fminf(fmaxf(v, -ep.clamp), ep.clamp);
             st(&outv.v[k], (typename Acc<T>::type)v);
+        }
+        if constexpr (sizeof(T) == 4) {
+            if (ep.y_split) {                      // this thread's four channels: hi at bf16 slots [4 chunk ..], lo at [32 + 4 chunk ..] of the 32-channel row
+                typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+                bf4 hi, lo;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = (float)ld(&outv.v[k]);
+                    const __bf16 h = (__bf16)v;
+                    hi[k] = h; lo[k] = (__bf16)(v - (float)h);
+                }
+                __bf16* row = (__bf16*)((T*)a.y + (int64_t)n * a.osn + (int64_t)oy * a.osy + (int64_t)ox * a.osx + cblk * CB);
+                *(bf4*)(row + chunk * 4) = hi;
+                *(bf4*)(row + 32 + chunk * 4) = lo;
+                continue;
+            }
         }
         *(P*)((T*)a.y + (int64_t)n * a.osn + (int64_t)oy * a.osy + (int64_t)ox * a.osx + c0) = outv;
     }
@@ -457,10 +474,31 @@ extern "C" int p3d_upfirdn2d_acc(const void* x, const float* f, void* y, int dty
     return upfirdn2d_run(x, f, y, dtype, in_size, in_stride, f_size, f_stride, out_size, out_stride, up_x, up_y, down_x, down_y, pad_x0, pad_y0, flip, gain, 1, stream);
 }
 
+static int fir4_bias_act_run(const void* x, const float* f, void* y, int dtype, int32_t n_img, int32_t c, int32_t in_h, int32_t in_w,
+                             int32_t pad_x0, int32_t pad_y0, int32_t out_h, int32_t out_w, int32_t flip, float gain,
+                             const float* bias, const float* noise, const float* noise_strength, int32_t act, float alpha, float act_gain,
+                             float clamp, int32_t y_split, p3d_stream_t stream);
+
 extern "C" int p3d_fir4_bias_act_nhwc(const void* x, const float* f, void* y, int dtype, int32_t n_img, int32_t c, int32_t in_h, int32_t in_w,
                                       int32_t pad_x0, int32_t pad_y0, int32_t out_h, int32_t out_w, int32_t flip, float gain,
                                       const float* bias, const float* noise, const float* noise_strength, int32_t act, float alpha, float act_gain,
                                       float clamp, p3d_stream_t stream)
+{
+    return fir4_bias_act_run(x, f, y, dtype, n_img, c, in_h, in_w, pad_x0, pad_y0, out_h, out_w, flip, gain, bias, noise, noise_strength, act, alpha, act_gain, clamp, 0, stream);
+}
+
+extern "C" int p3d_fir4_bias_act_nhwc_split(const void* x, const float* f, void* y, int32_t n_img, int32_t c, int32_t in_h, int32_t in_w,
+                                            int32_t pad_x0, int32_t pad_y0, int32_t out_h, int32_t out_w, int32_t flip, float gain,
+                                            const float* bias, const float* noise, const float* noise_strength, int32_t act, float alpha, float act_gain,
+                                            float clamp, p3d_stream_t stream)
+{
+    return fir4_bias_act_run(x, f, y, P3D_F32, n_img, c, in_h, in_w, pad_x0, pad_y0, out_h, out_w, flip, gain, bias, noise, noise_strength, act, alpha, act_gain, clamp, 1, stream);
+}
+
+static int fir4_bias_act_run(const void* x, const float* f, void* y, int dtype, int32_t n_img, int32_t c, int32_t in_h, int32_t in_w,
+                             int32_t pad_x0, int32_t pad_y0, int32_t out_h, int32_t out_w, int32_t flip, float gain,
+                             const float* bias, const float* noise, const float* noise_strength, int32_t act, float alpha, float act_gain,
+                             float clamp, int32_t y_split, p3d_stream_t stream)
 {
     using namespace p3d;
     P3D_REQUIRE(x && f && y, "fir4_bias_act_nhwc: null pointer");
@@ -475,7 +513,7 @@ extern "C" int p3d_fir4_bias_act_nhwc(const void* x, const float* f, void* y, in
     a.osc = 1; a.osx = c; a.osy = (int64_t)out_w * c; a.osn = (int64_t)out_h * out_w * c;
     a.fw = a.fh = 4; a.fsx = 1; a.fsy = 4; a.out_w = out_w; a.out_h = out_h;
     a.up_x = a.up_y = a.down_x = a.down_y = 1; a.pad_x0 = pad_x0; a.pad_y0 = pad_y0; a.flip = flip ? 1 : 0; a.gain = gain;
-    FirEpilogue ep{bias, noise, noise_strength, act, alpha, act_gain, clamp};
+    FirEpilogue ep{bias, noise, noise_strength, act, alpha, act_gain, clamp, y_split};
     const int64_t blocks = (int64_t)n_img * ((out_h + 15) / 16) * ((out_w + 15) / 16) * (c / cb);
     P3D_REQUIRE(blocks > 0 && blocks < (1ll << 31), "fir4_bias_act_nhwc: bad launch size");
     hipStream_t s = (hipStream_t)stream;

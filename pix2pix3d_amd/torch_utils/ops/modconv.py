@@ -70,9 +70,12 @@ def _zeros_page(device):
         z = _zero_pages[device] = torch.zeros(256, dtype=torch.float32, device=device)
     return z
 _lib.register('p3d_torgb_nhwc_f16', ctypes.c_int, [_vp] * 5 + [_i32] * 4 + [_f32, _i32, _vp])
+_lib.register('p3d_conv2d_nhwc_bf16x3_io', ctypes.c_int, [_vp] * 7 + [_i32] * 5 + [ctypes.c_int64, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _vp, ctypes.c_int64, _vp])
+_lib.register('p3d_fir4_bias_act_nhwc_split', ctypes.c_int, [_vp] * 3 + [_i32] * 9 + [_f32, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _vp])
 
 
 def _is_nhwc(x, dtypes=(torch.float16, torch.float32)):
+    x = _raw(x)
     return x.is_cuda and x.dtype in dtypes and x.ndim == 4 and x.is_contiguous(memory_format=torch.channels_last)
 
 
@@ -81,10 +84,11 @@ def _is_nhwc_f16(x):
 
 
 def _no_grad_needed(*tensors):
-    return not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors))
+    return not (torch.is_grad_enabled() and any(t is not None and _raw(t).requires_grad for t in tensors))
 
 
 def _dense_dev(x):
+    x = _raw(x)
     return x.is_cuda and x.dtype in (torch.float16, torch.float32) and x.ndim == 4 and (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last))
 
 
@@ -123,6 +127,52 @@ fuse_up2_f32_min_res = int(os.environ.get('P3D_FUSE_UP2_F32_MIN_RES', 1 << 30)) 
 fuse_up2 = os.environ.get('P3D_FUSE_UP2', '1') != '0'       # fp16 x2 layers: transposed conv + FIR + epilogue in one kernel (csrc/up2_fir.hip); 0 = the two-kernel form
 split_bf16 = os.environ.get('P3D_BF16X3', '1') != '0'      # use it for the fp32 layers that are bound by the fp32 matrix rate
 split_bf16_min_pixels = int(os.environ.get('P3D_BF16X3_MIN_PIXELS', 16))       # every fp32 3x3 layer (measured: 4096 -> 462, 1024 -> 472, 256 -> 474, 16 -> 476 img/s)
+split_activations = os.environ.get('P3D_SPLIT_ACTS', '1') != '0'               # bf16x3 inference: activations stay split between layers (SplitActs)
+
+
+class SplitActs:
+    """fp32 activations [N, C, H, W] of a bf16x3 inference pass, held channels-last as the K rows the matrix cores consume: per pixel and 32 channels
+    [32 x bf16 hi | 32 x bf16 lo] in the 128 bytes of 32 floats (hi = bf16(v), lo = bf16(v - hi)).  Written by the producing layer's epilogue
+    (p3d_conv2d_nhwc_bf16x3_io with y_split, p3d_fir4_bias_act_nhwc_split), read by the next layer's kernel without the per-tap split in registers
+    (13-21 % of those kernels, profiles/round3_ae_*).  Deliberately NOT a tensor: anything that is not one of the consuming kernels has to call
+    ``dense()`` = hi + lo, within 2^-17 of the value; a bf16x3 consumer of that works with a (hi, lo) pair that stands for the same number."""
+    __slots__ = ('t',)
+
+    def __init__(self, t):
+        assert t.dtype == torch.float32 and t.ndim == 4 and t.shape[1] % 32 == 0 and t.is_contiguous(memory_format=torch.channels_last)
+        self.t = t                                         # storage; its float VALUES are meaningless
+
+    shape = property(lambda self: self.t.shape)
+    ndim = property(lambda self: 4)
+    dtype = property(lambda self: torch.float32)
+    device = property(lambda self: self.t.device)
+    is_cuda = property(lambda self: self.t.is_cuda)
+    requires_grad = False
+
+    def is_contiguous(self, memory_format=torch.contiguous_format):
+        return memory_format == torch.channels_last
+
+    def dense(self):
+        n, c, h, w = self.t.shape
+        rows = self.t.permute(0, 2, 3, 1).reshape(n, h, w, c // 32, 32).view(torch.bfloat16).reshape(n, h, w, c // 32, 2, 32).float()
+        v = (rows[..., 0, :] + rows[..., 1, :]).reshape(n, h, w, c)
+        return v.permute(0, 3, 1, 2)                       # [N, C, H, W] with channels-last strides
+
+
+def _raw(x):
+    return x.t if isinstance(x, SplitActs) else x
+
+
+def accepts_split_input(n, ci, in_pixels, up):
+    """Will synthesis_layer / torgb run a layer with this input (per-image pixels, batch) on a kernel that reads SplitActs?  (The per-image bf16x3
+    routes do; the GEMM route of tiny images, the shared-weight form — it scales x first — and the one-kernel fp32 x2 layer do not.)"""
+    if not (enabled and split_bf16 and split_activations) or ci % 32 != 0 or in_pixels < split_bf16_min_pixels:
+        return False
+    if in_pixels <= (gemm_max_pixels if up == 1 else gemm_max_pixels_up):
+        return False
+    if shared_weight_max_pixels > 0 and 1 < n <= 16 and in_pixels <= shared_weight_max_pixels:
+        return False
+    return not (up == 2 and fuse_up2 and fuse_up2_f32_min_res <= 1 << 20)
 
 
 def use_split_bf16(x, ci):
@@ -203,10 +253,15 @@ def _pad_channels(x, wmod, transposed=False):
     return xp, wp
 
 
-def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None, act=0, gain=1.0, clamp=-1.0, down=1, split=False, out_scale=None):
+def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None, act=0, gain=1.0, clamp=-1.0, down=1, split=False, out_scale=None, out_split=False):
     """x NHWC [N,Ci,H,W] (channels_last strides), wmod [N or 1][Co][k*k][Ci] of the same dtype -> NHWC, same dtype.
     k*k = 9: 3x3 "same" correlation, or (transposed) the stride-2 transposed conv [N,Co,2H+1,2W+1], or (down=2) the valid
-    stride-2 correlation [N,Co,(H-3)//2+1,(W-3)//2+1]; k*k = 1: 1x1."""
+    stride-2 correlation [N,Co,(H-3)//2+1,(W-3)//2+1]; k*k = 1: 1x1.
+    bf16x3 (``split``): x may be a SplitActs; ``out_split`` asks for one back (granted by the 3x3 halo-slab kernel; otherwise a tensor)."""
+    x_split = isinstance(x, SplitActs)
+    if x_split or out_split:
+        assert split and out_scale is None
+        return _conv2d_split_io(x, wmod, transposed, bias, noise, noise_strength, act, gain, clamp, down, out_split)
     assert _is_nhwc(x) and wmod.dtype == x.dtype and wmod.is_contiguous() and wmod.shape[2] in (1, 9)
     assert down in (1, 2) and not (transposed and down == 2)
     x, wmod = _pad_channels(x, wmod, transposed)
@@ -239,6 +294,39 @@ def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None
     if log is not None:                                  # bench.py: FLOPs of the launches it is timing (2*Ci*Co*k*k per output / input pixel)
         log.append(('bf16x3' if split else str(x.dtype), 2.0 * n * ci * co * k * k * (oh * ow if down == 2 else h * w)))
     return y
+
+
+def _conv2d_split_io(x, wmod, transposed, bias, noise, noise_strength, act, gain, clamp, down, out_split):
+    """conv2d's bf16x3 form with the activations split on one or both sides (p3d_conv2d_nhwc_bf16x3_io)."""
+    x_split = isinstance(x, SplitActs)
+    xt = _raw(x)
+    assert _is_nhwc(xt, (torch.float32,)) and wmod.dtype == torch.float32 and wmod.is_contiguous() and wmod.shape[2] in (1, 9) and xt.shape[1] % 32 == 0
+    assert down in (1, 2) and not (transposed and down == 2)
+    n, ci, h, w = xt.shape
+    co, k = wmod.shape[1], (3 if wmod.shape[2] == 9 else 1)
+    oh, ow = (2 * h + 1, 2 * w + 1) if transposed else (((h - k) // 2 + 1, (w - k) // 2 + 1) if down == 2 else (h, w))
+    y = torch.empty([n, co, oh, ow], dtype=torch.float32, device=xt.device, memory_format=torch.channels_last)
+    assert wmod.shape[0] in (1, n) and wmod.shape[3] == ci
+    stride = 0 if wmod.shape[0] == 1 else wmod.shape[1] * wmod.shape[2] * wmod.shape[3]
+    b32 = None if bias is None else bias.detach().float().contiguous()
+    nz = None if noise is None else noise.detach().float().contiguous()
+    ns = None if noise is None else noise_strength.detach().float().reshape(1).contiguous()
+    mode = 1 if transposed else (2 if down == 2 else 0)
+    nbytes = int(_lib.lib().p3d_conv2d_nhwc_workspace(DTYPE_F32_BF16X3, n, h, w, ci, co, stride, k, mode))
+    work = torch.empty([nbytes // 4], dtype=torch.float32, device=xt.device) if nbytes > 0 else None
+    want = bool(out_split) and co % 32 == 0 and k == 3 and mode == 0
+    with _lib.kernel_timer('conv_bf16x3', xt):
+        for y_split in ((1, 0) if want else (0,)):
+            code = _lib.lib().p3d_conv2d_nhwc_bf16x3_io(_lib.ptr(xt), _lib.ptr(wmod), _lib.ptr(y), _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns), _lib.ptr(_zeros_page(xt.device)),
+                                                        n, h, w, ci, co, stride, k, mode, int(act), float(gain), float(clamp), int(x_split), y_split,
+                                                        _lib.ptr(work), nbytes, _lib.stream_of(xt))
+            if code != _lib.P3D_ERR_UNSUPPORTED or not y_split:
+                break
+    _lib.check(code, 'conv2d_nhwc_bf16x3_io')
+    log = _lib.kernel_events.get('conv_flops')
+    if log is not None:
+        log.append(('bf16x3', 2.0 * n * ci * co * k * k * (oh * ow if down == 2 else h * w)))
+    return SplitActs(y) if y_split else y
 
 
 conv3x3 = conv2d
@@ -456,11 +544,16 @@ def premodulate(weight, styles, up, in_pixels, dtype):
     return modulate_weights(weight, styles, demodulate=True, dtype=dtype), ('mfma', up, dtype)
 
 
-def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=None, noise_strength=None, act='lrelu', act_gain=1.0, clamp=None, pre=None, rgb=None):
+def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=None, noise_strength=None, act='lrelu', act_gain=1.0, clamp=None, pre=None, rgb=None,
+                    out_split=False):
     """Whole SynthesisLayer body after the style affine: modulated 3x3 conv (x2 up when ``up == 2``) + noise + bias + act.
-    ``pre`` = (modulated weights, route tag) from ``premodulate`` — used when the tag matches the route taken here."""
+    ``pre`` = (modulated weights, route tag) from ``premodulate`` — used when the tag matches the route taken here.
+    x may be a SplitActs (bf16x3 inference); ``out_split`` asks for the result as one (granted where the producing kernel can)."""
     small = is_small(x, up)
     split = (not small) and use_split_bf16(x, weight.shape[1])
+    if isinstance(x, SplitActs) and not (split and accepts_split_input(x.shape[0], x.shape[1], x.shape[2] * x.shape[3], up)):
+        x = x.dense()
+    out_split = bool(out_split) and split and split_activations and act in ('linear', 'lrelu')
     wtag = BF16X3 if split else x.dtype
     wpre = pre[0] if pre is not None and pre[1] == ('gemm' if small else 'mfma', up, wtag) else None
     if small:
@@ -484,7 +577,7 @@ def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=No
             return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
         y = conv2d(xs, wsh, transposed=True, split=True, out_scale=d)
         if act_idx is not None and tuple(resample_filter.shape) == (4, 4) and y.shape[1] % 32 == 0:
-            return fir4_bias_act(y, resample_filter, bias, noise_const, noise_strength, act, act_gain, clampv)
+            return fir4_bias_act(y, resample_filter, bias, noise_const, noise_strength, act, act_gain, clampv, out_split=out_split)
         y = upfirdn2d.upfirdn2d(y, resample_filter, padding=[1, 1, 1, 1], gain=4)
         if noise_const is not None:
             y = y.add_((noise_const * noise_strength).to(y.dtype))
@@ -495,7 +588,7 @@ def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=No
         rgb_wmod = modulate_weights(rgb_w, rgb_s, demodulate=False, dtype=torch.float32)
         return conv3x3_torgb(x, wmod, bias, act_idx, act_gain, clampv, rgb_wmod, rgb_b, rgb_c, img)
     if up == 1 and act_idx is not None:
-        return conv2d(x, wmod, bias=bias, noise=noise_const, noise_strength=noise_strength, act=act_idx, gain=act_gain, clamp=clampv, split=split)
+        return conv2d(x, wmod, bias=bias, noise=noise_const, noise_strength=noise_strength, act=act_idx, gain=act_gain, clamp=clampv, split=split, out_split=out_split)
     if up == 1:
         y = conv2d(x, wmod, noise=noise_const, noise_strength=noise_strength, split=split)
         return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
@@ -507,7 +600,7 @@ def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=No
     # x2: stride-2 transposed conv as four polyphase GEMMs, then the 4x4 low-pass with gain 4 (conv2d_resample.py:114-131)
     y = conv2d(x, wmod, transposed=True, split=split)
     if act_idx is not None and tuple(resample_filter.shape) == (4, 4) and y.shape[1] % (64 if y.dtype == torch.float16 else 32) == 0:
-        return fir4_bias_act(y, resample_filter, bias, noise_const, noise_strength, act, act_gain, clampv)     # FIR + noise + bias + act in one pass
+        return fir4_bias_act(y, resample_filter, bias, noise_const, noise_strength, act, act_gain, clampv, out_split=out_split)     # FIR + noise + bias + act in one pass
     y = upfirdn2d.upfirdn2d(y, resample_filter, padding=[1, 1, 1, 1], gain=4)
     if noise_const is not None:
         y = y.add_((noise_const * noise_strength).to(y.dtype))
@@ -556,14 +649,20 @@ def up2_fir(x, wmod, taps, bias, noise, noise_strength, act, act_gain, clamp):
     return y
 
 
-def fir4_bias_act(y, f, bias, noise, noise_strength, act, act_gain, clamp):
-    """4x4 FIR (pad 1, gain 4) + noise + bias + activation on an NHWC tensor [N,C,2H+1,2W+1] -> [N,C,2H,2W]."""
+def fir4_bias_act(y, f, bias, noise, noise_strength, act, act_gain, clamp, out_split=False):
+    """4x4 FIR (pad 1, gain 4) + noise + bias + activation on an NHWC tensor [N,C,2H+1,2W+1] -> [N,C,2H,2W] (``out_split``, fp32: a SplitActs)."""
     n, c, ih, iw = y.shape
     out = torch.empty([n, c, ih - 1, iw - 1], dtype=y.dtype, device=y.device, memory_format=torch.channels_last)
     f32 = f.detach().float().contiguous()
     b32 = None if bias is None else bias.detach().float().contiguous()
     nz = None if noise is None else noise.detach().float().contiguous()
     ns = None if noise is None else noise_strength.detach().float().reshape(1).contiguous()
+    if out_split and y.dtype == torch.float32 and c % 32 == 0:
+        code = _lib.lib().p3d_fir4_bias_act_nhwc_split(_lib.ptr(y), _lib.ptr(f32), _lib.ptr(out), n, c, ih, iw, 1, 1, ih - 1, iw - 1, 0, 4.0,
+                                                       _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns), {'linear': 1, 'lrelu': 3}[act], 0.2, float(act_gain), float(clamp),
+                                                       _lib.stream_of(y))
+        _lib.check(code, 'fir4_bias_act_nhwc_split')
+        return SplitActs(out)
     code = _lib.lib().p3d_fir4_bias_act_nhwc(_lib.ptr(y), _lib.ptr(f32), _lib.ptr(out), _lib.DTYPE_CODE[y.dtype], n, c, ih, iw, 1, 1, ih - 1, iw - 1, 0, 4.0,
                                              _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns), {'linear': 1, 'lrelu': 3}[act], 0.2, float(act_gain), float(clamp),
                                              _lib.stream_of(y))
@@ -623,6 +722,8 @@ def torgb(x, weight, styles, bias, clamp=None, out=None):
     tri-plane image of the backbone) go through the MFMA kernel as a 1x1 conv and stay channels-last."""
     n, ci, h, w = x.shape
     co = weight.shape[0]
+    if isinstance(x, SplitActs) and not (not is_small(x) and use_split_bf16(x, ci)):
+        x = x.dense()
     if is_small(x) and not (_is_nhwc_f16(x) and ci in (64, 128, 256) and co <= 32 and (h * w) % 4 == 0):
         wm = modulate_weights(weight, styles, demodulate=False, dtype=x.dtype).reshape(n, co, ci)
         y = torch.bmm(wm, x.contiguous().reshape(n, ci, h * w)).reshape(n, co, h, w)

@@ -248,13 +248,16 @@ class SynthesisLayer(torch.nn.Module):
             self.noise_strength = torch.nn.Parameter(torch.zeros([]))                       # state_dict / optimizer indices line up with its runs
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
 
-    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, rgb=None):
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, rgb=None, out_split=False):
         """``rgb`` (device inference, from SynthesisBlock): (torgb layer, its latent, skip image) — when the native kernel can, this layer
-        also adds the block's ToRGB output into the skip image from its own launch and returns (x, True); otherwise (x, False)."""
+        also adds the block's ToRGB output into the skip image from its own launch and returns (x, True); otherwise (x, False).
+        ``out_split`` (device inference, bf16x3): the caller's consumers read modconv.SplitActs; x may be one."""
         if noise_mode not in ('random', 'const', 'none'):
             raise AssertionError(f'unknown noise_mode {noise_mode!r}')
         in_res = self.resolution // self.up
         misc.assert_shape(x, [None, self.in_channels, in_res, in_res])
+        if isinstance(x, modconv.SplitActs) and (rgb is not None or not modconv.layer_supported(x, self.weight, None, noise_mode, fused_modconv, self.up)):
+            x = x.dense()
         planned = modconv.take_plan(self) if modconv._plan else None
         styles, pre = planned if planned is not None else (self.affine(w), None)
         noise = None
@@ -277,7 +280,7 @@ class SynthesisLayer(torch.nn.Module):
             y = modconv.synthesis_layer(x, self.weight, styles, self.bias, self.up, self.resample_filter,
                                         noise_const=self.noise_const if const_noise else None,
                                         noise_strength=self.noise_strength if const_noise else None,
-                                        act=self.activation, act_gain=self.act_gain * gain, clamp=clamp, pre=pre, rgb=fused_rgb)
+                                        act=self.activation, act_gain=self.act_gain * gain, clamp=clamp, pre=pre, rgb=fused_rgb, out_split=out_split)
             return y if rgb is None else (y, fused_rgb is not None)
         if self.use_noise and noise_mode == 'const':
             noise = self.noise_const * self.noise_strength
@@ -312,6 +315,8 @@ class ToRGBLayer(torch.nn.Module):
         if modconv.torgb_supported(x, self.weight, styles, fused_modconv):
             out = accumulate_into if accumulate_into is not None and modconv.torgb_accumulates(x, self.weight, accumulate_into) else None
             return modconv.torgb(x, self.weight, styles, self.bias, clamp=self.conv_clamp, out=out)      # fp32 NCHW, bias + clamp fused
+        if isinstance(x, modconv.SplitActs):
+            x = x.dense()
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
         return bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
 
@@ -399,8 +404,16 @@ class SynthesisBlock(torch.nn.Module):
         rgb_done = False
         wants_rgb = self.is_last or self.architecture == 'skip'
         if self.in_channels != 0 and self.architecture != 'resnet':
-            x = self.conv0(x, per_layer[0], **conv_kwargs)
-            if wants_rgb and img is not None and self.img_channels <= 8 and x.is_cuda and not torch.is_grad_enabled():
+            # bf16x3 device inference: x stays in the matrix cores' (hi, lo) layout between the layers whose kernels read it (modconv.SplitActs):
+            # conv0's result feeds conv1; conv1's feeds this block's ToRGB and the next block's conv0 (a consumer that cannot read it calls dense())
+            keep_split = (dtype == torch.float32 and fmt == torch.channels_last and fused_modconv is True and ws.is_cuda and not torch.is_grad_enabled()
+                          and self.conv1.out_channels % 32 == 0 and layer_kwargs.get('noise_mode', 'random') != 'random' and self.img_channels > 8
+                          and modconv.accepts_split_input(ws.shape[0], self.conv1.out_channels, self.resolution ** 2, 1))
+            x = self.conv0(x, per_layer[0], out_split=keep_split, **conv_kwargs)
+            if keep_split:
+                x = self.conv1(x, per_layer[1], out_split=True, **conv_kwargs)
+                img_carried = False
+            elif wants_rgb and img is not None and self.img_channels <= 8 and x.is_cuda and not torch.is_grad_enabled():
                 img = self._carry_image(img)                     # (independent of the convolutions: done first so that conv1 can add into it)
                 x, rgb_done = self.conv1(x, per_layer[1], rgb=(self.torgb, per_layer[self.num_conv], img), **conv_kwargs)
                 img_carried = True
@@ -446,6 +459,10 @@ class SynthesisBlock(torch.nn.Module):
             return self.const.to(dtype=dtype).unsqueeze(0).repeat([batch, 1, 1, 1]).contiguous(memory_format=fmt)
         in_res = self.resolution // self._in_div
         misc.assert_shape(x, [None, self.in_channels, in_res, in_res])
+        if isinstance(x, modconv.SplitActs):
+            if dtype == torch.float32 and fmt == torch.channels_last:
+                return x                                          # the previous block's conv1 left it in the layout this block's conv0 reads
+            x = x.dense()
         if fmt == torch.channels_last and native_channels_last and modconv.is_small(x, self._in_div) and x.is_cuda and not torch.is_grad_enabled():
             return x.to(dtype=dtype)      # first MFMA-sized block: its x2 layer still takes the GEMM route on NCHW; conv1 converts
         return x.to(dtype=dtype, memory_format=fmt)

@@ -1,0 +1,106 @@
+"""Activations that stay split between the bf16x3 layers of an inference pass (modconv.SplitActs; csrc/conv2d.hip XS / y_split,
+p3d_fir4_bias_act_nhwc_split).  The format is an internal hand-over between two modulated_conv2d calls of the reference
+(training/networks_stylegan2.py:436-459); what is pinned here: the kernels that read / write it produce the SAME BITS as the plain-tensor
+calls, and the generator's outputs do not change when it is switched on."""
+import numpy as np
+import pytest
+import torch
+
+
+def _split_storage(v):
+    """Reference packing on the CPU: fp32 [N,C,H,W] -> fp32-typed channels-last storage of [32 x bf16 hi | 32 x bf16 lo] rows."""
+    n, c, h, w = v.shape
+    x = v.permute(0, 2, 3, 1).reshape(n, h, w, c // 32, 32)
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    rows = torch.stack([hi, lo], dim=-2).reshape(n, h, w, c // 32, 64).view(torch.float32).reshape(n, h, w, c)
+    return rows.permute(0, 3, 1, 2)
+
+
+def test_dense_of_a_split_tensor_resplits_to_the_same_halves():
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    torch.manual_seed(0)
+    v = (torch.randn(2, 64, 5, 7) * torch.logspace(-3, 3, 64).view(1, 64, 1, 1)).contiguous(memory_format=torch.channels_last)
+    s = modconv.SplitActs(_split_storage(v).contiguous(memory_format=torch.channels_last))
+    d = s.dense()
+    assert d.shape == v.shape and s.shape == v.shape and s.dtype == torch.float32 and s.is_contiguous(memory_format=torch.channels_last)
+    assert float((d - v).abs().max() / v.abs().max()) < 2 ** -16
+    # a bf16x3 consumer of dense() splits it again into a pair that stands for the same number (to fp32 rounding: the pair itself may differ at a tie)
+    def halves(storage):
+        n, c, h, w = storage.shape
+        r = storage.permute(0, 2, 3, 1).reshape(n, h, w, c // 32, 32).view(torch.bfloat16).reshape(n, h, w, c // 32, 2, 32).double()
+        return r[..., 0, :], r[..., 1, :]
+    hi0, lo0 = halves(s.t)
+    hi1, lo1 = halves(_split_storage(d.contiguous(memory_format=torch.channels_last)).contiguous(memory_format=torch.channels_last))
+    assert float((((hi1 + lo1) - (hi0 + lo0)).abs() / hi0.abs().clamp_min(1e-30)).max()) < 2 ** -22
+    assert not modconv.accepts_split_input(4, 512, 32 * 32, 1) and modconv.accepts_split_input(4, 512, 64 * 64, 1) and modconv.accepts_split_input(4, 512, 64 * 64, 2)
+    assert modconv.accepts_split_input(1, 512, 32 * 32, 1) and not modconv.accepts_split_input(4, 48, 64 * 64, 1)
+
+
+def _nhwc(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('ci,co,h,w,n', [(128, 128, 128, 64, 4), (64, 96, 70, 52, 2), (256, 64, 72, 90, 3)])
+def test_kernels_read_and_write_the_split_layout_bit_exactly(hip_lib, ci, co, h, w, n):
+    from pix2pix3d_amd.torch_utils.ops import modconv, upfirdn2d
+    torch.manual_seed(ci + h)
+    x = _nhwc(torch.randn(n, ci, h, w, device='cuda'))
+    xs = modconv.SplitActs(_nhwc(_split_storage(x.cpu())).cuda())
+    weight = torch.randn(co, ci, 3, 3, device='cuda'); styles = torch.randn(n, ci, device='cuda') + 1
+    w3 = modconv.modulate_weights(weight, styles, dtype=modconv.BF16X3)
+    bias, noise, ns = torch.randn(co, device='cuda'), torch.randn(h, w, device='cuda'), torch.tensor(0.3, device='cuda')
+    kw = dict(bias=bias, noise=noise, noise_strength=ns, act=1, gain=2 ** 0.5, clamp=256.0, split=True)
+    y_plain = modconv.conv2d(x, w3, **kw)
+    y_in = modconv.conv2d(xs, w3, **kw)                                    # reads the split layout (3x3: the halo-slab kernel)
+    assert isinstance(y_in, torch.Tensor) and torch.equal(y_in, y_plain)
+    y_io = modconv.conv2d(xs, w3, out_split=True, **kw)                    # ... and writes it
+    if isinstance(y_io, modconv.SplitActs):                                # granted by the halo-slab kernel (launches whose own grid fills the chip)
+        assert torch.equal(y_io.t.cpu().view(torch.int32), _nhwc(_split_storage(y_plain.cpu())).view(torch.int32))
+    else:                                                                  # split-K route: a plain tensor comes back
+        assert (ci, co, h) != (128, 128, 128) and torch.equal(y_io, y_plain)
+    yt_plain, yt_in = modconv.conv2d(x, w3, transposed=True, split=True), modconv.conv2d(xs, w3, transposed=True, split=True)      # generic kernel, four parity classes
+    assert torch.equal(yt_in, yt_plain)
+    w1 = modconv.modulate_weights(torch.randn(96, ci, 1, 1, device='cuda'), styles, demodulate=False, dtype=modconv.BF16X3)
+    assert torch.equal(modconv.conv2d(xs, w1, bias=torch.zeros(96, device='cuda'), split=True), modconv.conv2d(x, w1, bias=torch.zeros(96, device='cuda'), split=True))   # 1x1 (ToRGB)
+    if co % 32 == 0:                                                       # the x2 layer's FIR + epilogue writing the split layout
+        f = upfirdn2d.setup_filter([1, 3, 3, 1], device=torch.device('cuda'))
+        nz2 = torch.randn(2 * h, 2 * w, device='cuda')
+        a = modconv.fir4_bias_act(yt_plain, f, bias, nz2, ns, 'lrelu', 2 ** 0.5, 256.0)
+        b = modconv.fir4_bias_act(yt_plain, f, bias, nz2, ns, 'lrelu', 2 ** 0.5, 256.0, out_split=True)
+        assert isinstance(b, modconv.SplitActs) and torch.equal(b.t.cpu().view(torch.int32), _nhwc(_split_storage(a.cpu())).view(torch.int32))
+
+
+@pytest.mark.gpu
+def test_generator_outputs_do_not_change_with_split_activations(hip_lib):
+    """G.synthesis at the benchmark's size (seg2cat, batch 4, 128^2 rays) with the activations of the >= 64^2 backbone blocks kept split vs.
+    plain tensors: same bits (the same operands go into the same MFMAs in the same order)."""
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    from conftest import load_golden
+    from model_cases import build_generator, uniforms, replay_uniforms
+    g = load_golden('model_full_seg2cat_128')
+    G = build_generator('seg2cat', 'cuda', depth=tuple(int(v) for v in g['depth']))
+    ws, c, nrr = torch.tensor(g['ws'], device='cuda'), torch.tensor(g['c'], device='cuda'), int(g['nrr'])
+    u_c, u_f = uniforms(g, ws.shape[0], nrr, G.rendering_kwargs)
+    prev = modconv.split_activations
+    orig = modconv.SplitActs.__init__
+    try:
+        outs = []
+        for on in (True, False):
+            modconv.split_activations = on
+            made = []
+
+            def spy(self, t, _made=made):
+                _made.append(tuple(t.shape)); orig(self, t)
+            modconv.SplitActs.__init__ = spy
+            with replay_uniforms(u_c, u_f), torch.no_grad():
+                o = G.synthesis(ws, c, noise_mode='const', neural_rendering_resolution=nrr)
+            outs.append((o, made))
+        (a, made_on), (b, made_off) = outs
+        assert len(made_on) == 6 and not made_off, (made_on, made_off)    # conv0 and conv1 of b64, b128, b256 hand their results over split
+        for k in ('image', 'image_raw', 'semantic', 'semantic_raw', 'image_depth'):
+            assert torch.equal(a[k], b[k]), k
+    finally:
+        modconv.split_activations = prev
+        modconv.SplitActs.__init__ = orig
