@@ -852,6 +852,202 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
     }
 }
 
+// ---- the same pipeline for the bf16x3 form of the fp32 layers, on activations that arrive split (XS) -----------------------------------
+// conv3x3_halo_kernel<float, true, true> waits for its whole prefetch at every tap (two-stage pipeline); with the split gone from its loop it is
+// LDS reads + MFMAs and that wait is what is left.  conv3x3_h2_f16_kernel's structure carries over byte for byte when an LDS row is taken to be
+// the 16-channel HALF of a split K row — [16 x bf16 hi | 16 x bf16 lo], 64 bytes — because its two K sub-steps (16-byte positions 0, 1 and 2, 3)
+// are then exactly the hi and the lo fragments: same slab (18 x 20 rows), same three-slot weight ring (8 KB tiles), same swizzle, same
+// fragment addresses, 70 KB, two blocks per CU.  What differs: the DMA source of a row is two 32-byte runs of the 128-byte source row, a tap is
+// 24 MFMAs (hi x hi, hi x lo, lo x hi) on 12 fragment reads, and the epilogue stores from registers.  Weights: p3d_modulate_weights(P3D_F32_BF16X3).
+__global__ void __launch_bounds__(256, 2) conv3x3_r2_bf16x3_kernel(ConvArgs a)
+{
+    // ONE __shared__ object on purpose: with two, hipcc drains vmcnt to 0 before the first ds_read of every step and the counted
+    // waits below are moot (cdna_hip_programming.md, 'three .s-level traps' (a))
+    __shared__ __attribute__((aligned(16))) char lds_b[H2_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.z;
+    const int tiles_x = (a.W + QW - 1) / QW;
+    int mt = blockIdx.x, cb = blockIdx.y;
+    {
+        const int nmt = gridDim.x, ncb = gridDim.y, L = blockIdx.x + blockIdx.y * nmt;
+        if ((nmt & 7) == 0) { const int q = L >> 3, r = L & 7; cb = q % ncb; mt = (q / ncb) * 8 + r; }
+    }
+    const int ty0 = mt / tiles_x, tx0 = mt - ty0 * tiles_x;
+    const int oy0 = ty0 * QH, ox0 = tx0 * QW, co0 = cb * BN;
+    const char* const xin_b = (const char*)((const float*)a.x + (int64_t)n * a.H * a.W * a.Ci);        // split rows: 128 bytes per pixel and 32 channels
+    const char* const wgt_b = (const char*)((const float*)a.w + (int64_t)n * a.w_img_stride);
+    // 16-byte piece q of a 64-byte LDS row [16 hi | 16 lo] inside its 128-byte source row [32 hi | 32 lo]: hi pieces at 16 q, lo pieces at 64 + 16 (q - 2)
+    auto piece = [](int q) { return 16 * q + (q >= 2 ? 32 : 0); };
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const int pos = lane & 3, prow = lane >> 2;                                // DMA lane: 16-byte position / row within its 16-row piece
+    const int kpairs = a.Ci / 32;                                              // the loop body covers the TWO 16-channel halves of a 32-channel row (18 taps)
+
+    unsigned woff[2];                                                          // weight pieces 2 * wave, 2 * wave + 1 (16 rows each)
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) {
+        const int row = (wave * 2 + p2) * 16 + prow;
+        woff[p2] = (unsigned)((co0 + row) * 9 * a.Ci * 4 + piece(pos ^ ((row >> 2) & 3)));
+    }
+    unsigned soff[6]; bool sok[6];                                             // slab pieces wave, wave + 4, ...  (6, or 5 for wave 3)
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+        const int q = (wave + 4 * g) * 16 + prow;
+        const int sy = q / H2_PITCH, sx = q - sy * H2_PITCH;
+        const int iy = oy0 - 1 + sy, ix = ox0 - 1 + sx;
+        sok[g] = (q < H2_SLAB_ROWS) & (sx < 18) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
+        soff[g] = (unsigned)((iy * a.W + ix) * a.Ci * 4 + piece(pos ^ ((sx >> 2) & 3)));
+    }
+    const int nslab = (wave == 3) ? 5 : 6;
+    auto stage_slab = [&](int cc, int buf) {
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            if (g < nslab) {
+                const char* src = sok[g] ? xin_b + soff[g] + (cc >> 1) * 128 + (cc & 1) * 32 : (const char*)a.zeros;
+                __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(lds_b + buf * H2_SLAB_BUF + (wave + 4 * g) * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto stage_w = [&](int cc, int t, int slot) {
+        const char* base = wgt_b + t * a.Ci * 4 + (cc >> 1) * 128 + (cc & 1) * 32;
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2)
+            __builtin_amdgcn_global_load_lds((glb_ptr)(base + woff[p2]), (lds_ptr)(lds_b + H2_WT_BASE + slot * H2_WT_BYTES + (wave * 2 + p2) * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // fragment addresses (LDS byte offsets).  A: pixel (wave*4 + 2i + frow/16, frow%16) of the patch at tap (ty, tx) is slab row
+    // (that pixel row + ty) * PITCH + column + tx; its 16-byte piece c sits at position c ^ key with the key taken from the slab
+    // COLUMN.  Only tx changes the key: 3 x 2 lane constants; i, ty, the slab buffer and the ring slot are instruction immediates.
+    const int frow = lane & 31, fk = lane >> 5;
+    const int acol = frow & 15;
+    int preA[3][2], preB[2];
+#pragma unroll
+    for (int tx2 = 0; tx2 < 3; ++tx2)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+            preA[tx2][kk] = ((wave * 4 + (frow >> 4)) * H2_PITCH + acol + tx2) * 64 + (((kk * 2 + fk) ^ (((acol + tx2) >> 2) & 3)) << 4);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) preB[kk] = H2_WT_BASE + frow * 64 + (((kk * 2 + fk) ^ ((frow >> 2) & 3)) << 4);
+
+    f32x4 hiA[2][2], hiB[2][4], loA[2], loB[4];                                 // hi fragments of two consecutive taps, lo fragments of the current one
+    auto load_frags = [&](int buf, int t, int kk, f32x4* pa, f32x4* pb) {      // buf, t, kk are compile-time after unrolling
+        // issued as opaque asm so that the compiler's own s_waitcnt (always lgkmcnt(0) here) stays out of the way: the waits are
+        // the counted ones written next to the MFMAs below
+        const int ty2 = t / 3, tx2 = t - ty2 * 3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pa[i]) : "v"(preA[tx2][kk]), "n"(buf * H2_SLAB_BUF + (i * 2 + ty2) * H2_PITCH * 64) : "memory");
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pb[j]) : "v"(preB[kk]), "n"((t % 3) * H2_WT_BYTES + j * 32 * 64) : "memory");
+    };
+
+    // Software pipeline: conv3x3_h2_f16_kernel's (one rendezvous per tap, three-slot weight ring, counted vmcnt), with the fragment traffic of
+    // three products: sub-step a runs the 8 hi x hi MFMAs while the tap's lo fragments load; sub-step b (after the rendezvous and the DMA issue)
+    // runs hi x lo and lo x hi — 16 MFMAs — while the NEXT tap's hi fragments load into the other hi register set.
+    stage_slab(0, 0);
+    stage_w(0, 0, 0);
+    stage_w(0, 1, 1);
+    stage_w(0, 2, 2);
+    wait_vmcnt<2>();                                                            // slab 0, tiles 0 and 1 (tile 2 stays in flight)
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, 0, 0, hiA[0], hiB[0]);
+    for (int cp = 0; cp < kpairs; ++cp) {
+        const bool more = cp + 1 < kpairs;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int cc = cp * 2 + h;
+            const bool next_chunk = (h == 0) || more;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int cur = (h * 9 + t) & 1, nxt = cur ^ 1;                 // (compile-time after unrolling: 18 taps per iteration of cp)
+                // ---- sub-step a
+                load_frags(h, t, 1, loA, loB);
+                asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, hiA[cur][i]), __builtin_bit_cast(bf8, hiB[cur][j]), acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- sub-step b
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                {
+                    const bool t2 = (t < 7) || next_chunk;                      // tile ks+2 exists
+                    if (t == 1 && next_chunk) { if (nslab == 6) wait_vmcnt<8>(); else wait_vmcnt<7>(); }
+                    else if (t2) wait_vmcnt<2>();
+                    else wait_vmcnt<0>();
+                }
+                __builtin_amdgcn_s_barrier();
+                if (t < 6) stage_w(cc, t + 3, t % 3);                           // tile ks+3 -> the slot tile ks just left
+                else if (next_chunk) stage_w(cc + 1, t - 6, t % 3);
+                if (t == 0 && next_chunk) stage_slab(cc + 1, h ^ 1);
+                if (t < 8) load_frags(h, t + 1, 0, hiA[nxt], hiB[nxt]);
+                else if (next_chunk) load_frags(h ^ 1, 0, 0, hiA[nxt], hiB[nxt]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, hiA[cur][i]), __builtin_bit_cast(bf8, loB[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, loA[i]), __builtin_bit_cast(bf8, hiB[cur][j]), acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();                                                            // every wave is done with the slabs and tiles
+
+    // Epilogue straight from the accumulators (an fp32 tile would not fit the LDS next to a second block): a lane holds ONE channel of 64 pixels;
+    // the 32 lanes of a half-wave are the 32 consecutive channels of one pixel — 128 bytes per store instruction, or, for a split result
+    // (ConvArgs::y_split), the pixel's [32 hi | 32 lo] K row as two 64-byte runs.
+    float* const nz = (float*)lds_b;
+    const float ns = a.noise ? a.noise_strength[0] : 0.f;
+    if (a.noise) {
+        const int oy = oy0 + (tid >> 4), ox = ox0 + (tid & 15);
+        nz[tid] = (oy < a.H && ox < a.W) ? a.noise[(int64_t)oy * a.W + ox] * ns : 0.f;
+        __syncthreads();
+    }
+    float* const yimg = (float*)a.y + (int64_t)n * a.H * a.W * a.Co;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int co = co0 + j * 32 + frow;
+        const float b = (a.bias && co < a.Co) ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
+                if (oy >= a.H || ox >= a.W || co >= a.Co) continue;
+                float v = acc[i][j][r];
+                if (a.noise) v += nz[p];
+                v += b;
+                if (a.act == 1) v = fmaxf(v, 0.2f * v);
+                v *= a.gain;
+                if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
+                float* px = yimg + ((int64_t)oy * a.W + ox) * a.Co;
+                if (a.y_split) {
+                    __bf16* row = (__bf16*)(px + co0 + j * 32);
+                    const __bf16 hv = (__bf16)v;
+                    row[frow] = hv;
+                    row[32 + frow] = (__bf16)(v - (float)hv);
+                } else px[co] = v;
+            }
+    }
+}
+
 // ---- stride-2 transposed 3x3 conv on the two-blocks-per-CU structure (fp16) ------------------------------------------------
 // The x2 layers' conv_transpose2d (conv2d_resample.py:114-127) is four dense sub-problems, one per output parity (4 / 2 / 2 / 1
 // taps, offsets in {-1, 0}).  Each block takes one 16 x 16 patch of ONE parity class and runs conv3x3_h2_f16_kernel's pipeline over
@@ -1405,6 +1601,16 @@ int p3d::conv2d_nhwc_run_io(const void* x, const void* w, void* y, int dtype, co
             hipLaunchKernelGGL(conv3x3_h2_f16_kernel, grid, dim3(256), 0, s, a);
             count_launch(FAM_CONV);
             return check_launch("conv3x3_h2_f16");
+        }
+        static const bool no_r2 = getenv("P3D_CONV_NO_R2") != nullptr;
+        const bool r2_ok = !no_r2 && !no_halo && kernel_size == 3 && dtype == P3D_F32_BF16X3 && x_split && h >= 32 && wdt >= 32 && ci % 32 == 0 && co % BN == 0 && !out_scale;
+        if (r2_ok && (int64_t)((h + QH - 1) / QH) * ((wdt + QW - 1) / QW) * (co / BN) * n_img >= 192) {      // (smaller grids: the 8 x 16 halo kernel, then split-K)
+            if (dry) return P3D_OK;                                       // split activations in: the ring pipeline on 16-channel half rows
+            a.y_split = y_split;
+            dim3 grid(((h + QH - 1) / QH) * ((wdt + QW - 1) / QW), co / BN, n_img);
+            hipLaunchKernelGGL(conv3x3_r2_bf16x3_kernel, grid, dim3(256), 0, s, a);
+            count_launch(FAM_CONV);
+            return check_launch("conv3x3_r2_bf16x3");
         }
         if (halo_ok && !prefer_split) {                                   // halo-reuse kernel for the plain 3x3 layers
             if (dry) return P3D_OK;

@@ -1,7 +1,7 @@
 """Activations that stay split between the bf16x3 layers of an inference pass (modconv.SplitActs; csrc/conv2d.hip XS / y_split,
 p3d_fir4_bias_act_nhwc_split).  The format is an internal hand-over between two modulated_conv2d calls of the reference
 (training/networks_stylegan2.py:436-459); what is pinned here: the kernels that read / write it produce the SAME BITS as the plain-tensor
-calls, and the generator's outputs do not change when it is switched on."""
+calls (or, on the ring pipeline, sum the same products in another order), and the generator's outputs do not move when it is switched on."""
 import numpy as np
 import pytest
 import torch
@@ -42,8 +42,12 @@ def _nhwc(t):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('ci,co,h,w,n', [(128, 128, 128, 64, 4), (64, 96, 70, 52, 2), (256, 64, 72, 90, 3)])
-def test_kernels_read_and_write_the_split_layout_bit_exactly(hip_lib, ci, co, h, w, n):
+@pytest.mark.parametrize('ci,co,h,w,n', [(128, 128, 128, 64, 4), (64, 96, 70, 52, 2), (256, 64, 72, 90, 3),            # halo-slab kernel / split-K generic kernel
+                                         (128, 128, 128, 128, 4), (64, 128, 100, 90, 5), (32, 256, 64, 64, 8)])      # the ring kernel: full tiles, ragged tiles, two channel blocks x one chunk pair
+def test_kernels_read_and_write_the_split_layout(hip_lib, ci, co, h, w, n):
+    """Kernels on split input vs the same layer on the plain tensor: bit-identical where the same pipeline runs (halo-slab, generic: same
+    operands into the same MFMAs in the same order); the ring kernel (conv3x3_r2_bf16x3_kernel) sums the same products in another order:
+    <= 2e-6 of the range.  A split RESULT is bit-for-bit the split of the plain result of the same kernel."""
     from pix2pix3d_amd.torch_utils.ops import modconv, upfirdn2d
     torch.manual_seed(ci + h)
     x = _nhwc(torch.randn(n, ci, h, w, device='cuda'))
@@ -52,14 +56,21 @@ def test_kernels_read_and_write_the_split_layout_bit_exactly(hip_lib, ci, co, h,
     w3 = modconv.modulate_weights(weight, styles, dtype=modconv.BF16X3)
     bias, noise, ns = torch.randn(co, device='cuda'), torch.randn(h, w, device='cuda'), torch.tensor(0.3, device='cuda')
     kw = dict(bias=bias, noise=noise, noise_strength=ns, act=1, gain=2 ** 0.5, clamp=256.0, split=True)
+    ring = co % 128 == 0 and h >= 32 and w >= 32 and ((h + 15) // 16) * ((w + 15) // 16) * (co // 128) * n >= 192
     y_plain = modconv.conv2d(x, w3, **kw)
-    y_in = modconv.conv2d(xs, w3, **kw)                                    # reads the split layout (3x3: the halo-slab kernel)
-    assert isinstance(y_in, torch.Tensor) and torch.equal(y_in, y_plain)
+    y_in = modconv.conv2d(xs, w3, **kw)                                    # reads the split layout
+    assert isinstance(y_in, torch.Tensor)
+    if ring:
+        e = float((y_in - y_plain).abs().max() / y_plain.abs().max())
+        print((ci, co, h, w, n), 'ring kernel vs halo kernel', e)
+        assert e < 2e-6
+    else:
+        assert torch.equal(y_in, y_plain)
     y_io = modconv.conv2d(xs, w3, out_split=True, **kw)                    # ... and writes it
-    if isinstance(y_io, modconv.SplitActs):                                # granted by the halo-slab kernel (launches whose own grid fills the chip)
-        assert torch.equal(y_io.t.cpu().view(torch.int32), _nhwc(_split_storage(y_plain.cpu())).view(torch.int32))
+    if isinstance(y_io, modconv.SplitActs):                                # granted by the halo-slab / ring kernels (launches whose own grid fills the chip)
+        assert torch.equal(y_io.t.cpu().view(torch.int32), _nhwc(_split_storage(y_in.cpu())).view(torch.int32))
     else:                                                                  # split-K route: a plain tensor comes back
-        assert (ci, co, h) != (128, 128, 128) and torch.equal(y_io, y_plain)
+        assert not ring and (ci, co, h) != (128, 128, 128) and torch.equal(y_io, y_plain)
     yt_plain, yt_in = modconv.conv2d(x, w3, transposed=True, split=True), modconv.conv2d(xs, w3, transposed=True, split=True)      # generic kernel, four parity classes
     assert torch.equal(yt_in, yt_plain)
     w1 = modconv.modulate_weights(torch.randn(96, ci, 1, 1, device='cuda'), styles, demodulate=False, dtype=modconv.BF16X3)
@@ -70,12 +81,22 @@ def test_kernels_read_and_write_the_split_layout_bit_exactly(hip_lib, ci, co, h,
         a = modconv.fir4_bias_act(yt_plain, f, bias, nz2, ns, 'lrelu', 2 ** 0.5, 256.0)
         b = modconv.fir4_bias_act(yt_plain, f, bias, nz2, ns, 'lrelu', 2 ** 0.5, 256.0, out_split=True)
         assert isinstance(b, modconv.SplitActs) and torch.equal(b.t.cpu().view(torch.int32), _nhwc(_split_storage(a.cpu())).view(torch.int32))
+    # the ring kernel against fp64 on its own (the bar of the bf16x3 formulation: 1e-5 of the range)
+    if ring:
+        import torch.nn.functional as F
+        w32 = modconv.modulate_weights(weight, styles, dtype=torch.float32)
+        wq = w32.double().reshape(n, co, 3, 3, ci).permute(0, 1, 4, 2, 3).cpu()
+        ref = torch.stack([F.conv2d(x[i:i + 1].double().cpu(), wq[i], padding=1)[0] for i in range(n)])
+        ref = (F.leaky_relu(ref + (noise * ns).double().cpu() + bias.double().cpu().view(1, -1, 1, 1), 0.2) * 2 ** 0.5).clamp(-256, 256)
+        e64 = float((y_in.double().cpu() - ref).abs().max() / ref.abs().max())
+        print('ring kernel vs fp64', e64)
+        assert e64 < 1e-5
 
 
 @pytest.mark.gpu
 def test_generator_outputs_do_not_change_with_split_activations(hip_lib):
     """G.synthesis at the benchmark's size (seg2cat, batch 4, 128^2 rays) with the activations of the >= 64^2 backbone blocks kept split vs.
-    plain tensors: same bits (the same operands go into the same MFMAs in the same order)."""
+    plain tensors: the same function to fp32 summation order."""
     from pix2pix3d_amd.torch_utils.ops import modconv
     from conftest import load_golden
     from model_cases import build_generator, uniforms, replay_uniforms
@@ -99,8 +120,9 @@ def test_generator_outputs_do_not_change_with_split_activations(hip_lib):
             outs.append((o, made))
         (a, made_on), (b, made_off) = outs
         assert len(made_on) == 6 and not made_off, (made_on, made_off)    # conv0 and conv1 of b64, b128, b256 hand their results over split
-        for k in ('image', 'image_raw', 'semantic', 'semantic_raw', 'image_depth'):
-            assert torch.equal(a[k], b[k]), k
+        for k in ('image', 'image_raw', 'semantic', 'semantic_raw', 'image_depth'):      # (the 3x3 layers on split input take the ring kernel: same products, another summation order)
+            e = float((a[k].float() - b[k].float()).abs().max() / b[k].float().abs().max())
+            assert e < (2e-3 if k in ('image', 'semantic') else 2e-5), (k, e)       # fp16 SR heads amplify a last-bit difference of their input to fp16 rounding
     finally:
         modconv.split_activations = prev
         modconv.SplitActs.__init__ = orig
