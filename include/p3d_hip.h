@@ -320,9 +320,10 @@ int p3d_conv2d_nhwc_scaled(const void* x, const void* w, void* y, int dtype, con
 /* Activations that stay split between the bf16x3 layers of an inference pass (training/networks_stylegan2.py:436-459: conv0 -> conv1 -> ToRGB /
  * the next block, each a modulated_conv2d :26-105 whose fp32 products this library forms as three bf16 MFMAs).  x_split != 0: x is NOT fp32 but,
  * per pixel and 32 channels, [32 x bf16 hi | 32 x bf16 lo] in the same 128 bytes (hi = bf16(v), lo = bf16(v - hi): exactly what the kernels
- * otherwise compute in registers for every tap) — as written by a call with y_split != 0 or by p3d_fir4_bias_act_nhwc_split.  Results are
- * bit-identical to the plain-tensor calls.  dtype is implied (P3D_F32_BF16X3: w from p3d_modulate_weights in that layout).  x_split is taken by
- * every route (3x3, 1x1, transposed, stride 2); y_split only by the 3x3 'same' layers the halo-slab kernel runs (Co % 32 == 0, an image of at
+ * otherwise compute in registers for every tap) — as written by a call with y_split != 0 or by p3d_fir4_bias_act_nhwc_split.  The same products
+ * as the plain-tensor calls: bit-identical where the same kernel runs; 3x3 'same' layers with x_split whose 16 x 16-patch grid fills the chip take a
+ * ring-pipeline kernel that sums them in another order (<= 1e-6 of the range apart).  dtype is implied (P3D_F32_BF16X3: w from p3d_modulate_weights in that layout).  x_split is taken by
+ * every route (3x3, 1x1, transposed, stride 2); y_split only by the 3x3 'same' layers the halo-slab / ring kernels run (Co % 32 == 0, an image of at
  * least 8 x 16 whose own grid fills the chip): otherwise P3D_ERR_UNSUPPORTED and nothing is launched — ask again with y_split = 0.           */
 int p3d_conv2d_nhwc_bf16x3_io(const void* x, const void* w, void* y, const float* bias, const float* noise, const float* noise_strength,
                               const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
