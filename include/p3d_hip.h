@@ -329,6 +329,13 @@ int p3d_conv2d_nhwc_bf16x3_io(const void* x, const void* w, void* y, const float
                               const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
                               int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, int32_t x_split, int32_t y_split,
                               void* workspace, int64_t workspace_bytes, p3d_stream_t stream);
+/* Wide ToRGB + skip-image sum of a synthesis block in one pass, on split activations (training/networks_stylegan2.py:355-359 ToRGBLayer and :453-459
+ * img = upsample2d(img) + y):  y[n][p][o] = clamp(sum_c x[n][p][c] * wmod[n][o][c] + bias[o]) + (prev ? upfirdn2d(prev, f, up = 2, pad 2, gain 4)[n][p][o] : 0).
+ * x_split [N][H][W][Ci] and wmod_split [N][Co][Ci] in the split K-row layout above (wmod: p3d_modulate_weights(..., demodulate = 0, P3D_F32_BF16X3));
+ * y [N][H][W][Co] and prev [N][H/2][W/2][Co] fp32 channels-last; f4x4_host: the 16 filter taps in HOST memory, row-major (read when prev != null).
+ * The skip term is summed exactly as p3d_upfirdn2d_acc sums it.  Ci in {128, 256}, Co in {32, 64, 96}, W % 32 == 0, else P3D_ERR_UNSUPPORTED.  */
+int p3d_torgb_wide_split(const void* x_split, const void* wmod_split, const float* bias, float* y_nhwc, const float* prev_nhwc, const float* f4x4_host,
+                         int32_t n_img, int32_t h, int32_t w, int32_t ci, int32_t co, float clamp, p3d_stream_t stream);
 /* d[n][o] = rsqrt(sum_i styles[n][i]^2 * w2[o][i] + 1e-8) with w2[o][i] = sum over the taps of weight[o][i][.]^2 (networks_stylegan2.py:57-63) */
 int p3d_demod_coefs(const float* styles, const float* w2, float* d, int32_t n_rows, int32_t ci, int32_t co, p3d_stream_t stream);
 

@@ -71,6 +71,7 @@ def _zeros_page(device):
     return z
 _lib.register('p3d_torgb_nhwc_f16', ctypes.c_int, [_vp] * 5 + [_i32] * 4 + [_f32, _i32, _vp])
 _lib.register('p3d_conv2d_nhwc_bf16x3_io', ctypes.c_int, [_vp] * 7 + [_i32] * 5 + [ctypes.c_int64, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _vp, ctypes.c_int64, _vp])
+_lib.register('p3d_torgb_wide_split', ctypes.c_int, [_vp] * 6 + [_i32] * 5 + [_f32, _vp])
 _lib.register('p3d_fir4_bias_act_nhwc_split', ctypes.c_int, [_vp] * 3 + [_i32] * 9 + [_f32, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _vp])
 
 
@@ -706,6 +707,49 @@ def conv3x3_torgb(x, wmod, bias, act, gain, clamp, rgb_wmod, rgb_bias, rgb_clamp
     log = _lib.kernel_events.get('conv_flops')
     if log is not None:
         log.append((str(x.dtype), 2.0 * n * ci * co * 9 * h * w))
+    return y
+
+
+fuse_wide_torgb = os.environ.get('P3D_FUSE_WIDE_TORGB', '1') != '0'      # the backbone's wide ToRGB + skip-image sum in one launch on split activations (csrc/torgb_split.hip)
+
+
+def _filter_host(f):
+    """The 4x4 resampling filter as 16 host floats (one device read per filter tensor, cached), or None."""
+    if tuple(f.shape) != (4, 4):
+        return None
+    return _cached_weight(f, 'fir_host16', lambda: ((ctypes.c_float * 16)(*[float(v) for v in f.detach().float().cpu().reshape(-1)]),))[0]
+
+
+def torgb_wide_skip_supported(x, weight, prev, f):
+    """p3d_torgb_wide_split takes it: SplitActs of 128 / 256 channels, 32 / 64 / 96 outputs, rows that are whole 32-pixel tiles, and (if given) a
+    channels-last fp32 predecessor image at half the resolution."""
+    if not (fuse_wide_torgb and enabled and isinstance(x, SplitActs) and tuple(weight.shape[2:]) == (1, 1) and not torch.is_grad_enabled()):
+        return False
+    n, ci, h, w = x.shape
+    co = weight.shape[0]
+    if ci not in (128, 256) or co not in (32, 64, 96) or w % 32 != 0:
+        return False
+    if prev is None:
+        return True
+    return (f is not None and tuple(f.shape) == (4, 4) and prev.dtype == torch.float32 and tuple(prev.shape) == (n, co, h // 2, w // 2) and h % 2 == 0
+            and prev.is_cuda and prev.is_contiguous(memory_format=torch.channels_last) and not prev.requires_grad)
+
+
+def torgb_wide_skip(x, weight, styles, bias, clamp, prev, f):
+    """ToRGB of a SplitActs (wide image: the backbone's tri-planes) + the block's skip-image sum ``upsample2d(prev, f) + y`` in one launch -> fp32 NHWC."""
+    n, ci, h, w = x.shape
+    co = weight.shape[0]
+    wmod = modulate_weights(weight, styles, demodulate=False, dtype=BF16X3)
+    y = torch.empty([n, co, h, w], dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    b32 = None if bias is None else bias.detach().float().contiguous()
+    fh = None if prev is None else _filter_host(f)
+    with _lib.kernel_timer('conv_bf16x3', x.t):
+        code = _lib.lib().p3d_torgb_wide_split(_lib.ptr(x.t), _lib.ptr(wmod), _lib.ptr(b32), _lib.ptr(y), _lib.ptr(prev), None if fh is None else ctypes.cast(fh, ctypes.c_void_p),
+                                               n, h, w, ci, co, -1.0 if clamp is None else float(clamp), _lib.stream_of(x.t))
+    _lib.check(code, 'torgb_wide_split')
+    log = _lib.kernel_events.get('conv_flops')
+    if log is not None:
+        log.append(('bf16x3', 2.0 * n * ci * co * h * w))
     return y
 
 

@@ -428,6 +428,12 @@ class SynthesisBlock(torch.nn.Module):
             # wide skip image (the 96 tri-plane channels), device inference: ToRGB first, then its upsampled predecessor is added INTO it by the
             # upsampling launch — one pass over the image instead of three (upsample, ToRGB, add)
             misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
+            if fused_modconv is True and modconv.torgb_wide_skip_supported(x, self.torgb.weight, img, self.resample_filter):
+                # split activations in: ToRGB and the skip-image sum in ONE pass over the image (csrc/torgb_split.hip)
+                planned = modconv.take_plan(self.torgb) if modconv._plan else None
+                s_rgb = planned[0] if planned is not None else self.torgb.affine(per_layer[self.num_conv], out_scale=self.torgb.weight_gain)
+                img = modconv.torgb_wide_skip(x, self.torgb.weight, s_rgb, self.torgb.bias, self.torgb.conv_clamp, img, self.resample_filter)
+                return x, img
             y = self.torgb(x, per_layer[self.num_conv], fused_modconv=fused_modconv)
             if y.dtype == torch.float32 and y.is_contiguous(memory_format=torch.channels_last):
                 img = upfirdn2d.upsample2d_add_(y, img, self.resample_filter)

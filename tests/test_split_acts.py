@@ -94,6 +94,36 @@ def test_kernels_read_and_write_the_split_layout(hip_lib, ci, co, h, w, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('ci,co,h,w,n,skip', [(128, 96, 64, 64, 4, True), (256, 96, 34, 96, 2, True), (128, 64, 40, 32, 3, False), (256, 32, 16, 64, 1, True)])
+def test_wide_torgb_with_the_skip_image_in_one_launch(hip_lib, ci, co, h, w, n, skip):
+    """csrc/torgb_split.hip: ToRGB of a SplitActs + upsample2d(prev) in one pass against the two-launch form (ToRGB on the generic kernel, then
+    p3d_upfirdn2d_acc) and against fp64: the products are the same (another summation order: <= 1e-6 of the range); the skip term is bit-for-bit
+    the upsampling kernel's."""
+    import torch.nn.functional as F
+    from pix2pix3d_amd.torch_utils.ops import modconv, upfirdn2d
+    torch.manual_seed(ci + co + h)
+    x = _nhwc(torch.randn(n, ci, h, w, device='cuda'))
+    xs = modconv.SplitActs(_nhwc(_split_storage(x.cpu())).cuda())
+    weight = torch.randn(co, ci, 1, 1, device='cuda'); styles = (torch.randn(n, ci, device='cuda') + 1) / ci ** 0.5; bias = torch.randn(co, device='cuda')
+    f = upfirdn2d.setup_filter([1, 3, 3, 1], device=torch.device('cuda'))
+    prev = _nhwc(torch.randn(n, co, h // 2, w // 2, device='cuda')) if skip else None
+    with torch.no_grad():
+        assert modconv.torgb_wide_skip_supported(xs, weight, prev, f)
+        got = modconv.torgb_wide_skip(xs, weight, styles, bias, 256.0, prev, f)
+        assert got.shape == (n, co, h, w) and got.is_contiguous(memory_format=torch.channels_last)
+        y = modconv.torgb(xs, weight, styles, bias, clamp=256.0)                               # generic 1x1 kernel on the same split input
+        two = upfirdn2d.upsample2d_add_(y.clone(memory_format=torch.channels_last), prev, f.detach()) if skip else y
+    e2 = float((got - two).abs().max() / two.abs().max())
+    ref = (torch.einsum('oc,nc,nchw->nohw', weight.reshape(co, ci).double().cpu(), styles.double().cpu(), xs.dense().double().cpu())
+           + bias.double().cpu().view(1, co, 1, 1)).clamp(-256, 256)
+    if skip:
+        ref = ref + upfirdn2d.upsample2d(prev.double().cpu().contiguous(), f.cpu())
+    e64 = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+    print((ci, co, h, w, n, skip), 'vs two launches', e2, 'vs fp64', e64)
+    assert e2 < 1e-6 and e64 < 1e-5
+
+
+@pytest.mark.gpu
 def test_generator_outputs_do_not_change_with_split_activations(hip_lib):
     """G.synthesis at the benchmark's size (seg2cat, batch 4, 128^2 rays) with the activations of the >= 64^2 backbone blocks kept split vs.
     plain tensors: the same function to fp32 summation order."""
