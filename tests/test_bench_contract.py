@@ -1,4 +1,4 @@
-"""The benchmark line's contract, checked on the line the final tree printed on an MI355X (profiles/round3_an_bench_line_default.json) and on
+"""The benchmark line's contract, checked on the line the final tree printed on an MI355X (profiles/round3_as_bench_line_default.json) and on
 bench.py's argument surface: the keys the driver parses, the roofline object backed by committed counter passes whose hash matches the
 kernel sources of this tree, the CPU baseline, the exact-fp32 leg and the four-phase training step."""
 import hashlib
@@ -15,7 +15,7 @@ def _line(name):
 
 
 def test_default_line_has_the_contract_keys():
-    d = _line('round3_an_bench_line_default.json')
+    d = _line('round3_as_bench_line_default.json')
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
               'roofline', 'cpu_baseline', 'exact_fp32', 'train_step'):
         assert k in d, k
