@@ -1413,9 +1413,12 @@ static int fold_batch(const ConvArgs& a, int dtype)
 // launch already fills the chip or the loop is short; otherwise enough splits for ~2 work-groups per CU with >= 4 steps each.
 static int splitk_plan(int64_t blocks, int nsteps)
 {
+    // tuning switches of tests/gpu_probe_splitk.sh (defaults = the values the sweep kept): work-groups per CU aimed at, fewest K steps per split
+    static const int per_cu = [] { const char* e = getenv("P3D_SPLITK_PER_CU"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 8 ? v : 2; }();
+    static const int min_steps = [] { const char* e = getenv("P3D_SPLITK_MIN_STEPS"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 64 ? v : 4; }();
     if (blocks >= kNumCU || nsteps < 8) return 1;
-    int64_t want = (2 * kNumCU + blocks - 1) / blocks;
-    if (want > nsteps / 4) want = nsteps / 4;
+    int64_t want = (per_cu * kNumCU + blocks - 1) / blocks;
+    if (want > nsteps / min_steps) want = nsteps / min_steps;
     if (want < 2) return 1;
     const int per = (int)((nsteps + want - 1) / want);
     return (nsteps + per - 1) / per;
