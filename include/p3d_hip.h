@@ -329,6 +329,11 @@ int p3d_conv2d_nhwc_bf16x3_io(const void* x, const void* w, void* y, const float
                               const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
                               int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, int32_t x_split, int32_t y_split,
                               void* workspace, int64_t workspace_bytes, p3d_stream_t stream);
+/* The route p3d_conv2d_nhwc_bf16x3_io would take for these sizes, without launching anything: returns 1 when a split result would be granted
+ * (want_y_split != 0 and the 3x3 halo-slab / ring kernel takes the layer), 0 when the result will be a plain tensor, or a negative error code;
+ * *workspace_bytes = the split-K scratch that route wants (0: none).  Ask once per geometry, then call with the granted flag.                 */
+int p3d_conv2d_nhwc_bf16x3_io_plan(int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride, int32_t kernel_size,
+                                   int32_t resample, int32_t x_split, int32_t want_y_split, int64_t* workspace_bytes);
 /* Wide ToRGB + skip-image sum of a synthesis block in one pass, on split activations (training/networks_stylegan2.py:355-359 ToRGBLayer and :453-459
  * img = upsample2d(img) + y):  y[n][p][o] = clamp(sum_c x[n][p][c] * wmod[n][o][c] + bias[o]) + (prev ? upfirdn2d(prev, f, up = 2, pad 2, gain 4)[n][p][o] : 0).
  * x_split [N][H][W][Ci] and wmod_split [N][Co][Ci] in the split K-row layout above (wmod: p3d_modulate_weights(..., demodulate = 0, P3D_F32_BF16X3));

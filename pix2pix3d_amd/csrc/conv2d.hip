@@ -1514,6 +1514,23 @@ extern "C" int p3d_conv2d_nhwc_bf16x3_io(const void* x, const void* w, void* y, 
                                    clamp, 0, 0, workspace, workspace_bytes, nullptr, nullptr, x_split, y_split, stream);
 }
 
+// The route p3d_conv2d_nhwc_bf16x3_io would take, without launching: returns 1 when a split result (y_split) would be granted for these sizes,
+// 0 when the caller has to ask for a plain tensor, < 0 on unusable arguments; *workspace_bytes = the split-K scratch of THAT route (0: none).
+extern "C" int p3d_conv2d_nhwc_bf16x3_io_plan(int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride, int32_t kernel_size,
+                                              int32_t resample, int32_t x_split, int32_t want_y_split, int64_t* workspace_bytes)
+{
+    P3D_REQUIRE(workspace_bytes, "conv2d_nhwc_bf16x3_io_plan: null pointer");
+    *workspace_bytes = 0;
+    for (int ys = (want_y_split && co % 32 == 0) ? 1 : 0; ys >= 0; --ys) {
+        int64_t bytes = 0;
+        const int rc = p3d::conv2d_nhwc_run_io(nullptr, nullptr, nullptr, P3D_F32_BF16X3, nullptr, nullptr, nullptr, nullptr, n_img, h, wdt, ci, co, w_img_stride, kernel_size,
+                                               resample, 0, 1.f, -1.f, 0, 0, nullptr, 0, &bytes, nullptr, x_split, ys, nullptr);
+        if (rc == P3D_OK) { *workspace_bytes = bytes; return ys; }
+        if (rc != P3D_ERR_UNSUPPORTED || ys == 0) return rc < 0 ? rc : -rc;
+    }
+    return 0;
+}
+
 extern "C" int p3d_conv2d_nhwc_scaled(const void* x, const void* w, void* y, int dtype, const float* out_scale, const float* bias, const float* noise,
                                       const float* noise_strength, const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co,
                                       int64_t w_img_stride, int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, void* workspace,
@@ -1579,7 +1596,7 @@ int p3d::conv2d_nhwc_run_io(const void* x, const void* w, void* y, int dtype, co
         a.OH = (h - kernel_size) / 2 + 1; a.OW = (wdt - kernel_size) / 2 + 1; a.osy = a.osx = 1; a.isy = a.isx = 2; a.ncls = 1;
         a.cls[0].SH = a.OH; a.cls[0].SW = a.OW; a.cls[0].ooy = a.cls[0].oox = 0; a.cls[0].ntaps = a.KT;
         for (int t = 0; t < a.KT; ++t) a.cls[0].taps[t] = ConvTap{t / kernel_size, t % kernel_size, t};
-        if (y_split) return fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc: a split result is produced by the 3x3 halo kernel only");
+        if (y_split) return dry ? (int)P3D_ERR_UNSUPPORTED : fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc: a split result is produced by the 3x3 halo kernel only");
         a.fold = fold_batch(a, dtype);
         return launch_conv(a, dtype, s, workspace, workspace_bytes, query, x_split != 0);
     }
@@ -1626,7 +1643,7 @@ int p3d::conv2d_nhwc_run_io(const void* x, const void* w, void* y, int dtype, co
             count_launch(FAM_CONV);
             return check_launch("conv3x3_halo");
         }
-        if (y_split) return fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc: a split result is produced by the 3x3 halo kernel only");
+        if (y_split) return dry ? (int)P3D_ERR_UNSUPPORTED : fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc: a split result is produced by the 3x3 halo kernel only");
         a.fold = fold_batch(a, dtype);
         return launch_conv(a, dtype, s, workspace, workspace_bytes, query, x_split != 0);
     }
@@ -1654,7 +1671,7 @@ int p3d::conv2d_nhwc_run_io(const void* x, const void* w, void* y, int dtype, co
             return check_launch("convT_h2_f16");
         }
     }
-    if (y_split) return fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc: a split result is produced by the 3x3 halo kernel only");
+    if (y_split) return dry ? (int)P3D_ERR_UNSUPPORTED : fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc: a split result is produced by the 3x3 halo kernel only");
     return launch_conv(a, dtype, s, workspace, workspace_bytes, query, x_split != 0);
 }
 

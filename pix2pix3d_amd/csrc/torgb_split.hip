@@ -214,11 +214,13 @@ extern "C" int p3d_torgb_wide_split(const void* x_split, const void* wmod_split,
     if (blocks < 1) blocks = 1;
     hipStream_t s = (hipStream_t)stream;
     static std::atomic<uint64_t> done8{0}, done16{0};
+    // the reservation is made once per device and must cover every later call: the kernel's maximum (Co = 96), not this call's Co
+    constexpr int kLdsMax8 = 3 * (128 / 16) * 2 * 64 * 16, kLdsMax16 = 3 * (256 / 16) * 2 * 64 * 16;      // 48 KB, 96 KB
     if (ci == 128) {
-        if (reserve_lds_once((const void*)torgb_wide_split_kernel<8, 256>, lds, done8) != hipSuccess) return fail(P3D_ERR_LAUNCH, "torgb_wide_split: cannot reserve %d bytes of LDS", lds);
+        if (reserve_lds_once((const void*)torgb_wide_split_kernel<8, 256>, kLdsMax8, done8) != hipSuccess) return fail(P3D_ERR_LAUNCH, "torgb_wide_split: cannot reserve %d bytes of LDS", kLdsMax8);
         hipLaunchKernelGGL((torgb_wide_split_kernel<8, 256>), dim3(blocks, n_img), dim3(256), lds, s, a);
     } else {
-        if (reserve_lds_once((const void*)torgb_wide_split_kernel<16, 512>, lds, done16) != hipSuccess) return fail(P3D_ERR_LAUNCH, "torgb_wide_split: cannot reserve %d bytes of LDS", lds);
+        if (reserve_lds_once((const void*)torgb_wide_split_kernel<16, 512>, kLdsMax16, done16) != hipSuccess) return fail(P3D_ERR_LAUNCH, "torgb_wide_split: cannot reserve %d bytes of LDS", kLdsMax16);
         hipLaunchKernelGGL((torgb_wide_split_kernel<16, 512>), dim3(blocks, n_img), dim3(512), lds, s, a);
     }
     count_launch(FAM_CONV);

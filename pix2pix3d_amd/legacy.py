@@ -47,6 +47,8 @@ def load_network_pkl(f, force_fp16=False):
                 new = type(old)(*old.init_args, **kwargs).eval().requires_grad_(False)
                 misc.copy_params_and_buffers(old, new, require_all=True)
                 data[key] = new
+    from .torch_utils.ops import modconv          # a process that reloads networks must not be served weight forms derived from the old ones
+    modconv.invalidate_caches()
     return data
 
 

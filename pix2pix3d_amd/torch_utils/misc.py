@@ -116,6 +116,8 @@ def copy_params_and_buffers(src_module, dst_module, require_all=False, allow_mis
                 tensor.copy_(s).requires_grad_(tensor.requires_grad)
             elif not allow_mismatch:
                 raise AssertionError(f'shape mismatch for {name}: {tuple(s.shape)} vs {tuple(tensor.shape)}')
+    from .ops import modconv                      # derived weight forms (modulated / bf16x3 layouts) of the overwritten parameters must not survive
+    modconv.invalidate_caches()
 
 
 def check_ddp_consistency(module, ignore_regex=None):

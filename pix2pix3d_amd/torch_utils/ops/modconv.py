@@ -70,6 +70,7 @@ def _zeros_page(device):
         z = _zero_pages[device] = torch.zeros(256, dtype=torch.float32, device=device)
     return z
 _lib.register('p3d_torgb_nhwc_f16', ctypes.c_int, [_vp] * 5 + [_i32] * 4 + [_f32, _i32, _vp])
+_lib.register('p3d_conv2d_nhwc_bf16x3_io_plan', ctypes.c_int, [_i32] * 5 + [ctypes.c_int64, _i32, _i32, _i32, _i32, ctypes.POINTER(ctypes.c_int64)])
 _lib.register('p3d_conv2d_nhwc_bf16x3_io', ctypes.c_int, [_vp] * 7 + [_i32] * 5 + [ctypes.c_int64, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _vp, ctypes.c_int64, _vp])
 _lib.register('p3d_torgb_wide_split', ctypes.c_int, [_vp] * 6 + [_i32] * 5 + [_f32, _vp])
 _lib.register('p3d_fir4_bias_act_nhwc_split', ctypes.c_int, [_vp] * 3 + [_i32] * 9 + [_f32, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _vp])
@@ -297,6 +298,21 @@ def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None
     return y
 
 
+_io_plans = {}
+
+
+def _split_io_plan(*key):
+    """(y_split granted, split-K scratch bytes) of the route p3d_conv2d_nhwc_bf16x3_io takes for these sizes: asked once per geometry, so that a layer
+    whose grid cannot hand back a split result is launched once, with the flag and the scratch its route really uses."""
+    hit = _io_plans.get(key)
+    if hit is None:
+        nbytes = ctypes.c_int64(0)
+        granted = int(_lib.lib().p3d_conv2d_nhwc_bf16x3_io_plan(*key, ctypes.byref(nbytes)))
+        _lib.check(min(granted, 0), 'conv2d_nhwc_bf16x3_io_plan')
+        hit = _io_plans[key] = (granted, int(nbytes.value))
+    return hit
+
+
 def _conv2d_split_io(x, wmod, transposed, bias, noise, noise_strength, act, gain, clamp, down, out_split):
     """conv2d's bf16x3 form with the activations split on one or both sides (p3d_conv2d_nhwc_bf16x3_io)."""
     x_split = isinstance(x, SplitActs)
@@ -313,16 +329,12 @@ def _conv2d_split_io(x, wmod, transposed, bias, noise, noise_strength, act, gain
     nz = None if noise is None else noise.detach().float().contiguous()
     ns = None if noise is None else noise_strength.detach().float().reshape(1).contiguous()
     mode = 1 if transposed else (2 if down == 2 else 0)
-    nbytes = int(_lib.lib().p3d_conv2d_nhwc_workspace(DTYPE_F32_BF16X3, n, h, w, ci, co, stride, k, mode))
-    work = torch.empty([nbytes // 4], dtype=torch.float32, device=xt.device) if nbytes > 0 else None
-    want = bool(out_split) and co % 32 == 0 and k == 3 and mode == 0
+    y_split, nbytes = _split_io_plan(n, h, w, ci, co, stride, k, mode, int(x_split), int(bool(out_split) and co % 32 == 0 and k == 3 and mode == 0))
+    work = torch.empty([nbytes // 4], dtype=torch.float32, device=xt.device) if nbytes > 0 else None          # scratch of the route that will run, if it has any
     with _lib.kernel_timer('conv_bf16x3', xt):
-        for y_split in ((1, 0) if want else (0,)):
-            code = _lib.lib().p3d_conv2d_nhwc_bf16x3_io(_lib.ptr(xt), _lib.ptr(wmod), _lib.ptr(y), _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns), _lib.ptr(_zeros_page(xt.device)),
-                                                        n, h, w, ci, co, stride, k, mode, int(act), float(gain), float(clamp), int(x_split), y_split,
-                                                        _lib.ptr(work), nbytes, _lib.stream_of(xt))
-            if code != _lib.P3D_ERR_UNSUPPORTED or not y_split:
-                break
+        code = _lib.lib().p3d_conv2d_nhwc_bf16x3_io(_lib.ptr(xt), _lib.ptr(wmod), _lib.ptr(y), _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns), _lib.ptr(_zeros_page(xt.device)),
+                                                    n, h, w, ci, co, stride, k, mode, int(act), float(gain), float(clamp), int(x_split), y_split,
+                                                    _lib.ptr(work), nbytes, _lib.stream_of(xt))
     _lib.check(code, 'conv2d_nhwc_bf16x3_io')
     log = _lib.kernel_events.get('conv_flops')
     if log is not None:

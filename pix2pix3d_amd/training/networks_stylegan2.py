@@ -386,7 +386,10 @@ class SynthesisBlock(torch.nn.Module):
 
     _in_div = 2          # input resolution = resolution // _in_div (the NoUp variant in superresolution.py uses 1)
 
-    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, **layer_kwargs):
+    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, _split_ok=False, **layer_kwargs):
+        """``_split_ok`` (private, set by SynthesisNetwork.forward only): the returned ``x`` may be a modconv.SplitActs that only the next block of the
+        same network reads.  Every other caller — a feature extractor stepping through the blocks, a forward hook — gets the reference's contract: a
+        tensor."""
         del update_emas
         misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
         dtype, fmt, fused_modconv = _block_mode(self, ws, force_fp32, fused_modconv)
@@ -406,7 +409,7 @@ class SynthesisBlock(torch.nn.Module):
         if self.in_channels != 0 and self.architecture != 'resnet':
             # bf16x3 device inference: x stays in the matrix cores' (hi, lo) layout between the layers whose kernels read it (modconv.SplitActs):
             # conv0's result feeds conv1; conv1's feeds this block's ToRGB and the next block's conv0 (a consumer that cannot read it calls dense())
-            keep_split = (dtype == torch.float32 and fmt == torch.channels_last and fused_modconv is True and ws.is_cuda and not torch.is_grad_enabled()
+            keep_split = (_split_ok and dtype == torch.float32 and fmt == torch.channels_last and fused_modconv is True and ws.is_cuda and not torch.is_grad_enabled()
                           and self.conv1.out_channels % 32 == 0 and layer_kwargs.get('noise_mode', 'random') != 'random' and self.img_channels > 8
                           and modconv.accepts_split_input(ws.shape[0], self.conv1.out_channels, self.resolution ** 2, 1))
             x = self.conv0(x, per_layer[0], out_split=keep_split, **conv_kwargs)
@@ -567,8 +570,10 @@ class SynthesisNetwork(torch.nn.Module):
         planned = self._prefetch(block_ws, block_kwargs)
         x = img = None
         try:
+            hooked = bool(torch.nn.modules.module._global_forward_hooks)
             for res, cur in zip(self.block_resolutions, block_ws):
-                x, img = getattr(self, f'b{res}')(x, img, cur, **block_kwargs)
+                block = getattr(self, f'b{res}')              # x is private to this loop unless somebody hooked a block: then it stays a tensor
+                x, img = block(x, img, cur, _split_ok=not (hooked or block._forward_hooks), **block_kwargs)
         finally:
             if planned:
                 finish_prefetch(ws.device)

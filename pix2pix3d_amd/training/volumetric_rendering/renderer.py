@@ -563,6 +563,7 @@ class _FusedRenderFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.autograd.function.once_differentiable          # the device kernels are not differentiable: a double backward must raise, not return zeros
     def backward(ctx, g_feat, g_depth, g_wsum):
         u_c, u_f, planes, ray_o, ray_d = ctx.saved_tensors
         params = [p for p in ctx.decoder.parameters()]
@@ -668,6 +669,7 @@ class _FusedPointsFn(torch.autograd.Function):
         return rgb, sigma
 
     @staticmethod
+    @torch.autograd.function.once_differentiable          # the device kernels are not differentiable: a double backward must raise, not return zeros
     def backward(ctx, g_rgb, g_sigma):
         planes, coordinates = ctx.saved_tensors
         backward_calls['points'] += 1

@@ -160,3 +160,17 @@ def test_tape_matches_the_compositing_backward_oracle(hip_lib, name):
     assert np.abs(tape[..., 0] - det['z_all']).max() < 2e-6
     assert rel_err(tape[..., 1], cw) < 2e-4
     assert rel_err(tape[..., 2], d_sig) < 2e-3
+
+
+def test_double_backward_through_the_fused_point_queries_raises(hip_lib):
+    """The fused backwards call device kernels autograd cannot see through: a ``create_graph=True`` gradient (a path-length or R1-style penalty on
+    G.sample_mixed) must raise on the second differentiation instead of silently contributing zeros."""
+    R, dec, opts, planes, _, _ = _setup('seg')
+    planes = planes.clone().requires_grad_(True)
+    torch.manual_seed(3)
+    xyz = (torch.rand(planes.shape[0], 256, 3, device='cuda') - 0.5) * float(opts.get('box_warp', 1))
+    rgb, sigma = R._FusedPointsFn.apply(dec, opts, xyz, planes, *dec.parameters())
+    g_planes, = torch.autograd.grad(sigma.sum(), [planes], create_graph=True)           # only sigma carries a gradient (g_rgb None), two nets
+    assert g_planes.shape == planes.shape and float(g_planes.abs().max()) > 0
+    with pytest.raises(RuntimeError, match='once_differentiable|differentiated twice|does not require grad'):
+        g_planes.square().sum().backward()

@@ -124,6 +124,36 @@ def test_wide_torgb_with_the_skip_image_in_one_launch(hip_lib, ci, co, h, w, n, 
 
 
 @pytest.mark.gpu
+def test_wide_torgb_narrow_output_first_then_wide_in_a_fresh_process(hip_lib):
+    """The kernel's dynamic-LDS limit is reserved once per device: a process whose FIRST call is the narrow form (Ci 256, Co 32: 32 KB) must still
+    be able to launch the widest one (Co 96: 96 KB) afterwards.  Needs its own process — in this one the order of the tests above decides."""
+    import os, subprocess, sys
+    code = (
+        "import torch\n"
+        "from pix2pix3d_amd.torch_utils.ops import modconv\n"
+        "def run(ci, co):\n"
+        "    torch.manual_seed(co)\n"
+        "    x = torch.randn(1, ci, 16, 64, device='cuda').contiguous(memory_format=torch.channels_last)\n"
+        "    v = x.cpu().permute(0, 2, 3, 1).reshape(1, 16, 64, ci // 32, 32)\n"
+        "    hi = v.to(torch.bfloat16); lo = (v - hi.float()).to(torch.bfloat16)\n"
+        "    rows = torch.stack([hi, lo], dim=-2).reshape(1, 16, 64, ci // 32, 64).view(torch.float32).reshape(1, 16, 64, ci).permute(0, 3, 1, 2)\n"
+        "    xs = modconv.SplitActs(rows.contiguous(memory_format=torch.channels_last).cuda())\n"
+        "    w = torch.randn(co, ci, 1, 1, device='cuda'); s = (torch.randn(1, ci, device='cuda') + 1) / ci ** 0.5; b = torch.randn(co, device='cuda')\n"
+        "    with torch.no_grad():\n"
+        "        assert modconv.torgb_wide_skip_supported(xs, w, None, None)\n"
+        "        got = modconv.torgb_wide_skip(xs, w, s, b, 256.0, None, None)\n"
+        "    ref = (torch.einsum('oc,nc,nchw->nohw', w.reshape(co, ci).double(), s.double(), xs.dense().double()) + b.double().view(1, co, 1, 1)).clamp(-256, 256)\n"
+        "    e = float((got.double() - ref).abs().max() / ref.abs().max())\n"
+        "    assert e < 1e-5, (ci, co, e)\n"
+        "for ci, co in ((128, 32), (128, 96), (256, 32), (256, 64), (256, 96)):\n"
+        "    run(ci, co)\n"
+        "torch.cuda.synchronize(); print('ORDER_OK')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and 'ORDER_OK' in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('batch', [4, 1])
 def test_generator_outputs_do_not_change_with_split_activations(hip_lib, batch):
     """G.synthesis at the benchmark's size (seg2cat, batch 4, 128^2 rays) with the activations of the >= 64^2 backbone blocks kept split vs.
