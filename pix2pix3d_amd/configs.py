@@ -103,3 +103,25 @@ def variant_kwargs(which):
 
 
 VARIANTS = ('two_backbone', 'with_bg', 'with_bg_edge', 'mask_entangled', 'edge_entangled')
+
+
+def small_train_kwargs():
+    """A training triple small enough for the CPU (128^2 label maps, 64^2 rays x 12+12 samples, 16-channel backbone, 2X SR heads): the
+    generator class, label-map mapping network and discriminators that train_scripts/afhq_seg.sh selects (train.py:374-380, 509-512,
+    528-531; training_loop.py:299-308), scaled down.  Returns (G kwargs, D kwargs, D_semantic kwargs).  Used by the golden recorder of
+    the training phases (reference modules) and by the tests that replay them (this package's modules)."""
+    g = generator_kwargs('edge2car', cbase=1024, cmax=16, depth=(12, 12))
+    g.update(semantic_channels=6, data_type='seg',
+             mapping_kwargs=dict(class_name='training.triplane_cond.MaskMappingNetwork_disentangle', in_resolution=128, in_channels=6, num_layers=2))
+    d = dict(class_name='training.dual_discriminator.DualDiscriminator', c_dim=25, img_resolution=128, img_channels=3, channel_base=1024, channel_max=32,
+             num_fp16_res=0, conv_clamp=None, disc_c_noise=0, block_kwargs=dict(freeze_layers=0), mapping_kwargs={}, epilogue_kwargs=dict(mbstd_group_size=2))
+    ds = dict(copy.deepcopy(d), img_channels=3 + 6)                   # training_loop.py:308: image + label channels
+    return g, d, ds
+
+
+# Pix2Pix3DLoss arguments of train_scripts/afhq_seg.sh (train.py:331-341, 469-483, 496-501: --resume disables the blur and the swapping
+# ramp), with the LPIPS weight as the script sets it
+AFHQ_SEG_LOSS = dict(r1_gamma=5, blur_init_sigma=0, blur_fade_kimg=200.0, gpc_reg_prob=0.5, gpc_reg_fade_kimg=0, dual_discrimination=True,
+                     neural_rendering_resolution_initial=128, neural_rendering_resolution_final=None, neural_rendering_resolution_fade_kimg=1000,
+                     filter_mode='antialiased', style_mixing_prob=0, random_c_prob=0.5, lambda_l1=0, lambda_lpips=1, lambda_D_semantic=0.1,
+                     seg_weight=0, edge_weight=2, only_raw_recons=True, silhouette_loss=False, lambda_cross_view=1e-4)

@@ -3,7 +3,7 @@
 Run in the authoring container only (it needs the read-only checkout at /root/reference, which does
 not exist on the GPU box):
 
-    python tests/golden/make_golden.py [group ...]      # groups: ops renderer semrenderer model model_full flrelu train train_full greg checkpoint variants discriminator api srheads architectures helpers
+    python tests/golden/make_golden.py [group ...]      # groups: ops renderer semrenderer model model_full flrelu train train_full greg checkpoint variants discriminator api srheads architectures helpers loss_phases discriminator_full
 
 The reference and this repo own the same top-level module names, so this script must never import
 ``pix2pix3d_amd``; it puts /root/reference first on sys.path and imports the reference's modules
@@ -959,6 +959,46 @@ def group_helpers():
 
 
 GROUPS['helpers'] = group_helpers
+
+
+# ---------------------------------------------------------------------------------------------------------
+def group_loss_phases():
+    """The reference's own ``training/loss.py::Pix2Pix3DLoss.accumulate_gradients`` (loss.py:509-1003) on a small G / D / D_semantic triple, every
+    phase of training_loop.py:360-373, on the CPU: per-phase gradient norms of every parameter, heads of a few gradients and every statistic the
+    loss reports (scores, reconstruction terms, cross-view loss, R1 penalties).  ``lpips`` is loss_phase_driver.py's stand-in; random draws come from det_rng.py.
+    Three configurations: the image-pose branch (random_c_prob 0), the random-pose branch (random_c_prob 1: Gmain / Dmain / D_semanticmain), and the
+    image-pose branch with the discriminator blur on (blur_sigma 1.5: a 9-tap separable filter on D's input, loss.py:457-466)."""
+    import dnnlib
+    configs = _load_by_path('p3d_configs', os.path.join(os.path.dirname(os.path.dirname(HERE)), 'pix2pix3d_amd', 'configs.py'))
+    weights = _load_by_path('p3d_weights', os.path.join(HERE, 'weights.py'))
+    drv = _load_by_path('p3d_loss_phase_driver', os.path.join(HERE, 'loss_phase_driver.py'))
+    drv.install_lpips_stub()
+    from training import loss as L
+    from torch_utils import training_stats
+    sink, training_stats.report = drv.make_sink()
+    gkw, dkw, dskw = configs.small_train_kwargs()
+    torch.manual_seed(0)
+    G = dnnlib.util.construct_class_by_name(**gkw).train().requires_grad_(False)
+    D = dnnlib.util.construct_class_by_name(**dkw).train().requires_grad_(False)
+    Ds = dnnlib.util.construct_class_by_name(**dskw).train().requires_grad_(False)
+    drv.seed_networks(weights, G, D, Ds)
+    nets = dict(G=G, D=D, D_semantic=Ds)
+    batch, gen_z, gen_c = drv.loss_phase_inputs(configs)
+    arrays = dict(gen_z=gen_z, gen_c=gen_c, image=batch['image'], mask=batch['mask'], pose=batch['pose'])
+    import time
+    for tag, extra, phases, nimg in drv.RUNS:
+        loss = L.Pix2Pix3DLoss(device=torch.device('cpu'), G=G, D=D, D_semantic=Ds, augment_pipe=None, **dict(drv.LOSS_KW, **extra))
+        t0 = time.time()
+        res = drv.run_loss_phases(loss, nets, batch, gen_z, gen_c, sink, phases=phases, cur_nimg=nimg)
+        print(tag, f'{time.time() - t0:.1f} s')
+        for phase, (names, norms, grads, stats, log) in res.items():
+            key = f'{tag}.{phase}'
+            arrays.update(drv.phase_record(key, names, norms, grads, stats, log))
+            print(' ', key, 'grads', int((norms >= 0).sum()), '/', len(names), 'max norm', float(norms.max()), 'draws', len(log), {k: round(float(np.mean(v)), 5) for k, v in stats.items()})
+    save('loss_phases', **arrays)
+
+
+GROUPS['loss_phases'] = group_loss_phases
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GROUPS)

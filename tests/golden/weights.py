@@ -40,3 +40,15 @@ def seed_module(module, seed=0):
             if v is not None:
                 t.copy_(v.to(t.device, t.dtype))
     return {k: v.detach() for k, v in module.state_dict().items()}
+
+
+def seed_discriminator(module, seed=0):
+    """seed_module for a discriminator, with its label-mapping network's weights at the scale their lr_multiplier of 0.01 implies (stored = effective /
+    0.01; the '.mapping.fc' rule above only matches names with a prefix, i.e. the generator's): logits and R1 penalties come out O(1) instead of 1e-3 /
+    1e-9.  (The round-2 golden 'discriminator' predates this and keeps plain seed_module.)"""
+    sd = seed_module(module, seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if name.startswith('mapping.fc') and name.endswith('.weight'):
+                p.mul_(100.0)
+    return sd

@@ -28,6 +28,8 @@ cls = dnnlib.util.get_obj_by_name('training.superresolution.SuperresolutionHybri
 assert cls.__module__.startswith('pix2pix3d_amd.')
 import legacy                                       # applications/generate_samples.py:16
 assert legacy.load_network_pkl.__module__ == 'pix2pix3d_amd.legacy'
+cls = dnnlib.util.get_obj_by_name('training.loss.Pix2Pix3DLoss')           # train.py:288; no checkout registered: the restated phases serve the name
+assert cls.__module__ == 'pix2pix3d_amd.training.loss'
 print('ok')
 ''' % ROOT
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)

@@ -1,0 +1,143 @@
+"""Every training phase of training_loop.py:360-373 against gradients recorded from the reference's own ``training/loss.py``
+(tests/golden/make_golden.py, group ``loss_phases``: reference loss + reference modules, CPU, lpips replaced by a stand-in):
+
+  * ``test_reference_loss_runs_unchanged_on_the_mirrors``: the reference's loss.py itself, imported from the checkout, driving this
+    package's G / D / D_semantic through ``dropin.install(reference_root=...)`` — the consumer-level proof of "drops in unchanged"
+    (skipped where no checkout exists: the GPU box);
+  * the others: this package's restatement (pix2pix3d_amd/training/loss.py — what bench.py --train-step times), on the CPU and on the
+    device with every convolution on libp3d_hip.so.
+
+Compared per phase: the gradient norm of EVERY parameter of the phase's network (and that exactly the same parameters have none), the first 64
+entries of four gradients, every statistic the loss reports (scores, reconstruction / cross-view terms, R1 penalties) and the sequence of
+random draws (kind + shape) the phase made.
+"""
+import importlib.util
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+def _by_path(name, fname):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(GOLD, fname))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    return mod
+
+
+drv = _by_path('p3d_loss_phase_driver', 'loss_phase_driver.py')
+weights = _by_path('p3d_weights', 'weights.py')
+
+
+def compare_phase(g, key, names, norms, grads, stats, log, tol, draws=True):
+    assert names == list(g[key + '.grad_names']), key
+    ref = g[key + '.grad_norms']
+    assert np.array_equal(norms < 0, ref < 0), (key, 'parameters without a gradient differ', [n for n, a, b in zip(names, norms, ref) if (a < 0) != (b < 0)])
+    have = ref >= 0
+    scale = float(ref[have].max())
+    err = np.abs(norms[have] - ref[have])
+    worst = int(np.argmax(err / np.maximum(ref[have], 1e-3 * scale)))
+    assert err.max() < tol * scale, (key, 'largest norm error', float(err.max()), scale)
+    assert np.all(err <= 10 * tol * np.maximum(ref[have], 1e-3 * scale)), (key, np.array(names)[have][worst], float(norms[have][worst]), float(ref[have][worst]))
+    for j, nm in enumerate(g[key + '.head_names'].tolist()):
+        a, b = grads[nm].detach().float().cpu().reshape(-1)[:64].numpy(), g[f'{key}.h{j}']
+        assert np.abs(a - b).max() < tol * max(np.abs(b).max(), 1e-3 * float(ref[names.index(nm)]), 1e-12), (key, nm)
+    assert sorted(stats) == list(g[key + '.stat_names']), (key, sorted(stats))
+    for nm, want in zip(g[key + '.stat_names'].tolist(), g[key + '.stat_means']):
+        got = float(np.mean(stats[nm]))
+        assert abs(got - want) < tol * max(abs(want), 1.0 if 'signs' in nm else 1e-2), (key, nm, got, want)
+    if draws:
+        assert [f'{k}{list(s)}' for k, s in log] == list(g[key + '.draws']), (key, 'the phase drew other random tensors than the reference')
+
+
+def _networks(device):
+    from pix2pix3d_amd import configs, dnnlib
+    gkw, dkw, dskw = configs.small_train_kwargs()
+    torch.manual_seed(0)
+    nets = [dnnlib.util.construct_class_by_name(**kw).train().requires_grad_(False) for kw in (gkw, dkw, dskw)]
+    drv.seed_networks(weights, *nets)
+    return configs, dict(zip(('G', 'D', 'D_semantic'), [n.to(device) for n in nets]))
+
+
+def _replay(device, tol, tags=('img', 'rnd', 'blur')):
+    from pix2pix3d_amd.training.loss import Pix2Pix3DLoss
+    g = load_golden('loss_phases')
+    configs, nets = _networks(device)
+    batch, gen_z, gen_c = drv.loss_phase_inputs(configs, device=device)
+    assert np.array_equal(batch['mask'].cpu().numpy(), g['mask']) and np.allclose(gen_z.cpu().numpy(), g['gen_z'])
+    for tag, extra, phases, nimg in drv.RUNS:
+        if tag not in tags:
+            continue
+        sink, report = drv.make_sink()
+        loss = Pix2Pix3DLoss(device=torch.device(device), G=nets['G'], D=nets['D'], D_semantic=nets['D_semantic'], augment_pipe=None,
+                             lpips=drv.lpips_standin, report=report, **dict(drv.LOSS_KW, **extra))
+        res = drv.run_loss_phases(loss, nets, batch, gen_z, gen_c, sink, phases=phases, cur_nimg=nimg)
+        for phase, (names, norms, grads, stats, log) in res.items():
+            compare_phase(g, f'{tag}.{phase}', names, norms, grads, stats, log, tol)
+    return nets
+
+
+def test_restated_phases_match_the_reference_loss_on_cpu():
+    _replay('cpu', 2e-4)
+
+
+def test_reference_loss_runs_unchanged_on_the_mirrors():
+    """training/loss.py of the checkout, not a line changed, on top of dropin.install(): its imports (torch_utils.ops.*, training.dual_discriminator,
+    training.loss_utils, torch_utils.training_stats) resolve to the mirrors where they exist and to the checkout's files where they do not."""
+    ref = os.environ.get('P3D_REFERENCE', '/root/reference')
+    if not os.path.isfile(os.path.join(ref, 'training', 'loss.py')):
+        pytest.skip('no reference checkout here (the GPU box): the restated phases are compared instead')
+    code = r'''
+import sys, os
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+import numpy as np, torch
+torch.set_num_threads(8)
+from pix2pix3d_amd import dropin
+dropin.install(reference_root=%(ref)r)
+import test_loss_phases as T
+T.drv.install_lpips_stub()
+from training import loss as L                                   # the checkout's file
+from torch_utils import training_stats                           # the checkout's file
+assert os.path.samefile(L.__file__, os.path.join(%(ref)r, 'training', 'loss.py')), L.__file__
+import training.dual_discriminator, torch_utils.ops.conv2d_gradfix
+assert L.filtered_resizing.__module__.startswith('pix2pix3d_amd.') and L.conv2d_gradfix.__name__.startswith('pix2pix3d_amd.')
+g = T.load_golden('loss_phases')
+configs, nets = T._networks('cpu')
+assert type(nets['G']).__module__.startswith('pix2pix3d_amd.')
+batch, gen_z, gen_c = T.drv.loss_phase_inputs(configs)
+sink, training_stats.report = T.drv.make_sink()
+for tag, extra, phases, nimg in T.drv.RUNS:
+    loss = L.Pix2Pix3DLoss(device=torch.device('cpu'), G=nets['G'], D=nets['D'], D_semantic=nets['D_semantic'], augment_pipe=None, **dict(T.drv.LOSS_KW, **extra))
+    res = T.drv.run_loss_phases(loss, nets, batch, gen_z, gen_c, sink, phases=phases, cur_nimg=nimg)
+    for phase, (names, norms, grads, stats, log) in res.items():
+        T.compare_phase(g, f'{tag}.{phase}', names, norms, grads, stats, log, 2e-4)
+print('PHASES_OK')
+''' % dict(root=ROOT, ref=ref)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=900, cwd='/tmp')
+    assert r.returncode == 0 and 'PHASES_OK' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_restated_phases_match_the_reference_loss_on_the_device(hip_lib):
+    """The same six phases on the device as the training loop runs them (conv2d_gradfix.enabled, training_loop.py:281): every convolution, data
+    gradient, weight gradient and the R1 double backward on libp3d_hip.so, the renderer's forward and backward on the fused kernels."""
+    from pix2pix3d_amd import _lib
+    from pix2pix3d_amd.torch_utils.ops import conv2d_gradfix
+    from pix2pix3d_amd.training.volumetric_rendering import renderer as rmod
+    prev, conv2d_gradfix.enabled = conv2d_gradfix.enabled, True
+    c0, b0, r0 = dict(conv2d_gradfix.native_calls), dict(rmod.backward_calls), _lib.launch_count('render')
+    try:
+        _replay('cuda', 2e-3)
+    finally:
+        conv2d_gradfix.enabled = prev
+    assert conv2d_gradfix.native_calls['aten'] == c0['aten'], conv2d_gradfix.native_calls
+    assert conv2d_gradfix.native_calls['weight_grad'] > c0['weight_grad'] + 50
+    assert rmod.backward_calls['fused'] >= b0['fused'] + 2 * 3 and rmod.backward_calls['replay'] == b0['replay']       # Gmain: two differentiated renders, three runs
+    assert rmod.backward_calls['points'] >= b0['points'] + 1 and _lib.launch_count('render') > r0
