@@ -18,8 +18,9 @@ the PMC passes; ``exact_fp32`` = the same timed loop with every bf16x3 switch of
 reference's own arithmetic class, training_loop.py:278-280); ``cpu_baseline`` (the REFERENCE itself in a child
 process when its checkout is reachable — ``kind: "reference"`` — else the CPU oracle, a port of the reference's force_fp32 CPU
 path — ``kind: "port"``; a bounded sample: batch 1, same resolution and sample counts) and ``train_step`` (one training
-iteration of BASELINE config 3 on the same GPUs: the four phases of training_loop.py — Gmain, Greg (density regularisation), Dmain, Dreg (R1)
-— each with its flat gradient all-reduce over RCCL and its Adam step, then the G_ema update).
+iteration of BASELINE config 3 on the same GPUs: the SIX phases of training_loop.py:360-373 for train_scripts/afhq_seg.sh — Gmain (with the D_semantic
+term and the cross-view block: four generator passes), Greg (density regularisation), Dmain, Dreg (R1), D_semanticmain, D_semanticreg — each driven
+through Pix2Pix3DLoss.accumulate_gradients, followed by its flat gradient all-reduce over RCCL and its Adam step, then the G_ema update).
 """
 import argparse
 import json
@@ -55,7 +56,7 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--miopen-find', action='store_true', help='let MIOpen benchmark its solvers for the vendor-library convs (slow warm-up)')
     p.add_argument('--cpu-reps', type=int, default=6, help='CPU baseline runs per thread count: 1 warm-up + (n - 1) timed (median reported; SURVEY 8(d): >= 5)')
-    p.add_argument('--train-step', action='store_true', help='time training iterations of BASELINE config 3 (G pass + D pass with R1 + gradient all-reduce) instead of inference')
+    p.add_argument('--train-step', action='store_true', help='time training iterations of BASELINE config 3 (all six phases of training_loop.py, gradient all-reduce + Adam per phase) instead of inference')
     p.add_argument('--no-train-step', action='store_true', help='skip the short train_step extra of the default run')
     p.add_argument('--no-exact-fp32', action='store_true', help='skip the second timed loop with the bf16x3 switches off')
     p.add_argument('--train-nrr', type=int, default=128, help='neural rendering resolution of the training passes (train.py: 128 for the 512^2 configs)')
@@ -155,119 +156,81 @@ def pmc_record(args, nrr, exact=False):
 
 
 G_REG_INTERVAL, D_REG_INTERVAL = 4, 16        # train.py:239, 466 (--density_reg_every) and training_loop.py:249: the lazy-regularisation schedule
-R1_GAMMA = 10.0                               # the --gamma of the shipped afhq script (train_scripts/afhq_seg.sh)
+PHASE_ORDER = ('Gmain', 'Greg', 'Dmain', 'Dreg', 'D_semanticmain', 'D_semanticreg')
 
 
 def train_setup(args, device, world):
-    """BASELINE config 3 per GPU: seg2cat generator in training mode (unfused modulation, fp16 SR heads) and the dual discriminator
-    (fp16 top blocks, conv_clamp 256, train.py:289-318, 381-387, 509-512), batch 4, 128^2 rays x 48+48 samples; G_ema; one Adam per
-    network with the lazy-regularisation correction of training_loop.py:360-373."""
+    """BASELINE config 3 per GPU, as train_scripts/afhq_seg.sh + train.py assemble it: seg2cat generator in training mode (unfused modulation, fp16 SR
+    heads), the dual discriminator D and — ``--dis_mask=True`` — the label-aware D_semantic on image + 6 label channels (fp16 top blocks, conv_clamp 256;
+    train.py:289-318, 381-387, 509-512, 528-531; training_loop.py:299-308), batch 4, 128^2 rays x 48+48 samples; G_ema; one Adam per network with the
+    lazy-regularisation correction of training_loop.py:360-373; the loss with the script's weights (configs.AFHQ_SEG_LOSS) minus LPIPS."""
     import copy
     from pix2pix3d_amd import configs, dnnlib
+    from pix2pix3d_amd.training.loss import Pix2Pix3DLoss
     kw = configs.generator_kwargs(args.dataset, depth=(48, 48))
     rk = kw['rendering_kwargs']
     info = configs.dataset_info(args.dataset)
     torch.manual_seed(0)
     G = dnnlib.util.construct_class_by_name(**kw).to(device).train().requires_grad_(False)
-    D = dnnlib.util.construct_class_by_name(class_name='training.dual_discriminator.DualDiscriminator', c_dim=25, img_resolution=info['res'], img_channels=3,
-                                            channel_base=32768, channel_max=512, num_fp16_res=4, conv_clamp=256, disc_c_noise=0,
-                                            block_kwargs=dict(freeze_layers=0), mapping_kwargs={}, epilogue_kwargs=dict(mbstd_group_size=4)).to(device).train().requires_grad_(False)
+    d_kw = dict(class_name='training.dual_discriminator.DualDiscriminator', c_dim=25, img_resolution=info['res'], channel_base=32768, channel_max=512, num_fp16_res=4,
+                conv_clamp=256, disc_c_noise=0, block_kwargs=dict(freeze_layers=0), mapping_kwargs={}, epilogue_kwargs=dict(mbstd_group_size=4))
+    D = dnnlib.util.construct_class_by_name(img_channels=3, **d_kw).to(device).train().requires_grad_(False)
+    D_sem = dnnlib.util.construct_class_by_name(img_channels=3 + info['sem'], **d_kw).to(device).train().requires_grad_(False)      # training_loop.py:308
     G_ema = copy.deepcopy(G).eval()
-    opts = {}
-    for name, module, lr, interval in (('G', G, 0.0025, G_REG_INTERVAL), ('D', D, 0.002, D_REG_INTERVAL)):
+    nets = {'G': G, 'D': D, 'D_semantic': D_sem}
+    phases = []                                                        # training_loop.py:360-373
+    for name, lr, interval in (('G', 0.0025, G_REG_INTERVAL), ('D', 0.002, D_REG_INTERVAL), ('D_semantic', 0.002, D_REG_INTERVAL)):
         mb = interval / (interval + 1)
-        opts[name] = torch.optim.Adam(module.parameters(), lr=lr * mb, betas=[0 ** mb, 0.99 ** mb], eps=1e-8)
+        opt = torch.optim.Adam(nets[name].parameters(), lr=lr * mb, betas=[0 ** mb, 0.99 ** mb], eps=1e-8)
+        phases += [dict(name=name + 'main', module=nets[name], opt=opt, interval=1), dict(name=name + 'reg', module=nets[name], opt=opt, interval=interval)]
     n = args.batch
     g = torch.Generator().manual_seed(99 + int(os.environ.get('RANK', 0)))
-    z = torch.randn(n, 512, generator=g).to(device)
-    mask = torch.randint(0, info['sem'], [n, 1, info['res'], info['res']], generator=g).to(device) if info['data_type'] == 'seg' else \
-        (torch.rand([n, 1, info['res'], info['res']], generator=g) * 2 - 1).to(device)
-    c = torch.tensor(np.stack([configs.orbit_camera(7 * k + 3, radius=rk['avg_camera_radius'], pivot=rk['avg_camera_pivot']) for k in range(n)]), dtype=torch.float32).to(device)
-    real = {'image': torch.randn(n, 3, info['res'], info['res'], generator=g).to(device), 'image_raw': torch.randn(n, 3, args.train_nrr, args.train_nrr, generator=g).to(device)}
-    return dict(G=G, D=D, G_ema=G_ema, opts=opts, z=z, mask=mask, c=c, real=real, rk=rk, seg=info['data_type'] == 'seg', nrr=args.train_nrr, world=world)
+    mask = torch.randint(0, info['sem'], [n, 1, info['res'], info['res']], generator=g, dtype=torch.uint8) if info['data_type'] == 'seg' else \
+        torch.rand([n, 1, info['res'], info['res']], generator=g) * 2 - 1
+
+    def cams(k0):
+        return torch.tensor(np.stack([configs.orbit_camera(7 * k + k0, radius=rk['avg_camera_radius'], pivot=rk['avg_camera_pivot']) for k in range(n)]), dtype=torch.float32).to(device)
+    batch = {'image': (torch.rand(n, 3, info['res'], info['res'], generator=g) * 2 - 1).to(device), 'mask': mask.to(device), 'pose': cams(3)}
+    for i, ph in enumerate(phases):                                    # training_loop.py:501-507: every phase gets its own z and gen_c
+        ph['gen_z'], ph['gen_c'] = torch.randn(n, 512, generator=g).to(device), cams(11 + 5 * i)
+    loss_kw = dict(configs.AFHQ_SEG_LOSS, lambda_lpips=0, neural_rendering_resolution_initial=args.train_nrr)
+    loss = Pix2Pix3DLoss(device=device, G=G, D=D, D_semantic=D_sem, augment_pipe=None, lpips=None, **loss_kw)
+    return dict(G=G, G_ema=G_ema, nets=nets, phases=phases, loss=loss, batch=batch, world=world, flat={})
 
 
-def _finish_phase(module, opt, world):
+def _finish_phase(st, ph):
     """training_loop.py:528-543: flat gradient all-reduce of the phase's module, then its optimizer step."""
     from pix2pix3d_amd import dp
-    flat = dp.allreduce_gradients(module, world_size=world)
-    opt.step()
+    flat = dp.allreduce_gradients(ph['module'], world_size=st['world'], out=st['flat'])
+    ph['opt'].step()
     return flat.numel() * 4 if flat is not None else 0
 
 
-def train_iteration(st, timers, phases=('Gmain', 'Greg', 'Dmain', 'Dreg')):
-    """One iteration with EVERY phase of training_loop.py:487-543 (i.e. what the loop does on an iteration where both lazy regularisers
-    fire): Gmain (loss.py:557-656: mapping + synthesis at 128^2 rays, D on the generated pair, adversarial + image / label-map
-    reconstruction terms; the LPIPS network is not part of this path and is left out), Greg (loss.py:681-706: density regularisation through
-    G.sample_mixed on 2 x 1000 points), Dmain (loss.py:827-869: D on generated and on real images), Dreg (loss.py:871-887: R1 with the
-    double backward), each followed by its flat gradient all-reduce + Adam step; then the G_ema update (training_loop.py:545-557).
-    ``timers``: dict of lists of events, one mark after every phase."""
-    from pix2pix3d_amd.torch_utils.ops import conv2d_gradfix
-    F = torch.nn.functional
-    G, D, c, real, rk, world = st['G'], st['D'], st['c'], st['real'], st['rk'], st['world']
-    batch = {'mask': st['mask'], 'pose': c}
+def train_iteration(st, timers, only=None):
+    """One iteration with EVERY phase of training_loop.py:487-543 (what the loop does on an iteration where both lazy regularisers fire), driven exactly
+    as the loop drives them: zero_grad, requires_grad_(True), ``loss.accumulate_gradients(phase, batch, gen_z, gen_c, gain = interval, cur_nimg)``
+    (pix2pix3d_amd/training/loss.py, the restatement of loss.py:509-1003 pinned by tests/test_loss_phases.py), requires_grad_(False), flat gradient
+    all-reduce, Adam step — for Gmain (incl. the D_semantic term and the cross-view block: four generator passes), Greg, Dmain, Dreg, D_semanticmain,
+    D_semanticreg; then the G_ema update (training_loop.py:545-557).  ``timers``: dict of lists of events, one mark after every phase."""
     sizes = {}
 
     def mark(key):
         e = torch.cuda.Event(enable_timing=True); e.record()
         timers.setdefault(key, []).append(e)
     mark('t0')
-    if 'Gmain' in phases:
-        G.requires_grad_(True); st['opts']['G'].zero_grad(set_to_none=True)
-        ws = G.mapping(st['z'], c, batch, update_emas=False)           # label-map Encoder + MLP: every run_G of the loop starts here (loss.py:440)
-        out = G.synthesis(ws, c, neural_rendering_resolution=st['nrr'])      # noise_mode defaults to 'random', as run_G leaves it
-        logits = D({'image': out['image'], 'image_raw': out['image_raw']}, c)
-        loss = F.softplus(-logits).mean()
-        loss = loss + F.smooth_l1_loss(out['image'].float(), real['image']) + F.smooth_l1_loss(out['image_raw'], real['image_raw'])
-        if st['seg']:                                                      # cross_entropy2d on the label map and its raw rendering (loss.py:609-617)
-            tgt = st['mask'].squeeze(1).long()
-            loss = loss + F.cross_entropy(out['semantic'].float(), tgt) + F.cross_entropy(out['semantic_raw'], F.interpolate(st['mask'].float(), size=st['nrr'], mode='nearest').squeeze(1).long())
-        else:
-            loss = loss + F.smooth_l1_loss(out['semantic'].float(), st['mask']) + F.smooth_l1_loss(out['semantic_raw'], F.interpolate(st['mask'], size=st['nrr'], mode='nearest'))
-        loss.backward()
-        sizes['G'] = _finish_phase(G, st['opts']['G'], world)
-        G.requires_grad_(False)
-        del out, logits, loss
-    mark('Gmain')
-    if 'Greg' in phases:
-        G.requires_grad_(True); st['opts']['G'].zero_grad(set_to_none=True)
-        ws = G.mapping(st['z'], c, batch, update_emas=False)
-        initial = torch.rand((ws.shape[0], 1000, 3), device=ws.device) * 2 - 1
-        coords = torch.cat([initial, initial + torch.randn_like(initial) * rk['density_reg_p_dist']], dim=1)
-        sigma = G.sample_mixed(coords, torch.randn_like(coords), ws, update_emas=False)['sigma']
-        half = sigma.shape[1] // 2
-        (F.l1_loss(sigma[:, :half], sigma[:, half:]) * rk['density_reg'] * G_REG_INTERVAL).backward()      # gain = the phase interval (training_loop.py:519)
-        sizes['Greg'] = _finish_phase(G, st['opts']['G'], world)
-        G.requires_grad_(False)
-        del sigma
-    mark('Greg')
-    if 'Dmain' in phases:
-        D.requires_grad_(True); st['opts']['D'].zero_grad(set_to_none=True)
-        with torch.no_grad():                                              # G.requires_grad_(False) in the loop: no graph through the generator
-            ws = G.mapping(st['z'], c, batch, update_emas=True)
-            gen = G.synthesis(ws, c, neural_rendering_resolution=st['nrr'], update_emas=True)
-        F.softplus(D({'image': gen['image'].float(), 'image_raw': gen['image_raw']}, c)).mean().backward()
-        F.softplus(-D({k: v.detach() for k, v in real.items()}, c)).mean().backward()
-        sizes['D'] = _finish_phase(D, st['opts']['D'], world)
-        D.requires_grad_(False)
-        del gen
-    mark('Dmain')
-    if 'Dreg' in phases:
-        D.requires_grad_(True); st['opts']['D'].zero_grad(set_to_none=True)
-        img = {k: v.detach().requires_grad_(True) for k, v in real.items()}
-        logits = D(img, c)
-        with conv2d_gradfix.no_weight_gradients():
-            grads = torch.autograd.grad(outputs=[logits.sum()], inputs=list(img.values()), create_graph=True, only_inputs=True)
-        r1 = sum(gr.square().sum([1, 2, 3]) for gr in grads)
-        (logits * 0 + r1 * (R1_GAMMA / 2)).mean().mul(D_REG_INTERVAL).backward()
-        sizes['Dreg'] = _finish_phase(D, st['opts']['D'], world)
-        D.requires_grad_(False)
-        del logits, grads, r1
-    mark('Dreg')
-    with torch.no_grad():                                                  # G_ema (training_loop.py:545-557), beta for batch 32 / ema_kimg 10
-        beta = 0.5 ** (4 * world / (10 * 1000))
-        torch._foreach_lerp_(list(st['G_ema'].parameters()), list(G.parameters()), 1.0 - beta)
-        for b_ema, b in zip(st['G_ema'].buffers(), G.buffers()):
+    for ph in st['phases']:
+        if only is None or ph['name'] in only:
+            ph['opt'].zero_grad(set_to_none=True)
+            ph['module'].requires_grad_(True)
+            st['loss'].accumulate_gradients(phase=ph['name'], batch=st['batch'], gen_z=ph['gen_z'], gen_c=ph['gen_c'], gain=ph['interval'], cur_nimg=200000)
+            ph['module'].requires_grad_(False)
+            sizes[ph['name']] = _finish_phase(st, ph)
+        mark(ph['name'])
+    with torch.no_grad():                                                  # G_ema (training_loop.py:545-557), beta for batch 4 x world / ema_kimg = batch * 10 / 32
+        batch_size = st['batch']['image'].shape[0] * st['world']
+        beta = 0.5 ** (batch_size / max(batch_size * 10 / 32 * 1000, 1e-8))
+        torch._foreach_lerp_(list(st['G_ema'].parameters()), list(st['G'].parameters()), 1.0 - beta)
+        for b_ema, b in zip(st['G_ema'].buffers(), st['G'].buffers()):
             b_ema.copy_(b)
     mark('ema')
     return sizes
@@ -276,15 +239,22 @@ def train_iteration(st, timers, phases=('Gmain', 'Greg', 'Dmain', 'Dreg')):
 def train_summary(timers, sizes, world, batch, wall_ms):
     def avg(a, b):
         return float(np.mean([x.elapsed_time(y) for x, y in zip(timers[a], timers[b])]))
-    ph = {'Gmain': avg('t0', 'Gmain'), 'Greg': avg('Gmain', 'Greg'), 'Dmain': avg('Greg', 'Dmain'), 'Dreg': avg('Dmain', 'Dreg'), 'ema': avg('Dreg', 'ema')}
-    lazy = ph['Gmain'] + ph['Greg'] / G_REG_INTERVAL + ph['Dmain'] + ph['Dreg'] / D_REG_INTERVAL + ph['ema']
-    return {'what': 'BASELINE config 3 per GPU, every phase of training_loop.py in one iteration: Gmain (mapping incl. the label-map Encoder + synthesis + D on the generated pair, fwd + bwd) '
-                    '+ Greg (density regularisation: G.sample_mixed under autograd on the fused point kernels) + Dmain (generated + real) + Dreg (R1 double backward), each with its flat gradient '
-                    f'all-reduce and Adam step, then G_ema; batch {batch}/GPU; every convolution forward / data gradient / weight gradient on libp3d_hip.so; LPIPS and augmentation are not part of this path',
+    marks = ('t0',) + PHASE_ORDER + ('ema',)
+    ph = {b: avg(a, b) for a, b in zip(marks[:-1], marks[1:])}
+    lazy = (ph['Gmain'] + ph['Greg'] / G_REG_INTERVAL + ph['Dmain'] + ph['Dreg'] / D_REG_INTERVAL + ph['D_semanticmain'] + ph['D_semanticreg'] / D_REG_INTERVAL + ph['ema'])
+    four = ph['Gmain'] + ph['Greg'] + ph['Dmain'] + ph['Dreg'] + ph['ema']
+    return {'what': 'BASELINE config 3 per GPU (train_scripts/afhq_seg.sh: --dis_mask=True, random_c_prob 0.5, gamma 5, lambda_d_semantic 0.1, lambda_cross_view 1e-4, only_raw_recons), every phase of '
+                    'training_loop.py in one iteration, each driven through Pix2Pix3DLoss.accumulate_gradients as the loop does: Gmain (mapping incl. the label-map Encoder + synthesis + D and D_semantic on '
+                    'the generated pair, fwd + bwd; then the cross-view block: no-grad render from gen_c -> arg-max label map -> differentiated render -> no-grad reconstruction -> smooth-L1 backward: FOUR '
+                    'generator passes) + Greg (density regularisation on the fused point kernels) + Dmain (one no-grad generator pass, generated + real) + Dreg (R1 double backward) + D_semanticmain + '
+                    f'D_semanticreg (the same two on image + 6 label channels), each with its flat gradient all-reduce and Adam step, then G_ema; batch {batch}/GPU, 128^2 rays x 48+48; every convolution '
+                    'forward / data gradient / weight gradient on libp3d_hip.so.  Not in it: LPIPS (lambda_lpips 0: a pretrained VGG that does not exist offline) and the augmentation pipe (--aug=noaug)',
             'ms_per_iteration': round(wall_ms, 2), 'img_per_s': round(batch * world / (wall_ms * 1e-3), 2),
             'phase_ms': {k: round(v, 2) for k, v in ph.items()},
             'lazy_schedule': {'G_reg_interval': G_REG_INTERVAL, 'D_reg_interval': D_REG_INTERVAL, 'ms_per_iteration': round(lazy, 2), 'img_per_s': round(batch * world / (lazy * 1e-3), 2),
-                              'note': 'amortised as the loop runs it: Gmain + Greg / 4 + Dmain + Dreg / 16 + ema'},
+                              'note': 'amortised as the loop runs it: Gmain + Greg / 4 + Dmain + Dreg / 16 + D_semanticmain + D_semanticreg / 16 + ema'},
+            'four_phase_ms': {'value': round(four, 2), 'note': "round 3's workload for comparison: Gmain + Greg + Dmain + Dreg + ema of THIS run (Gmain here carries the D_semantic term and the cross-view block, "
+                                                               'which round 3 did not have)'},
             'allreduce': {'bytes_per_phase': sizes, 'note': ('world 1: concatenate + nan_to_num + scatter only' if world == 1 else 'RCCL ring over xGMI') + '; inside the phase times'}}
 
 
@@ -313,7 +283,7 @@ def run_train(args, device, world, dist, iters, warm):
     if world > 1:                                                        # the exchange alone: one more all-reduce of each flat vector, timed
         from pix2pix3d_amd import dp
         bus = {}
-        for name, mod in (('G', st['G']), ('D', st['D'])):
+        for name, mod in st['nets'].items():
             mod.requires_grad_(True)
             for p_ in mod.parameters():
                 p_.grad = torch.zeros_like(p_)
@@ -355,7 +325,7 @@ def main():
     if args.train_step:                                              # BASELINE config 3 as the timed workload
         summary, elapsed = run_train(args, device, world, dist, args.steps, max(args.warmup, 1))
         if rank == 0:
-            line = {'metric': 'training img/s (seg2cat 512^2, batch 4/GPU, 128^2 rays x 48+48 samples; Gmain + Greg + Dmain + Dreg, all-reduce + Adam per phase)',
+            line = {'metric': 'training img/s (seg2cat 512^2, batch 4/GPU, 128^2 rays x 48+48 samples; Gmain + Greg + Dmain + Dreg + D_semanticmain + D_semanticreg, all-reduce + Adam per phase)',
                     'value': summary['img_per_s'], 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                     'ms_per_step': summary['ms_per_iteration'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                     'dtype': 'f32 (backbone, ray-marcher) + f16/f32-acc (super-resolution, discriminator top blocks), as train.py configures', 'data': 'synthetic',

@@ -18,16 +18,30 @@ def is_distributed():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
-def allreduce_gradients(module_or_params, world_size=None, group=None):
+def allreduce_gradients(module_or_params, world_size=None, group=None, out=None):
     """Average gradients across ranks in place; returns the flat vector that was exchanged (or None).
 
     Parameters without a gradient are skipped, exactly like the reference's ``if param.grad is not None`` filter, so
-    every rank must have the same set of parameters with gradients (true when all ranks run the same phase)."""
+    every rank must have the same set of parameters with gradients (true when all ranks run the same phase).
+    ``out``: a dict the caller keeps between phases — the flat vector of each size is then allocated once and reused (the gradients
+    are views of it after the call, so it must not be handed to a second module of the same size before that module's optimizer
+    step; the training loop steps right after every exchange)."""
     params = module_or_params.parameters() if isinstance(module_or_params, torch.nn.Module) else module_or_params
     params = [p for p in params if p.grad is not None]
     if not params:
         return None
-    flat = torch.cat([p.grad.flatten() for p in params])
+    grads = [p.grad.flatten() for p in params]
+    if out is None:
+        flat = torch.cat(grads)
+    else:
+        key = (sum(g.numel() for g in grads), grads[0].dtype, grads[0].device)
+        flat = out.get(key)
+        if flat is None:
+            flat = out[key] = torch.empty(key[0], dtype=key[1], device=key[2])
+        try:
+            torch.cat(grads, out=flat)
+        except RuntimeError:                             # some gradient still is a view of this buffer (two exchanges without a backward in between)
+            flat.copy_(torch.cat(grads))
     if world_size is None:
         world_size = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     if world_size > 1:

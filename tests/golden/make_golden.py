@@ -1000,6 +1000,49 @@ def group_loss_phases():
 
 GROUPS['loss_phases'] = group_loss_phases
 
+
+def group_discriminator_full():
+    """The reference DualDiscriminator of config 3 at its REAL size — 512^2, channel_base 32768, conv_clamp 256, batch 2 — for 3 image channels (D) and
+    3 + 6 (D_semantic), in the 'Dboth' phase on real input (loss.py:871-893 / 977-1000, gamma 5): logits, the R1 gradient fields w.r.t. both inputs
+    (per-32x32-tile sums and abs-maxima of every channel + norms), the penalty, and the gradient norm of every parameter.  On the CPU the reference
+    runs its fp16 blocks in fp32 (networks_stylegan2.py:624-626): this is the fp32 function, clamps included."""
+    import dnnlib
+    from torch_utils.ops import conv2d_gradfix
+    weights = _load_by_path('p3d_weights', os.path.join(HERE, 'weights.py'))
+    cases = _load_by_path('p3d_disc_full_cases', os.path.join(HERE, 'disc_full_cases.py'))
+    _tile_stats = cases.tile_stats
+    arrays = {}
+    import time
+    for tag, ch in cases.CASES:
+        torch.manual_seed(0)
+        D = dnnlib.util.construct_class_by_name(**cases.full_discriminator_kwargs(ch)).train().requires_grad_(True)
+        weights.seed_discriminator(D, seed=9 + ch)
+        img, raw, c = cases.full_discriminator_inputs(ch)
+        t0 = time.time()
+        x = {'image': img.clone().requires_grad_(True), 'image_raw': raw.clone().requires_grad_(True)}
+        logits = D(x, c)
+        with conv2d_gradfix.no_weight_gradients():
+            g_img, g_raw = torch.autograd.grad(outputs=[logits.sum()], inputs=[x['image'], x['image_raw']], create_graph=True, only_inputs=True)
+        r1 = g_img.square().sum([1, 2, 3]) + g_raw.square().sum([1, 2, 3])
+        (torch.nn.functional.softplus(-logits) + r1 * (5 / 2)).mean().backward()
+        print(tag, f'{time.time() - t0:.1f} s', 'logits', logits.detach().flatten().tolist(), 'r1', r1.detach().tolist())
+        a = dict(logits=logits.detach(), r1=r1.detach(), g_img_norm=g_img.detach().double().norm(), g_raw_norm=g_raw.detach().double().norm())
+        a['g_img_tile_sum'], a['g_img_tile_max'] = _tile_stats(g_img)
+        a['g_raw_tile_sum'], a['g_raw_tile_max'] = _tile_stats(g_raw, 8)
+        a['g_img_crop'] = g_img.detach()[:, :, 240:272, 240:272].clone()
+        params = dict(D.named_parameters())
+        names = [n for n, p in params.items() if p.grad is not None]
+        a['grad_names'] = np.array(names)
+        a['grad_norms'] = np.array([float(params[n].grad.double().norm()) for n in names])
+        for j, nm in enumerate((names[0], names[len(names) // 2], names[-1])):
+            a[f'h{j}'] = params[nm].grad.reshape(-1)[:64].clone()
+        a['head_names'] = np.array([names[0], names[len(names) // 2], names[-1]])
+        arrays.update({f'{tag}.{k}': v for k, v in a.items()})
+    save('discriminator_full', **arrays)
+
+
+GROUPS['discriminator_full'] = group_discriminator_full
+
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GROUPS)
     for nm in names:

@@ -105,3 +105,75 @@ def test_discriminator_dboth_phase_on_the_native_convolutions(hip_lib, name):
         conv2d_gradfix.enabled, conv2d_gradfix.split_bf16 = prev, prev_split
     assert conv2d_gradfix.native_calls['aten'] == c0['aten'], conv2d_gradfix.native_calls
     assert conv2d_gradfix.native_calls['forward'] > c0['forward'] + 10 and conv2d_gradfix.native_calls['weight_grad'] > c0['weight_grad'] + 5
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------------
+# Config 3's discriminators at their REAL size (512^2, channel_base 32768, conv_clamp 256, batch 2): D on 3 image channels and D_semantic on 3 + 6
+# (training_loop.py:308), the 'Dboth' phase on real input with gamma 5 — goldens from the reference on the CPU (make_golden.py discriminator_full).
+def _full_cases():
+    import importlib.util, os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location('p3d_disc_full_cases', os.path.join(ROOT, 'tests', 'golden', 'disc_full_cases.py'))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    return mod
+
+
+def _dboth_full(tag, ch, device, tol, fp16=False, grad_tol=None):
+    gt = tol if grad_tol is None else grad_tol
+    from pix2pix3d_amd import dnnlib
+    from pix2pix3d_amd.torch_utils.ops import conv2d_gradfix
+    cases = _full_cases()
+    g = {k.split('.', 1)[1]: v for k, v in load_golden('discriminator_full').items() if k.startswith(tag + '.')}
+    torch.manual_seed(0)
+    D = dnnlib.util.construct_class_by_name(**cases.full_discriminator_kwargs(ch)).train().requires_grad_(True)
+    weights.seed_discriminator(D, seed=9 + ch)
+    D = D.to(device)
+    img, raw, c = (t.to(device) for t in cases.full_discriminator_inputs(ch))
+    x = {'image': img.clone().requires_grad_(True), 'image_raw': raw.clone().requires_grad_(True)}
+    logits = D(x, c) if fp16 else D(x, c, force_fp32=True)
+    scale = max(float(np.abs(g['logits']).max()), 0.1)
+    assert np.abs(logits.detach().float().cpu().numpy() - g['logits']).max() < tol * scale, (logits.detach().flatten().tolist(), g['logits'].flatten().tolist())
+    with conv2d_gradfix.no_weight_gradients():
+        g_img, g_raw = torch.autograd.grad(outputs=[logits.sum()], inputs=[x['image'], x['image_raw']], create_graph=True, only_inputs=True)
+    r1 = g_img.square().sum([1, 2, 3]) + g_raw.square().sum([1, 2, 3])
+    (torch.nn.functional.softplus(-logits) + r1 * (5 / 2)).mean().backward()
+    assert rel_err(r1.detach().cpu().numpy(), g['r1']) < gt
+    for name, field, tile in (('g_img', g_img, 32), ('g_raw', g_raw, 8)):
+        s, m = cases.tile_stats(field.detach().float().cpu(), tile)             # every element of the field is in one tile's sum and abs-max
+        assert abs(float(field.detach().double().norm()) - float(g[name + '_norm'])) < gt * float(g[name + '_norm']), name
+        assert np.abs(m.numpy() - g[name + '_tile_max']).max() < gt * g[name + '_tile_max'].max(), name
+        assert np.abs(s.numpy() - g[name + '_tile_sum']).max() < gt * tile * g[name + '_tile_max'].max(), name      # a sum of tile^2 entries of either sign
+    assert rel_err(g_img.detach()[:, :, 240:272, 240:272].float().cpu().numpy(), g['g_img_crop']) < gt
+    params = dict(D.named_parameters())
+    names = [n for n, p in params.items() if p.grad is not None]
+    assert names == list(g['grad_names'])
+    norms = np.array([float(params[n].grad.double().norm()) for n in names])
+    assert np.abs(norms - g['grad_norms']).max() / g['grad_norms'].max() < gt
+    assert np.all(np.abs(norms - g['grad_norms']) <= gt * 10 * np.maximum(g['grad_norms'], 1e-3 * g['grad_norms'].max())), \
+        [(n, a, b) for n, a, b in zip(names, norms, g['grad_norms']) if abs(a - b) > gt * 10 * max(b, 1e-3 * g['grad_norms'].max())]
+    for j, nm in enumerate(g['head_names'].tolist()):
+        assert rel_err(params[nm].grad.reshape(-1)[:64].float().cpu().numpy(), g[f'h{j}']) < gt * 5, nm
+
+
+@pytest.mark.parametrize('tag,ch', [('d', 3), ('dsem', 9)])
+def test_full_size_discriminators_match_reference_cpu(tag, ch):
+    _dboth_full(tag, ch, 'cpu', 5e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag,ch', [('d', 3), ('dsem', 9)])
+def test_full_size_discriminators_on_the_native_convolutions(hip_lib, tag, ch):
+    """Same phase on the device through libp3d_hip.so (conv2d_gradfix.enabled): the all-fp32 leg (force_fp32: the function the CPU reference computes)
+    within 2e-3 everywhere; then the configuration training uses — fp16 top-4 blocks with fp32 accumulation, conv_clamp 256 — at the fp16 class
+    (logits 2e-2 of their scale, R1 fields / penalties / parameter-gradient norms 5e-2: fp16 storage of 512^2 x 64..512-channel activations through
+    four blocks and a double backward)."""
+    from pix2pix3d_amd.torch_utils.ops import conv2d_gradfix
+    prev, conv2d_gradfix.enabled = conv2d_gradfix.enabled, True
+    c0 = dict(conv2d_gradfix.native_calls)
+    try:
+        _dboth_full(tag, ch, 'cuda', 2e-3)
+        _dboth_full(tag, ch, 'cuda', 2e-2, fp16=True, grad_tol=5e-2)
+    finally:
+        conv2d_gradfix.enabled = prev
+    assert conv2d_gradfix.native_calls['aten'] == c0['aten'], conv2d_gradfix.native_calls
+    assert conv2d_gradfix.native_calls['forward'] > c0['forward'] + 20 and conv2d_gradfix.native_calls['weight_grad'] > c0['weight_grad'] + 20
