@@ -232,6 +232,13 @@ int p3d_importance_sample(const float* z_coarse, const float* w_coarse, const fl
                           int32_t n_rays, int32_t depth_resolution, int32_t n_importance, int32_t sorted,
                           p3d_stream_t stream);
 
+/* The same launch with the INTEGER results of the index work exposed (parity tests: bit-exact against torch.searchsorted / a stable argsort):
+ *   bin_index   [R][S_f] int32, optional: per importance draw j the index torch.searchsorted(cdf, u, right=True) returns (renderer.py:240), in draw order;
+ *   merge_words [R][4] uint32, optional (needs `sorted`): bit k set <=> sample k of the merged, depth-ordered ray (unify_samples, renderer.py:157-167) is an
+ *               importance sample — computed by the merge step the fused ray-marcher runs (csrc/render_device.h: merge_takes_coarse).                       */
+int p3d_importance_sample_index(const float* z_coarse, const float* w_coarse, const float* u_fine, float* z_fine, int32_t* bin_index, uint32_t* merge_words,
+                                int32_t n_rays, int32_t depth_resolution, int32_t n_importance, int32_t sorted, p3d_stream_t stream);
+
 /* ---- modulated convolution on the matrix cores (fp16 channels-last) --------------------------
  * Stand in for the per-layer inference chain of the StyleGAN2 synthesis layers:
  *   modulated_conv2d, fused branch      training/networks_stylegan2.py:34-69, 81-91

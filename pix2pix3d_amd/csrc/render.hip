@@ -91,7 +91,7 @@ sample_points_kernel(RenderArgs a, const float* coords, int pts_per_img, int tot
 
 // ---- importance sampling alone (unit-testable index work) ---------------------------------------------
 __global__ void __launch_bounds__(64) importance_kernel(const float* z_coarse, const float* w_coarse, const float* u_fine,
-                                                        float* z_fine, int rays, int Sc, int Sf, int sort)
+                                                        float* z_fine, int32_t* bins, uint32_t* merge, int rays, int Sc, int Sf, int sort)
 {
     const int lane = threadIdx.x;
     for (int r = blockIdx.x; r < rays; r += gridDim.x) {
@@ -100,9 +100,21 @@ __global__ void __launch_bounds__(64) importance_kernel(const float* z_coarse, c
         const float u = (lane < Sf) ? u_fine[(size_t)r * Sf + lane] : 2.f;
         const float w1[1] = {w_i}, z1[1] = {z_i}, u1[1] = {u};
         float zf[1];
-        importance_depth<1>(Sc, Sf, lane, w1, z1, u1, zf);
+        int ind[1];
+        importance_depth<1>(Sc, Sf, lane, w1, z1, u1, zf, &ind);
+        if (bins && lane < Sf) bins[(size_t)r * Sf + lane] = ind[0];
         if (sort) bitonic_sort64<1>(zf, lane);
         if (lane < Sf) z_fine[(size_t)r * Sf + lane] = zf[0];
+        if (merge) {                                             // the fused kernel's phase-C merge over the same heads (every lane walks it; lane 0 writes)
+            uint32_t word[4] = {0u, 0u, 0u, 0u};
+            int ic = 0, jf = 0;
+            float zc = lane_bcast(z_i, 0), zfh = lane_bcast(zf[0], 0);
+            for (int k = 0; k < Sc + Sf; ++k) {
+                if (merge_takes_coarse(zc, zfh)) { ++ic; zc = (ic < Sc) ? lane_bcast(z_i, ic) : INFINITY; }
+                else { word[k >> 5] |= 1u << (k & 31); ++jf; zfh = (jf < Sf) ? lane_bcast(zf[0], jf) : INFINITY; }
+            }
+            if (lane == 0) { for (int i = 0; i < 4; ++i) merge[(size_t)r * 4 + i] = word[i]; }
+        }
         wave_sync();
     }
 }
@@ -404,15 +416,28 @@ extern "C" int p3d_sample_points_dual(const float* planes_tex_cl, const float* p
     return sample_points_impl(planes_tex_cl, planes_sem_cl, decoder_dual, coords, d, pts_per_img, rgb, sigma, stream);
 }
 
-extern "C" int p3d_importance_sample(const float* z_coarse, const float* w_coarse, const float* u_fine, float* z_fine,
-                                     int32_t n_rays, int32_t depth_resolution, int32_t n_importance, int32_t sorted, p3d_stream_t stream)
+static int importance_sample_impl(const float* z_coarse, const float* w_coarse, const float* u_fine, float* z_fine, int32_t* bins, uint32_t* merge,
+                                  int32_t n_rays, int32_t depth_resolution, int32_t n_importance, int32_t sorted, p3d_stream_t stream)
 {
     P3D_REQUIRE(z_coarse && w_coarse && u_fine && z_fine, "importance_sample: null pointer");
+    P3D_REQUIRE(!merge || sorted, "importance_sample: the merge pattern is defined on the sorted importance depths");
     if (depth_resolution < 4 || depth_resolution > kMaxS || n_importance < 1 || n_importance > kMaxS)
         return fail(P3D_ERR_UNSUPPORTED, "importance_sample: needs 4 <= depth_resolution <= %d, 1 <= n_importance <= %d", kMaxS, kMaxS);
     if (n_rays <= 0) return P3D_OK;
     const int blocks = n_rays < kNumCU * 16 ? n_rays : kNumCU * 16;
-    hipLaunchKernelGGL(importance_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, z_coarse, w_coarse, u_fine, z_fine, n_rays, depth_resolution, n_importance, sorted);
+    hipLaunchKernelGGL(importance_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, z_coarse, w_coarse, u_fine, z_fine, bins, merge, n_rays, depth_resolution, n_importance, sorted);
     count_launch(FAM_RENDER);
     return check_launch("importance_sample");
+}
+
+extern "C" int p3d_importance_sample(const float* z_coarse, const float* w_coarse, const float* u_fine, float* z_fine,
+                                     int32_t n_rays, int32_t depth_resolution, int32_t n_importance, int32_t sorted, p3d_stream_t stream)
+{
+    return importance_sample_impl(z_coarse, w_coarse, u_fine, z_fine, nullptr, nullptr, n_rays, depth_resolution, n_importance, sorted, stream);
+}
+
+extern "C" int p3d_importance_sample_index(const float* z_coarse, const float* w_coarse, const float* u_fine, float* z_fine, int32_t* bin_index, uint32_t* merge_words,
+                                           int32_t n_rays, int32_t depth_resolution, int32_t n_importance, int32_t sorted, p3d_stream_t stream)
+{
+    return importance_sample_impl(z_coarse, w_coarse, u_fine, z_fine, bin_index, merge_words, n_rays, depth_resolution, n_importance, sorted, stream);
 }

@@ -491,7 +491,8 @@ __device__ __forceinline__ void mlp_layer2_bf3(const float* lds, int n, int lane
 // kernel (profiles/round3_n_render_ablation.log) — so NR rays go through it TOGETHER: NR independent chains in every loop.
 __device__ __forceinline__ float lane_bcast(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
 template <int NR>
-__device__ __forceinline__ void importance_depth(int Sc, int Sf, int lane, const float (&w_i)[NR], const float (&z_i)[NR], const float (&u)[NR], float (&z)[NR])
+__device__ __forceinline__ void importance_depth(int Sc, int Sf, int lane, const float (&w_i)[NR], const float (&z_i)[NR], const float (&u)[NR], float (&z)[NR],
+                                                 int (*bins)[NR] = nullptr)          // bins (tests): lane j's searchsorted index, as torch.searchsorted(cdf, u, right=True) returns it
 {
 #pragma clang fp contract(off)
     const float ninf = -INFINITY;
@@ -524,6 +525,10 @@ __device__ __forceinline__ void importance_depth(int Sc, int Sf, int lane, const
             inds[q] += (cdf[q] <= u[q]) ? 1 : 0;
             mycdf[q] = (lane == k + 1) ? cdf[q] : mycdf[q];    // lane k keeps cdf entry k
         }
+    if (bins) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q) (*bins)[q] = inds[q];
+    }
 #pragma unroll
     for (int q = 0; q < NR; ++q) {
         const int below = max(inds[q] - 1, 0), above = min(inds[q], nw);
@@ -536,6 +541,10 @@ __device__ __forceinline__ void importance_depth(int Sc, int Sf, int lane, const
         z[q] = (lane < Sf) ? zz : INFINITY;
     }
 }
+
+// One step of unify_samples (renderer.py:157-167: sort of cat(coarse, fine) depths, both halves already ascending): take the coarse head unless the
+// fine head is strictly smaller — the order a stable sort of [coarse, fine] gives.
+__device__ __forceinline__ bool merge_takes_coarse(float zc, float zf) { return zc <= zf; }
 
 template <int NR>
 __device__ __forceinline__ void bitonic_sort64(float (&v)[NR], int lane)
@@ -717,7 +726,7 @@ render_forward_kernel(RenderArgs a)
     float zf = (Sf > 0) ? tile[j] : INFINITY;
     const int S = Sc + Sf;
     for (int k = 0; k < S; ++k) {
-        const bool take_c = (zc <= zf);
+        const bool take_c = merge_takes_coarse(zc, zf);
         const float z = take_c ? zc : zf;
         if (take_c) { ++ic; zc = (ic < Sc) ? coarse_depth(a, g, ic, uc[ic]) : INFINITY; }
         else        { ++jf; zf = (jf < Sf) ? tile[jf * kPitch + j] : INFINITY; }

@@ -59,6 +59,7 @@ _lib.register('p3d_render_forward', ctypes.c_int, [_vp] * 8 + [ctypes.POINTER(_R
 _lib.register('p3d_sample_points', ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(_RenderDesc), _i32, _vp, _vp, _vp])
 _lib.register('p3d_sample_points_backward', ctypes.c_int, [_vp] * 4 + [ctypes.POINTER(_RenderDesc), _i32] + [_vp] * 4 + [_vp])
 _lib.register('p3d_importance_sample', ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp])
+_lib.register('p3d_importance_sample_index', ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp])
 _lib.register('p3d_render_decoder_floats_dual', ctypes.c_int, [])
 _lib.register('p3d_pack_decoder_dual', ctypes.c_int, [_vp] * 8 + [_f32, _vp, _vp])
 _lib.register('p3d_render_forward_dual', ctypes.c_int, [_vp] * 9 + [ctypes.POINTER(_RenderDesc)] + [_vp] * 4 + [_vp])
@@ -522,6 +523,21 @@ def importance_sample_native(z_coarse, w_coarse, u_fine, sort=False):
     code = _lib.lib().p3d_importance_sample(_lib.ptr(z), _lib.ptr(w), _lib.ptr(u), _lib.ptr(out), z.shape[0], z.shape[1], u.shape[1], int(sort), _lib.stream_of(z))
     _lib.check(code, 'importance_sample')
     return out
+
+
+def importance_sample_index_native(z_coarse, w_coarse, u_fine):
+    """p3d_importance_sample_index: (sorted z_fine [R,Sf], bin index per draw [R,Sf] int32, merge pattern [R,Sc+Sf] bool: True where the k-th sample of
+    the merged ray is an importance sample) — the integer side of sample_pdf / unify_samples, for the parity tests."""
+    z, w, u = _f32c(z_coarse), _f32c(w_coarse), _f32c(u_fine)
+    out = torch.empty_like(u)
+    bins = torch.empty(u.shape, dtype=torch.int32, device=u.device)
+    words = torch.empty([u.shape[0], 4], dtype=torch.int32, device=u.device)
+    code = _lib.lib().p3d_importance_sample_index(_lib.ptr(z), _lib.ptr(w), _lib.ptr(u), _lib.ptr(out), _lib.ptr(bins), _lib.ptr(words), z.shape[0], z.shape[1], u.shape[1], 1,
+                                                  _lib.stream_of(z))
+    _lib.check(code, 'importance_sample_index')
+    k = torch.arange(z.shape[1] + u.shape[1], device=u.device)
+    merged = ((words[:, (k >> 5)] >> (k & 31)) & 1).bool()
+    return out, bins, merged
 
 
 class _replay_draws:

@@ -381,6 +381,11 @@ def group_model_full():
             arrays[k + '_step'] = np.int64(step)
             arrays[k + '_mean'] = t.double().mean(dim=[2, 3])
             arrays[k + '_absmax'] = t.abs().max()
+            # every pixel of the output is in exactly one 8x8 tile's sum and abs-max (4x4 for the 128^2 renderings): a defect ANYWHERE moves a record
+            tile = 8 if t.shape[-1] >= 512 else 4
+            v = t.double().reshape(t.shape[0], t.shape[1], t.shape[2] // tile, tile, t.shape[3] // tile, tile)
+            arrays[k + '_tile_sum'], arrays[k + '_tile_max'] = v.sum(dim=(3, 5)).float(), v.abs().amax(dim=(3, 5)).float()
+            arrays[k + '_tile'] = np.int64(tile)
         save('model_full_' + run['tag'], **arrays)
 
 

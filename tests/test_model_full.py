@@ -7,7 +7,8 @@ At these sizes the fused kernel takes the schedule bench.py times (R = 128 raste
 the small renderer goldens never reach.
 
 Tolerances: rendered pixels <= 1e-3 relative-to-max, depth <= 1e-4 absolute, SR images <= 1e-3 (all-fp32) / 3e-2 (fp16 SR
-blocks, the reference's GPU precision); per-image means of every output (which see all 16 384 rays) to the same bounds."""
+blocks, the reference's GPU precision); per-image means of every output (which see all 16 384 rays) to the same bounds; per-tile
+abs-maxima and sums of EVERY output over its whole area (8x8 tiles at 512^2: all 262 144 pixels of every channel are in a record)."""
 import numpy as np
 import pytest
 import torch
@@ -31,6 +32,15 @@ def compare_full(out, g, tol_raw, tol_sr, tol_depth=1e-4):
         errs[k] = float(max(e) / scale)
         tol = tol_depth if k == 'image_depth' else (tol_raw if k.endswith('_raw') else tol_sr)
         assert errs[k] < tol, (k, errs[k], e)
+        # EVERY pixel: per-tile abs-max and sum over the whole output (8x8 tiles of the 512^2 images, 4x4 of the 128^2 renderings) — a defect in any
+        # tile of any channel moves one of these records.  abs-max to the pixel tolerance; a tile's sum to tile x tolerance (a full row or column of
+        # the tile off by the tolerance, e.g. a patch-edge defect of a convolution kernel)
+        tile = int(g[k + '_tile'])
+        v = t.double().reshape(t.shape[0], t.shape[1], h // tile, tile, h // tile, tile)
+        e_max = float(np.abs(v.abs().amax(dim=(3, 5)).numpy() - g[k + '_tile_max']).max() / scale)
+        e_sum = float(np.abs(v.sum(dim=(3, 5)).numpy() - g[k + '_tile_sum']).max() / scale)
+        errs[k + '.tile_max'], errs[k + '.tile_sum'] = e_max, e_sum
+        assert e_max < tol and e_sum < tile * tol, (k, 'tile records', e_max, e_sum)
     return errs
 
 

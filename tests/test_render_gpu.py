@@ -98,6 +98,69 @@ def test_importance_sampling_is_index_exact(hip_lib):
     assert np.abs(zf - g['z_fine']).max() < 3e-5                           # and the reference's record
 
 
+def _check_index_work(rmod, z, w, u, allow_ties):
+    """Integers against integers: the device's searchsorted index per draw == the oracle's (``sample_pdf(return_index=True)``, pinned to
+    torch.searchsorted by tests/test_render_oracle.py) and the device's merge pattern == a stable argsort of cat(coarse, the device's own sorted
+    fine depths).  ``allow_ties``: at 65 536 rays x 64 draws a handful of draws sit on a cdf entry to the last bit, where the (bit-identical in
+    exact arithmetic) running sums of the two implementations may round apart — each such draw must BE such a tie, and is counted."""
+    zt, wt, ut = (torch.tensor(v, device='cuda') for v in (z, w, u))
+    zf_dev, bins_dev, merged_dev = rmod.importance_sample_index_native(zt, wt, ut)
+    zf_dev, bins_dev, merged_dev = zf_dev.cpu().numpy(), bins_dev.cpu().numpy().astype(np.int64), merged_dev.cpu().numpy()
+    bins, wp = R.importance_bins(z, w)
+    zo, inds = R.sample_pdf(bins, wp, u, return_index=True)
+    differ = bins_dev != inds
+    n_diff = int(differ.sum())
+    if not allow_ties:
+        assert n_diff == 0, n_diff
+    else:
+        rows, cols = np.nonzero(differ)
+        assert np.all(np.abs(bins_dev[rows, cols] - inds[rows, cols]) == 1)
+        wq = (wp + np.float32(1e-5)).astype(np.float32)
+        cdf = np.concatenate([np.zeros([wq.shape[0], 1]), np.cumsum(wq.astype(np.float64), 1) / wq.astype(np.float64).sum(1, keepdims=True)], 1)
+        edge = cdf[rows, np.minimum(bins_dev, inds)[rows, cols]]
+        assert np.all(np.abs(edge - u[rows, cols]) <= 1e-6), np.abs(edge - u[rows, cols]).max()       # u within ~8 ulp of the cdf entry that decides the bin
+        assert n_diff <= 1e-5 * differ.size, (n_diff, differ.size)
+    same = ~differ.any(axis=1)
+    assert np.array_equal(zf_dev[same], np.sort(rmod.importance_sample_native(zt, wt, ut).cpu().numpy(), axis=1)[same])
+    assert np.abs(zf_dev[same] - np.sort(zo, axis=1)[same]).max() <= 4e-7                           # identical bins -> values to the last ulps of the interpolation
+    z_all = np.concatenate([z, zf_dev], 1)
+    order = np.argsort(z_all, axis=1, kind='stable')
+    assert np.array_equal(merged_dev, order >= z.shape[1])                                          # which slots of the merged ray hold importance samples
+    return n_diff, differ.size
+
+
+def test_importance_bins_and_merge_pattern_are_integer_exact(hip_lib):
+    rmod = _renderer()
+    g = load_golden('renderer_importance')
+    n_diff, total = _check_index_work(rmod, g['z'], g['w'], g['u'], allow_ties=False)
+    assert total == 64 * 48 and n_diff == 0
+
+
+def test_index_work_at_bench_size(hip_lib):
+    """The same comparison on what the benchmark's launch actually samples: seg2cat, batch 4, 128^2 rays x 64+64 — the coarse weights come out of
+    the fused kernel's own coarse pass (debug output), every one of the 65 536 rays is compared."""
+    from model_cases import build_generator, uniforms
+    rmod = _renderer()
+    g = load_golden('model_full_seg2cat_128')
+    G = build_generator('seg2cat', 'cuda', depth=tuple(int(v) for v in g['depth']))
+    ws, c, nrr = torch.tensor(g['ws'], device='cuda'), torch.tensor(g['c'], device='cuda'), int(g['nrr'])
+    rk = G.rendering_kwargs
+    u_c, u_f = uniforms(g, ws.shape[0], nrr, rk)
+    with torch.no_grad():
+        planes = G.backbone.synthesis(ws, noise_mode='const')
+        planes = planes.view(planes.shape[0], 3, 32, planes.shape[-2], planes.shape[-1])
+        o, d = G.ray_sampler(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), nrr)
+        _, _, _, zf_fused, w_coarse = rmod.fused_render(planes, G.decoder, o, d, rk, u_c.to('cuda'), u_f.to('cuda'), debug=True)
+    n, m, sc = u_c.shape[0], u_c.shape[1], u_c.shape[2]
+    z_c = R.sample_stratified(u_c.numpy().reshape(n, m, sc), rk['ray_start'], rk['ray_end']).reshape(n * m, sc)
+    n_diff, total = _check_index_work(rmod, z_c, w_coarse.cpu().numpy(), u_f.numpy(), allow_ties=True)
+    print(f'bench-size index work: {n_diff} of {total} draws are cdf ties that rounded apart')
+    # and the fused launch itself produced the depths of the stand-alone sampler on its own coarse pass (same device function, same inputs up to the
+    # coarse depths' last ulp, which only enter the final interpolation)
+    zf_alone = rmod.importance_sample_native(torch.tensor(z_c, device='cuda'), w_coarse, u_f.to('cuda'), sort=True)
+    assert float((zf_alone - zf_fused).abs().max()) <= 5e-7
+
+
 def test_edge_cases_empty_space_tail_tile_and_oob(hip_lib):
     """Zero density everywhere (depth -> nan -> clamp), a ray count that is not a multiple of 32, points far
     outside the box (all taps zero-padded)."""

@@ -50,6 +50,31 @@ def test_importance_sampling_oracle_indices_and_values():
     assert (np.abs(inds[:8] - exp) <= 1).all() and (inds[:8] == exp).mean() > 0.98
 
 
+def test_oracle_index_work_is_torchs_index_work():
+    """The integer results the oracle hands the GPU tests are what the reference's torch calls return on the same inputs: its bin index ==
+    torch.searchsorted(cdf, u, right=True) (renderer.py:240) and its stable argsort of cat(coarse, fine) == the permutation torch.sort applies
+    in unify_samples (renderer.py:157-167)."""
+    import torch
+    g = load_golden('renderer_importance')
+    bins, w = R.importance_bins(g['z'], g['w'])
+    zf, inds = R.sample_pdf(bins, w, g['u'], return_index=True)
+    wt = torch.tensor(w) + 1e-5                                               # the reference's own tensor ops (renderer.py:230-240)
+    pdf = wt / torch.sum(wt, -1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
+    ti = torch.searchsorted(cdf, torch.tensor(g['u']).contiguous(), right=True).numpy()
+    differ = ti != inds                                                       # cumsum may round its running sum differently than the sequential loop
+    assert differ.mean() < 2e-3
+    rows, cols = np.nonzero(differ)
+    assert np.all(np.abs(ti[rows, cols] - inds[rows, cols]) == 1)
+    edge = np.minimum(cdf.numpy()[rows, np.minimum(ti, inds)[rows, cols]], 1.0)
+    assert np.all(np.abs(edge - g['u'][rows, cols]) <= 4 * np.spacing(np.float32(1)))      # ... only where u sits on a cdf entry to an ulp
+    z_all = np.concatenate([g['z'], zf], 1)
+    order = np.argsort(z_all, axis=1, kind='stable')
+    _, tidx = torch.sort(torch.tensor(z_all), dim=1, stable=True)
+    assert np.array_equal(order, tidx.numpy())
+    assert np.array_equal(np.take_along_axis(z_all, order, 1), torch.sort(torch.tensor(z_all), dim=1)[0].numpy())
+
+
 @pytest.mark.parametrize('white_back', [False, True])
 def test_compositing_backward_oracle_is_autograd_of_the_ray_marcher(white_back):
     """oracle.render_oracle.ray_march_backward (the two sweeps the fused backward runs on the device) against autograd through this
