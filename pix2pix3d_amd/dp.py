@@ -18,6 +18,21 @@ def is_distributed():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+def _gloo_on_device(t, group):
+    """gloo (the CPU tests' backend, and the only way to run two ranks on ONE GPU: RCCL refuses a duplicate device) moves host memory; a device
+    tensor is staged through the host explicitly, whatever this build's gloo would do with it."""
+    return t.is_cuda and dist.get_backend(group) == 'gloo'
+
+
+def _all_reduce(t, group):
+    if _gloo_on_device(t, group):
+        host = t.cpu()
+        dist.all_reduce(host, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, group=group)                  # SUM over ranks: RCCL on the GPUs of a node
+
+
 def allreduce_gradients(module_or_params, world_size=None, group=None, out=None):
     """Average gradients across ranks in place; returns the flat vector that was exchanged (or None).
 
@@ -45,7 +60,7 @@ def allreduce_gradients(module_or_params, world_size=None, group=None, out=None)
     if world_size is None:
         world_size = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     if world_size > 1:
-        dist.all_reduce(flat, group=group)              # SUM over ranks (RCCL on GPUs, gloo in the CPU tests)
+        _all_reduce(flat, group)                        # SUM over ranks (RCCL on GPUs, gloo in the CPU tests)
         flat /= world_size
     torch.nan_to_num(flat, nan=0, posinf=1e5, neginf=-1e5, out=flat)
     for p, g in zip(params, flat.split([p.numel() for p in params])):
@@ -58,7 +73,13 @@ def broadcast_module(module, src=0, group=None):
     if not is_distributed():
         return
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data if t.is_leaf else t, src=src, group=group)
+        t = t.data if t.is_leaf else t
+        if _gloo_on_device(t, group):
+            host = t.cpu()
+            dist.broadcast(host, src=src, group=group)
+            t.copy_(host)
+        else:
+            dist.broadcast(t, src=src, group=group)
     from .torch_utils.ops import modconv                  # writes through .data do not bump the version counter the weight caches watch
     modconv.invalidate_caches()
 
