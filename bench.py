@@ -53,6 +53,9 @@ def parse():
     p.add_argument('--dataset', default='seg2cat')
     p.add_argument('--force-fp32', action='store_true', help='run the super-resolution heads in fp32 too')
     p.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a captured hipGraph')
+    p.add_argument('--streams', type=int, default=int(os.environ.get('P3D_BENCH_STREAMS', 1)),
+                   help='independent steps in flight: S consecutive steps (each a whole batch) are captured on S HIP streams of ONE hipGraph, so the launch-bound '
+                        'low-resolution layers of one batch overlap the chip-filling kernels of another; --steps must be a multiple of S')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--miopen-find', action='store_true', help='let MIOpen benchmark its solvers for the vendor-library convs (slow warm-up)')
     p.add_argument('--cpu-reps', type=int, default=6, help='CPU baseline runs per thread count: 1 warm-up + (n - 1) timed (median reported; SURVEY 8(d): >= 5)')
@@ -365,22 +368,34 @@ def main():
                 break
         assert out['image'].shape == (args.batch, 3, info['res'], info['res'])
         launch, graph = 'eager', None
+        in_flight = args.streams if (args.streams > 1 and not args.no_graph and args.steps % args.streams == 0) else 1
         if not args.no_graph:
-            try:                                                         # replay the whole step as one hipGraph
+            try:                                                         # replay the whole step as one hipGraph (in_flight > 1: that many steps, one per stream)
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):
                     step()
                 torch.cuda.current_stream().wait_stream(s)
+                lanes = [torch.cuda.Stream() for _ in range(in_flight)] if in_flight > 1 else []
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    out = step()
+                    if in_flight == 1:
+                        out = step()
+                    else:
+                        outs, cur = [], torch.cuda.current_stream()
+                        for ln in lanes:                                 # fork: every lane renders its own batch, nothing shared but the weights
+                            ln.wait_stream(cur)
+                            with torch.cuda.stream(ln):
+                                outs.append(step())
+                        for ln in lanes:
+                            cur.wait_stream(ln)
+                        out = outs[0]
                 graph.replay()
                 torch.cuda.synchronize()
-                launch = 'hipgraph'
+                launch = 'hipgraph' if in_flight == 1 else f'hipgraph, {in_flight} steps in flight on {in_flight} streams'
             except Exception as e:                                       # noqa: BLE001 - report and fall back to eager launches
-                graph = None
-                launch = f'eager (graph capture failed: {type(e).__name__})'
+                graph, in_flight = None, 1
+                launch = f'eager (graph capture failed: {type(e).__name__}: {str(e)[:120]})'
                 torch.cuda.synchronize()
         run = graph.replay if graph is not None else step
         # untimed settling: a box that has just booted (or idled) needs a moment of sustained load before its clocks / power state level
@@ -388,7 +403,7 @@ def main():
         chunks, t_start = [], time.perf_counter()
         while True:
             t0 = time.perf_counter()
-            for _ in range(10):
+            for _ in range(10 // in_flight if in_flight > 1 else 10):
                 run()
             torch.cuda.synchronize()
             chunks.append(time.perf_counter() - t0)
@@ -399,7 +414,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(args.steps // in_flight):                        # EXACTLY args.steps steps: every replay holds in_flight of them
             run()
         torch.cuda.synchronize()
         if dist is not None:

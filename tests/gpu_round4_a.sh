@@ -1,0 +1,36 @@
+#!/bin/bash
+# round 4, first session: the new parity tests (verbose), the whole -m gpu suite, smoke(), the default benchmark line (now with the six-phase training
+# step), the steps-in-flight variants, the rocprofv3 kernel statistics of the training iteration, and the counter passes of the ray-marcher (re-taken:
+# the kernel sources changed by a codegen-neutral refactor, the committed passes are bound to the source hash).   usage: bash tests/gpu_round4_a.sh <tag>
+tag=${1:-round4_a}
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
+echo "== new tests"
+timeout 900 python -m pytest tests/test_loss_phases.py tests/test_discriminator.py tests/test_render_gpu.py tests/test_model_full.py tests/test_dp_two_ranks_gpu.py \
+    "tests/test_split_acts.py::test_wide_torgb_narrow_output_first_then_wide_in_a_fresh_process" "tests/test_render_bwd_gpu.py::test_double_backward_through_the_fused_point_queries_raises" \
+    -m gpu -q -s --tb=short -rf -p no:cacheprovider > gpurun_out/${tag}_new_tests.log 2>&1; tail -n 25 gpurun_out/${tag}_new_tests.log | cut -c1-600
+echo "== suite"
+timeout 900 python -m pytest tests -m gpu -q --tb=short -rf -p no:cacheprovider > gpurun_out/${tag}_gputest.log 2>&1; tail -n 8 gpurun_out/${tag}_gputest.log | cut -c1-400
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${tag}_smoke.log 2>&1; tail -n 2 gpurun_out/${tag}_smoke.log | cut -c1-400
+echo "== bench"
+timeout 900 python bench.py > gpurun_out/${tag}_bench_line_default.json 2> gpurun_out/${tag}_bench.err; head -c 900 gpurun_out/${tag}_bench_line_default.json; echo; tail -n 3 gpurun_out/${tag}_bench.err
+python - <<PY
+import json
+try:
+    d = json.load(open('gpurun_out/${tag}_bench_line_default.json'))
+    print('TRAIN', json.dumps(d.get('train_step'))[:1800])
+    print('STAGES', d.get('stage_ms'), 'exact', (d.get('exact_fp32') or {}).get('value'))
+except Exception as e:
+    print('no line', e)
+PY
+for s in 2 4; do
+  timeout 300 python bench.py --streams $s --no-train-step --no-cpu-baseline --no-exact-fp32 > gpurun_out/${tag}_bench_line_streams$s.json 2>> gpurun_out/${tag}_bench.err
+  python -c "import json; d=json.load(open('gpurun_out/${tag}_bench_line_streams$s.json')); print('STREAMS $s', d['value'], d['ms_per_step'], d['config']['launch'])"
+done
+timeout 300 python bench.py --streams 1 --no-train-step --no-cpu-baseline --no-exact-fp32 > gpurun_out/${tag}_bench_line_streams1.json 2>> gpurun_out/${tag}_bench.err
+python -c "import json; d=json.load(open('gpurun_out/${tag}_bench_line_streams1.json')); print('STREAMS 1', d['value'], d['ms_per_step'], d['config']['launch'])"
+echo "== train profile"
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_train -o t -- python $GRAFT_REPO_ROOT/bench.py --train-step --steps 3 --warmup 2 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_bench_line_train.json 2> /tmp/prof_train.err)
+cp $(find /tmp/prof_train -name '*kernel_stats.csv' | head -1) gpurun_out/${tag}_train_kernel_stats.csv; head -n 16 gpurun_out/${tag}_train_kernel_stats.csv | cut -c1-170
+echo "== ray-marcher counters"
+PMC_PASS_TIMEOUT=70 timeout 700 python tests/gpu_pmc_render.py > gpurun_out/${tag}_pmc.log 2>&1; tail -n 1 gpurun_out/${tag}_pmc.log | cut -c1-700
+P3D_MLP_BF16X3=0 PMC_PASS_TIMEOUT=70 timeout 700 python tests/gpu_pmc_render.py > gpurun_out/${tag}_pmc_exact.log 2>&1; tail -n 1 gpurun_out/${tag}_pmc_exact.log | cut -c1-400
