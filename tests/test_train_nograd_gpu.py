@@ -1,0 +1,56 @@
+"""Generator passes of a training iteration that record no graph — the sample D is trained on (loss.py:834-836, 903-905) and two of the three passes of
+the cross-view block (loss.py:657-675) — run in training mode under ``torch.no_grad()``.  On the device they take the fused inference kernels
+(networks_stylegan2._block_mode) with the batch's per-image random noise added after the convolution; the reference runs its unfused training
+formulation there.  Same function: compared here against this package's own unfused route on identical noise draws."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _det_rng():
+    spec = importlib.util.spec_from_file_location('p3d_det_rng', os.path.join(ROOT, 'tests', 'golden', 'det_rng.py'))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize('name,depth', [('seg2cat', (48, 48))])
+def test_no_grad_training_pass_takes_the_fused_kernels_and_matches_the_unfused_route(hip_lib, name, depth):
+    from pix2pix3d_amd import _lib, configs
+    from pix2pix3d_amd.torch_utils.ops import conv2d_gradfix
+    from pix2pix3d_amd.training import networks_stylegan2 as ns
+    from model_cases import build_generator
+    det = _det_rng()
+    G = build_generator(name, 'cuda', depth=depth).train()                   # training mode: fused_modconv_default 'inference_only' -> unfused in the reference
+    try:
+        rk = G.rendering_kwargs
+        gen = torch.Generator().manual_seed(21)
+        n = 2
+        ws = torch.randn(n, G.backbone.num_ws, 512, generator=gen).cuda()
+        c = torch.tensor(np.stack([configs.orbit_camera(k, radius=rk['avg_camera_radius'], pivot=rk['avg_camera_pivot']) for k in (5, 60)])).cuda()
+        prev_en, conv2d_gradfix.enabled = conv2d_gradfix.enabled, True
+        prev = ns.no_grad_fused_in_training
+        outs = {}
+        try:
+            for fused in (True, False):
+                ns.no_grad_fused_in_training = fused
+                c0 = _lib.launch_count('conv')
+                with det.DetRNG(5), torch.no_grad():
+                    outs[fused] = G.synthesis(ws, c, neural_rendering_resolution=128, update_emas=True)      # noise_mode defaults to 'random', as run_G leaves it
+                torch.cuda.synchronize()
+                outs[fused]['launches'] = _lib.launch_count('conv') - c0
+        finally:
+            ns.no_grad_fused_in_training, conv2d_gradfix.enabled = prev, prev_en
+        a, b = outs[True], outs[False]
+        errs = {k: float((a[k].float() - b[k].float()).abs().max() / b[k].float().abs().max()) for k in ('image', 'semantic', 'image_raw', 'semantic_raw', 'image_depth')}
+        print(errs, 'conv-family launches fused / unfused:', a['launches'], b['launches'])
+        for k, e in errs.items():
+            assert e < (3e-2 if k in ('image', 'semantic') else 1e-4), (k, e)      # fp16 SR heads: the fp16 class; the fp32 part: bf16x3 vs exact fp32 products
+    finally:
+        G.eval()
