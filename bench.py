@@ -261,6 +261,29 @@ def train_summary(timers, sizes, world, batch, wall_ms):
             'allreduce': {'bytes_per_phase': sizes, 'note': ('world 1: concatenate + nan_to_num + scatter only' if world == 1 else 'RCCL ring over xGMI') + '; inside the phase times'}}
 
 
+def train_roofline():
+    """Which resource the largest kernels of the six-phase iteration keep busiest, from the committed per-kernel counter passes of that workload
+    (profiles/kernel_pmc_train6.json, taken by tests/gpu_pmc_kernels.py train6 over `bench.py --train-step`): not live — a training iteration launches
+    ~3 000 kernels of ~60 kinds, the counters need one profiled run per group."""
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'kernel_pmc_train6.json')))
+    except (OSError, ValueError):
+        return None
+    rows = d.get('kernels') or []
+    total = sum(r['total_ms'] for r in rows)
+    out = []
+    for r in rows[:4]:
+        res = {k: r.get(k) for k in ('valu_issue', 'mfma_pipe', 'lds_array', 'hbm_frac') if r.get(k) is not None}
+        if not res:
+            continue
+        bound = max(res, key=res.get)
+        out.append({'kernel': r['kernel'], 'share_of_kernel_time': round(r['total_ms'] / total, 3), 'launches_per_profiled_run': r['launches'], 'avg_us': round(r['avg_us'], 1),
+                    'bound': {'valu_issue': 'valu_issue', 'mfma_pipe': 'mfma', 'lds_array': 'lds', 'hbm_frac': 'hbm'}[bound], 'frac': round(res[bound], 3),
+                    'all': {k: round(v, 3) for k, v in res.items()}, 'waves_per_simd': round(r.get('waves_per_simd') or 0.0, 2)})
+    return {'source': 'profiles/kernel_pmc_train6.json (rocprofv3 --kernel-trace --pmc passes over bench.py --train-step; utilisation over each kernel\'s life at the clock the pass held)',
+            'dominant': out[0] if out else None, 'next': out[1:]}
+
+
 def run_train(args, device, world, dist, iters, warm):
     st = train_setup(args, device, world)
     timers = {}
@@ -283,6 +306,7 @@ def run_train(args, device, world, dist, iters, warm):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     summary = train_summary(timers, sizes, world, args.batch, elapsed / iters * 1e3)
+    summary['roofline'] = train_roofline()
     if world > 1:                                                        # the exchange alone: one more all-reduce of each flat vector, timed
         from pix2pix3d_amd import dp
         bus = {}

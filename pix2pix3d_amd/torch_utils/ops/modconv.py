@@ -577,7 +577,7 @@ def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=No
             return noise_bias_act(y, bias, noise_const, noise_strength, act, act_gain, clamp)
         if noise_const is not None:
             y = y.add_((noise_const * noise_strength).to(y.dtype))
-        return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
+        return bias_act.bias_act(y, (None if bias is None else bias.to(y.dtype)), act=act, gain=act_gain, clamp=clamp)
     act_idx = {'linear': 0, 'lrelu': 1}.get(act)
     clampv = -1.0 if clamp is None else float(clamp)
     if split and use_shared_weights(x, weight, styles):
@@ -587,14 +587,14 @@ def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=No
             return conv2d(xs, wsh, bias=bias, noise=noise_const, noise_strength=noise_strength, act=act_idx, gain=act_gain, clamp=clampv, split=True, out_scale=d)
         if up == 1:
             y = conv2d(xs, wsh, noise=noise_const, noise_strength=noise_strength, split=True, out_scale=d)
-            return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
+            return bias_act.bias_act(y, (None if bias is None else bias.to(y.dtype)), act=act, gain=act_gain, clamp=clamp)
         y = conv2d(xs, wsh, transposed=True, split=True, out_scale=d)
         if act_idx is not None and tuple(resample_filter.shape) == (4, 4) and y.shape[1] % 32 == 0:
             return fir4_bias_act(y, resample_filter, bias, noise_const, noise_strength, act, act_gain, clampv, out_split=out_split)
         y = upfirdn2d.upfirdn2d(y, resample_filter, padding=[1, 1, 1, 1], gain=4)
         if noise_const is not None:
             y = y.add_((noise_const * noise_strength).to(y.dtype))
-        return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
+        return bias_act.bias_act(y, (None if bias is None else bias.to(y.dtype)), act=act, gain=act_gain, clamp=clamp)
     wmod = wpre if wpre is not None else modulate_weights(weight, styles, demodulate=True, dtype=wtag)
     if rgb is not None:                                    # (rgb_weight, rgb_styles, rgb_bias, rgb_clamp, img): checked by torgb_fusable
         rgb_w, rgb_s, rgb_b, rgb_c, img = rgb
@@ -604,7 +604,7 @@ def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=No
         return conv2d(x, wmod, bias=bias, noise=noise_const, noise_strength=noise_strength, act=act_idx, gain=act_gain, clamp=clampv, split=split, out_split=out_split)
     if up == 1:
         y = conv2d(x, wmod, noise=noise_const, noise_strength=noise_strength, split=split)
-        return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
+        return bias_act.bias_act(y, (None if bias is None else bias.to(y.dtype)), act=act, gain=act_gain, clamp=clamp)
     if fuse_up2 and act_idx is not None and x.shape[1] % 32 == 0 and wmod.shape[1] % 32 == 0 and (
             x.dtype == torch.float16 or (split and min(x.shape[2], x.shape[3]) >= fuse_up2_f32_min_res)):
         taps = _separable_fir(resample_filter)
@@ -617,7 +617,7 @@ def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=No
     y = upfirdn2d.upfirdn2d(y, resample_filter, padding=[1, 1, 1, 1], gain=4)
     if noise_const is not None:
         y = y.add_((noise_const * noise_strength).to(y.dtype))
-    return bias_act.bias_act(y, bias.to(y.dtype), act=act, gain=act_gain, clamp=clamp)
+    return bias_act.bias_act(y, (None if bias is None else bias.to(y.dtype)), act=act, gain=act_gain, clamp=clamp)
 
 
 def _separable_fir(f):

@@ -40,16 +40,18 @@ def test_no_grad_training_pass_takes_the_fused_kernels_and_matches_the_unfused_r
         try:
             for fused in (True, False):
                 ns.no_grad_fused_in_training = fused
-                c0 = _lib.launch_count('conv')
+                c0, n0 = _lib.launch_count('conv'), dict(conv2d_gradfix.native_calls)
                 with det.DetRNG(5), torch.no_grad():
                     outs[fused] = G.synthesis(ws, c, neural_rendering_resolution=128, update_emas=True)      # noise_mode defaults to 'random', as run_G leaves it
                 torch.cuda.synchronize()
                 outs[fused]['launches'] = _lib.launch_count('conv') - c0
+                outs[fused]['gradfix_forward_calls'] = conv2d_gradfix.native_calls['forward'] - n0['forward']
         finally:
             ns.no_grad_fused_in_training, conv2d_gradfix.enabled = prev, prev_en
         a, b = outs[True], outs[False]
         errs = {k: float((a[k].float() - b[k].float()).abs().max() / b[k].float().abs().max()) for k in ('image', 'semantic', 'image_raw', 'semantic_raw', 'image_depth')}
-        print(errs, 'conv-family launches fused / unfused:', a['launches'], b['launches'])
+        print(errs, 'conv-family launches fused / unfused:', a['launches'], b['launches'], 'conv2d_gradfix forward calls:', a['gradfix_forward_calls'], b['gradfix_forward_calls'])
+        assert a['gradfix_forward_calls'] == 0 and b['gradfix_forward_calls'] > 20          # the fused pass never enters the training-mode convolution op
         for k, e in errs.items():
             assert e < (3e-2 if k in ('image', 'semantic') else 1e-4), (k, e)      # fp16 SR heads: the fp16 class; the fp32 part: bf16x3 vs exact fp32 products
     finally:
