@@ -53,9 +53,6 @@ def parse():
     p.add_argument('--dataset', default='seg2cat')
     p.add_argument('--force-fp32', action='store_true', help='run the super-resolution heads in fp32 too')
     p.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a captured hipGraph')
-    p.add_argument('--streams', type=int, default=int(os.environ.get('P3D_BENCH_STREAMS', 1)),
-                   help='independent steps in flight: S consecutive steps (each a whole batch) are captured on S HIP streams of ONE hipGraph, so the launch-bound '
-                        'low-resolution layers of one batch overlap the chip-filling kernels of another; --steps must be a multiple of S')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--miopen-find', action='store_true', help='let MIOpen benchmark its solvers for the vendor-library convs (slow warm-up)')
     p.add_argument('--cpu-reps', type=int, default=6, help='CPU baseline runs per thread count: 1 warm-up + (n - 1) timed (median reported; SURVEY 8(d): >= 5)')
@@ -392,8 +389,6 @@ def main():
                 break
         assert out['image'].shape == (args.batch, 3, info['res'], info['res'])
         launch, graph = 'eager', None
-        in_flight = args.streams if (args.streams > 1 and not args.no_graph and args.steps % args.streams == 0) else 1
-        lanes = []
         if not args.no_graph:
             try:                                                         # replay the whole step as one hipGraph
                 s = torch.cuda.Stream()
@@ -407,31 +402,17 @@ def main():
                 graph.replay()
                 torch.cuda.synchronize()
                 launch = 'hipgraph'
-                if in_flight > 1:                                        # in_flight independent steps: one captured graph per lane, each replayed on its own stream
-                    lanes = [(torch.cuda.Stream(), graph)]
-                    for _ in range(in_flight - 1):
-                        g2 = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g2):
-                            step()
-                        lanes.append((torch.cuda.Stream(), g2))
-                    torch.cuda.synchronize()
-                    launch = f'hipgraph, {in_flight} steps in flight ({in_flight} captured graphs, each replayed on its own HIP stream)'
             except Exception as e:                                       # noqa: BLE001 - report and fall back to eager launches
-                graph, in_flight, lanes = None, 1, []
+                graph = None
                 launch = f'eager (graph capture failed: {type(e).__name__}: {str(e)[:120]})'
                 torch.cuda.synchronize()
-
-        def replay_lanes():                                              # one call = in_flight steps; the caller's synchronize() joins the lanes
-            for ln, g in lanes:
-                with torch.cuda.stream(ln):
-                    g.replay()
-        run = replay_lanes if lanes else (graph.replay if graph is not None else step)
+        run = graph.replay if graph is not None else step
         # untimed settling: a box that has just booted (or idled) needs a moment of sustained load before its clocks / power state level
         # out.  Replay in chunks of 10 until at least 1.5 s have passed and three consecutive chunks agree within 1.5 % (at most settle_s).
         chunks, t_start = [], time.perf_counter()
         while True:
             t0 = time.perf_counter()
-            for _ in range(10 // in_flight if in_flight > 1 else 10):
+            for _ in range(10):
                 run()
             torch.cuda.synchronize()
             chunks.append(time.perf_counter() - t0)
@@ -442,7 +423,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps // in_flight):                        # EXACTLY args.steps steps: every replay holds in_flight of them
+        for _ in range(args.steps):
             run()
         torch.cuda.synchronize()
         if dist is not None:
@@ -453,7 +434,7 @@ def main():
             t = torch.tensor([elapsed], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        del graph, lanes
+        del graph
         # per-kernel / per-stage HIP-event timing: a second, eager pass over the same steps (events cannot be read back from inside a
         # captured graph); the ray-marcher is one launch per step, so its event pair IS its launch duration.  Events are recorded on
         # torch's current stream == the stream every kernel of the step is launched on.
