@@ -2,6 +2,9 @@
 conditional generators of ``triplane_cond`` share with it: camera split, backbone with the one-slot plane cache, fused
 ray-marcher, point queries.  pix2pix3D's train.py selects the conditional generators (train.py:374-380); the unconditional
 ``TriPlaneGenerator`` is what EG3D checkpoints (``afhqcats512-128.pkl``) hold, so ``legacy.load_network_pkl`` resolves to it."""
+import functools
+import os
+
 import torch
 
 from .. import dnnlib
@@ -9,6 +12,33 @@ from ..torch_utils import persistence
 from .networks_stylegan2 import FullyConnectedLayer, Generator as StyleGAN2Backbone
 from .volumetric_rendering.renderer import ImportanceRenderer
 from .volumetric_rendering.ray_sampler import RaySampler
+
+
+frozen_passes_without_graph = os.environ.get('P3D_FROZEN_NO_GRAD', '1') != '0'
+
+
+def _tensors_of(values):
+    for v in values:
+        if isinstance(v, torch.Tensor):
+            yield v
+        elif isinstance(v, dict):
+            yield from _tensors_of(v.values())
+
+
+def frozen_pass(method):
+    """Device passes through a generator that CANNOT record a graph — grad mode is on, but neither an argument nor a parameter requires a gradient: the
+    generator passes of the discriminator phases (training_loop.py:516 leaves ``requires_grad`` on for the phase's own network only; loss.py:834-836,
+    903-905 call run_G without no_grad) — run under ``torch.no_grad()``.  Same values and the same (graph-less) outputs; what changes is that the layers
+    below see what they key their inference kernels on."""
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        if frozen_passes_without_graph and torch.is_grad_enabled():
+            tensors = list(_tensors_of(list(args) + list(kwargs.values())))
+            if tensors and all(t.is_cuda for t in tensors) and not any(t.requires_grad for t in tensors) and not any(p.requires_grad for p in self.parameters()):
+                with torch.no_grad():
+                    return method(self, *args, **kwargs)
+        return method(self, *args, **kwargs)
+    return wrapper
 
 
 def _osg_mlp(n_features, hidden, out_dim, lr_mul):
@@ -82,6 +112,7 @@ class _TriPlaneCore(torch.nn.Module):
         kw = {k: v for k, v in synthesis_kwargs.items() if k != 'noise_mode'}
         return dict(noise_mode=self.rendering_kwargs['superresolution_noise_mode'], **kw)
 
+    @frozen_pass
     def sample_mixed(self, coordinates, directions, ws, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
         """Colour features + density at arbitrary 3-D points for given latents (shape extraction, density regularisation)."""
         planes = self._planes(ws, update_emas, synthesis_kwargs)
@@ -103,12 +134,14 @@ class TriPlaneGenerator(_TriPlaneCore):
         self.decoder = OSGDecoder(32, {'decoder_lr_mul': rendering_kwargs.get('decoder_lr_mul', 1), 'decoder_output_dim': 32})
         self._finish_init(rendering_kwargs)
 
+    @frozen_pass
     def mapping(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False):
         if self.rendering_kwargs['c_gen_conditioning_zero']:
             c = torch.zeros_like(c)
         return self.backbone.mapping(z, c * self.rendering_kwargs.get('c_scale', 0), truncation_psi=truncation_psi,
                                      truncation_cutoff=truncation_cutoff, update_emas=update_emas)
 
+    @frozen_pass
     def synthesis(self, ws, c, neural_rendering_resolution=None, update_emas=False, cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
         feature_image, depth_image = self._render(ws, c, neural_rendering_resolution, update_emas, cache_backbone, use_cached_backbone, synthesis_kwargs)
         rgb_image = feature_image[:, :3]

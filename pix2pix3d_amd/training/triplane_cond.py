@@ -18,7 +18,7 @@ from ..torch_utils import persistence
 from ..torch_utils.ops import conv2d_gradfix
 from .networks_stylegan2 import SynthesisNetwork, FullyConnectedLayer, normalize_2nd_moment, DiscriminatorBlock, track_w_avg, truncate_ws
 from .networks_stylegan2 import Generator as StyleGAN2Backbone
-from .triplane import OSGDecoder, _osg_mlp, _TriPlaneCore
+from .triplane import OSGDecoder, _osg_mlp, _TriPlaneCore, frozen_pass
 from .volumetric_rendering.renderer import ImportanceSemanticRenderer
 from .volumetric_rendering.ray_sampler import RaySampler
 
@@ -369,6 +369,7 @@ class _TriPlaneBase(_TriPlaneCore):
     """The conditional generators' entry points: ``mapping`` / ``sample`` / ``forward`` take the data batch (label map + pose)."""
     _backbone_class = None      # Generator_cond, set below the class
 
+    @frozen_pass
     def mapping(self, z, c, batch, truncation_psi=1, truncation_cutoff=None, update_emas=False):
         if self.rendering_kwargs['c_gen_conditioning_zero']:
             c = torch.zeros_like(c)
@@ -404,6 +405,7 @@ class TriPlaneGenerator(_TriPlaneBase):
         self.decoder = OSGDecoder(32, {'decoder_lr_mul': rendering_kwargs.get('decoder_lr_mul', 1), 'decoder_output_dim': 32})
         self._finish_init(rendering_kwargs)
 
+    @frozen_pass
     def synthesis(self, ws, c, neural_rendering_resolution=None, update_emas=False, cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
         feature_image, depth_image = self._render(ws, c, neural_rendering_resolution, update_emas, cache_backbone, use_cached_backbone, synthesis_kwargs)
         rgb_image = feature_image[:, :3]
@@ -428,6 +430,7 @@ class TriPlaneSemanticEntangleGenerator(_TriPlaneBase):
                                                              'sigmoid': semantic_channels == 1, 'semantic_channels': semantic_channels})
         self._finish_init(rendering_kwargs)
 
+    @frozen_pass
     def synthesis(self, ws, c, neural_rendering_resolution=None, update_emas=False, cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
         feature_image, depth_image = self._render(ws, c, neural_rendering_resolution, update_emas, cache_backbone, use_cached_backbone, synthesis_kwargs)
         half = feature_image.shape[1] // 2
@@ -469,6 +472,7 @@ class TriPlaneSemanticGenerator(_TriPlaneBase):
         self.decoder_semantic = OSGDecoder_semantic(32, {'decoder_lr_mul': lr_mul, 'decoder_output_dim': 32, 'sigmoid': semantic_channels == 1})
         self._finish_init(rendering_kwargs)
 
+    @frozen_pass
     def mapping(self, z, c, batch, truncation_psi=1, truncation_cutoff=None, update_emas=False):
         if self.rendering_kwargs['c_gen_conditioning_zero']:
             c = torch.zeros_like(c)
@@ -483,6 +487,7 @@ class TriPlaneSemanticGenerator(_TriPlaneBase):
         sem = self.backbone_semantic.synthesis(ws_semantic, update_emas=update_emas, **synthesis_kwargs)
         return _split_planes(tex, 3, 32), _split_planes(sem, 3, 32), ws_texture, ws_semantic
 
+    @frozen_pass
     def synthesis(self, ws, c, neural_rendering_resolution=None, update_emas=False, cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
         cam2world, intrinsics = c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3)
         if neural_rendering_resolution is None:
@@ -505,6 +510,7 @@ class TriPlaneSemanticGenerator(_TriPlaneBase):
         sr_semantic = self.superresolution_semantic(semantic_image, sem_feat, ws_semantic, **sr_kw)
         return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image, 'semantic': sr_semantic, 'semantic_raw': semantic_image}
 
+    @frozen_pass
     def sample_mixed(self, coordinates, directions, ws, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
         tex, sem, _, _ = self._both_planes(ws, update_emas, synthesis_kwargs)
         return self.renderer.run_model(tex, sem, self.decoder, self.decoder_semantic, coordinates, directions, self.rendering_kwargs)
@@ -525,6 +531,7 @@ class TriPlaneSemanticEntangleGenerator_withBG(TriPlaneSemanticEntangleGenerator
         mapping_bg_kwargs['class_name'] = None
         self.backbone_bg = StyleGAN2Backbone(z_dim, 0, w_dim, img_resolution=256, img_channels=32 * 2, mapping_kwargs=mapping_bg_kwargs, **synthesis_kwargs)
 
+    @frozen_pass
     def synthesis(self, ws, c, neural_rendering_resolution=None, update_emas=False, cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
         cam2world, intrinsics = c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3)
         if neural_rendering_resolution is None:

@@ -58,7 +58,7 @@ def phase_problems(g, key, names, norms, grads, stats, log, tol, draws=True):
         a, b = grads[nm].detach().float().cpu().reshape(-1)[:64].numpy(), g[f'{key}.h{j}']
         # (floor: 1e-3 of the phase's largest gradient norm — e.g. the density bias in Greg has an analytically ZERO gradient, d|s_a - s_b|/db = 0: what is
         #  left there is rounding noise of the two terms that cancel)
-        lim = tol * max(np.abs(b).max(), 1e-3 * float(ref[names.index(nm)]), 1e-3 * scale)
+        lim = 2.5 * tol * max(np.abs(b).max(), 1e-3 * float(ref[names.index(nm)]), 1e-3 * scale)      # single entries: 2.5x the bound on the norms
         if np.abs(a - b).max() >= lim:
             bad.append(f'{key}: head of {nm} off by {np.abs(a - b).max():.3e} (limit {lim:.3e})')
     if sorted(stats) != list(g[key + '.stat_names']):

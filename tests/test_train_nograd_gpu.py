@@ -54,5 +54,19 @@ def test_no_grad_training_pass_takes_the_fused_kernels_and_matches_the_unfused_r
         assert a['gradfix_forward_calls'] == 0 and b['gradfix_forward_calls'] > 20          # the fused pass never enters the training-mode convolution op
         for k, e in errs.items():
             assert e < (3e-2 if k in ('image', 'semantic') else 1e-4), (k, e)      # fp16 SR heads: the fp16 class; the fp32 part: bf16x3 vs exact fp32 products
+        # the D phases call run_G with grad mode ON and the generator frozen (training_loop.py:516; loss.py:834-836): no graph can be recorded, so the
+        # pass is the same one (triplane.frozen_pass) — bit for bit, and without a single training-mode convolution call
+        G.requires_grad_(False)
+        prev_en, conv2d_gradfix.enabled = conv2d_gradfix.enabled, True
+        try:
+            n0 = dict(conv2d_gradfix.native_calls)
+            with det.DetRNG(5):
+                frozen = G.synthesis(ws, c, neural_rendering_resolution=128, update_emas=True)
+            torch.cuda.synchronize()
+        finally:
+            conv2d_gradfix.enabled = prev_en
+        assert conv2d_gradfix.native_calls['forward'] == n0['forward'] and not frozen['image'].requires_grad
+        for k in ('image', 'semantic', 'image_raw', 'semantic_raw', 'image_depth'):
+            assert torch.equal(frozen[k], a[k]), k
     finally:
         G.eval()
