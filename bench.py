@@ -529,6 +529,19 @@ def main():
             train, _ = run_train(args, device, world, dist, 3, 2)
         except Exception as e:                                       # noqa: BLE001 - the headline line must still be printed
             train = {'error': f'{type(e).__name__}: {e}'[:300]}
+        if 'error' not in train:                                     # the same iteration with the generator's fp32 training convolutions as bf16x3 (opt-in)
+            from pix2pix3d_amd.training import triplane as _tp
+            prev_tp, _tp.train_products_bf16x3 = _tp.train_products_bf16x3, True
+            try:
+                t2, _ = run_train(args, device, world, dist, 3, 1)
+                train['generator_bf16x3'] = {'what': 'P3D_TRAIN_G_BF16X3=1: forward and data-gradient convolutions of the GENERATOR (backbone, label-map Encoder, fp32 part of the SR '
+                                                     'heads) as three bf16 MFMAs per product — the arithmetic its inference passes use; discriminators and every weight gradient exact fp32',
+                                             'ms_per_iteration': t2['ms_per_iteration'], 'img_per_s': t2['img_per_s'], 'phase_ms': t2['phase_ms'],
+                                             'lazy_schedule_ms': t2['lazy_schedule']['ms_per_iteration']}
+            except Exception as e:                                   # noqa: BLE001
+                train['generator_bf16x3'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+            finally:
+                _tp.train_products_bf16x3 = prev_tp
 
     if rank == 0:
         bb = ('f32 tensors + f32 accumulation; the backbone convolutions (3x3 and the 1x1 ToRGB) form each product as 3 bf16 MFMAs of (hi, lo) splits ("bf16x3", <= 5e-6 of the '

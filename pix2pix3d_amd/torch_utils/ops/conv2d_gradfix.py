@@ -12,6 +12,7 @@ the forward nor any gradient order of a training step enters the vendor convolut
 Anything else (groups, dilation, other strides; CPU tensors) takes torch's own operators.
 """
 import contextlib
+import threading
 import ctypes
 import os
 
@@ -33,6 +34,23 @@ def no_weight_gradients(disable=True):
         yield
     finally:
         weight_gradients_disabled = prev
+
+
+_scope = threading.local()          # .split: None = the module default (split_bf16), True / False = what the enclosing products() asked for
+
+
+@contextlib.contextmanager
+def products(bf16x3):
+    """Arithmetic of the fp32 forward / data-gradient convolutions CALLED inside this block (and of their gradients, whenever those run: the choice
+    travels with the op's configuration): True = three bf16 MFMAs per product ("bf16x3"), False = exact fp32 products, None = the module default.
+    The generator wraps its own passes in it (training/triplane.py: ``train_products``) — the discriminators' convolutions, called outside, keep the
+    default (exact fp32: their R1 gradient fields are the ones that react to 5e-6, see split_bf16 below)."""
+    prev = getattr(_scope, 'split', None)
+    _scope.split = bf16x3
+    try:
+        yield
+    finally:
+        _scope.split = prev
 
 
 def _tup(v, n=2):
@@ -61,10 +79,12 @@ def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_paddi
 
 class _Cfg:
     """Static description of one convolution (the cache key of the reference, conv2d_gradfix.py:78-80)."""
-    __slots__ = ('transpose', 'wshape', 'stride', 'padding', 'output_padding', 'dilation', 'groups')
+    __slots__ = ('transpose', 'wshape', 'stride', 'padding', 'output_padding', 'dilation', 'groups', 'split')
 
-    def __init__(self, transpose, wshape, stride, padding, output_padding, dilation, groups):
+    def __init__(self, transpose, wshape, stride, padding, output_padding, dilation, groups, split=None):
         self.transpose, self.wshape, self.groups = bool(transpose), tuple(wshape), int(groups)
+        scoped = getattr(_scope, 'split', None)
+        self.split = split if split is not None else (split_bf16 if scoped is None else bool(scoped))      # fixed when the op is first called; its gradients inherit it
         self.stride, self.padding = _tup(stride), _tup(padding)
         self.output_padding, self.dilation = _tup(output_padding), _tup(dilation)
         assert self.groups >= 1 and len(self.wshape) == 4
@@ -82,7 +102,7 @@ class _Cfg:
             kh, kw = self.wshape[2:]
             op = tuple(in_shape[i + 2] - (out_shape[i + 2] - 1) * self.stride[i] - (1 - 2 * self.padding[i]) - self.dilation[i] * (k - 1)
                        for i, k in enumerate((kh, kw)))
-        return _Cfg(not self.transpose, self.wshape, self.stride, self.padding, op, self.dilation, self.groups)
+        return _Cfg(not self.transpose, self.wshape, self.stride, self.padding, op, self.dilation, self.groups, split=self.split)
 
 
 native = True              # device tensors of the covered family go to libp3d_hip.so; False = torch's operators everywhere
@@ -154,7 +174,7 @@ def _native_conv(x, w, cfg, k, stride):
         x, ci = xp, cip
     y = torch.empty([n, co, oh, ow], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     scratch = None if skinny else torch.empty([co * ci * k * k], dtype=x.dtype, device=x.device)
-    code_dtype = 3 if (split_bf16 and x.dtype == torch.float32 and not skinny and k == 3 and ci % 32 == 0) else _lib.DTYPE_CODE[x.dtype]     # 3 = P3D_F32_BF16X3
+    code_dtype = 3 if (cfg.split and x.dtype == torch.float32 and not skinny and k == 3 and ci % 32 == 0) else _lib.DTYPE_CODE[x.dtype]     # 3 = P3D_F32_BF16X3
     nbytes = 0 if skinny else int(_lib.lib().p3d_conv2d_forward_workspace(code_dtype, n, h, wd, ci, co, k, stride, int(tr)))
     work = torch.empty([nbytes // 4], dtype=torch.float32, device=x.device) if nbytes > 0 else None      # split-K partial tiles (low-resolution layers)
     code = _lib.lib().p3d_conv2d_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), _lib.ptr(scratch), _lib.ptr(_zeros_page(x.device)), code_dtype,

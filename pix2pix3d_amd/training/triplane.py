@@ -15,6 +15,9 @@ from .volumetric_rendering.ray_sampler import RaySampler
 
 
 frozen_passes_without_graph = os.environ.get('P3D_FROZEN_NO_GRAD', '1') != '0'
+train_products_bf16x3 = os.environ.get('P3D_TRAIN_G_BF16X3', '0') == '1'     # opt-in: the GENERATOR's fp32 training convolutions (forward + data gradient; the label-map
+                                                                             # Encoder included) as bf16x3 — the arithmetic its inference passes use — while the
+                                                                             # discriminators keep exact fp32 products (conv2d_gradfix.products)
 
 
 def _tensors_of(values):
@@ -37,6 +40,10 @@ def frozen_pass(method):
             if tensors and all(t.is_cuda for t in tensors) and not any(t.requires_grad for t in tensors) and not any(p.requires_grad for p in self.parameters()):
                 with torch.no_grad():
                     return method(self, *args, **kwargs)
+        if train_products_bf16x3 and torch.is_grad_enabled():
+            from ..torch_utils.ops import conv2d_gradfix
+            with conv2d_gradfix.products(True):
+                return method(self, *args, **kwargs)
         return method(self, *args, **kwargs)
     return wrapper
 

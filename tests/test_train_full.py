@@ -184,6 +184,25 @@ def test_config3_gradients_bf16x3_opt_in(hip_lib):
 
 
 @pytest.mark.gpu
+def test_config3_gradients_generator_scoped_bf16x3(hip_lib):
+    """P3D_TRAIN_G_BF16X3=1 (training/triplane.py: train_products_bf16x3): the module default stays exact fp32, the generator's own passes ask
+    conv2d_gradfix.products(True) for bf16x3 — forward and data gradients inherit it through the op's configuration, whenever the backward runs."""
+    from pix2pix3d_amd.torch_utils.ops import conv2d_gradfix
+    from pix2pix3d_amd.training import triplane
+    prev, triplane.train_products_bf16x3 = triplane.train_products_bf16x3, True
+    try:
+        with _native_training(bf16x3=False):
+            assert conv2d_gradfix._Cfg(False, (8, 8, 3, 3), 1, 1, 0, 1, 1).split is False            # a discriminator's convolution, called outside the generator
+            with conv2d_gradfix.products(True):
+                cfg = conv2d_gradfix._Cfg(False, (8, 8, 3, 3), 1, 1, 0, 1, 1)
+            assert cfg.split is True and cfg.flipped((1, 8, 4, 4), (1, 8, 4, 4)).split is True      # ... and one called inside: its gradient op inherits the choice
+            worst = _train_full('cuda', 5e-3)
+    finally:
+        triplane.train_products_bf16x3 = prev
+    print('worst gradient-norm error (generator-scoped bf16x3)', worst)
+
+
+@pytest.mark.gpu
 def test_config3_gradients_fp16_sr_heads(hip_lib):
     """BASELINE config 3 as train.py configures it on a GPU: fp16 super-resolution heads (sr_num_fp16_res = 4, conv_clamp 256).  The
     reference record is fp32 (its CPU path), so this leg is held to the fp16 class.  The record's loss is a MEAN over 3 x 512^2 pixels, i.e.
