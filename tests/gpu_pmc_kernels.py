@@ -116,6 +116,8 @@ def main():
         for k, v in errors.items():
             f.write(f'# FAILED PASS [{k}]: {v[-300:]}\n')
     print(open(os.path.join(ROOT, 'gpurun_out', f'kernel_pmc_{what}.txt')).read())
+    import shutil
+    shutil.rmtree(out_root, ignore_errors=True)              # raw per-pass CSVs: tens of MB for a training iteration; gpurun copies back at most 64 MiB
 
 
 if __name__ == '__main__':

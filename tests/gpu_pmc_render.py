@@ -164,6 +164,8 @@ def main():
         for k, v in errors.items():
             f.write(f'# FAILED PASS [{k}]: {v[-300:]}\n')
     print(json.dumps({'binding': rec['binding'], 'derived': derived, 'traffic': rec['traffic_bytes_per_launch'], 'errors': list(errors)}))
+    import shutil
+    shutil.rmtree(out_root, ignore_errors=True)
 
 
 if __name__ == '__main__':
