@@ -137,10 +137,24 @@ def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
 
+def pack_decoder(decoder_info, device, bf16x3):
+    """The decoder's FullyConnectedLayer parameters in the kernels' LDS image (p3d_pack_decoder / _bf16x3), on the current stream."""
+    nets, lr_mul, _ = decoder_info
+    lib = _lib.lib()
+    packed = torch.empty([lib.p3d_render_decoder_floats()], dtype=torch.float32, device=device)
+    ws = []
+    for fc1, fc2 in nets:
+        ws += [_f32c(fc1.weight), _f32c(fc1.bias), _f32c(fc2.weight), _f32c(fc2.bias)]
+    ptrs = [_lib.ptr(t) for t in ws] + [None] * (8 - len(ws))
+    pack = lib.p3d_pack_decoder_bf16x3 if bf16x3 else lib.p3d_pack_decoder
+    _lib.check(pack(*ptrs, len(nets), lr_mul, _lib.ptr(packed), _lib.stream_of(packed)), 'pack_decoder')
+    return packed, ws
+
+
 class _FusedContext:
     """Device-side operands shared by the fused entry points: channels-last planes + packed decoder."""
 
-    def __init__(self, planes, decoder_info, bf16x3=False):
+    def __init__(self, planes, decoder_info, bf16x3=False, packed=None):
         nets, lr_mul, sem_sigmoid = decoder_info
         self.bf16x3 = bool(bf16x3)
         lib = _lib.lib()
@@ -158,14 +172,10 @@ class _FusedContext:
             src = _f32c(planes)
             self.planes_cl = torch.empty([n, 3, h, w, 32], dtype=torch.float32, device=planes.device)
             _lib.check(lib.p3d_planes_to_channels_last(_lib.ptr(src), _lib.ptr(self.planes_cl), n, h, w, _lib.stream_of(src)), 'planes_to_channels_last')
-        self.packed = torch.empty([lib.p3d_render_decoder_floats()], dtype=torch.float32, device=planes.device)
-        ws = []
-        for fc1, fc2 in nets:
-            ws += [_f32c(fc1.weight), _f32c(fc1.bias), _f32c(fc2.weight), _f32c(fc2.bias)]
-        ptrs = [_lib.ptr(t) for t in ws] + [None] * (8 - len(ws))
-        pack = lib.p3d_pack_decoder_bf16x3 if self.bf16x3 else lib.p3d_pack_decoder
-        _lib.check(pack(*ptrs, len(nets), lr_mul, _lib.ptr(self.packed), _lib.stream_of(src)), 'pack_decoder')
-        self._keep = ws
+        if packed is not None:                                 # (packed by pack_decoder() ahead of time, same arithmetic)
+            self.packed, self._keep = packed
+        else:
+            self.packed, self._keep = pack_decoder(decoder_info, planes.device, self.bf16x3)
         self.n_nets, self.sem_sigmoid, self.n, self.h, self.w = len(nets), sem_sigmoid, n, h, w
 
     def desc(self, options, rays_per_img=1, start=0.0, end=0.0, raster=False):
@@ -207,13 +217,25 @@ class ImportanceRenderer(torch.nn.Module):
             raise RuntimeError(f'ImportanceRenderer: fused HIP path required but unavailable: {reason}')
         _warn_tensor_op_route(type(self).__name__, reason)
 
-    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options):
+    def prepare(self, decoder, n, m, opt, device):
+        """Everything of a fused inference render that does not depend on the planes — the two uniform draws (in the reference's order) and the packed
+        decoder — so that a caller can issue it on another stream while the backbone still runs (training/triplane.py: _render).  None when the fused
+        kernel would not take the call anyway, or for the per-ray ('auto') limits, whose draw layout depends on them."""
+        info = _decoder_nets(decoder)
+        sc, sf = int(opt.get('depth_resolution', 0)), int(opt.get('depth_resolution_importance', 0))
+        if info is None or fused_policy == 'never' or not (4 <= sc <= 64 and 1 <= sf <= 64) or opt['ray_start'] == 'auto' or opt.get('density_noise', 0) > 0:
+            return None
+        u_c = torch.rand([n, m, sc, 1], device=device, dtype=torch.float32)
+        u_f = torch.rand([n * m, sf], device=device, dtype=torch.float32)
+        return dict(u_c=u_c, u_f=u_f, packed=pack_decoder(info, device, mlp_bf16x3), bf16x3=mlp_bf16x3)
+
+    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, prepared=None):
         self.plane_axes = self.plane_axes.to(ray_origins.device)
         needs_grad = torch.is_grad_enabled() and (planes.requires_grad or ray_origins.requires_grad or ray_directions.requires_grad
                                                   or any(p.requires_grad for p in decoder.parameters()))
         reason = self._fused_reason(planes, decoder, rendering_options, needs_grad)
         if reason is None:
-            out = self._forward_fused(planes, decoder, ray_origins, ray_directions, rendering_options, needs_grad)
+            out = self._forward_fused(planes, decoder, ray_origins, ray_directions, rendering_options, needs_grad, prepared)
             if out is not None:
                 return out
             reason = 'sample counts outside the fused kernel envelope (<= 64 coarse, 1..64 fine)'
@@ -230,8 +252,10 @@ class ImportanceRenderer(torch.nn.Module):
             t1[~ok] = t0[ok].max()
         return t0, t1
 
-    def _forward_fused(self, planes, decoder, ray_origins, ray_directions, opt, needs_grad=False):
+    def _forward_fused(self, planes, decoder, ray_origins, ray_directions, opt, needs_grad=False, prepared=None):
         n, m, _ = ray_origins.shape
+        if prepared is not None and not needs_grad and prepared['bf16x3'] == mlp_bf16x3:
+            return fused_render(planes, decoder, ray_origins, ray_directions, opt, prepared['u_c'], prepared['u_f'], packed=prepared['packed'])
         sc, sf = int(opt['depth_resolution']), int(opt['depth_resolution_importance'])
         if not (4 <= sc <= 64 and 1 <= sf <= 64):
             return None
@@ -736,7 +760,7 @@ def fused_render_backward(planes, decoder, ray_origins, ray_directions, opt, u_c
     return g_planes, g_params
 
 
-def fused_render(planes, decoder, ray_origins, ray_directions, opt, u_coarse, u_fine, t_start=None, t_end=None, debug=False, exact_fp32=False):
+def fused_render(planes, decoder, ray_origins, ray_directions, opt, u_coarse, u_fine, t_start=None, t_end=None, debug=False, exact_fp32=False, packed=None):
     """One launch of the fused ray-marcher with explicit uniforms (u_coarse [N,M,Sc(,1)], u_fine [N*M,Sf]).
     Returns (feat [N,M,C], depth [N,M,1], wsum [N,M,1]) and, with debug, the sorted fine depths [N*M,Sf] and the
     coarse weights [N*M,Sc-1] the kernel used."""
@@ -746,7 +770,7 @@ def fused_render(planes, decoder, ray_origins, ray_directions, opt, u_coarse, u_
     n, m, _ = ray_origins.shape
     sc, sf = int(opt['depth_resolution']), int(opt['depth_resolution_importance'])
     dev = planes.device
-    ctx = _FusedContext(planes, info, bf16x3=mlp_bf16x3 and not exact_fp32)      # (the training forward stays exact fp32: its backward recomputes in fp32)
+    ctx = _FusedContext(planes, info, bf16x3=mlp_bf16x3 and not exact_fp32, packed=packed)      # (the training forward stays exact fp32: its backward recomputes in fp32)
     auto = t_start is not None
     t0 = _f32c(t_start).reshape(-1) if auto else None
     t1 = _f32c(t_end).reshape(-1) if auto else None
