@@ -57,22 +57,24 @@ class EqualConv2d(torch.nn.Module):
 class Encoder(torch.nn.Module):
     """Discriminator-style pyramid down to 4x4 then a 4x4 projection to ``n_latents`` w vectors (:65-196).
 
-    Only the configuration pix2pix3D instantiates is implemented (non-progressive, no low-res head,
-    output_mode in W / W+ / None); the progressive-growing branches of the original raise."""
+    Every branch of the original that CAN execute is here.  Its progressive-growing code calls two functions that exist nowhere in the reference
+    (``downsample`` at :160, :163 and ``camera_9d_to_16d`` at :183 — neither defined nor imported: a NameError there), so: ``progressive`` works with the
+    full pyramid (alpha = -1) and with a low-resolution head at alpha = 0 fed an image already at that resolution; an input that would have to be
+    down-sized, a blend (0 < alpha < 1) and ``predict_camera`` raise NotImplementedError here, where the reference raises NameError."""
 
     def __init__(self, img_resolution, img_channels, bottleneck_factor=2, architecture='resnet', channel_base=1, channel_max=512,
                  num_fp16_res=0, conv_clamp=None, lowres_head=None, block_kwargs={}, model_kwargs={}, upsample_type='default',
                  progressive=False, **unused):
         super().__init__()
-        if progressive or lowres_head is not None or model_kwargs.get('predict_camera', False):
-            raise NotImplementedError('Encoder: progressive / lowres_head / predict_camera variants are not part of the pix2pix3D path')
         self.img_resolution, self.img_channels = img_resolution, img_channels
         self.img_resolution_log2 = int(np.log2(img_resolution))
         self.block_resolutions = [2 ** i for i in range(self.img_resolution_log2, bottleneck_factor, -1)]
         self.architecture, self.lowres_head, self.upsample_type, self.progressive = architecture, lowres_head, upsample_type, progressive
         self.model_kwargs = model_kwargs
         self.output_mode = model_kwargs.get('output_mode', 'styles')
-        self.predict_camera = False
+        if self.progressive:
+            assert self.architecture == 'skip', 'not supporting other types for now.'
+        self.predict_camera = model_kwargs.get('predict_camera', False)
         channel_base = int(channel_base * 32768)
         channels = {res: min(channel_base // res, channel_max) for res in self.block_resolutions + [4]}
         fp16_resolution = max(2 ** (self.img_resolution_log2 + 1 - num_fp16_res), 8)
@@ -88,7 +90,7 @@ class Encoder(torch.nn.Module):
         self.num_ws = model_kwargs.get('num_ws', 0)
         self.n_latents = self.num_ws if self.output_mode == 'W+' else (0 if self.output_mode == 'None' else 1)
         self.w_dim = model_kwargs.get('w_dim', 512)
-        self.add_dim = model_kwargs.get('add_dim', 0)
+        self.add_dim = model_kwargs.get('add_dim', 0) if not self.predict_camera else 9
         self.out_dim = self.w_dim * self.n_latents + self.add_dim
         assert self.out_dim > 0, 'output dimenstion has to be larger than 0'
         assert self.block_resolutions[-1] // 2 == 4, 'make sure the last resolution is 4x4'
@@ -96,18 +98,44 @@ class Encoder(torch.nn.Module):
         self.register_buffer('alpha', torch.scalar_tensor(-1))
 
     def set_resolution(self, res):
-        self.curr_status = res                       # progressive-growing hook of the original encoder; nothing here reads it
+        self.curr_status = res                       # (n_levels, _, before_res, target_res) of the progressive schedule (:131)
 
     def set_alpha(self, alpha):
         if alpha is None:
             return
         self.alpha.fill_(alpha)
 
+    def get_block_resolutions(self, input_img):
+        """Which blocks run, the blend weight and the head resolution (:133-153)."""
+        block_resolutions, lowres_head, alpha = self.block_resolutions, self.lowres_head, self.alpha
+        if self.progressive and (self.lowres_head is not None) and (self.alpha > -1):
+            if 0 < self.alpha < 1:
+                try:
+                    n_levels, _, before_res, target_res = self.curr_status
+                    alpha, index = math.modf(self.alpha * n_levels)
+                except Exception:                    # no schedule set: the original falls back to the input's own size
+                    before_res = target_res = input_img.size(-1)
+                if before_res == target_res:
+                    alpha = 0                        # the generator did not upsample either: no blend
+                block_resolutions = [res for res in self.block_resolutions if res <= target_res]
+                lowres_head = before_res
+            elif self.alpha == 0:
+                block_resolutions = [res for res in self.block_resolutions if res <= lowres_head]
+        return block_resolutions, alpha, lowres_head
+
     def forward(self, inputs, **block_kwargs):
         img = inputs['img'] if isinstance(inputs, dict) else inputs
-        assert img.size(-1) == self.block_resolutions[0], 'Encoder: input must already be at img_resolution'
-        x = None
-        for res in self.block_resolutions:
+        block_resolutions, alpha, lowres_head = self.get_block_resolutions(img)
+        blending = self.progressive and (self.lowres_head is not None) and (-1 < self.alpha < 1) and (alpha > 0)
+        if img.size(-1) > block_resolutions[0] or blending:
+            raise NotImplementedError('Encoder: this call needs the `downsample` function of the original (triplane_cond.py:160-163), which the reference never '
+                                      'defines (it raises NameError there); feed the image at the resolution of the first active block')
+        if self.predict_camera:
+            raise NotImplementedError('Encoder: predict_camera needs `camera_9d_to_16d` (triplane_cond.py:183), which the reference never defines')
+        assert img.size(-1) == block_resolutions[0], 'Encoder: input must already be at the first active block\'s resolution'
+        # progressive growing entered below the top of the pyramid: the first active block sees fromrgb(img) as its feature input (:165-166)
+        x = None if (not self.progressive) or (block_resolutions[0] == self.img_resolution) else getattr(self, f'b{block_resolutions[0]}').fromrgb(img)
+        for res in block_resolutions:
             x, img = getattr(self, f'b{res}')(x, img, **block_kwargs)
         out = self.projector(x)[:, :, 0, 0]
         if self.output_mode == 'W+':

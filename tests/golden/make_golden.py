@@ -3,7 +3,7 @@
 Run in the authoring container only (it needs the read-only checkout at /root/reference, which does
 not exist on the GPU box):
 
-    python tests/golden/make_golden.py [group ...]      # groups: ops renderer semrenderer model model_full flrelu train train_full greg checkpoint variants discriminator api srheads architectures helpers loss_phases discriminator_full
+    python tests/golden/make_golden.py [group ...]      # groups: ops renderer semrenderer model model_full flrelu train train_full greg checkpoint variants discriminator api srheads architectures helpers loss_phases discriminator_full encoder_variants
 
 The reference and this repo own the same top-level module names, so this script must never import
 ``pix2pix3d_amd``; it puts /root/reference first on sys.path and imports the reference's modules
@@ -1047,6 +1047,53 @@ def group_discriminator_full():
 
 
 GROUPS['discriminator_full'] = group_discriminator_full
+
+
+ENCODER_KW = dict(img_resolution=64, img_channels=3, architecture='skip', channel_base=1 / 64, channel_max=32, progressive=True, lowres_head=16,
+                  model_kwargs=dict(output_mode='W+', num_ws=3, w_dim=8))
+
+
+def group_encoder_variants():
+    """The branches of the reference ``Encoder`` (triplane_cond.py:65-196) that pix2pix3D never configures but that CAN execute: progressive growing with the
+    full pyramid (alpha = -1) and entered at the low-resolution head (alpha = 0, image already at 16^2: the first active block gets fromrgb(img) as its
+    feature input).  The other progressive paths and predict_camera call `downsample` / `camera_9d_to_16d`, which the reference defines nowhere — recorded
+    here as the NameError they raise."""
+    from training.triplane_cond import Encoder
+    weights = _load_by_path('p3d_weights', os.path.join(HERE, 'weights.py'))
+    torch.manual_seed(0)
+    enc = Encoder(**ENCODER_KW).eval().requires_grad_(False)
+    weights.seed_module(enc, seed=3)
+    g = torch.Generator().manual_seed(8)
+    full, low = torch.randn(2, 3, 64, 64, generator=g), torch.randn(2, 3, 16, 16, generator=g)
+    arrays = dict(full=full, low=low, ws_full=enc(full)['ws'])
+    enc.set_alpha(0.0)
+    arrays['ws_low'] = enc({'img': low})['ws']
+    enc.set_alpha(0.5)                                   # no schedule set: before_res == target_res == the input's size -> no blend, the alpha = 0 path (:140-147)
+    arrays['ws_half'] = enc(low)['ws']
+    mid = torch.randn(2, 3, 32, 32, generator=g)
+    arrays['mid'] = mid
+    errs = []
+
+    def blend():
+        enc.set_resolution((2, None, 16, 32)); enc.set_alpha(0.25)      # a real blend between the 16^2 head and the 32^2 block
+        return enc(mid)
+    for make in (lambda: (enc.set_alpha(0.0), enc(full)), blend):
+        try:
+            make(); errs.append('none')
+        except NameError as e:
+            errs.append(str(e))
+    cam = Encoder(**dict(ENCODER_KW, progressive=False, lowres_head=None, model_kwargs=dict(output_mode='W+', num_ws=3, w_dim=8, predict_camera=True))).eval()
+    try:
+        cam(full); errs.append('none')
+    except NameError as e:
+        errs.append(str(e))
+    arrays['name_errors'] = np.array(errs)
+    arrays['camera_out_dim'] = np.int64(cam.out_dim)
+    print(errs)
+    save('encoder_variants', **arrays)
+
+
+GROUPS['encoder_variants'] = group_encoder_variants
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GROUPS)

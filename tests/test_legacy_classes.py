@@ -59,3 +59,37 @@ def test_deepfp32_head_cpu_matches_reference():
 def test_deepfp32_head_device_matches_reference(hip_lib):
     _sr('cuda', 1e-3, force_fp32=True)
     _sr('cuda', 3e-2)
+
+
+def test_encoder_progressive_branches_that_the_reference_can_execute():
+    """Encoder (triplane_cond.py:65-196) beyond the configuration pix2pix3D instantiates: progressive growing with the full pyramid and entered at the
+    low-resolution head match the reference's records; where the reference itself raises NameError (its `downsample` / `camera_9d_to_16d` are defined
+    nowhere) this package raises NotImplementedError that says so."""
+    import importlib.util, os
+    import pytest
+    from conftest import ROOT
+    from pix2pix3d_amd.training.triplane_cond import Encoder
+    spec = importlib.util.spec_from_file_location('p3d_weights', os.path.join(ROOT, 'tests', 'golden', 'weights.py'))
+    weights = importlib.util.module_from_spec(spec); spec.loader.exec_module(weights)
+    g = load_golden('encoder_variants')
+    kw = dict(img_resolution=64, img_channels=3, architecture='skip', channel_base=1 / 64, channel_max=32, progressive=True, lowres_head=16,
+              model_kwargs=dict(output_mode='W+', num_ws=3, w_dim=8))
+    torch.manual_seed(0)
+    enc = Encoder(**kw).eval().requires_grad_(False)
+    weights.seed_module(enc, seed=3)
+    full, low = torch.tensor(g['full']), torch.tensor(g['low'])
+    assert rel_err(enc(full)['ws'].numpy(), g['ws_full']) < 1e-5
+    enc.set_alpha(0.0)
+    assert rel_err(enc({'img': low})['ws'].numpy(), g['ws_low']) < 1e-5
+    assert list(g['name_errors']) == ["name 'downsample' is not defined", "name 'downsample' is not defined", "name 'camera_9d_to_16d' is not defined"]
+    with pytest.raises(NotImplementedError, match='downsample'):
+        enc(full)                                                    # alpha = 0 with a full-size image: would have to be down-sized
+    enc.set_alpha(0.5)                                               # no schedule: no blend, the alpha = 0 path
+    assert rel_err(enc(low)['ws'].numpy(), g['ws_half']) < 1e-5
+    enc.set_resolution((2, None, 16, 32)); enc.set_alpha(0.25)
+    with pytest.raises(NotImplementedError, match='downsample'):
+        enc(torch.tensor(g['mid']))                                  # a real blend between the 16^2 head and the 32^2 block
+    cam = Encoder(**dict(kw, progressive=False, lowres_head=None, model_kwargs=dict(output_mode='W+', num_ws=3, w_dim=8, predict_camera=True)))
+    assert cam.out_dim == int(g['camera_out_dim']) == 8 * 3 + 9
+    with pytest.raises(NotImplementedError, match='camera_9d_to_16d'):
+        cam(full)
