@@ -113,6 +113,13 @@ split_bf16 = os.environ.get('P3D_TRAIN_BF16X3', '0') == '1'      # opt-in: fp32 
                                                                  # which moves R1 gradient fields by ~1 % in L2 (tests/test_discriminator.py) — fine for inference, not a
                                                                  # default for a training run that is meant to reproduce the reference's
 native_calls = {'forward': 0, 'weight_grad': 0, 'aten': 0}      # which route the dense arithmetic took (tests)
+aten_log = []                # the first few calls that went to torch's operators: (what, transpose, weight shape, stride, padding, output_padding, dtypes, input shape)
+
+
+def _note_aten(what, cfg, x, other):
+    native_calls['aten'] += 1
+    if len(aten_log) < 16:
+        aten_log.append((what, cfg.transpose, cfg.wshape, cfg.stride, cfg.padding, cfg.output_padding, cfg.groups, str(x.dtype), str(getattr(other, 'dtype', None)), tuple(x.shape), str(x.device)))
 
 _vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
 _lib.register('p3d_conv2d_forward', ctypes.c_int, [_vp] * 5 + [ctypes.c_int] + [_i32] * 10 + [_vp, _i64, _vp])
@@ -191,7 +198,7 @@ def _conv_impl(x, w, b, cfg):
     if geo is not None:
         y = _native_conv(x, w, cfg, *geo)
         return y if b is None else y + b.to(y.dtype).reshape(1, -1, 1, 1)
-    native_calls['aten'] += 1
+    _note_aten('conv', cfg, x, w)
     if not cfg.transpose:
         return torch.nn.functional.conv2d(x, w, b, stride=cfg.stride, padding=cfg.padding, dilation=cfg.dilation, groups=cfg.groups)
     return torch.nn.functional.conv_transpose2d(x, w, b, stride=cfg.stride, padding=cfg.padding, output_padding=cfg.output_padding,
@@ -225,7 +232,7 @@ def _weight_grad_impl(grad_output, x, cfg):
     geo = None if grad_output.dtype != x.dtype else _native_geometry(x, torch.empty(0, dtype=x.dtype), cfg)
     if geo is not None:
         return _native_weight_grad(grad_output, x, cfg, *geo)
-    native_calls['aten'] += 1
+    _note_aten('weight_grad', cfg, x, grad_output)
     if _is_pointwise(cfg) and not cfg.transpose:          # 1x1: a batched matmul over pixels (conv2d_gradfix.py:165-170)
         g = cfg.groups
         a = grad_output.reshape(grad_output.shape[0], g, grad_output.shape[1] // g, -1).permute(1, 2, 0, 3).flatten(2)

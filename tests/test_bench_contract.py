@@ -1,6 +1,6 @@
-"""The benchmark line's contract, checked on the line the final tree printed on an MI355X (profiles/round3_as_bench_line_default.json) and on
+"""The benchmark line's contract, checked on the line this round's tree printed on an MI355X (profiles/round4_bench_line_default.json) and on
 bench.py's argument surface: the keys the driver parses, the roofline object backed by committed counter passes whose hash matches the
-kernel sources of this tree, the CPU baseline, the exact-fp32 leg and the four-phase training step."""
+kernel sources of this tree, the CPU baseline, the exact-fp32 leg and the six-phase training step."""
 import hashlib
 import json
 import os
@@ -15,7 +15,7 @@ def _line(name):
 
 
 def test_default_line_has_the_contract_keys():
-    d = _line('round3_as_bench_line_default.json')
+    d = _line('round4_bench_line_default.json')
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
               'roofline', 'cpu_baseline', 'exact_fp32', 'train_step'):
         assert k in d, k
@@ -33,7 +33,13 @@ def test_default_line_has_the_contract_keys():
     e = d['exact_fp32']
     assert e['value'] < d['value'] and e['mfma_conv']['conv_f32']['tflops'] is not None and e['roofline']['bound'] == 'mfma_pipe'
     t = d['train_step']
-    assert set(t['phase_ms']) == {'Gmain', 'Greg', 'Dmain', 'Dreg', 'ema'} and t['lazy_schedule']['ms_per_iteration'] < t['ms_per_iteration']
+    assert set(t['phase_ms']) == {'Gmain', 'Greg', 'Dmain', 'Dreg', 'D_semanticmain', 'D_semanticreg', 'ema'}          # config 3 with --dis_mask=True: six phases
+    assert t['lazy_schedule']['ms_per_iteration'] < t['ms_per_iteration'] and abs(sum(t['phase_ms'].values()) - t['ms_per_iteration']) < 0.05 * t['ms_per_iteration']
+    assert t['phase_ms']['Gmain'] > 2.5 * t['phase_ms']['Dmain']                       # four generator passes, two of them differentiated
+    g = t['generator_bf16x3']
+    assert g['ms_per_iteration'] < t['ms_per_iteration'] and abs(g['phase_ms']['Dreg'] - t['phase_ms']['Dreg']) < 0.1 * t['phase_ms']['Dreg']     # the discriminators' arithmetic is untouched
+    r = t['roofline']
+    assert r is None or (r['dominant']['bound'] in ('mfma', 'valu_issue', 'lds', 'hbm') and 0 < r['dominant']['frac'] <= 1)
 
 
 def test_committed_counter_passes_belong_to_this_trees_kernel():
