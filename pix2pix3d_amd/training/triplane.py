@@ -109,7 +109,7 @@ class _TriPlaneCore(torch.nn.Module):
             # device inference: the rays, the renderer's two uniform draws and the packed decoder do not depend on the planes — they are issued on the
             # side stream and run under the backbone instead of between it and the ray-marcher (six launches, ~60 us of a 5.6 ms step).  With
             # noise_mode 'random' the backbone draws from the same generator first (the reference's order), so nothing is hoisted there.
-            main, side = torch.cuda.current_stream(), modconv.side_stream(ws.device)
+            main, side = torch.cuda.current_stream(), modconv.side_stream(ws.device, lane=1)      # (its own lane: lane 0 carries the backbone's first dependency, the style affines)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 ray_o, ray_d = self.ray_sampler(cam2world, intrinsics, neural_rendering_resolution)
