@@ -60,6 +60,10 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
         weight, styles = _fp16_prescale(weight, styles)
     demod = _demod_coefficients(weight, styles) if demodulate else None
     resample = dict(f=resample_filter, up=up, down=down, padding=padding, flip_weight=flip_weight)
+    if fused_modconv and x.is_cuda and conv2d_gradfix.enabled and conv2d_gradfix.native:
+        # A device call that reaches this function with fused_modconv set is one the native fused kernels did not take (e.g. a 16-channel layer).  The
+        # grouped convolution below would go to the vendor library; the unfused formulation is the same function on the native shared-weight kernels.
+        fused_modconv = False
 
     if fused_modconv:
         w_each = weight.unsqueeze(0) * styles.reshape(n, 1, cin, 1, 1)
