@@ -21,11 +21,10 @@ _plan = {}                   # id(layer) -> (styles, (wmod, route tag) or None, 
 _side = {}
 
 
-def side_stream(device, lane=0):
-    """lane 0: the style / weight-modulation prefetch of the synthesis networks; lane 1: the renderer's plane-independent preparation (training/triplane.py)."""
-    st = _side.get((device, lane))
+def side_stream(device):
+    st = _side.get(device)
     if st is None:
-        st = _side[(device, lane)] = torch.cuda.Stream(device=device)
+        st = _side[device] = torch.cuda.Stream(device=device)
     return st
 
 

@@ -9,14 +9,12 @@ import torch
 
 from .. import dnnlib
 from ..torch_utils import persistence
-from ..torch_utils.ops import modconv
 from .networks_stylegan2 import FullyConnectedLayer, Generator as StyleGAN2Backbone
 from .volumetric_rendering.renderer import ImportanceRenderer
 from .volumetric_rendering.ray_sampler import RaySampler
 
 
 frozen_passes_without_graph = os.environ.get('P3D_FROZEN_NO_GRAD', '1') != '0'
-hoist_render_prep = os.environ.get('P3D_HOIST_RENDER_PREP', '1') != '0'        # device inference: rays / uniform draws / decoder packing on the side stream, under the backbone
 train_products_bf16x3 = os.environ.get('P3D_TRAIN_G_BF16X3', '0') == '1'     # opt-in: the GENERATOR's fp32 training convolutions (forward + data gradient; the label-map
                                                                              # Encoder included) as bf16x3 — the arithmetic its inference passes use — while the
                                                                              # discriminators keep exact fp32 products (conv2d_gradfix.products)
@@ -103,29 +101,10 @@ class _TriPlaneCore(torch.nn.Module):
             neural_rendering_resolution = self.neural_rendering_resolution
         else:
             self.neural_rendering_resolution = neural_rendering_resolution
-        prepared = None
-        if hoist_render_prep and ws.is_cuda and not torch.is_grad_enabled() and synthesis_kwargs.get('noise_mode', 'random') != 'random' \
-                and type(self.renderer) is ImportanceRenderer and not (use_cached_backbone and self._last_planes is not None):
-            # device inference: the rays, the renderer's two uniform draws and the packed decoder do not depend on the planes — they are issued on the
-            # side stream and run under the backbone instead of between it and the ray-marcher (six launches, ~60 us of a 5.6 ms step).  With
-            # noise_mode 'random' the backbone draws from the same generator first (the reference's order), so nothing is hoisted there.
-            main, side = torch.cuda.current_stream(), modconv.side_stream(ws.device, lane=1)      # (its own lane: lane 0 carries the backbone's first dependency, the style affines)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                ray_o, ray_d = self.ray_sampler(cam2world, intrinsics, neural_rendering_resolution)
-                r2 = int(neural_rendering_resolution) ** 2
-                prepared = self.renderer.prepare(self.decoder, ray_o.shape[0], r2, self.rendering_kwargs, ws.device)
-            ready = torch.cuda.Event()
-            ready.record(side)
-        else:
-            ray_o, ray_d = self.ray_sampler(cam2world, intrinsics, neural_rendering_resolution)
+        ray_o, ray_d = self.ray_sampler(cam2world, intrinsics, neural_rendering_resolution)
         n = ray_o.shape[0]
         planes = self._planes(ws, update_emas, synthesis_kwargs, cache_backbone, use_cached_backbone)
-        if prepared is not None:
-            torch.cuda.current_stream().wait_event(ready)
-            feat, depth, _ = self.renderer(planes, self.decoder, ray_o, ray_d, self.rendering_kwargs, prepared=prepared)
-        else:
-            feat, depth, _ = self.renderer(planes, self.decoder, ray_o, ray_d, self.rendering_kwargs)
+        feat, depth, _ = self.renderer(planes, self.decoder, ray_o, ray_d, self.rendering_kwargs)
         r = self.neural_rendering_resolution
         if feat.is_cuda and not torch.is_grad_enabled():
             # the fused renderer's [N, rays, C] IS the channels-last image: the SR heads (channels-last, fp16) convert their half of it in the

@@ -217,25 +217,13 @@ class ImportanceRenderer(torch.nn.Module):
             raise RuntimeError(f'ImportanceRenderer: fused HIP path required but unavailable: {reason}')
         _warn_tensor_op_route(type(self).__name__, reason)
 
-    def prepare(self, decoder, n, m, opt, device):
-        """Everything of a fused inference render that does not depend on the planes — the two uniform draws (in the reference's order) and the packed
-        decoder — so that a caller can issue it on another stream while the backbone still runs (training/triplane.py: _render).  None when the fused
-        kernel would not take the call anyway, or for the per-ray ('auto') limits, whose draw layout depends on them."""
-        info = _decoder_nets(decoder)
-        sc, sf = int(opt.get('depth_resolution', 0)), int(opt.get('depth_resolution_importance', 0))
-        if info is None or fused_policy == 'never' or not (4 <= sc <= 64 and 1 <= sf <= 64) or opt['ray_start'] == 'auto' or opt.get('density_noise', 0) > 0:
-            return None
-        u_c = torch.rand([n, m, sc, 1], device=device, dtype=torch.float32)
-        u_f = torch.rand([n * m, sf], device=device, dtype=torch.float32)
-        return dict(u_c=u_c, u_f=u_f, packed=pack_decoder(info, device, mlp_bf16x3), bf16x3=mlp_bf16x3)
-
-    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, prepared=None):
+    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options):
         self.plane_axes = self.plane_axes.to(ray_origins.device)
         needs_grad = torch.is_grad_enabled() and (planes.requires_grad or ray_origins.requires_grad or ray_directions.requires_grad
                                                   or any(p.requires_grad for p in decoder.parameters()))
         reason = self._fused_reason(planes, decoder, rendering_options, needs_grad)
         if reason is None:
-            out = self._forward_fused(planes, decoder, ray_origins, ray_directions, rendering_options, needs_grad, prepared)
+            out = self._forward_fused(planes, decoder, ray_origins, ray_directions, rendering_options, needs_grad)
             if out is not None:
                 return out
             reason = 'sample counts outside the fused kernel envelope (<= 64 coarse, 1..64 fine)'
@@ -252,10 +240,8 @@ class ImportanceRenderer(torch.nn.Module):
             t1[~ok] = t0[ok].max()
         return t0, t1
 
-    def _forward_fused(self, planes, decoder, ray_origins, ray_directions, opt, needs_grad=False, prepared=None):
+    def _forward_fused(self, planes, decoder, ray_origins, ray_directions, opt, needs_grad=False):
         n, m, _ = ray_origins.shape
-        if prepared is not None and not needs_grad and prepared['bf16x3'] == mlp_bf16x3:
-            return fused_render(planes, decoder, ray_origins, ray_directions, opt, prepared['u_c'], prepared['u_f'], packed=prepared['packed'])
         sc, sf = int(opt['depth_resolution']), int(opt['depth_resolution_importance'])
         if not (4 <= sc <= 64 and 1 <= sf <= 64):
             return None
