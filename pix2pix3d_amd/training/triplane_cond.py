@@ -467,30 +467,9 @@ class TriPlaneSemanticEntangleGenerator(_TriPlaneBase):
         sr_kw = self._sr_kwargs(synthesis_kwargs)
         rgb_image = rgb_feat[:, :3]
         semantic_image = sem_feat[:, :self.semantic_channels]
-        if concurrent_sr_heads and ws.is_cuda and not torch.is_grad_enabled():
-            # the two heads are independent: the label head is issued on its own stream, so its small launches (ToRGB, layout copies, skip-image
-            # upsampling) and kernel tails run under the image head's chip-filling kernels
-            main, other = torch.cuda.current_stream(), _head_stream(ws.device)
-            other.wait_stream(main)
-            with torch.cuda.stream(other):
-                sr_semantic = self.superresolution_semantic(semantic_image, sem_feat, ws, **sr_kw)
-            sr_image = self.superresolution(rgb_image, rgb_feat, ws, **sr_kw)
-            main.wait_stream(other)
-        else:
-            sr_image = self.superresolution(rgb_image, rgb_feat, ws, **sr_kw)
-            sr_semantic = self.superresolution_semantic(semantic_image, sem_feat, ws, **sr_kw)
+        sr_image = self.superresolution(rgb_image, rgb_feat, ws, **sr_kw)
+        sr_semantic = self.superresolution_semantic(semantic_image, sem_feat, ws, **sr_kw)
         return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image, 'semantic': sr_semantic, 'semantic_raw': semantic_image}
-
-
-concurrent_sr_heads = os.environ.get('P3D_CONCURRENT_SR', '0') == '1'
-_head_streams = {}
-
-
-def _head_stream(device):
-    st = _head_streams.get(device)
-    if st is None:
-        st = _head_streams[device] = torch.cuda.Stream(device=device)
-    return st
 
 
 def _split_planes(planes, n_planes, channels):
