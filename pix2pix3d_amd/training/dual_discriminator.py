@@ -1,6 +1,8 @@
 """Discriminators of the tri-plane GAN.  Mirror of training/dual_discriminator.py (line refs are to that file): same
 class names, constructor arguments and parameter names.  ``DualDiscriminator`` sees the super-resolved image
 concatenated with the bilinearly (anti-aliased) up-sized raw neural rendering (:157-172)."""
+import os
+
 import numpy as np
 import torch
 
@@ -59,10 +61,34 @@ class SingleDiscriminator(torch.nn.Module):
         return f'c_dim={self.c_dim:d}, img_resolution={self.img_resolution:d}, img_channels={self.img_channels:d}'
 
 
+native_upsize = os.environ.get('P3D_NATIVE_UPSIZE', '1') != '0'
+_tri_filters = {}
+
+
+def bilinear_upsize(x, s):
+    """Bilinear up-sizing by an even integer factor (align_corners=False) on the native upfirdn2d kernels — forward, gradient and double backward (R1
+    differentiates the discriminator's input resize twice).  Anti-aliasing does nothing when up-sizing (the filter support is max(1, in/out) = 1), so this
+    IS ``interpolate(mode='bilinear', antialias=True)`` of the reference's filtered_resizing for the raw image (dual_discriminator.py:86-90, 166) to fp32
+    rounding: zero-insertion by s, then the separable triangle of 2 s taps ((k + 0.5) / s), the clamped border rows realised by one replicated pixel.
+    ATen's anti-aliased backward kernel took 1.0 ms per call for this 128^2 -> 512^2 resize (profiles/round4_a_train_kernel_stats.csv)."""
+    assert s in (2, 4, 8)
+    key = (s, x.device)
+    f = _tri_filters.get(key)
+    if f is None:
+        taps = [(k + 0.5) / s for k in range(s)]
+        f = _tri_filters[key] = upfirdn2d.setup_filter(taps + taps[::-1], device=x.device)
+    xp = torch.nn.functional.pad(x, (1, 1, 1, 1), mode='replicate')
+    p0, p1 = s // 2 - 1, -(s // 2)
+    return upfirdn2d.upfirdn2d(xp, f, up=s, padding=[p0, p1, p0, p1], gain=s * s)
+
+
 def filtered_resizing(image_orig_tensor, size, f, filter_mode='antialiased'):
     """Resize the raw rendering to the discriminator resolution (:86-102)."""
     interp = lambda t, s, aa=False: torch.nn.functional.interpolate(t, size=(s, s), mode='bilinear', align_corners=False, antialias=aa)
     if filter_mode == 'antialiased':
+        h, w = image_orig_tensor.shape[-2:]
+        if native_upsize and image_orig_tensor.is_cuda and h == w and size in (2 * h, 4 * h, 8 * h) and image_orig_tensor.dtype == torch.float32:
+            return bilinear_upsize(image_orig_tensor, size // h)
         return interp(image_orig_tensor, size, True)
     if filter_mode == 'classic':
         t = upfirdn2d.upsample2d(image_orig_tensor, f, up=2)

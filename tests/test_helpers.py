@@ -45,3 +45,65 @@ def test_math_utils():
     tv = math_utils.transform_vectors(torch.tensor(g['mu.m']), torch.randn(50, 4, generator=torch.Generator().manual_seed(92)))
     assert rel_err(tv.numpy(), g['mu.tv']) < 1e-6
     assert rel_err(math_utils.normalize_vecs(o).numpy(), g['mu.nv']) < 1e-6 and rel_err(math_utils.torch_dot(o, d).numpy(), g['mu.dot']) < 1e-6
+
+
+def test_native_bilinear_upsize_is_the_antialiased_interpolate():
+    """dual_discriminator.bilinear_upsize (zero-insertion + triangle FIR on the upfirdn2d op) against torch's anti-aliased bilinear interpolate, which the
+    reference's filtered_resizing calls for the discriminator's raw-image input (dual_discriminator.py:86-90): values, gradient and double backward."""
+    import torch
+    import torch.nn.functional as F
+    from pix2pix3d_amd.training.dual_discriminator import bilinear_upsize
+    torch.manual_seed(0)
+    for s, n in ((4, 12), (2, 9), (8, 6)):
+        x = torch.randn(2, 3, n, n, requires_grad=True)
+        ref = F.interpolate(x, size=(n * s, n * s), mode='bilinear', align_corners=False, antialias=True)
+        got = bilinear_upsize(x, s)
+        assert got.shape == ref.shape and float((got - ref).abs().max()) < 2e-6
+        g = torch.randn_like(ref)
+        (ga,) = torch.autograd.grad(ref, x, g, create_graph=True)
+        (gb,) = torch.autograd.grad(got, x, g, create_graph=True)
+        assert float((ga - gb).abs().max()) < 1e-5
+        x2 = torch.randn(2, 3, n, n, requires_grad=True)                      # double backward: d/dg of <grad(g), v> is the forward applied to v
+        y = bilinear_upsize(x2, s)
+        gg = torch.randn_like(y).requires_grad_(True)
+        (gx,) = torch.autograd.grad(y, x2, gg, create_graph=True)
+        v = torch.randn_like(gx)
+        (d,) = torch.autograd.grad((gx * v).sum(), gg)
+        assert float((d - F.interpolate(v, size=(n * s, n * s), mode='bilinear', align_corners=False)).abs().max()) < 2e-6
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_filtered_resizing_upsizes_on_the_native_kernels(hip_lib):
+    """On the device the discriminator's raw-image resize (128^2 -> 512^2, config 3) runs on upfirdn2d kernels: against torch's anti-aliased interpolate
+    on the same device — values, gradient, and the double backward R1 takes through it."""
+    import torch
+    import torch.nn.functional as F
+    from pix2pix3d_amd import _lib
+    from pix2pix3d_amd.torch_utils.ops import upfirdn2d
+    from pix2pix3d_amd.training import dual_discriminator as dd
+    torch.manual_seed(1)
+    f = upfirdn2d.setup_filter([1, 3, 3, 1], device=torch.device('cuda'))
+    for ch in (3, 9):
+        x = torch.randn(4, ch, 128, 128, device='cuda', requires_grad=True)
+        n0 = _lib.launch_count('upfirdn2d')
+        got = dd.filtered_resizing(x, size=512, f=f)
+        assert _lib.launch_count('upfirdn2d') > n0
+        ref = F.interpolate(x, size=(512, 512), mode='bilinear', align_corners=False, antialias=True)
+        assert got.shape == ref.shape and float((got - ref).abs().max()) < 5e-6
+        g = torch.randn_like(ref)
+        (ga,) = torch.autograd.grad(ref, x, g, create_graph=True)
+        (gb,) = torch.autograd.grad(got, x, g, create_graph=True)
+        assert float((ga - gb).abs().max()) < 5e-5 * float(ga.abs().max())
+        (da,) = torch.autograd.grad(ga.square().sum(), x)                     # R1-style: gradient of |grad|^2
+        (db,) = torch.autograd.grad(gb.square().sum(), x)
+        assert float((da - db).abs().max()) <= 1e-4 * max(float(da.abs().max()), 1e-12)
+    prev, dd.native_upsize = dd.native_upsize, False
+    try:
+        n0 = _lib.launch_count('upfirdn2d')
+        dd.filtered_resizing(x.detach(), size=512, f=f)
+        assert _lib.launch_count('upfirdn2d') == n0
+    finally:
+        dd.native_upsize = prev
