@@ -93,12 +93,12 @@ def test_filtered_resizing_upsizes_on_the_native_kernels(hip_lib):
         assert _lib.launch_count('upfirdn2d') > n0
         ref = F.interpolate(x, size=(512, 512), mode='bilinear', align_corners=False, antialias=True)
         assert got.shape == ref.shape and float((got - ref).abs().max()) < 5e-6
-        g = torch.randn_like(ref)
+        g = torch.randn_like(ref).requires_grad_(True)
         (ga,) = torch.autograd.grad(ref, x, g, create_graph=True)
         (gb,) = torch.autograd.grad(got, x, g, create_graph=True)
         assert float((ga - gb).abs().max()) < 5e-5 * float(ga.abs().max())
-        (da,) = torch.autograd.grad(ga.square().sum(), x)                     # R1-style: gradient of |grad|^2
-        (db,) = torch.autograd.grad(gb.square().sum(), x)
+        (da,) = torch.autograd.grad(ga.square().sum(), g)                     # R1-style second differentiation: through the resize's backward
+        (db,) = torch.autograd.grad(gb.square().sum(), g)
         assert float((da - db).abs().max()) <= 1e-4 * max(float(da.abs().max()), 1e-12)
     prev, dd.native_upsize = dd.native_upsize, False
     try:
