@@ -367,6 +367,21 @@ static bool try_channels_last(const UpfirArgs& a, hipStream_t s)
     int64_t blocks64 = (total + 255) / 256;
     const int blocks = (int)(blocks64 > (int64_t)kNumCU * 32 ? (int64_t)kNumCU * 32 : blocks64);
     const int u = a.up_x, d = a.down_x, f = a.fw;
+    if constexpr (sizeof(T) <= 4) {
+        // plain 4x4 filtering at full rate (the blur in front of every stride-2 convolution of D and of the label-map Encoder, and its gradient): the
+        // LDS-tiled kernel of the fused FIR + epilogue with an empty epilogue — one HBM round trip per 19 x 19 x 128-byte tile instead of sixteen
+        // cache-served taps per output (upfirdn2d_cl_kernel<., 1, 1, 4>: 0.18 of the HBM peak, waves 69 % at s_waitcnt in a training iteration)
+        constexpr int CB = 8 * VEC;
+        static const bool no_fir4 = getenv("P3D_UPFIRDN_NO_FIR4") != nullptr;               // (A/B switch)
+        if (!no_fir4 && u == 1 && d == 1 && f == 4 && !a.accumulate && a.C % CB == 0 && a.out_h >= 1 && a.out_w >= 1) {
+            FirEpilogue ep{nullptr, nullptr, nullptr, 1, 0.2f, 1.0f, -1.0f, 0};
+            const int64_t fb = (int64_t)a.N * ((a.out_h + 15) / 16) * ((a.out_w + 15) / 16) * (a.C / CB);
+            if (fb > 0 && fb < (1ll << 31)) {
+                hipLaunchKernelGGL(fir4_cl_fused_kernel<T>, dim3((unsigned)fb), dim3(256), 0, s, a, ep);
+                return true;
+            }
+        }
+    }
 #define P3D_CL(U, D, FF) if (u == U && d == D && f == FF) { hipLaunchKernelGGL((upfirdn2d_cl_kernel<T, U, D, FF>), dim3(blocks), dim3(256), 0, s, a); return true; }
     P3D_CL(1, 1, 4) P3D_CL(2, 1, 4) P3D_CL(1, 2, 4) P3D_CL(2, 2, 4)
 #undef P3D_CL
