@@ -96,7 +96,28 @@ __global__ void __launch_bounds__(256) col_dot_kernel(const T* __restrict__ p, c
     const int a_begin = chunk * rows_per_chunk, a_end = min(A, a_begin + rows_per_chunk);
     if (col < bv && r0 < rl) {
         const int64_t base = (int64_t)n * A * bv + col;
-        for (int a = a_begin + r0; a < a_end; a += rl) {
+        // four rows in flight per tensor: the loop is nothing but dependent-free 16-byte loads, and with one pair per iteration a wave waited a full
+        // memory round trip per 32 bytes (0.3 of the HBM peak at ~1 wave per SIMD in a training iteration: profiles/round4_d_kernel_pmc_train6.txt)
+        int a = a_begin + r0;
+        for (; a + 3 * rl < a_end; a += 4 * rl) {
+            V pv[4], qv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pv[u] = ((const V*)p)[base + (int64_t)(a + u * rl) * bv];
+            if (q) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) qv[u] = ((const V*)q)[base + (int64_t)(a + u * rl) * bv];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[e] = fmaf((float)pv[u][e], (float)qv[u][e], acc[e]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[e] += (float)pv[u][e];
+            }
+        }
+        for (; a < a_end; a += rl) {
             const V pv = ((const V*)p)[base + (int64_t)a * bv];
             if (q) {
                 const V qv = ((const V*)q)[base + (int64_t)a * bv];

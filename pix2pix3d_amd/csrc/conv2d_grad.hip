@@ -318,6 +318,42 @@ __global__ void __launch_bounds__(256) skinny_contract_kernel(const T* __restric
     const int sub = lane & (lpp - 1), slot = lane / lpp, ppw = 64 / lpp;         // lane within its pixel group, group within the wave
     const int groups = Ci / EPC;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    // Fast path (ToRGB and its relatives: every lane of a pixel group owns exactly ONE 16-byte channel group, at most 8 outputs): four pixel groups per
+    // iteration, their loads issued together — the loop below it keeps one 16-byte load per lane in flight and spent its life waiting for it
+    // (207 us for a 268 MB fp16 image = 1.3 TB/s in a training iteration, profiles/round4_a_train_kernel_stats.csv).
+    if (groups == lpp && Co <= 8) {
+        constexpr int U = 4;
+        for (int64_t p0 = wave * ppw; p0 < npix; p0 += nwaves * ppw * U) {
+            f32x4 xr[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t p = p0 + (int64_t)u * nwaves * ppw + slot;
+                xr[u] = p < npix ? *(const f32x4*)(x + p * Ci + sub * EPC) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t p = p0 + (int64_t)u * nwaves * ppw + slot;
+                T xv[EPC];
+                *(f32x4*)xv = xr[u];
+                float acc[8];
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    acc[o] = 0.f;
+                    if (o < Co) {
+                        const float* wr = wl + o * Ci + sub * EPC;
+#pragma unroll
+                        for (int q = 0; q < EPC; ++q) acc[o] = fmaf(ld(xv + q), wr[q], acc[o]);
+                        for (int m = lpp >> 1; m > 0; m >>= 1) acc[o] += __shfl_xor(acc[o], m, 64);
+                    }
+                }
+                if (p < npix && sub == 0)
+#pragma unroll
+                    for (int o = 0; o < 8; ++o)
+                        if (o < Co) st(y + p * Co + o, acc[o]);
+            }
+        }
+        return;
+    }
     for (int64_t p0 = wave * ppw; p0 < npix; p0 += nwaves * ppw) {
         const int64_t p = p0 + slot;
         const bool live = p < npix;
