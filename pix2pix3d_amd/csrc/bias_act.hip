@@ -107,11 +107,17 @@ __global__ void __launch_bounds__(256) bias_act_kernel(BiasActArgs a)
         if (yrp) pyr = *(const P*)(yrp + i0);
         if (dyp) pdy = *(const P*)(dyp + i0);
         uint32_t q = 0, r = 0;                       // bias row and position inside it
-        if (bp) { q = i0 / a.step_b; r = i0 - q * a.step_b; q %= a.size_b; }
-        S bias = bp ? ld(bp + q) : S(0);
+        // channels-last (the bias axis is the fastest one, a whole vector never wraps): the VEC biases are ONE vector load at i0 % C — the general path
+        // below re-derives row and position per element (this kernel ran at 0.67 of the VALU issue rate for a memory pass, profiles/round4_d_kernel_pmc_train6.txt)
+        const bool cl_bias = bp && VEC > 1 && a.step_b == 1 && (a.size_b % VEC) == 0 && ((((uintptr_t)bp) & (sizeof(P) - 1)) == 0);
+        P pb;
+        if (cl_bias) pb = *(const P*)(bp + (i0 % a.size_b));
+        else if (bp) { q = i0 / a.step_b; r = i0 - q * a.step_b; q %= a.size_b; }
+        S bias = (bp && !cl_bias) ? ld(bp + q) : S(0);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            if (bp && k > 0 && ++r == a.step_b) { r = 0; if (++q == a.size_b) q = 0; bias = ld(bp + q); }
+            if (cl_bias) bias = ld(&pb.v[k]);
+            else if (bp && k > 0 && ++r == a.step_b) { r = 0; if (++q == a.size_b) q = 0; bias = ld(bp + q); }
             S v  = ld(&px.v[k]);
             S xr = xrp ? ld(&pxr.v[k]) : S(0);
             S yr = yrp ? ld(&pyr.v[k]) : S(0);
