@@ -74,6 +74,8 @@ struct WgradArgs {
     int k, stride, pad;
     int ksplit, chunks, chunks_per_split;
     int tiles_s, tiles_b, CsP, CbP;
+    int small;              // Cs <= 64 and Cb <= 64: ONE 64 x 64 tile is all there is — the four waves split the chunk's pixels instead of the tile's quadrants and
+                            // each writes its own partial tile (workspace [ksplit * 4][taps][CsP][CbP]); the quadrant mapping would leave three waves multiplying zeros
 };
 
 template <class T> struct WgradTraits;
@@ -99,7 +101,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
     constexpr int OPER = sizeof(T) == 2 ? 128 * PITCH : KP * PITCH;            // elements of one operand image
     __shared__ __attribute__((aligned(16))) T lds[2][2][OPER];                  // [buffer][S | B][...]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = a.small ? 0 : wave >> 1, wn = a.small ? 0 : wave & 1;
     const int taps = a.k * a.k;
     // work item: (group = (split, tile), tap); the taps of a group sit on one XCD (work-group L runs on XCD L % 8)
     const int groups = a.ksplit * a.tiles_s * a.tiles_b;
@@ -222,6 +224,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int kk = 0; kk < KP / 16; ++kk) {
+                if (a.small && kk != wave) continue;                            // (wave-uniform)
                 h8 fa[2], fb[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -237,6 +240,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
         } else {
 #pragma unroll
             for (int kk = 0; kk < KP / 2; ++kk) {
+                if (a.small && (kk & 3) != wave) continue;
                 float fa[2], fb[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -254,7 +258,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
     }
 
     // partial tile -> workspace [split][tap][CsP][CbP]: accumulator element r of tile (i, j) is row (r&3) + 8(r>>2) + 4 fk, column frow
-    float* out = a.ws + ((int64_t)split * taps + tap) * a.CsP * a.CbP;
+    float* out = a.ws + ((int64_t)(a.small ? split * 4 + wave : split) * taps + tap) * a.CsP * a.CbP;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -555,7 +559,8 @@ extern "C" int64_t p3d_conv2d_bwd_weight_workspace(int dtype, int32_t n_img, int
 {
     int ksplit, chunks, cps;
     const int taps = wgrad_plan(dtype, (int64_t)n_img * small_h * small_w, c_small, c_big, kernel_size, &ksplit, &chunks, &cps);
-    return (int64_t)ksplit * taps * (ceil_div(c_small, 128) * 128) * (ceil_div(c_big, 128) * 128) * 4;
+    const int per_wave = (c_small <= 64 && c_big <= 64) ? 4 : 1;                  // WgradArgs::small: one partial tile per wave
+    return (int64_t)ksplit * per_wave * taps * (ceil_div(c_small, 128) * 128) * (ceil_div(c_big, 128) * 128) * 4;
 }
 
 extern "C" int p3d_conv2d_bwd_weight(const void* small_img, const void* big_img, void* gw, void* workspace, int64_t workspace_bytes, int dtype,
@@ -575,6 +580,7 @@ extern "C" int p3d_conv2d_bwd_weight(const void* small_img, const void* big_img,
     const int taps = wgrad_plan(dtype, (int64_t)n_img * small_h * small_w, c_small, c_big, kernel_size, &a.ksplit, &a.chunks, &a.chunks_per_split);
     a.tiles_s = ceil_div(c_small, 128); a.tiles_b = ceil_div(c_big, 128);
     a.CsP = a.tiles_s * 128; a.CbP = a.tiles_b * 128;
+    a.small = (c_small <= 64 && c_big <= 64) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const int blocks = a.ksplit * a.tiles_s * a.tiles_b * taps;
     if (dtype == P3D_F16) hipLaunchKernelGGL(conv_wgrad_kernel<__half>, dim3(blocks), dim3(256), 0, s, a);
@@ -584,8 +590,8 @@ extern "C" int p3d_conv2d_bwd_weight(const void* small_img, const void* big_img,
     if (rc != P3D_OK) return rc;
     const int64_t total = (int64_t)taps * c_small * (a.CbP / 4);
     const int rblocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    if (dtype == P3D_F16) hipLaunchKernelGGL(wgrad_reduce_kernel<__half>, dim3(rblocks), dim3(256), 0, s, a.ws, (__half*)gw, c_small, c_big, taps, a.ksplit, a.CsP, a.CbP);
-    else                  hipLaunchKernelGGL(wgrad_reduce_kernel<float>, dim3(rblocks), dim3(256), 0, s, a.ws, (float*)gw, c_small, c_big, taps, a.ksplit, a.CsP, a.CbP);
+    if (dtype == P3D_F16) hipLaunchKernelGGL(wgrad_reduce_kernel<__half>, dim3(rblocks), dim3(256), 0, s, a.ws, (__half*)gw, c_small, c_big, taps, a.ksplit * (a.small ? 4 : 1), a.CsP, a.CbP);
+    else                  hipLaunchKernelGGL(wgrad_reduce_kernel<float>, dim3(rblocks), dim3(256), 0, s, a.ws, (float*)gw, c_small, c_big, taps, a.ksplit * (a.small ? 4 : 1), a.CsP, a.CbP);
     count_launch(FAM_CONV);
     return check_launch("conv_wgrad reduce");
 }
