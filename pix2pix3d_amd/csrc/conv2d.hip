@@ -447,7 +447,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(ConvArgs a)
     __shared__ __attribute__((aligned(16))) f32x4 slab[2][SLAB_SLOTS];       // [buffer][slab pixel * 8 + chunk]
     __shared__ __attribute__((aligned(16))) f32x4 wt[2][BN * 8];             // [buffer][co row * 8 + chunk]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    // Co <= 64 (the 64-channel layers at 512^2 of the discriminators and the label-map Encoder): the block's 128-column weight tile is half zeros, and
+    // the 2 x 2 quadrant mapping left the waves of the upper column half multiplying them (55 instead of 115 TFLOP/s in fp32, profiles/round4_m_*).  There
+    // the four waves take a QUARTER of the patch's pixels each (one 32-row tile) against the 64 live columns: half the MFMAs, all of them useful.
+    const bool co64 = a.Co <= 64;
+    const int wm = co64 ? 0 : wave >> 1, wn = co64 ? 0 : wave & 1;
+    const int prow0 = co64 ? wave * 2 : (wave >> 1) * 4;                     // first patch row of this wave's tile i = 0 (tile i adds 2 rows)
     const int n = blockIdx.z;
     const int tiles_x = (a.W + PW - 1) / PW;
     int mt = blockIdx.x, cb = blockIdx.y;
@@ -499,7 +504,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(ConvArgs a)
     const int frow = lane & 31, fk = lane >> 5;
     int arow[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) arow[i] = (wm * 4 + i * 2 + (frow >> 4) + 1) * SLAB_W + (frow & 15) + 1;    // slab pixel under tap (0,0)
+    for (int i = 0; i < 2; ++i) arow[i] = (prow0 + ((co64 && i == 1) ? 0 : i * 2) + (frow >> 4) + 1) * SLAB_W + (frow & 15) + 1;    // slab pixel under tap (0,0); (co64: tile 1 is not
+                                                                                                                                  // used — its fragment reads just stay inside the slab)
 
     stage_slab(0, 0);
     stage_w(0, 0, 0);
@@ -532,10 +538,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(ConvArgs a)
 #pragma unroll
                 for (int term = 0; term < kBf16Terms; ++term)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i) {
+                        if (co64 && i == 1) continue;
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(term >= 2 ? al[i] : ah[i], (term & 1) ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
+                    }
             }
         } else
 #pragma unroll
@@ -550,7 +558,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(ConvArgs a)
 #pragma unroll
             for (int e = 0; e < (sizeof(T) == 2 ? 1 : 4); ++e)                  // fp32: e outermost, so consecutive MFMAs never share an accumulator
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i) {
+                    if (co64 && i == 1) continue;
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         if constexpr (sizeof(T) == 2) {
@@ -559,6 +568,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(ConvArgs a)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
                         }
                     }
+                }
         }
         __syncthreads();
     }
@@ -570,11 +580,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(ConvArgs a)
         if (co >= a.Co) continue;
         const float b = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+            if (co64 && i == 1) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int mrow = (r & 3) + 8 * (r >> 2) + 4 * fk;             // accumulator row within the 32-row tile
-                const int oy = oy0 + wm * 4 + i * 2 + (mrow >> 4), ox = ox0 + (mrow & 15);
+                const int oy = oy0 + prow0 + i * 2 + (mrow >> 4), ox = ox0 + (mrow & 15);
                 if (oy >= a.H || ox >= a.W) continue;
                 float v = acc[i][j][r];
                 if (a.noise) v = fmaf(a.noise[(int64_t)oy * a.W + ox], ns, v);
@@ -593,6 +604,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(ConvArgs a)
                 }
                 st((T*)a.y + (((int64_t)n * a.H + oy) * a.W + ox) * a.Co + co, v);
             }
+        }
     }
 }
 
