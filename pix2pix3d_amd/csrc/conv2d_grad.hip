@@ -303,6 +303,83 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// ---- weight gradient of the skinny 1x1 layers (fromrgb: 6 / 18 -> 64, ToRGB: 128 / 256 -> 3): part[split][f][w] = sum_m few[m][f] * many[m][w] --------------------
+// The MFMA kernel above pads the few-channel side to a 64-row tile and walks a million pixels for it (460-510 us per call at 512^2, batch 4:
+// profiles/round4_o_train_conv_geometries.txt); the contraction is a memory pass over `many`.  A thread owns one 16-byte channel vector of `many` and up to
+// eight `few` channels; row lanes split the block's pixels; the sums are folded across the lanes of a wave with xor-shuffles, across the four waves through
+// LDS, and one partial tile per block goes to the workspace in the layout wgrad_reduce_kernel sums ([split][CsP][CbP], `few_is_rows` says which side is cs).
+template <class T>
+__global__ void __launch_bounds__(256) skinny_wgrad_kernel(const T* __restrict__ few, const T* __restrict__ many, float* __restrict__ part, int64_t M, int F, int W,
+                                                           int rows_per_block, int few_is_rows, int CsP, int CbP)
+{
+    constexpr int EPC = 16 / sizeof(T);
+    __shared__ float red[4][32][8 * EPC];
+    const int wv = W / EPC, cpb = wv < 32 ? wv : 32, rl = 256 / cpb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cv = tid % cpb, r0 = tid / cpb, col = blockIdx.y * cpb + cv;
+    const int64_t a_begin = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t a_end = a_begin + rows_per_block < M ? a_begin + rows_per_block : M;
+    const bool live_col = col < wv;
+    float* const out = part + (int64_t)blockIdx.x * CsP * CbP;
+    for (int f0 = 0; f0 < F; f0 += 8) {
+        float acc[8][EPC];
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[f][e] = 0.f;
+        if (live_col) {
+            for (int64_t m = a_begin + r0; m < a_end; m += 2 * rl) {            // two pixels in flight per lane
+                const bool two = m + rl < a_end;
+                T mv[2][EPC];
+                *(f32x4*)mv[0] = *(const f32x4*)(many + m * W + col * EPC);
+                *(f32x4*)mv[1] = two ? *(const f32x4*)(many + (m + rl) * W + col * EPC) : f32x4{0.f, 0.f, 0.f, 0.f};
+                float fv[2][8];
+#pragma unroll
+                for (int f = 0; f < 8; ++f) {
+                    fv[0][f] = (f0 + f < F) ? (float)ld(few + m * F + f0 + f) : 0.f;
+                    fv[1][f] = (two && f0 + f < F) ? (float)ld(few + (m + rl) * F + f0 + f) : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int f = 0; f < 8; ++f)
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) acc[f][e] = fmaf(fv[u][f], (float)ld(&mv[u][e]), acc[f][e]);
+            }
+        }
+        // fold the row lanes of this wave (lanes that share cv differ by multiples of cpb), then the four waves
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                float v = acc[f][e];
+                for (int msk = cpb; msk < 64; msk <<= 1) v += __shfl_xor(v, msk, 64);
+                acc[f][e] = v;
+            }
+        __syncthreads();                                                            // (red is reused by the next group of few-channels)
+        if (lane < cpb) {
+#pragma unroll
+            for (int f = 0; f < 8; ++f)
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) red[wave][lane][f * EPC + e] = acc[f][e];
+        }
+        __syncthreads();
+        if (wave == 0 && lane < cpb && live_col) {
+#pragma unroll
+            for (int f = 0; f < 8; ++f) {
+                if (f0 + f >= F) continue;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float v = (red[0][lane][f * EPC + e] + red[1][lane][f * EPC + e]) + (red[2][lane][f * EPC + e] + red[3][lane][f * EPC + e]);
+                    const int w = col * EPC + e;
+                    if (few_is_rows) out[(int64_t)(f0 + f) * CbP + w] = v;
+                    else             out[(int64_t)w * CbP + f0 + f] = v;
+                }
+            }
+        }
+    }
+}
+
 // ---- skinny 1x1: y[n, p, o] = sum_i x[n, p, i] * w[o, i] with a handful of channels on one side, channels-last ---------------------
 // Memory-bound by construction (ToRGB reads Ci * sizeof(T) per pixel for 3 outputs; fromrgb writes Co * sizeof(T) per pixel from 6
 // inputs).  w is addressed by (w_so, w_si) so the data gradient passes the same tensor transposed.  The weights sit in LDS as fp32.
@@ -582,6 +659,38 @@ extern "C" int p3d_conv2d_bwd_weight(const void* small_img, const void* big_img,
     a.CsP = a.tiles_s * 128; a.CbP = a.tiles_b * 128;
     a.small = (c_small <= 64 && c_big <= 64) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
+    {   // skinny 1x1 (one side with a handful of channels, the other a whole number of 16-byte vectors): the memory-pass kernel
+        const int epc = dtype == P3D_F16 ? 8 : 4;
+        const bool few_small = c_small <= 32 && c_big % epc == 0, few_big = c_big <= 32 && c_small % epc == 0;
+        static const bool no_skinny = getenv("P3D_WGRAD_NO_SKINNY") != nullptr;
+        if (!no_skinny && kernel_size == 1 && stride == 1 && pad == 0 && small_h == big_h && small_w == big_w && (few_small || few_big)) {
+            const bool few_is_rows = few_small && !(few_big && c_big < c_small);            // which side is the `few` one (the smaller if both qualify)
+            const void* few = few_is_rows ? small_img : big_img;
+            const void* many = few_is_rows ? big_img : small_img;
+            const int F = few_is_rows ? c_small : c_big, W = few_is_rows ? c_big : c_small;
+            const int CsP = c_small, CbP = (c_big + 3) & ~3;
+            const int64_t M = (int64_t)n_img * small_h * small_w;
+            const int wv = W / epc, cpb = wv < 32 ? wv : 32, rl = 256 / cpb;
+            int64_t rows = (M + 1023) / 1024;
+            if (rows < (int64_t)rl * 16) rows = (int64_t)rl * 16;
+            const int64_t nsplit = (M + rows - 1) / rows;
+            const int64_t need = nsplit * CsP * CbP * 4;
+            if ((cpb & (cpb - 1)) == 0 && need <= workspace_bytes && (((uintptr_t)many) & 15u) == 0 && rows < (1ll << 31)) {
+                dim3 grid((unsigned)nsplit, (unsigned)((wv + cpb - 1) / cpb));
+                if (dtype == P3D_F16) hipLaunchKernelGGL(skinny_wgrad_kernel<__half>, grid, dim3(256), 0, s, (const __half*)few, (const __half*)many, a.ws, M, F, W, (int)rows, (int)few_is_rows, CsP, CbP);
+                else                  hipLaunchKernelGGL(skinny_wgrad_kernel<float>, grid, dim3(256), 0, s, (const float*)few, (const float*)many, a.ws, M, F, W, (int)rows, (int)few_is_rows, CsP, CbP);
+                count_launch(FAM_CONV);
+                int rc2 = check_launch("skinny_wgrad");
+                if (rc2 != P3D_OK) return rc2;
+                const int64_t total2 = (int64_t)c_small * (CbP / 4);
+                const int rb2 = (int)((total2 + 255) / 256 < 8192 ? (total2 + 255) / 256 : 8192);
+                if (dtype == P3D_F16) hipLaunchKernelGGL(wgrad_reduce_kernel<__half>, dim3(rb2), dim3(256), 0, s, a.ws, (__half*)gw, c_small, c_big, 1, (int)nsplit, CsP, CbP);
+                else                  hipLaunchKernelGGL(wgrad_reduce_kernel<float>, dim3(rb2), dim3(256), 0, s, a.ws, (float*)gw, c_small, c_big, 1, (int)nsplit, CsP, CbP);
+                count_launch(FAM_CONV);
+                return check_launch("skinny_wgrad reduce");
+            }
+        }
+    }
     const int blocks = a.ksplit * a.tiles_s * a.tiles_b * taps;
     if (dtype == P3D_F16) hipLaunchKernelGGL(conv_wgrad_kernel<__half>, dim3(blocks), dim3(256), 0, s, a);
     else                  hipLaunchKernelGGL(conv_wgrad_kernel<float>, dim3(blocks), dim3(256), 0, s, a);
