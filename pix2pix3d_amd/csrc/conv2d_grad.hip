@@ -74,13 +74,16 @@ struct WgradArgs {
     int k, stride, pad;
     int ksplit, chunks, chunks_per_split;
     int tiles_s, tiles_b, CsP, CbP;
-    int small;              // Cs <= 64 and Cb <= 64: ONE 64 x 64 tile is all there is — the four waves split the chunk's pixels instead of the tile's quadrants and
-                            // each writes its own partial tile (workspace [ksplit * 4][taps][CsP][CbP]); the quadrant mapping would leave three waves multiplying zeros
+    int xcd_pad;            // the grid holds ceil(groups / 8) * 8 groups: group g runs on XCD g % 8 whatever the group count, the surplus work-groups leave at once
+    int psplit;             // 1, 2 or 4: how many ways the waves split the chunk's PIXELS instead of the 128 x 128 tile's quadrants.  A side of <= 64 channels leaves half
+                            // of the tile empty: the waves that would multiply zeros take a share of the pixels instead and write their own partial tile
+                            // (workspace [ksplit * psplit][taps][CsP][CbP]).  4: both sides <= 64 (one 64 x 64 tile is all there is); 2: one side
+    int narrow_b;           // psplit == 2: the narrow side is B (the waves pair up along S) — else S
 };
 
 template <class T> struct WgradTraits;
-template <> struct WgradTraits<__half> { static constexpr int KP = 64, EPC = 8, PITCH = 72;  };   // pixels per chunk, elements per 16 B, LDS row pitch (elements)
-template <> struct WgradTraits<float>  { static constexpr int KP = 16, EPC = 4, PITCH = 128; };
+template <> struct WgradTraits<__half> { static constexpr int EPC = 8, PITCH = 72;  };   // elements per 16 B, LDS row pitch (elements); pixels per chunk KP: 64
+template <> struct WgradTraits<float>  { static constexpr int EPC = 4, PITCH = 128; };   // KP: 32 (64 KB of LDS, two work-groups per CU), 16 behind P3D_WGRAD_F32_KP16
 
 struct PixPos { int n, i, j; };
 __device__ __forceinline__ void pix_advance(PixPos& p, int d, int HS, int WS)
@@ -93,21 +96,28 @@ __device__ __forceinline__ void pix_advance(PixPos& p, int d, int HS, int WS)
     }
 }
 
-template <class T>
+// FAST: both images hold whole, 16-byte aligned channel groups and fewer than 2^31 bytes each (32-bit offsets on a uniform base, no element-wise tail code in
+// the loop); fp16 also wants rows of a multiple of four pixels (a lane's four pixels then share one row: one position, one row test).  The general loop carried
+// the tail path's branches through every chunk: ~1000 instructions for 16 MFMAs in the fp16 kernel (the ISA of round 4's library).
+template <class T, int KP, bool FAST>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
 {
     typedef WgradTraits<T> TR;
-    constexpr int KP = TR::KP, EPC = TR::EPC, PITCH = TR::PITCH;
+    constexpr int EPC = TR::EPC, PITCH = TR::PITCH;
     constexpr int OPER = sizeof(T) == 2 ? 128 * PITCH : KP * PITCH;            // elements of one operand image
     __shared__ __attribute__((aligned(16))) T lds[2][2][OPER];                  // [buffer][S | B][...]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = a.small ? 0 : wave >> 1, wn = a.small ? 0 : wave & 1;
+    // (wave-uniform roles) quadrant (wm, wn) of the tile and the share `part` of the chunk's pixels
+    const int wm = a.psplit == 1 ? wave >> 1 : (a.psplit == 2 && a.narrow_b ? wave & 1 : 0);
+    const int wn = a.psplit == 1 ? wave & 1 : (a.psplit == 2 && !a.narrow_b ? wave & 1 : 0);
+    const int part = a.psplit == 1 ? 0 : (a.psplit == 2 ? wave >> 1 : wave), pmask = a.psplit - 1;
     const int taps = a.k * a.k;
     // work item: (group = (split, tile), tap); the taps of a group sit on one XCD (work-group L runs on XCD L % 8)
     const int groups = a.ksplit * a.tiles_s * a.tiles_b;
     int L = blockIdx.x, g, tap;
-    if ((groups & 7) == 0) { g = (L & 7) + 8 * ((L >> 3) / taps); tap = (L >> 3) % taps; }
-    else                   { g = L / taps; tap = L - g * taps; }
+    if (a.xcd_pad)              { g = (L & 7) + 8 * ((L >> 3) / taps); tap = (L >> 3) % taps; if (g >= groups) return; }    // (grid padded to 8 groups a round)
+    else if ((groups & 7) == 0) { g = (L & 7) + 8 * ((L >> 3) / taps); tap = (L >> 3) % taps; }
+    else                        { g = L / taps; tap = L - g * taps; }
     const int tile = g % (a.tiles_s * a.tiles_b), split = g / (a.tiles_s * a.tiles_b);
     const int cs0 = (tile / a.tiles_b) * 128, cb0 = (tile % a.tiles_b) * 128;
     const int ky = tap / a.k, kx = tap - ky * a.k;
@@ -132,8 +142,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
 
     // ---- loader role of this thread -------------------------------------------------------------------------------------
     // fp16: pixel quad pq = lane & 15 (pixels 4pq .. 4pq+3 of the chunk), channel group cg = (lane >> 4) + 4 * wave (8 channels)
-    // fp32: two 16-byte pieces r = 0, 1: pixel (tid >> 5) + 8 r of the chunk, channels 4 * (tid & 31) ..
-    constexpr int NLD = sizeof(T) == 2 ? 4 : 2;                                // 16-byte loads per operand per chunk
+    // fp32: KP / 8 16-byte pieces r: pixel (tid >> 5) + 8 r of the chunk, channels 4 * (tid & 31) ..
+    constexpr int NLD = sizeof(T) == 2 ? 4 : KP / 8;                           // 16-byte loads per operand per chunk
     int lp[NLD];                                                               // chunk-local pixel of each load
     int lc;                                                                    // first tile-local channel of this thread's loads
     if constexpr (sizeof(T) == 2) {
@@ -144,7 +154,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
     } else {
         lc = (tid & 31) * 4;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) lp[q] = (tid >> 5) + 8 * q;
+        for (int q = 0; q < NLD; ++q) lp[q] = (tid >> 5) + 8 * q;
     }
     PixPos pos[NLD];                                                           // (n, i, j) of each load's pixel in the current chunk
 #pragma unroll
@@ -167,7 +177,41 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
         for (int e = 0; e < EPC; ++e) tmp[e] = (c_first + e < C) ? base[elem_off + c_first + e] : (T)0.f;
         return *(const f32x4*)tmp;
     };
+    const bool s_ok = cs0 + lc < a.Cs, b_ok = cb0 + lc < a.Cb;                  // (FAST) this thread's channel group exists on either side
+    const char* const Sb = (const char*)a.s;
+    const char* const Bb = (const char*)a.b;
     auto fetch = [&](int chunk) {
+        if constexpr (FAST && sizeof(T) == 2) {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const int m0 = chunk * KP + lp[0];
+            const bool live = m0 < (int)Mtot;                                       // (rows of 4 k pixels: the lane's four pixels are live together)
+            const int bi = pos[0].i * a.stride + dy, bj0 = pos[0].j * a.stride + dx;
+            const bool row_ok = live && b_ok && bi >= 0 && bi < a.HB;
+            const unsigned so = (unsigned)(m0 * a.Cs + cs0 + lc) * 2u;
+            const unsigned bo = (unsigned)(((pos[0].n * a.HB + bi) * a.WB + bj0) * a.Cb + cb0 + lc) * 2u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int bj = bj0 + q * a.stride;
+                rs[q] = (live && s_ok) ? *(const f32x4*)(Sb + (so + (unsigned)(q * a.Cs) * 2u)) : zero;
+                rb[q] = (row_ok && bj >= 0 && bj < a.WB) ? *(const f32x4*)(Bb + (bo + (unsigned)(q * a.stride * a.Cb) * 2u)) : zero;
+            }
+            pix_advance(pos[0], KP, a.HS, a.WS);
+            return;
+        } else if constexpr (FAST) {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NLD; ++q) {
+                const int m = chunk * KP + lp[q];
+                const bool live = m < (int)Mtot;
+                const int bi = pos[q].i * a.stride + dy, bj = pos[q].j * a.stride + dx;
+                const unsigned so = (unsigned)(m * a.Cs + cs0 + lc) * 4u;
+                const unsigned bo = (unsigned)(((pos[q].n * a.HB + bi) * a.WB + bj) * a.Cb + cb0 + lc) * 4u;
+                rs[q] = (live && s_ok) ? *(const f32x4*)(Sb + so) : zero;
+                rb[q] = (live && b_ok && bi >= 0 && bi < a.HB && bj >= 0 && bj < a.WB) ? *(const f32x4*)(Bb + bo) : zero;
+                pix_advance(pos[q], KP, a.HS, a.WS);
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
             const int64_t m = (int64_t)chunk * KP + lp[q];
@@ -224,7 +268,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int kk = 0; kk < KP / 16; ++kk) {
-                if (a.small && kk != wave) continue;                            // (wave-uniform)
+                if ((kk & pmask) != part) continue;                             // (wave-uniform)
                 h8 fa[2], fb[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -240,7 +284,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
         } else {
 #pragma unroll
             for (int kk = 0; kk < KP / 2; ++kk) {
-                if (a.small && (kk & 3) != wave) continue;
+                if ((kk & pmask) != part) continue;
                 float fa[2], fb[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -258,7 +302,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
     }
 
     // partial tile -> workspace [split][tap][CsP][CbP]: accumulator element r of tile (i, j) is row (r&3) + 8(r>>2) + 4 fk, column frow
-    float* out = a.ws + ((int64_t)(a.small ? split * 4 + wave : split) * taps + tap) * a.CsP * a.CbP;
+    float* out = a.ws + ((int64_t)(split * a.psplit + part) * taps + tap) * a.CsP * a.CbP;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -510,21 +554,61 @@ __global__ void __launch_bounds__(256) skinny_expand_kernel(const T* __restrict_
     }
 }
 
+static int wgrad_f32_chunk()
+{
+    static const int kp = getenv("P3D_WGRAD_F32_KP") && atoi(getenv("P3D_WGRAD_F32_KP")) == 32 ? 32 : 16;      // (A/B switch of the measurement scripts)
+    return kp;
+}
+
+static int wgrad_pixel_split(int cs, int cb)
+{
+    static const bool no_half = getenv("P3D_WGRAD_NO_HALF") != nullptr;         // (A/B switch of the measurement scripts)
+    if (cs <= 64 && cb <= 64) return 4;
+    return (cs <= 64 || cb <= 64) && !no_half ? 2 : 1;
+}
+
+static bool wgrad_plan_old()
+{
+    static const bool v = getenv("P3D_WGRAD_PLAN_OLD") != nullptr;              // (A/B switch of the measurement scripts)
+    return v;
+}
+
+// Split of the pixel axis.  The kernel is MFMA-bound and its work-groups cost the same, so the launch ends when the fullest CU does: every work-group should be
+// resident at once, and the same number on every CU.  Work-group L runs on XCD L % 8 (32 CUs, r resident work-groups each) and a group's taps share an XCD, so
+// the unit is groups per XCD: floor(32 r / taps) of them, 8 times that in the launch, floor(that / tiles) splits.  Round 4's plan aimed at 3 work-groups per
+// CU and rounded UP: 22 splits of a 256 x 256 x 9 problem = 99 work-groups on an XCD's 96 places, 88 TFLOP/s; 28 splits at r = 4 (126 on 128) run 105
+// (profiles/round4_t_wgrad_variants.txt: every variant that overfills an XCD is the slow one of its row).
 static int wgrad_plan(int dtype, int64_t pixels, int cs, int cb, int k, int* ksplit, int* chunks, int* cps)
 {
-    const int KP = dtype == P3D_F16 ? 64 : 16;
+    const int KP = dtype == P3D_F16 ? 64 : wgrad_f32_chunk();
     const int taps = k * k;
     const int tiles = ceil_div(cs, 128) * ceil_div(cb, 128);
     const int64_t nchunks = (pixels + KP - 1) / KP;
-    int64_t want = (3 * kNumCU + tiles * taps - 1) / (tiles * taps);            // ~3 work-groups per CU
-    if (want < 1) want = 1;
-    if (want > nchunks) want = nchunks;
-    if (want > 1024) want = 1024;
-    int64_t per = (nchunks + want - 1) / want;
-    int64_t split = (nchunks + per - 1) / per;
-    if (tiles * split >= 8) {                                                   // a multiple of 8 groups keeps a group's taps on one XCD
-        const int64_t up = ((tiles * split + 7) / 8) * 8;
-        if (up % tiles == 0 && up / tiles <= nchunks) { split = up / tiles; per = (nchunks + split - 1) / split; }
+    static const int env_per_cu = getenv("P3D_WGRAD_WG_PER_CU") ? atoi(getenv("P3D_WGRAD_WG_PER_CU")) : 0;
+    int64_t per, split;
+    if (wgrad_plan_old()) {
+        const int per_cu = env_per_cu > 0 ? env_per_cu : 3;
+        int64_t want = ((int64_t)per_cu * kNumCU + tiles * taps - 1) / (tiles * taps);
+        if (want < 1) want = 1;
+        if (want > nchunks) want = nchunks;
+        if (want > 1024) want = 1024;
+        per = (nchunks + want - 1) / want;
+        split = (nchunks + per - 1) / per;
+        if (tiles * split >= 8) {                                               // a multiple of 8 groups keeps a group's taps on one XCD
+            const int64_t up = ((tiles * split + 7) / 8) * 8;
+            if (up % tiles == 0 && up / tiles <= nchunks) { split = up / tiles; per = (nchunks + split - 1) / split; }
+        }
+    } else {
+        // resident work-groups per CU: fp16 holds 72 KB of LDS (2); fp32 32 KB and 120 VGPRs (4)
+        const int per_cu = env_per_cu > 0 ? env_per_cu : (dtype == P3D_F16 || KP == 32 ? 2 : 4);
+        int gpx = (kNumCU / 8) * per_cu / taps;                                 // groups per XCD
+        if (gpx < 1) gpx = 1;
+        int64_t want = 8 * gpx / tiles;
+        if (want < 1) want = 1;
+        if (want > nchunks) want = nchunks;
+        if (want > 1024) want = 1024;
+        per = (nchunks + want - 1) / want;
+        split = (nchunks + per - 1) / per;
     }
     *ksplit = (int)split; *chunks = (int)nchunks; *cps = (int)per;
     return taps;
@@ -636,7 +720,7 @@ extern "C" int64_t p3d_conv2d_bwd_weight_workspace(int dtype, int32_t n_img, int
 {
     int ksplit, chunks, cps;
     const int taps = wgrad_plan(dtype, (int64_t)n_img * small_h * small_w, c_small, c_big, kernel_size, &ksplit, &chunks, &cps);
-    const int per_wave = (c_small <= 64 && c_big <= 64) ? 4 : 1;                  // WgradArgs::small: one partial tile per wave
+    const int per_wave = wgrad_pixel_split(c_small, c_big);                       // WgradArgs::psplit partial tiles per split
     return (int64_t)ksplit * per_wave * taps * (ceil_div(c_small, 128) * 128) * (ceil_div(c_big, 128) * 128) * 4;
 }
 
@@ -657,7 +741,8 @@ extern "C" int p3d_conv2d_bwd_weight(const void* small_img, const void* big_img,
     const int taps = wgrad_plan(dtype, (int64_t)n_img * small_h * small_w, c_small, c_big, kernel_size, &a.ksplit, &a.chunks, &a.chunks_per_split);
     a.tiles_s = ceil_div(c_small, 128); a.tiles_b = ceil_div(c_big, 128);
     a.CsP = a.tiles_s * 128; a.CbP = a.tiles_b * 128;
-    a.small = (c_small <= 64 && c_big <= 64) ? 1 : 0;
+    a.psplit = wgrad_pixel_split(c_small, c_big);
+    a.narrow_b = c_big <= 64 ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     {   // skinny 1x1 (one side with a handful of channels, the other a whole number of 16-byte vectors): the memory-pass kernel
         const int epc = dtype == P3D_F16 ? 8 : 4;
@@ -691,16 +776,31 @@ extern "C" int p3d_conv2d_bwd_weight(const void* small_img, const void* big_img,
             }
         }
     }
-    const int blocks = a.ksplit * a.tiles_s * a.tiles_b * taps;
-    if (dtype == P3D_F16) hipLaunchKernelGGL(conv_wgrad_kernel<__half>, dim3(blocks), dim3(256), 0, s, a);
-    else                  hipLaunchKernelGGL(conv_wgrad_kernel<float>, dim3(blocks), dim3(256), 0, s, a);
+    a.xcd_pad = wgrad_plan_old() ? 0 : 1;
+    const int ngroups = a.ksplit * a.tiles_s * a.tiles_b;
+    const int blocks = (a.xcd_pad ? (ngroups + 7) / 8 * 8 : ngroups) * taps;
+    const int esz = dtype == P3D_F16 ? 2 : 4, epc16 = 16 / esz;
+    static const bool no_fast = getenv("P3D_WGRAD_NO_FAST") != nullptr;          // (A/B switch of the measurement scripts)
+    const bool fast = !no_fast && c_small % epc16 == 0 && c_big % epc16 == 0 && ((((uintptr_t)small_img) | ((uintptr_t)big_img)) & 15u) == 0
+                      && (int64_t)n_img * small_h * small_w * c_small * esz < (1ll << 31) && (int64_t)n_img * big_h * big_w * c_big * esz < (1ll << 31)
+                      && (dtype != P3D_F16 || small_w % 4 == 0);
+    if (dtype == P3D_F16) {
+        if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<__half, 64, true>), dim3(blocks), dim3(256), 0, s, a);
+        else      hipLaunchKernelGGL((conv_wgrad_kernel<__half, 64, false>), dim3(blocks), dim3(256), 0, s, a);
+    } else if (wgrad_f32_chunk() == 32) {
+        if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<float, 32, true>), dim3(blocks), dim3(256), 0, s, a);
+        else      hipLaunchKernelGGL((conv_wgrad_kernel<float, 32, false>), dim3(blocks), dim3(256), 0, s, a);
+    } else {
+        if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<float, 16, true>), dim3(blocks), dim3(256), 0, s, a);
+        else      hipLaunchKernelGGL((conv_wgrad_kernel<float, 16, false>), dim3(blocks), dim3(256), 0, s, a);
+    }
     count_launch(FAM_CONV);
     int rc = check_launch("conv_wgrad");
     if (rc != P3D_OK) return rc;
     const int64_t total = (int64_t)taps * c_small * (a.CbP / 4);
     const int rblocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    if (dtype == P3D_F16) hipLaunchKernelGGL(wgrad_reduce_kernel<__half>, dim3(rblocks), dim3(256), 0, s, a.ws, (__half*)gw, c_small, c_big, taps, a.ksplit * (a.small ? 4 : 1), a.CsP, a.CbP);
-    else                  hipLaunchKernelGGL(wgrad_reduce_kernel<float>, dim3(rblocks), dim3(256), 0, s, a.ws, (float*)gw, c_small, c_big, taps, a.ksplit * (a.small ? 4 : 1), a.CsP, a.CbP);
+    if (dtype == P3D_F16) hipLaunchKernelGGL(wgrad_reduce_kernel<__half>, dim3(rblocks), dim3(256), 0, s, a.ws, (__half*)gw, c_small, c_big, taps, a.ksplit * a.psplit, a.CsP, a.CbP);
+    else                  hipLaunchKernelGGL(wgrad_reduce_kernel<float>, dim3(rblocks), dim3(256), 0, s, a.ws, (float*)gw, c_small, c_big, taps, a.ksplit * a.psplit, a.CsP, a.CbP);
     count_launch(FAM_CONV);
     return check_launch("conv_wgrad reduce");
 }
