@@ -83,7 +83,7 @@ struct WgradArgs {
 
 template <class T> struct WgradTraits;
 template <> struct WgradTraits<__half> { static constexpr int EPC = 8, PITCH = 72;  };   // elements per 16 B, LDS row pitch (elements); pixels per chunk KP: 64
-template <> struct WgradTraits<float>  { static constexpr int EPC = 4, PITCH = 128; };   // KP: 32 (64 KB of LDS, two work-groups per CU), 16 behind P3D_WGRAD_F32_KP16
+template <> struct WgradTraits<float>  { static constexpr int EPC = 4, PITCH = 128; };   // KP: 16 (32 pixels a chunk, 64 KB, two resident work-groups: 96 vs 104 TFLOP/s)
 
 struct PixPos { int n, i, j; };
 __device__ __forceinline__ void pix_advance(PixPos& p, int d, int HS, int WS)
@@ -99,12 +99,17 @@ __device__ __forceinline__ void pix_advance(PixPos& p, int d, int HS, int WS)
 // FAST: both images hold whole, 16-byte aligned channel groups and fewer than 2^31 bytes each (32-bit offsets on a uniform base, no element-wise tail code in
 // the loop); fp16 also wants rows of a multiple of four pixels (a lane's four pixels then share one row: one position, one row test).  The general loop carried
 // the tail path's branches through every chunk: ~1000 instructions for 16 MFMAs in the fp16 kernel (the ISA of round 4's library).
-template <class T, int KP, bool FAST>
+// SMALL (with FAST, psplit == 4): both sides hold at most 64 channels.  The 128-channel loader would leave half of its threads without a load and a wave with a
+// quarter of a chunk's MFMAs against a whole chunk's staging and barrier (61 TFLOP/s on the fp32 64 x 64 layers at 512^2); here every thread loads, the chunk
+// is twice as long (KP = two chunks of the split plan) and the LDS image is 64 channels wide.
+template <class T, int KP, bool FAST, bool SMALL = false>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
 {
     typedef WgradTraits<T> TR;
-    constexpr int EPC = TR::EPC, PITCH = TR::PITCH;
-    constexpr int OPER = sizeof(T) == 2 ? 128 * PITCH : KP * PITCH;            // elements of one operand image
+    static_assert(FAST || !SMALL, "the 64-channel form exists for aligned geometries only");
+    constexpr int EPC = TR::EPC, PITCH = !SMALL ? TR::PITCH : (sizeof(T) == 2 ? KP + 8 : 64);
+    constexpr int KPB = SMALL ? KP / 2 : KP;                                   // pixels of one chunk of the split plan
+    constexpr int OPER = sizeof(T) == 2 ? (SMALL ? 64 : 128) * PITCH : KP * PITCH;   // elements of one operand image
     __shared__ __attribute__((aligned(16))) T lds[2][2][OPER];                  // [buffer][S | B][...]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // (wave-uniform roles) quadrant (wm, wn) of the tile and the share `part` of the chunk's pixels
@@ -143,23 +148,25 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
     // ---- loader role of this thread -------------------------------------------------------------------------------------
     // fp16: pixel quad pq = lane & 15 (pixels 4pq .. 4pq+3 of the chunk), channel group cg = (lane >> 4) + 4 * wave (8 channels)
     // fp32: KP / 8 16-byte pieces r: pixel (tid >> 5) + 8 r of the chunk, channels 4 * (tid & 31) ..
-    constexpr int NLD = sizeof(T) == 2 ? 4 : KP / 8;                           // 16-byte loads per operand per chunk
+    // SMALL: fp16 pixel quad (lane & 15) + 16 * (wave >> 1), channel group (lane >> 4) + 4 * (wave & 1); fp32 pixel (tid >> 4) + 16 r, channels 4 * (tid & 15) ..
+    constexpr int NLD = sizeof(T) == 2 ? 4 : (SMALL ? KP / 16 : KP / 8);       // 16-byte loads per operand per chunk
     int lp[NLD];                                                               // chunk-local pixel of each load
     int lc;                                                                    // first tile-local channel of this thread's loads
+    const int pq = SMALL ? (lane & 15) + 16 * (wave >> 1) : (lane & 15);       // (fp16) the thread's pixel quad
     if constexpr (sizeof(T) == 2) {
-        const int pq = lane & 15;
-        lc = ((lane >> 4) + 4 * wave) * 8;
+        lc = ((lane >> 4) + 4 * (SMALL ? (wave & 1) : wave)) * 8;
 #pragma unroll
         for (int q = 0; q < 4; ++q) lp[q] = pq * 4 + q;
     } else {
-        lc = (tid & 31) * 4;
+        lc = SMALL ? (tid & 15) * 4 : (tid & 31) * 4;
 #pragma unroll
-        for (int q = 0; q < NLD; ++q) lp[q] = (tid >> 5) + 8 * q;
+        for (int q = 0; q < NLD; ++q) lp[q] = SMALL ? (tid >> 4) + 16 * q : (tid >> 5) + 8 * q;
     }
+    const int64_t m_end64 = (int64_t)c_end * KPB < Mtot ? (int64_t)c_end * KPB : Mtot;     // this work-group's pixels end here
     PixPos pos[NLD];                                                           // (n, i, j) of each load's pixel in the current chunk
 #pragma unroll
     for (int q = 0; q < NLD; ++q) {
-        const int64_t m = (int64_t)c_begin * KP + lp[q];
+        const int64_t m = (int64_t)c_begin * KPB + lp[q];
         const int64_t per = (int64_t)a.HS * a.WS;
         pos[q].n = (int)(m / per);
         const int rem = (int)(m - (int64_t)pos[q].n * per);
@@ -183,8 +190,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
     auto fetch = [&](int chunk) {
         if constexpr (FAST && sizeof(T) == 2) {
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            const int m0 = chunk * KP + lp[0];
-            const bool live = m0 < (int)Mtot;                                       // (rows of 4 k pixels: the lane's four pixels are live together)
+            const int m0 = chunk * KPB + lp[0];
+            const bool live = m0 < (int)m_end64;                                    // (rows of 4 k pixels: the lane's four pixels are live together)
             const int bi = pos[0].i * a.stride + dy, bj0 = pos[0].j * a.stride + dx;
             const bool row_ok = live && b_ok && bi >= 0 && bi < a.HB;
             const unsigned so = (unsigned)(m0 * a.Cs + cs0 + lc) * 2u;
@@ -201,8 +208,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < NLD; ++q) {
-                const int m = chunk * KP + lp[q];
-                const bool live = m < (int)Mtot;
+                const int m = chunk * KPB + lp[q];
+                const bool live = m < (int)m_end64;
                 const int bi = pos[q].i * a.stride + dy, bj = pos[q].j * a.stride + dx;
                 const unsigned so = (unsigned)(m * a.Cs + cs0 + lc) * 4u;
                 const unsigned bo = (unsigned)(((pos[q].n * a.HB + bi) * a.WB + bj) * a.Cb + cb0 + lc) * 4u;
@@ -230,7 +237,6 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
     auto deposit = [&](int buf) {
         if constexpr (sizeof(T) == 2) {
             // registers hold [pixel q][8 channels]; LDS wants [channel][4 pixels] as one 8-byte run per channel
-            const int pq = lane & 15;
 #pragma unroll
             for (int op = 0; op < 2; ++op) {
                 const f32x4* r = op ? rb : rs;
@@ -257,12 +263,13 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
         }
     };
 
+    constexpr int STEP = KP / KPB;                                             // plan chunks per iteration
     if (c_begin < c_end) fetch(c_begin);
     int buf = 0;
-    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    for (int chunk = c_begin; chunk < c_end; chunk += STEP) {
         deposit(buf);
         __syncthreads();
-        if (chunk + 1 < c_end) fetch(chunk + 1);                               // flies under this chunk's MFMAs
+        if (chunk + STEP < c_end) fetch(chunk + STEP);                         // flies under this chunk's MFMAs
         const T* ls = lds[buf][0];
         const T* lb = lds[buf][1];
         if constexpr (sizeof(T) == 2) {
@@ -554,12 +561,6 @@ __global__ void __launch_bounds__(256) skinny_expand_kernel(const T* __restrict_
     }
 }
 
-static int wgrad_f32_chunk()
-{
-    static const int kp = getenv("P3D_WGRAD_F32_KP") && atoi(getenv("P3D_WGRAD_F32_KP")) == 32 ? 32 : 16;      // (A/B switch of the measurement scripts)
-    return kp;
-}
-
 static int wgrad_pixel_split(int cs, int cb)
 {
     static const bool no_half = getenv("P3D_WGRAD_NO_HALF") != nullptr;         // (A/B switch of the measurement scripts)
@@ -580,7 +581,7 @@ static bool wgrad_plan_old()
 // (profiles/round4_t_wgrad_variants.txt: every variant that overfills an XCD is the slow one of its row).
 static int wgrad_plan(int dtype, int64_t pixels, int cs, int cb, int k, int* ksplit, int* chunks, int* cps)
 {
-    const int KP = dtype == P3D_F16 ? 64 : wgrad_f32_chunk();
+    const int KP = dtype == P3D_F16 ? 64 : 16;
     const int taps = k * k;
     const int tiles = ceil_div(cs, 128) * ceil_div(cb, 128);
     const int64_t nchunks = (pixels + KP - 1) / KP;
@@ -600,7 +601,7 @@ static int wgrad_plan(int dtype, int64_t pixels, int cs, int cb, int k, int* ksp
         }
     } else {
         // resident work-groups per CU: fp16 holds 72 KB of LDS (2); fp32 32 KB and 120 VGPRs (4)
-        const int per_cu = env_per_cu > 0 ? env_per_cu : (dtype == P3D_F16 || KP == 32 ? 2 : 4);
+        const int per_cu = env_per_cu > 0 ? env_per_cu : (dtype == P3D_F16 ? 2 : 4);
         int gpx = (kNumCU / 8) * per_cu / taps;                                 // groups per XCD
         if (gpx < 1) gpx = 1;
         int64_t want = 8 * gpx / tiles;
@@ -780,19 +781,20 @@ extern "C" int p3d_conv2d_bwd_weight(const void* small_img, const void* big_img,
     const int ngroups = a.ksplit * a.tiles_s * a.tiles_b;
     const int blocks = (a.xcd_pad ? (ngroups + 7) / 8 * 8 : ngroups) * taps;
     const int esz = dtype == P3D_F16 ? 2 : 4, epc16 = 16 / esz;
-    static const bool no_fast = getenv("P3D_WGRAD_NO_FAST") != nullptr;          // (A/B switch of the measurement scripts)
+    static const bool no_fast = getenv("P3D_WGRAD_NO_FAST") != nullptr;          // (A/B switches of the measurement scripts)
+    static const bool no_small = getenv("P3D_WGRAD_NO_SMALL") != nullptr;
     const bool fast = !no_fast && c_small % epc16 == 0 && c_big % epc16 == 0 && ((((uintptr_t)small_img) | ((uintptr_t)big_img)) & 15u) == 0
                       && (int64_t)n_img * small_h * small_w * c_small * esz < (1ll << 31) && (int64_t)n_img * big_h * big_w * c_big * esz < (1ll << 31)
                       && (dtype != P3D_F16 || small_w % 4 == 0);
+    const bool small64 = fast && !no_small && a.psplit == 4;
     if (dtype == P3D_F16) {
-        if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<__half, 64, true>), dim3(blocks), dim3(256), 0, s, a);
-        else      hipLaunchKernelGGL((conv_wgrad_kernel<__half, 64, false>), dim3(blocks), dim3(256), 0, s, a);
-    } else if (wgrad_f32_chunk() == 32) {
-        if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<float, 32, true>), dim3(blocks), dim3(256), 0, s, a);
-        else      hipLaunchKernelGGL((conv_wgrad_kernel<float, 32, false>), dim3(blocks), dim3(256), 0, s, a);
+        if (small64)   hipLaunchKernelGGL((conv_wgrad_kernel<__half, 128, true, true>), dim3(blocks), dim3(256), 0, s, a);
+        else if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<__half, 64, true>), dim3(blocks), dim3(256), 0, s, a);
+        else           hipLaunchKernelGGL((conv_wgrad_kernel<__half, 64, false>), dim3(blocks), dim3(256), 0, s, a);
     } else {
-        if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<float, 16, true>), dim3(blocks), dim3(256), 0, s, a);
-        else      hipLaunchKernelGGL((conv_wgrad_kernel<float, 16, false>), dim3(blocks), dim3(256), 0, s, a);
+        if (small64)   hipLaunchKernelGGL((conv_wgrad_kernel<float, 32, true, true>), dim3(blocks), dim3(256), 0, s, a);
+        else if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<float, 16, true>), dim3(blocks), dim3(256), 0, s, a);
+        else           hipLaunchKernelGGL((conv_wgrad_kernel<float, 16, false>), dim3(blocks), dim3(256), 0, s, a);
     }
     count_launch(FAM_CONV);
     int rc = check_launch("conv_wgrad");

@@ -31,6 +31,9 @@ GEOM = [
     ('torgb', False, 1, 1, 128, 3, 24, 24, 2, 0),                    # skinny 1x1, many -> few
     ('fromrgb', False, 1, 1, 6, 64, 24, 24, 2, 0),                   # skinny 1x1, few -> many
     ('odd_channels', False, 3, 1, 33, 40, 4, 4, 2, 0),               # channel padding route (the 513-channel epilogue conv of D)
+    ('small64_mid', False, 3, 1, 64, 64, 40, 44, 3, 0),              # weight gradient: the 64-channel form over several double chunks, an odd count per split, a half-filled last one
+    ('half_tile_b', False, 3, 1, 128, 64, 40, 44, 3, 0),             # weight gradient: waves pair up on pixels when one side holds <= 64 channels ...
+    ('half_tile_s', False, 3, 1, 64, 128, 40, 44, 3, 0),             # ... either side
 ]
 
 
