@@ -108,7 +108,10 @@ template <> struct ConvTraits<float>  { static constexpr int BK = 32; };
 // (ConvArgs::y_split, fir4_cl_fused_kernel) — so A fragments are two plain 16-byte LDS reads like the weights': the in-register split (8
 // conversions + 8 subtractions + the conversion -> MFMA guard per fragment, repeated by every tap and every wave that reads the pixel) cost
 // the bf16x3 kernels 13-21 % (profiles/round3_ae_*).  Staging is unchanged: the rows have the same bytes either way.
-template <class T, bool BF3 = false, bool XS = false>
+// CO64: the launch has at most 64 output channels (one column block, half of its weight tile zeros).  The four waves then take 32 GEMM rows each against both
+// 32-column tiles instead of a 64 x 64 quadrant each — two of which would multiply the zero half (the 128 -> 64 channel transposed convolutions of the
+// discriminators' data gradient ran at 47 TFLOP/s in fp32 where their 128-column neighbours run at 90).
+template <class T, bool BF3 = false, bool XS = false, bool CO64 = false>
 __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
 {
     static_assert(!BF3 || sizeof(T) == 4, "bf16x3 is a formulation of the fp32 convolution");
@@ -117,7 +120,9 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
     constexpr int EPC = 16 / sizeof(T);                                        // elements per 16-byte chunk
     __shared__ __attribute__((aligned(16))) f32x4 lds[2][2][BM * 8];          // [buffer][A|B][row*8 + chunk], 16-byte slots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;                                   // wave's 64x64 quadrant
+    static_assert(!CO64 || !BF3, "the 64-column form is instantiated for the exact kernels only");
+    constexpr int NI = CO64 ? 1 : 2;                                           // 32-row tiles per wave
+    const int rbase = CO64 ? wave * 32 : (wave >> 1) * 64, wn = CO64 ? 0 : wave & 1;   // wave's first tile row / 64-column half
     const int split = blockIdx.z % a.ksplit, zz = blockIdx.z / a.ksplit;
     const int n = a.fold ? 0 : zz / a.ncls;
     const ConvArgs::Cls& kc = a.cls[a.fold ? 0 : zz - n * a.ncls];
@@ -184,9 +189,9 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[NI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -202,12 +207,12 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
     if (s_begin < s_end) stage(cc, t, 0);
     __syncthreads();
     const int frow = lane & 31, fk = lane >> 5;                                 // fragment row / k-group of this lane
-    int pa[2][4], pb[2][4];                                                     // fragment slots of this lane (buffer 0)
+    int pa[NI][4], pb[2][4];                                                    // fragment slots of this lane (buffer 0)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            pa[i][kk] = swz(wm * 64 + i * 32 + frow, kk * 2 + fk);
+            if (i < NI) pa[i][kk] = swz(rbase + i * 32 + frow, kk * 2 + fk);
             pb[i][kk] = swz(wn * 64 + i * 32 + frow, kk * 2 + fk);
         }
     int buf = 0;
@@ -222,7 +227,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
                     bf8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        const int ra = wm * 64 + i * 32 + frow, rb = wn * 64 + i * 32 + frow;
+                        const int ra = rbase + i * 32 + frow, rb = wn * 64 + i * 32 + frow;
                         if constexpr (XS) {
                             ah[i] = __builtin_bit_cast(bf8, lds[buf][0][swz(ra, 2 * m + fk)]);
                             al[i] = __builtin_bit_cast(bf8, lds[buf][0][swz(ra, 4 + 2 * m + fk)]);
@@ -242,16 +247,16 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
             } else
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {                                    // 4 x 32 bytes of K per 128-byte row
-                f32x4 fa[2], fb[2];
+                f32x4 fa[NI], fb[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    fa[i] = lds[buf][0][pa[i][kk]];
+                    if (i < NI) fa[i] = lds[buf][0][pa[i][kk]];
                     fb[i] = lds[buf][1][pb[i][kk]];
                 }
 #pragma unroll
                 for (int e = 0; e < (sizeof(T) == 2 ? 1 : 4); ++e)              // fp32: e outermost, so consecutive MFMAs never share an accumulator
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < NI; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             if constexpr (sizeof(T) == 2) {                     // 8 halfs per lane = one 32x32x16 step
@@ -269,13 +274,13 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
         const int Mpad = gridDim.x * BM, CoP = gridDim.y * BN;
         float* out = a.partial + ((int64_t)split * (gridDim.z / a.ksplit) + zz) * Mpad * CoP;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int col = co0 + wn * 64 + j * 32 + frow;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    const int row = m0 + rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
                     out[(int64_t)row * CoP + col] = acc[i][j][r];
                 }
             }
@@ -296,10 +301,10 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
             const int cl = wn * 64 + j * 32 + frow, co = co0 + cl;
             const float b = (a.bias && co < a.Co) ? a.bias[co] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    const int ml = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
                     float v = acc[i][j][r] + b;
                     if (!a.noise) {                                             // (with noise the activation waits for the read-back pass)
                         if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
@@ -346,14 +351,14 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
             }
         }
     } else {
-        int opix[2][16];                                                        // output pixel offset of each accumulator row (or -1)
+        int opix[NI][16];                                                        // output pixel offset of each accumulator row (or -1)
         // one division for the wave's first row, then every row by carry (its 32 rows span 64 consecutive m): the 32 runtime
         // divisions this replaces were a fifth of a short-K (1x1) block's life
-        const int mb = m0 + wm * 64;
+        const int mb = m0 + rbase;
         const int imgb = a.fold ? mb / MI : 0;
         const int sib = (mb - imgb * MI) / kc.SW, sjb = (mb - imgb * MI) - sib * kc.SW;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int d = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
@@ -369,7 +374,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
             if (co >= a.Co) continue;
             const float b = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     if (opix[i][r] < 0) continue;
@@ -1461,7 +1466,11 @@ static int launch_conv(ConvArgs& a, int dtype, hipStream_t s, void* workspace, i
     if (query) { *query = need; return P3D_OK; }
     if (want > 1 && workspace && workspace_bytes >= need && (((uintptr_t)workspace) & 15u) == 0) { a.ksplit = want; a.partial = (float*)workspace; }
     dim3 grid(gx, gy, z * a.ksplit);
-    if (dtype == P3D_F16)             hipLaunchKernelGGL(conv2d_nhwc_kernel<__half>, grid, dim3(256), 0, s, a);
+    static const bool no_co64 = getenv("P3D_CONV_NO_CO64") != nullptr;          // (A/B switch of the measurement scripts)
+    const bool co64 = !no_co64 && a.Co <= 64;
+    if (dtype == P3D_F16 && co64)     hipLaunchKernelGGL((conv2d_nhwc_kernel<__half, false, false, true>), grid, dim3(256), 0, s, a);
+    else if (dtype == P3D_F32 && co64) hipLaunchKernelGGL((conv2d_nhwc_kernel<float, false, false, true>), grid, dim3(256), 0, s, a);
+    else if (dtype == P3D_F16)        hipLaunchKernelGGL(conv2d_nhwc_kernel<__half>, grid, dim3(256), 0, s, a);
     else if (dtype == P3D_F32_BF16X3 && x_split) hipLaunchKernelGGL((conv2d_nhwc_kernel<float, true, true>), grid, dim3(256), 0, s, a);
     else if (dtype == P3D_F32_BF16X3) hipLaunchKernelGGL((conv2d_nhwc_kernel<float, true>), grid, dim3(256), 0, s, a);
     else                              hipLaunchKernelGGL(conv2d_nhwc_kernel<float>, grid, dim3(256), 0, s, a);
