@@ -301,6 +301,12 @@ int64_t p3d_conv2d_bwd_weight_workspace(int dtype, int32_t n_img, int32_t small_
 int p3d_conv2d_bwd_weight(const void* small_img, const void* big_img, void* gw, void* workspace, int64_t workspace_bytes, int dtype,
                           int32_t n_img, int32_t small_h, int32_t small_w, int32_t c_small, int32_t big_h, int32_t big_w, int32_t c_big,
                           int32_t kernel_size, int32_t stride, int32_t pad, p3d_stream_t stream);
+/* The same sums, written as fp32 whatever the activation dtype and multiplied by `scale` on the way out — the gradient of a PARAMETER that entered the
+ * convolution as (weight * gain).to(activation dtype) (Conv2dLayer, networks_stylegan2.py:177-180: the cast's and the gain's gradients in the final pass
+ * over the partial sums instead of two more launches).  gw_f32 [cs][cb][k][k] float.                                                                  */
+int p3d_conv2d_bwd_weight_scaled(const void* small_img, const void* big_img, float* gw_f32, void* workspace, int64_t workspace_bytes, int dtype,
+                                 int32_t n_img, int32_t small_h, int32_t small_w, int32_t c_small, int32_t big_h, int32_t big_w, int32_t c_big,
+                                 int32_t kernel_size, int32_t stride, int32_t pad, float scale, p3d_stream_t stream);
 
 /* p3d_conv2d_nhwc with optional split-K scratch (see p3d_conv2d_forward): workspace of p3d_conv2d_nhwc_workspace(...) bytes, or null */
 int p3d_conv2d_nhwc_ws(const void* x, const void* w, void* y, int dtype, const float* bias, const float* noise, const float* noise_strength,

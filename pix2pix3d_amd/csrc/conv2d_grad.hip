@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
 // along the workspace's fastest axis, four splits in flight at a time (the first version walked taps x splits with scalar loads from
 // 16 K threads and took 100-200 us for 50 MB).
 template <class T>
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, T* __restrict__ gw, int Cs, int Cb, int taps, int ksplit, int CsP, int CbP)
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, T* __restrict__ gw, int Cs, int Cb, int taps, int ksplit, int CsP, int CbP, float scale)
 {
     const int cb4 = CbP / 4;
     const int64_t total = (int64_t)taps * Cs * cb4;
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int cb = q * 4 + c;
-            if (cb < Cb) st(gw + ((int64_t)cs * Cb + cb) * taps + t, sum[c]);
+            if (cb < Cb) st(gw + ((int64_t)cs * Cb + cb) * taps + t, sum[c] * scale);          // (scale 1: the sum itself, bit for bit)
         }
     }
 }
@@ -725,9 +725,9 @@ extern "C" int64_t p3d_conv2d_bwd_weight_workspace(int dtype, int32_t n_img, int
     return (int64_t)ksplit * per_wave * taps * (ceil_div(c_small, 128) * 128) * (ceil_div(c_big, 128) * 128) * 4;
 }
 
-extern "C" int p3d_conv2d_bwd_weight(const void* small_img, const void* big_img, void* gw, void* workspace, int64_t workspace_bytes, int dtype,
-                                     int32_t n_img, int32_t small_h, int32_t small_w, int32_t c_small, int32_t big_h, int32_t big_w, int32_t c_big,
-                                     int32_t kernel_size, int32_t stride, int32_t pad, p3d_stream_t stream)
+static int bwd_weight_impl(const void* small_img, const void* big_img, void* gw, void* workspace, int64_t workspace_bytes, int dtype,
+                           int32_t n_img, int32_t small_h, int32_t small_w, int32_t c_small, int32_t big_h, int32_t big_w, int32_t c_big,
+                           int32_t kernel_size, int32_t stride, int32_t pad, bool out_f32, float scale, p3d_stream_t stream)
 {
     P3D_REQUIRE(small_img && big_img && gw && workspace, "conv2d_bwd_weight: null pointer");
     P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32, "conv2d_bwd_weight: dtype must be fp16 or fp32");
@@ -770,8 +770,8 @@ extern "C" int p3d_conv2d_bwd_weight(const void* small_img, const void* big_img,
                 if (rc2 != P3D_OK) return rc2;
                 const int64_t total2 = (int64_t)c_small * (CbP / 4);
                 const int rb2 = (int)((total2 + 255) / 256 < 8192 ? (total2 + 255) / 256 : 8192);
-                if (dtype == P3D_F16) hipLaunchKernelGGL(wgrad_reduce_kernel<__half>, dim3(rb2), dim3(256), 0, s, a.ws, (__half*)gw, c_small, c_big, 1, (int)nsplit, CsP, CbP);
-                else                  hipLaunchKernelGGL(wgrad_reduce_kernel<float>, dim3(rb2), dim3(256), 0, s, a.ws, (float*)gw, c_small, c_big, 1, (int)nsplit, CsP, CbP);
+                if (dtype == P3D_F16 && !out_f32) hipLaunchKernelGGL(wgrad_reduce_kernel<__half>, dim3(rb2), dim3(256), 0, s, a.ws, (__half*)gw, c_small, c_big, 1, (int)nsplit, CsP, CbP, scale);
+                else                              hipLaunchKernelGGL(wgrad_reduce_kernel<float>, dim3(rb2), dim3(256), 0, s, a.ws, (float*)gw, c_small, c_big, 1, (int)nsplit, CsP, CbP, scale);
                 count_launch(FAM_CONV);
                 return check_launch("skinny_wgrad reduce");
             }
@@ -801,8 +801,22 @@ extern "C" int p3d_conv2d_bwd_weight(const void* small_img, const void* big_img,
     if (rc != P3D_OK) return rc;
     const int64_t total = (int64_t)taps * c_small * (a.CbP / 4);
     const int rblocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    if (dtype == P3D_F16) hipLaunchKernelGGL(wgrad_reduce_kernel<__half>, dim3(rblocks), dim3(256), 0, s, a.ws, (__half*)gw, c_small, c_big, taps, a.ksplit * a.psplit, a.CsP, a.CbP);
-    else                  hipLaunchKernelGGL(wgrad_reduce_kernel<float>, dim3(rblocks), dim3(256), 0, s, a.ws, (float*)gw, c_small, c_big, taps, a.ksplit * a.psplit, a.CsP, a.CbP);
+    if (dtype == P3D_F16 && !out_f32) hipLaunchKernelGGL(wgrad_reduce_kernel<__half>, dim3(rblocks), dim3(256), 0, s, a.ws, (__half*)gw, c_small, c_big, taps, a.ksplit * a.psplit, a.CsP, a.CbP, scale);
+    else                              hipLaunchKernelGGL(wgrad_reduce_kernel<float>, dim3(rblocks), dim3(256), 0, s, a.ws, (float*)gw, c_small, c_big, taps, a.ksplit * a.psplit, a.CsP, a.CbP, scale);
     count_launch(FAM_CONV);
     return check_launch("conv_wgrad reduce");
+}
+
+extern "C" int p3d_conv2d_bwd_weight(const void* small_img, const void* big_img, void* gw, void* workspace, int64_t workspace_bytes, int dtype,
+                                     int32_t n_img, int32_t small_h, int32_t small_w, int32_t c_small, int32_t big_h, int32_t big_w, int32_t c_big,
+                                     int32_t kernel_size, int32_t stride, int32_t pad, p3d_stream_t stream)
+{
+    return bwd_weight_impl(small_img, big_img, gw, workspace, workspace_bytes, dtype, n_img, small_h, small_w, c_small, big_h, big_w, c_big, kernel_size, stride, pad, false, 1.f, stream);
+}
+
+extern "C" int p3d_conv2d_bwd_weight_scaled(const void* small_img, const void* big_img, float* gw_f32, void* workspace, int64_t workspace_bytes, int dtype,
+                                            int32_t n_img, int32_t small_h, int32_t small_w, int32_t c_small, int32_t big_h, int32_t big_w, int32_t c_big,
+                                            int32_t kernel_size, int32_t stride, int32_t pad, float scale, p3d_stream_t stream)
+{
+    return bwd_weight_impl(small_img, big_img, gw_f32, workspace, workspace_bytes, dtype, n_img, small_h, small_w, c_small, big_h, big_w, c_big, kernel_size, stride, pad, true, scale, stream);
 }

@@ -45,7 +45,12 @@ def allreduce_gradients(module_or_params, world_size=None, group=None, out=None)
     params = [p for p in params if p.grad is not None]
     if not params:
         return None
-    grads = [p.grad.flatten() for p in params]
+    # each parameter's piece of the flat vector is laid out in the PARAMETER's memory order (channels-last weights of the fp16 super-resolution blocks:
+    # fp16_channels_last), so the gradient handed back has the parameter's strides — the optimizer's multi-tensor kernels take a list only when every
+    # (param, grad, state) triple has equal strides; with contiguous gradients on channels-last weights the whole Gmain step of 194 tensors fell back to
+    # per-tensor lerp_ / addcmul_ launches
+    orders = [_memory_order(p) for p in params]
+    grads = [(p.grad if o is None else p.grad.permute(o)).reshape(-1) for p, o in zip(params, orders)]
     if out is None:
         flat = torch.cat(grads)
     else:
@@ -63,9 +68,27 @@ def allreduce_gradients(module_or_params, world_size=None, group=None, out=None)
         _all_reduce(flat, group)                        # SUM over ranks (RCCL on GPUs, gloo in the CPU tests)
         flat /= world_size
     torch.nan_to_num(flat, nan=0, posinf=1e5, neginf=-1e5, out=flat)
-    for p, g in zip(params, flat.split([p.numel() for p in params])):
-        p.grad = g.reshape(p.shape)
+    for p, o, g in zip(params, orders, flat.split([p.numel() for p in params])):
+        p.grad = g.reshape(p.shape) if o is None else g.as_strided(p.shape, p.stride())
     return flat
+
+
+def _memory_order(p):
+    """None for a contiguous parameter; otherwise the permutation of its dimensions from the slowest to the fastest in memory (dense, non-overlapping
+    tensors only: anything else is treated as contiguous and simply gets a contiguous gradient)."""
+    canonical, span = [], 1
+    for n in reversed(p.shape):                                # the strides reshape() gives a piece of the flat vector (size-1 dimensions included: the
+        canonical.append(span)                                 # multi-tensor kernels compare strides literally)
+        span *= max(n, 1)
+    if p.dim() < 2 or tuple(reversed(canonical)) == tuple(p.stride()):
+        return None
+    order = sorted(range(p.dim()), key=lambda d: (-p.stride(d), d))
+    span = 1
+    for d in reversed(order):                                  # dense in that order?
+        if p.shape[d] != 1 and p.stride(d) != span:
+            return None
+        span *= p.shape[d]
+    return order
 
 
 def broadcast_module(module, src=0, group=None):

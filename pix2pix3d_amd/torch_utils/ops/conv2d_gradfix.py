@@ -127,6 +127,7 @@ _lib.register('p3d_conv2d_bwd_data', ctypes.c_int, [_vp] * 5 + [ctypes.c_int] + 
 _lib.register('p3d_conv2d_forward_workspace', _i64, [ctypes.c_int] + [_i32] * 8)
 _lib.register('p3d_conv2d_bwd_weight_workspace', _i64, [ctypes.c_int] + [_i32] * 6)
 _lib.register('p3d_conv2d_bwd_weight', ctypes.c_int, [_vp] * 4 + [_i64, ctypes.c_int] + [_i32] * 10 + [_vp])
+_lib.register('p3d_conv2d_bwd_weight_scaled', ctypes.c_int, [_vp] * 4 + [_i64, ctypes.c_int] + [_i32] * 10 + [ctypes.c_float, _vp])
 
 _zero_pages = {}
 
@@ -220,29 +221,36 @@ def _is_pointwise(cfg):
     return cfg.wshape[2:] == (1, 1) and cfg.stride == (1, 1) and cfg.dilation == (1, 1) and cfg.padding == (0, 0)
 
 
-def _native_weight_grad(grad_output, x, cfg, k, stride):
-    """p3d_conv2d_bwd_weight: the SMALL image of (x, grad_output) is correlated against the big one, pixels are the contraction."""
+def _native_weight_grad(grad_output, x, cfg, k, stride, scale=None):
+    """p3d_conv2d_bwd_weight: the SMALL image of (x, grad_output) is correlated against the big one, pixels are the contraction.
+    ``scale``: the gradient of the fp32 PARAMETER behind a (weight * scale).to(dtype) operand — fp32, scaled (p3d_conv2d_bwd_weight_scaled)."""
     small, big = (x, grad_output) if cfg.transpose else (grad_output, x)
     small, big = _channels_last(small), _channels_last(big)
     n, cs, hs, ws_ = small.shape
     _, cb, hb, wb = big.shape
     assert (cs, cb) == tuple(cfg.wshape[:2]) and big.shape[0] == n
-    gw = torch.empty(cfg.wshape, dtype=x.dtype, device=x.device)
+    gw = torch.empty(cfg.wshape, dtype=x.dtype if scale is None else torch.float32, device=x.device)
     code_dtype = _lib.DTYPE_CODE[x.dtype]
     nbytes = int(_lib.lib().p3d_conv2d_bwd_weight_workspace(code_dtype, n, hs, ws_, cs, cb, k))
     work = torch.empty([nbytes // 4], dtype=torch.float32, device=x.device)
-    code = _lib.lib().p3d_conv2d_bwd_weight(_lib.ptr(small), _lib.ptr(big), _lib.ptr(gw), _lib.ptr(work), nbytes, code_dtype, n, hs, ws_, cs, hb, wb, cb,
-                                            k, stride, cfg.padding[0], _lib.stream_of(gw))
+    if scale is None:
+        code = _lib.lib().p3d_conv2d_bwd_weight(_lib.ptr(small), _lib.ptr(big), _lib.ptr(gw), _lib.ptr(work), nbytes, code_dtype, n, hs, ws_, cs, hb, wb, cb,
+                                                k, stride, cfg.padding[0], _lib.stream_of(gw))
+    else:
+        code = _lib.lib().p3d_conv2d_bwd_weight_scaled(_lib.ptr(small), _lib.ptr(big), _lib.ptr(gw), _lib.ptr(work), nbytes, code_dtype, n, hs, ws_, cs, hb, wb, cb,
+                                                       k, stride, cfg.padding[0], float(scale), _lib.stream_of(gw))
     _lib.check(code, 'conv2d_bwd_weight')
     native_calls['weight_grad'] += 1
     return gw
 
 
-def _weight_grad_impl(grad_output, x, cfg):
+def _weight_grad_impl(grad_output, x, cfg, scale=None):
     """d(weight) for y = conv(x, w): for the transposed op the roles of x and grad_output swap."""
     geo = None if grad_output.dtype != x.dtype else _native_geometry(x, torch.empty(0, dtype=x.dtype), cfg)
     if geo is not None:
-        return _native_weight_grad(grad_output, x, cfg, *geo)
+        return _native_weight_grad(grad_output, x, cfg, *geo, scale=scale)
+    if scale is not None:
+        return _weight_grad_impl(grad_output, x, cfg).to(torch.float32) * scale
     _note_aten('weight_grad', cfg, x, grad_output)
     if _is_pointwise(cfg) and not cfg.transpose:          # 1x1: a batched matmul over pixels (conv2d_gradfix.py:165-170)
         g = cfg.groups
@@ -285,21 +293,25 @@ class _Conv(torch.autograd.Function):
 
 
 class _ConvWeightGrad(torch.autograd.Function):
+    """``scale`` (conv_layer.py): the result is (gradient.float() * scale) — what reaches an fp32 parameter whose (weight * scale).to(dtype) was the operand."""
+
     @staticmethod
-    def forward(ctx, gy, x, cfg):
+    def forward(ctx, gy, x, cfg, scale=None):
         ctx.save_for_backward(gy if x.requires_grad else None, x if gy.requires_grad else None)
-        ctx.cfg, ctx.gy_shape, ctx.x_shape = cfg, gy.shape, x.shape
-        return _weight_grad_impl(gy, x, cfg)
+        ctx.cfg, ctx.gy_shape, ctx.x_shape, ctx.scale, ctx.dtype = cfg, gy.shape, x.shape, scale, x.dtype
+        return _weight_grad_impl(gy, x, cfg, scale)
 
     @staticmethod
     def backward(ctx, ggw):
         gy, x = ctx.saved_tensors
         cfg = ctx.cfg
         ggy = gx = None
+        if ctx.scale is not None:
+            ggw = (ggw * ctx.scale).to(ctx.dtype)
         if ctx.needs_input_grad[0]:
             ggy = _Conv.apply(x, ggw, None, cfg)
             assert ggy.shape == ctx.gy_shape
         if ctx.needs_input_grad[1]:
             gx = _Conv.apply(gy, ggw, None, cfg.flipped(ctx.gy_shape, ctx.x_shape))
             assert gx.shape == ctx.x_shape
-        return ggy, gx, None
+        return ggy, gx, None, None

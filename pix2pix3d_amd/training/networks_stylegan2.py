@@ -11,7 +11,7 @@ import torch
 
 from ..torch_utils import misc
 from ..torch_utils import persistence
-from ..torch_utils.ops import conv2d_resample, conv2d_gradfix, upfirdn2d, bias_act, fma, modconv, bcast
+from ..torch_utils.ops import conv2d_resample, conv2d_gradfix, upfirdn2d, bias_act, fma, modconv, bcast, conv_layer
 
 
 @misc.profiled_function
@@ -163,6 +163,9 @@ class Conv2dLayer(torch.nn.Module):
         if modconv.plain_layer_supported(x, self.weight, self.up, self.down, self.activation):
             return modconv.plain_layer(x, self.weight, self.bias, self.weight_gain, self.resample_filter, self.down, self.padding,
                                        self.activation, self.act_gain * gain, clamp)
+        if conv_layer.supported(x, self.weight, self.bias, self.up, self.down, self.activation):       # training passes on the device: one launch, same gradients
+            return conv_layer.conv_layer(x, self.weight, self.bias, self.weight_gain, self.resample_filter, self.down, self.padding,
+                                         self.activation, self.act_gain * gain, clamp)
         w = self.weight * self.weight_gain
         b = self.bias.to(x.dtype) if self.bias is not None else None
         x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,

@@ -1,65 +1,54 @@
-"""Census of the kernels of one G.synthesis step that are NOT this package's: which ATen / vendor kernels are still launched, how often,
-how long, and from which Python line.  Run on a GPU box:  python tests/gpu_aten_census.py [dataset] [batch]"""
-import os
-import sys
-from types import SimpleNamespace
-
-import torch
-
+"""Which Python lines issue the ATen glue launches of one six-phase training iteration (bench.train_setup / train_iteration): torch.profiler with stacks,
+CPU-side op records only, grouped by (op, innermost frame inside this repository).  Backward ops run on the autograd thread without a Python stack; they are
+listed by op name alone ('<autograd>').
+    python tests/gpu_aten_census.py -> gpurun_out/aten_census.txt"""
+import collections, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench  # noqa: E402
+import torch
+import bench
+from pix2pix3d_amd.torch_utils.ops import conv2d_gradfix as cg
+from pix2pix3d_amd.training.volumetric_rendering import renderer as rmod
 
 
-def main():
-    dataset = sys.argv[1] if len(sys.argv) > 1 else 'seg2cat'
-    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-    args = SimpleNamespace(dataset=dataset, batch=batch, depth=128)
-    G, kw, info, ws, c = bench.build(args, 'cuda')
-    G, ws, c = G.cuda(), ws.cuda(), c.cuda()
-    from pix2pix3d_amd.training.volumetric_rendering import renderer as rmod
-    rmod.fused_policy = 'require'
-    syn = dict(noise_mode='const', neural_rendering_resolution=info['nrr'])
-    with torch.no_grad():
-        for _ in range(3):
-            G.synthesis(ws, c, **syn)
-        torch.cuda.synchronize()
-        from torch.profiler import profile, ProfilerActivity
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-            G.synthesis(ws, c, **syn)
-            torch.cuda.synchronize()
-    rows = {}
-    total = 0.0
-    n_launch = 0
-    for ev in prof.events():
-        if ev.device_type != torch.autograd.DeviceType.CUDA:
-            continue
-        dur = ev.device_time if hasattr(ev, 'device_time') else ev.cuda_time
-        total += dur
-        n_launch += 1
-        name = ev.name
-        if 'p3d::' in name:
-            continue
-        key = name[:90]
-        r = rows.setdefault(key, [0, 0.0])
-        r[0] += 1
-        r[1] += dur
-    print(f'step: {n_launch} device events, {total / 1e3:.3f} ms of kernel time')
-    print('kernels outside p3d::')
-    for k, (n, t) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
-        print(f'{n:4d} x {t / max(n, 1):8.1f} us = {t / 1e3:7.3f} ms  {k}')
-    # ATen ops (CPU side) with their innermost package frame
-    ops = {}
-    for ev in prof.events():
-        if ev.device_type != torch.autograd.DeviceType.CPU or not ev.name.startswith('aten::') or ev.cpu_parent is not None and ev.cpu_parent.name.startswith('aten::'):
-            continue
-        frame = next((f for f in (ev.stack or []) if 'pix2pix3d_amd' in f), '?')
-        k = (ev.name, frame.split('pix2pix3d_amd/')[-1][:70])
-        ops[k] = ops.get(k, 0) + 1
-    print('top-level aten ops by call site')
-    for (name, frame), n in sorted(ops.items(), key=lambda kv: -kv[1])[:70]:
-        print(f'{n:4d}  {name:32s} {frame}')
-
-
-if __name__ == '__main__':
-    main()
+class A: pass
+args = A(); args.dataset, args.batch, args.train_nrr = 'seg2cat', 4, 128
+dev = torch.device('cuda', 0)
+cg.enabled = True
+rmod.fused_policy = 'require'
+st = bench.train_setup(args, dev, 1)
+for _ in range(2):
+    bench.train_iteration(st, {})
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=False, experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
+    bench.train_iteration(st, {})
+    torch.cuda.synchronize()
+GLUE = ('aten::mul', 'aten::mul_', 'aten::copy_', 'aten::add', 'aten::add_', 'aten::fill_', 'aten::zero_', 'aten::sum', 'aten::div', 'aten::div_', 'aten::neg', 'aten::sub',
+        'aten::clone', 'aten::contiguous', 'aten::_to_copy', 'aten::cat', 'aten::pow', 'aten::sqrt', 'aten::rsqrt', 'aten::where', 'aten::clamp', 'aten::square',
+        'aten::addcmul_', 'aten::lerp_', 'aten::zeros', 'aten::zeros_like', 'aten::empty_like', 'aten::index', 'aten::mean', 'aten::exp', 'aten::sigmoid')
+LEAF = {'aten::mul', 'aten::mul_', 'aten::copy_', 'aten::add', 'aten::add_', 'aten::fill_', 'aten::sum', 'aten::div', 'aten::div_', 'aten::neg', 'aten::sub', 'aten::cat',
+        'aten::pow', 'aten::sqrt', 'aten::rsqrt', 'aten::where', 'aten::clamp', 'aten::addcmul_', 'aten::lerp_', 'aten::index', 'aten::mean', 'aten::exp', 'aten::sigmoid',
+        'aten::sub_', 'aten::addcdiv_', 'aten::clamp_', 'aten::clamp_min', 'aten::gt', 'aten::lt', 'aten::softplus', 'aten::softplus_backward', 'aten::abs', 'aten::sgn',
+        'aten::maximum', 'aten::minimum', 'aten::argmax', 'aten::scatter_', 'aten::nan_to_num', 'aten::nan_to_num_', 'aten::normal_', 'aten::uniform_', 'aten::bernoulli_'}
+count = collections.Counter()
+for ev in prof.events():
+    if ev.name not in LEAF:
+        continue
+    where = '<autograd>'
+    for fr in (ev.stack or []):
+        if ('pix2pix3d_amd' in fr or 'bench.py' in fr) and 'site-packages' not in fr:
+            where = fr.replace(ROOT + '/', '')
+            break
+    count[(ev.name, where)] += 1
+rows = sorted(count.items(), key=lambda kv: -kv[1])
+os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+with open(os.path.join(ROOT, 'gpurun_out', 'aten_census.txt'), 'w') as f:
+    f.write(f'# ATen element-wise / copy / reduce ops of one training iteration by issuing line: {sum(count.values())} ops\n')
+    byop = collections.Counter()
+    for (op, _), n in rows:
+        byop[op] += n
+    f.write('# by op: ' + ', '.join(f'{op} {n}' for op, n in byop.most_common()) + '\n')
+    for (op, where), n in rows[:150]:
+        f.write(f'{n:6d}  {op:22s} {where[:170]}\n')
+print(open(os.path.join(ROOT, 'gpurun_out', 'aten_census.txt')).read()[:6000])

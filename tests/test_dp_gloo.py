@@ -72,3 +72,29 @@ def test_flat_gradient_allreduce_and_sharded_inference(tmp_path):
         full = net(ws, noise_mode='const')
     for r in (r0, r1):
         assert torch.allclose(full[r['idx']], r['img'], atol=1e-5)
+
+
+def test_flat_gradients_keep_each_parameters_strides():
+    """The pieces of the flat vector come back with the PARAMETER's strides (channels-last weights of the fp16 blocks, size-1 dimensions included, a
+    transposed matrix): the optimizer's multi-tensor kernels only take lists whose (param, grad, state) strides agree.  Values are those of the reference's
+    flatten / reshape round trip (training_loop.py:531-542) whatever layout the incoming gradient has, with and without the persistent buffer."""
+    from pix2pix3d_amd import dp
+    g = torch.Generator().manual_seed(5)
+    ps = [torch.nn.Parameter(torch.randn(8, 4, 3, 3, generator=g).to(memory_format=torch.channels_last)), torch.nn.Parameter(torch.randn(5, 7, generator=g)),
+          torch.nn.Parameter(torch.randn(3, 6, 1, 1, generator=g).to(memory_format=torch.channels_last)), torch.nn.Parameter(torch.randn(4, generator=g)),
+          torch.nn.Parameter(torch.randn(1, 6, 1, 1, generator=g)), torch.nn.Parameter(torch.randn(6, 5, generator=g).t())]
+    assert ps[2].stride() == (6, 1, 6, 6)
+    ref = [torch.randn(p.shape, generator=g) for p in ps]
+    for own_layout in (False, True):
+        for buf in (None, {}):
+            for p, r in zip(ps, ref):
+                p.grad = torch.empty_like(p).copy_(r) if own_layout else r.clone().contiguous()
+            for _ in range(2):                                   # the second exchange meets gradients that are views of the buffer
+                flat = dp.allreduce_gradients(ps, world_size=1, out=buf)
+                assert flat.numel() == sum(p.numel() for p in ps)
+                for p, r in zip(ps, ref):
+                    assert torch.equal(p.grad, r) and p.grad.stride() == p.stride()
+    opt = torch.optim.Adam(ps, lr=1e-3, betas=(0.0, 0.99))
+    before = [p.detach().clone() for p in ps]
+    opt.step()
+    assert all(not torch.equal(a, p.detach()) for a, p in zip(before, ps))
