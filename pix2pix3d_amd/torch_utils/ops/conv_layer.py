@@ -108,3 +108,55 @@ class _ConvBiasAct(torch.autograd.Function):
         if ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled:
             gw = conv2d_gradfix._ConvWeightGrad.apply(g, x, cfg, geo.wgain)                         # fp32, times the gain: the cast's and the gain's own gradients ride in the kernel's last pass
         return gx, gw, gb, None
+
+
+# ---- FullyConnectedLayer (networks_stylegan2.py:96-130) in training passes: the style affines and mapping MLPs, a few rows each ---------------------------------
+# Unfused that is weight * gain, bias * gain, the product, the bias / activation pass and their four gradients — eight launches around a 4 x 512 x 512 product,
+# ~210 calls per six-phase iteration.  Forward: the one-launch fc kernel inference uses (gains, bias, activation inside); backward: bias_act's gradient operator on the
+# saved output, the data gradient as the same kernel on the transposed matrix (kept per weight version), the weight gradient on conv2d_gradfix's operator with the gain
+# in its final pass.  All of them differentiable again (the discriminator epilogue's layers sit on R1's path).
+
+def fc_supported(x, weight, bias, activation):
+    if not (enabled and conv2d_gradfix.enabled and conv2d_gradfix.native and modconv.enabled and torch.is_grad_enabled()):
+        return False
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.ndim == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32 and activation in ('linear', 'lrelu')):
+        return False
+    if not (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+        return False
+    n, rows = x.shape[0], max(weight.shape[0], weight.shape[1])
+    return 1 <= n <= 16 and n * ((rows + 3) // 4 * 4) <= 16384          # the fc kernel's row budget, for the product and for its data gradient
+
+
+def fc_layer(x, weight, bias, weight_gain, bias_gain, activation):
+    return _Fc.apply(x, weight, bias, float(weight_gain), float(bias_gain), activation)
+
+
+class _Fc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, wgain, bgain, activation):
+        y = modconv.fc(x, weight, bias, wgain, bgain, activation)
+        spec = bias_act._Spec.make(y, None, 1, activation, None, None, None)
+        ctx.save_for_backward(x, weight, y if 'y' in spec.ref else None)
+        ctx.misc = (wgain, bgain, spec, bias is not None)
+        calls['forward'] += 1
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        wgain, bgain, spec, has_bias = ctx.misc
+        calls['backward'] += 1
+        g = dy if spec.identity else bias_act._BiasActGrad.apply(dy, None, None, y, spec)
+        gx = gw = gb = None
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(0) * bgain
+        if ctx.needs_input_grad[0]:
+            if torch.is_grad_enabled() and weight.requires_grad:          # create_graph: the matrix stays a view of the parameter
+                wt = weight.t()
+            else:
+                wt = modconv._cached_weight(weight, ('fc_transposed',), lambda: weight.detach().t().contiguous())
+            gx = _Fc.apply(g, wt, None, wgain, 1.0, 'linear')
+        if ctx.needs_input_grad[1]:
+            cfg = conv2d_gradfix._Cfg(False, (weight.shape[0], weight.shape[1], 1, 1), 1, 0, 0, 1, 1, split=False)
+            gw = conv2d_gradfix._ConvWeightGrad.apply(g[:, :, None, None], x[:, :, None, None], cfg, wgain).reshape(weight.shape)
+        return gx, gw, gb, None, None, None

@@ -103,7 +103,10 @@ class FullyConnectedLayer(torch.nn.Module):
         """``out_scale`` multiplies the result (ToRGBLayer folds its weight gain in here instead of a separate launch)."""
         if modconv.fc_supported(x, self.weight, self.bias, self.activation):
             return modconv.fc(x, self.weight, self.bias, self.weight_gain, self.bias_gain, self.activation, out_scale)
-        y = self._forward_as_conv(x) if self._conv_route(x) else self._forward(x)
+        if conv_layer.fc_supported(x, self.weight, self.bias, self.activation):      # training passes on the device: one launch, same gradients
+            y = conv_layer.fc_layer(x, self.weight, self.bias, self.weight_gain, self.bias_gain, self.activation)
+        else:
+            y = self._forward_as_conv(x) if self._conv_route(x) else self._forward(x)
         return y if out_scale == 1 else y * out_scale
 
     def _conv_route(self, x):

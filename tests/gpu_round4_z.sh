@@ -1,0 +1,12 @@
+#!/bin/bash
+# round-4 session z: FullyConnectedLayer's one-launch training form — its test, the reference-pinned suites, the training line with and without the one-launch layers
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_conv_layer_gpu.py -m gpu -q --tb=short > gpurun_out/z_pytest1.log 2>&1; echo "pytest exit $?" >> gpurun_out/z_pytest1.log
+tail -12 gpurun_out/z_pytest1.log | cut -c1-1500
+timeout 900 python -m pytest tests/test_discriminator.py tests/test_loss_phases.py tests/test_train_full.py tests/test_train_step.py tests/test_model_gpu.py -m gpu -q --tb=short > gpurun_out/z_pytest2.log 2>&1; echo "pytest exit $?" >> gpurun_out/z_pytest2.log
+tail -4 gpurun_out/z_pytest2.log | cut -c1-1200
+timeout 300 python bench.py --train-step --steps 3 --warmup 2 > gpurun_out/z_train.json 2>> gpurun_out/z_bench.err
+python -c "import json; d=json.load(open('gpurun_out/z_train.json')); print('TRAIN', d['ms_per_step'], d['train_step']['phase_ms'])" || tail -n 5 gpurun_out/z_bench.err
+P3D_CONV_LAYER=0 timeout 300 python bench.py --train-step --steps 3 --warmup 2 > gpurun_out/z_train_off.json 2>> gpurun_out/z_bench.err
+python -c "import json; d=json.load(open('gpurun_out/z_train_off.json')); print('TRAIN unfused', d['ms_per_step'], d['train_step']['phase_ms'])" || tail -n 5 gpurun_out/z_bench.err

@@ -83,3 +83,59 @@ def test_one_launch_layer_matches_the_unfused_formulation(hip_lib, case, dtype, 
     else:
         l2 = {key: float((a[key].double() - b[key].double()).norm() / b[key].double().norm().clamp_min(1e-12)) for key in a}
         assert errs['y'] < 2e-3 and all(e < 0.2 for e in errs.values()) and all(e < 3e-2 for e in l2.values()), (errs, l2)
+
+
+# (name, in, out, activation, bias, lr_multiplier, N)
+FC_CASES = [('affine', 512, 512, 'linear', True, 1.0, 4), ('mapping', 512, 512, 'lrelu', True, 0.01, 4), ('camera', 25, 512, 'linear', True, 1.0, 4),
+            ('logit', 512, 1, 'linear', True, 1.0, 4), ('narrow', 512, 96, 'lrelu', False, 1.0, 3)]
+
+
+@pytest.mark.parametrize('second_order', [False, True], ids=['first_order', 'second_order'])
+@pytest.mark.parametrize('case', FC_CASES, ids=[c[0] for c in FC_CASES])
+def test_one_launch_fully_connected_layer_matches_the_unfused_formulation(hip_lib, case, second_order):
+    """FullyConnectedLayer in training passes (conv_layer.fc_layer) against the route it replaces (weight * gain, 1x1 convolution of a 1x1 image, bias_act): output,
+    gradients, and a gradient-of-gradient pattern (d/dparams of |d sum(y) / dx|^2 — what R1 asks of the discriminator epilogue's layers)."""
+    from pix2pix3d_amd.training.networks_stylegan2 import FullyConnectedLayer
+    from pix2pix3d_amd.torch_utils.ops import conv_layer, conv2d_gradfix
+    name, fin, fout, act, bias, lrm, n = case
+    torch.manual_seed(11)
+    layer = FullyConnectedLayer(fin, fout, bias=bias, activation=act, lr_multiplier=lrm, bias_init=0.3).cuda()
+    x0 = torch.randn(n, fin, device='cuda')
+    g = torch.Generator(device='cuda').manual_seed(5)
+    probe = torch.randn(n, fout, device='cuda', generator=g)
+
+    def run(fused):
+        prev = conv_layer.enabled
+        conv_layer.enabled = fused
+        try:
+            for p in layer.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            y = layer(x)
+            out = dict(y=y.detach().clone())
+            if second_order:
+                gx, = torch.autograd.grad(outputs=[(y * probe).sum()], inputs=[x], create_graph=True, only_inputs=True)
+                (gx.square().sum() * 0.5 + y.mean()).backward()
+                out['field'] = gx.detach().clone()
+            else:
+                (y * probe).sum().backward()
+                out['gx'] = x.grad.detach().clone()
+            out['gw'] = layer.weight.grad.detach().clone()
+            if bias:
+                out['gb'] = layer.bias.grad.detach().clone()
+            return out
+        finally:
+            conv_layer.enabled = prev
+    prev, conv2d_gradfix.enabled = conv2d_gradfix.enabled, True
+    try:
+        c0 = dict(conv_layer.calls)
+        a = run(True)
+        assert conv_layer.calls['forward'] > c0['forward'] and conv_layer.calls['backward'] > c0['backward']
+        c1 = dict(conv_layer.calls)
+        b = run(False)
+        assert conv_layer.calls == c1
+    finally:
+        conv2d_gradfix.enabled = prev
+    assert set(a) == set(b)
+    errs = {key: rel(a[key], b[key]) for key in a}
+    assert all(e < 2e-5 for e in errs.values()), errs
