@@ -356,6 +356,11 @@ int p3d_torgb_wide_split(const void* x_split, const void* wmod_split, const floa
                          int32_t n_img, int32_t h, int32_t w, int32_t ci, int32_t co, float clamp, p3d_stream_t stream);
 /* d[n][o] = rsqrt(sum_i styles[n][i]^2 * w2[o][i] + 1e-8) with w2[o][i] = sum over the taps of weight[o][i][.]^2 (networks_stylegan2.py:57-63) */
 int p3d_demod_coefs(const float* styles, const float* w2, float* d, int32_t n_rows, int32_t ci, int32_t co, p3d_stream_t stream);
+/* Its gradient for the training passes: given gd = dL/dd [N][Co] and the forward's d, writes gs = dL/dstyles [N][Ci] and gw = dL/dweight [Co][Ci][taps]
+ * (weight: the fp32 [Co][Ci][taps] tensor w2 was summed from); either output may be null.  The reference gets these from autograd through
+ * (w * s).square().sum().rsqrt() on the [N][Co][Ci][k][k] product (networks_stylegan2.py:57-63).                                                    */
+int p3d_demod_coefs_backward(const float* gd, const float* d, const float* styles, const float* w2, const float* weight, float* gs, float* gw,
+                             int32_t n_rows, int32_t ci, int32_t co, int32_t taps, p3d_stream_t stream);
 
 int64_t p3d_conv2d_nhwc_workspace(int dtype, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride, int32_t kernel_size,
                                   int32_t resample);

@@ -101,6 +101,57 @@ __global__ void __launch_bounds__(256) demod_coefs_kernel(const float* __restric
     }
 }
 
+// Gradient of the demodulation coefficients (training passes).  With t[n][o] = gd[n][o] * d[n][o]^3:
+//   gs[n][i]      = -styles[n][i] * sum_o t[n][o] * w2[o][i]                     (demod_bwd_styles_kernel: a thread per input channel, four slices of o per block)
+//   gw[o][i][tap] = -weight[o][i][tap] * sum_n t[n][o] * styles[n][i]^2          (demod_bwd_weight_kernel: a thread per weight element)
+// (d = u^-1/2 with u = sum_i s^2 w2 + eps: dd/du = -d^3 / 2, du/ds = 2 s w2, du/dw = 2 w s^2.)
+__global__ void __launch_bounds__(256) demod_bwd_styles_kernel(const float* __restrict__ gd, const float* __restrict__ d, const float* __restrict__ styles,
+                                                               const float* __restrict__ w2, float* __restrict__ gs, int n_rows, int ci, int co)
+{
+    extern __shared__ float ts[];                                   // [n_rows][co] of t, then [4][64][n_rows] partial sums
+    for (int e = threadIdx.x; e < n_rows * co; e += 256) { const float dv = d[e]; ts[e] = gd[e] * dv * dv * dv; }
+    __syncthreads();
+    const int il = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + il;
+    float acc[FC_MAXN];
+#pragma unroll
+    for (int n = 0; n < FC_MAXN; ++n) acc[n] = 0.f;
+    if (i < ci)
+        for (int o = slice; o < co; o += 4) {
+            const float wv = w2[(int64_t)o * ci + i];
+#pragma unroll
+            for (int n = 0; n < FC_MAXN; ++n)
+                if (n < n_rows) acc[n] = fmaf(ts[n * co + o], wv, acc[n]);
+        }
+    __syncthreads();                                                // t is done with: the partial sums take its place
+    float* const part = ts;
+#pragma unroll
+    for (int n = 0; n < FC_MAXN; ++n)
+        if (n < n_rows) part[(slice * 64 + il) * n_rows + n] = acc[n];
+    __syncthreads();
+    if (slice == 0 && i < ci)
+        for (int n = 0; n < n_rows; ++n) {
+            const float sum = (part[il * n_rows + n] + part[(64 + il) * n_rows + n]) + (part[(128 + il) * n_rows + n] + part[(192 + il) * n_rows + n]);
+            gs[(int64_t)n * ci + i] = -styles[(int64_t)n * ci + i] * sum;
+        }
+}
+
+__global__ void __launch_bounds__(256) demod_bwd_weight_kernel(const float* __restrict__ gd, const float* __restrict__ d, const float* __restrict__ styles,
+                                                               const float* __restrict__ weight, float* __restrict__ gw, int n_rows, int ci, int co, int taps)
+{
+    const int64_t total = (int64_t)co * ci * taps;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t oi = e / taps;
+        const int o = (int)(oi / ci), i = (int)(oi - (int64_t)o * ci);
+        float coef = 0.f;
+        for (int n = 0; n < n_rows; ++n) {
+            const float dv = d[n * co + o], sv = styles[n * ci + i];
+            coef = fmaf(gd[n * co + o] * dv * dv * dv, sv * sv, coef);
+        }
+        gw[e] = -weight[e] * coef;
+    }
+}
+
 // Several independent FC layers in ONE launch (the 20 style affines of a synthesis network are 20 launches of ~6 us each otherwise):
 // the jobs travel in the kernel arguments; first_block[j] is the first block of job j.
 constexpr int FC_MAX_JOBS = P3D_FC_MAX_JOBS;
@@ -240,6 +291,32 @@ extern "C" int p3d_demod_coefs(const float* styles, const float* w2, float* d, i
     hipLaunchKernelGGL(demod_coefs_kernel, dim3((co + 3) / 4), dim3(256), shm, (hipStream_t)stream, styles, w2, d, n_rows, ci, co);
     count_launch(FAM_AUX);
     return check_launch("demod_coefs");
+}
+
+extern "C" int p3d_demod_coefs_backward(const float* gd, const float* d, const float* styles, const float* w2, const float* weight, float* gs, float* gw,
+                                        int32_t n_rows, int32_t ci, int32_t co, int32_t taps, p3d_stream_t stream)
+{
+    using namespace p3d;
+    P3D_REQUIRE(gd && d && styles && w2 && weight, "demod_coefs_backward: null pointer");
+    P3D_REQUIRE(n_rows >= 1 && n_rows <= FC_MAXN && ci >= 1 && co >= 1 && taps >= 1, "demod_coefs_backward: 1 .. %d rows", FC_MAXN);
+    hipStream_t s = (hipStream_t)stream;
+    if (gs) {
+        const size_t a = (size_t)n_rows * co, b = (size_t)256 * n_rows;
+        const size_t shm = (a > b ? a : b) * sizeof(float);
+        P3D_REQUIRE(shm <= 64 * 1024, "demod_coefs_backward: n_rows * co too large for the LDS stage");
+        hipLaunchKernelGGL(demod_bwd_styles_kernel, dim3((ci + 63) / 64), dim3(256), shm, s, gd, d, styles, w2, gs, n_rows, ci, co);
+        count_launch(FAM_AUX);
+        int rc = check_launch("demod_coefs_backward (styles)");
+        if (rc != P3D_OK) return rc;
+    }
+    if (gw) {
+        const int64_t total = (int64_t)co * ci * taps;
+        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(demod_bwd_weight_kernel, dim3(blocks), dim3(256), 0, s, gd, d, styles, weight, gw, n_rows, ci, co, taps);
+        count_launch(FAM_AUX);
+        return check_launch("demod_coefs_backward (weight)");
+    }
+    return P3D_OK;
 }
 
 extern "C" int p3d_fc_multi(const p3d_fc_job* jobs_host, int32_t n_jobs, int32_t n_rows, p3d_stream_t stream)

@@ -160,3 +160,64 @@ class _Fc(torch.autograd.Function):
             cfg = conv2d_gradfix._Cfg(False, (weight.shape[0], weight.shape[1], 1, 1), 1, 0, 0, 1, 1, split=False)
             gw = conv2d_gradfix._ConvWeightGrad.apply(g[:, :, None, None], x[:, :, None, None], cfg, wgain).reshape(weight.shape)
         return gx, gw, gb, None, None, None
+
+
+# ---- demodulation coefficients of the modulated convolution (networks_stylegan2.py:57-63) in training passes ------------------------------------------------------
+# rsqrt(sum_{i,taps} (w * s)^2 + 1e-8) as [N, Co]: written with tensor operators that is square / tap sum / square / broadcast product / sum / add / rsqrt and their
+# gradients — ~15 launches for a [4, 512] result, ~55 calls per iteration.  Forward: the kernel inference uses (tap sums of w^2 kept per weight version); backward: two
+# kernels (p3d_demod_coefs_backward).  When the backward is itself being recorded (create_graph) the tensor-operator formulation is differentiated instead.
+
+import ctypes as _ct
+
+_lib = modconv._lib
+_lib.register('p3d_demod_coefs_backward', _ct.c_int, [_ct.c_void_p] * 7 + [_ct.c_int32] * 4 + [_ct.c_void_p])
+
+
+def demod_supported(weight, styles):
+    if not (enabled and conv2d_gradfix.enabled and conv2d_gradfix.native and modconv.enabled and torch.is_grad_enabled()):
+        return False
+    if not (isinstance(weight, torch.nn.Parameter) and weight.is_cuda and weight.dtype == torch.float32 and weight.ndim == 4 and weight.is_contiguous()):
+        return False                                       # (a derived tensor — the fp16 pre-scaled weights — has no version to key the tap sums on)
+    if not (styles.is_cuda and styles.dtype == torch.float32 and styles.ndim == 2 and (weight.requires_grad or styles.requires_grad)):
+        return False
+    n = styles.shape[0]
+    return 1 <= n <= 16 and n * max(weight.shape[0], weight.shape[1]) * 4 <= 64 * 1024
+
+
+def demod_reference(weight, styles):
+    """The tensor-operator formulation (taps summed first: the [N, O, I, k, k] product of the reference is never formed)."""
+    energy = weight.square().sum(dim=(2, 3))
+    return torch.rsqrt((styles.square().unsqueeze(1) * energy.unsqueeze(0)).sum(dim=2) + 1e-8)
+
+
+def demod(weight, styles):
+    return _Demod.apply(weight, styles)
+
+
+class _Demod(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, styles):
+        d = modconv.demod_coefs(weight, styles)
+        ctx.save_for_backward(weight, styles, d)
+        calls['forward'] += 1
+        return d
+
+    @staticmethod
+    def backward(ctx, gd):
+        weight, styles, d = ctx.saved_tensors
+        calls['backward'] += 1
+        if torch.is_grad_enabled():                        # create_graph: differentiate the plain formulation, to any order
+            with torch.enable_grad():
+                wanted = [t for t, need in ((weight, ctx.needs_input_grad[0]), (styles, ctx.needs_input_grad[1])) if need]
+                grads = list(torch.autograd.grad(demod_reference(weight, styles), wanted, gd, create_graph=True))
+            return (grads.pop(0) if ctx.needs_input_grad[0] else None), (grads.pop(0) if ctx.needs_input_grad[1] else None)
+        co, ci, kh, kw = weight.shape
+        n = styles.shape[0]
+        w2 = modconv._cached_weight(weight, 'w2_tapsum', lambda: weight.detach().float().square().sum(dim=[2, 3]).contiguous())
+        s32, gd32 = styles.detach().contiguous(), gd.detach().float().contiguous()
+        gw = torch.empty_like(weight, memory_format=torch.contiguous_format) if ctx.needs_input_grad[0] else None
+        gs = torch.empty_like(s32) if ctx.needs_input_grad[1] else None
+        code = _lib.lib().p3d_demod_coefs_backward(_lib.ptr(gd32), _lib.ptr(d), _lib.ptr(s32), _lib.ptr(w2), _lib.ptr(weight.detach()), _lib.ptr(gs), _lib.ptr(gw),
+                                                   n, ci, co, kh * kw, _lib.stream_of(gd32))
+        _lib.check(code, 'demod_coefs_backward')
+        return gw, gs

@@ -32,8 +32,9 @@ def _fp16_prescale(weight, styles):
 def _demod_coefficients(weight, styles):
     """rsqrt(sum_{i,ky,kx} (w[o,i,ky,kx] * s[n,i])^2 + 1e-8) as [N, O] (:65) — the taps are summed first, so the [N,O,I,k,k] product
     the reference forms for this is never materialised: an [N,O,I] broadcast product."""
-    energy = weight.square().sum(dim=(2, 3))                     # [O, I]
-    return torch.rsqrt((styles.square().unsqueeze(1) * energy.unsqueeze(0)).sum(dim=2) + 1e-8)      # [N, O]; broadcast-sum, not a GEMM call
+    if conv_layer.demod_supported(weight, styles):               # training passes on the device: one kernel, two for its gradient
+        return conv_layer.demod(weight, styles)
+    return conv_layer.demod_reference(weight, styles)            # [N, O]; broadcast-sum, not a GEMM call
 
 
 def _per_sample_conv(x, w_each, **resample):

@@ -32,7 +32,7 @@ def test_python_binding_covers_every_declared_symbol():
     from pix2pix3d_amd import _lib
     _lib.lib()
     import importlib
-    for m in ('torch_utils.ops.bias_act', 'torch_utils.ops.upfirdn2d', 'torch_utils.ops.modconv', 'torch_utils.ops.filtered_lrelu', 'torch_utils.ops.conv2d_gradfix', 'torch_utils.ops.bcast',
+    for m in ('torch_utils.ops.bias_act', 'torch_utils.ops.upfirdn2d', 'torch_utils.ops.modconv', 'torch_utils.ops.filtered_lrelu', 'torch_utils.ops.conv2d_gradfix', 'torch_utils.ops.bcast', 'torch_utils.ops.conv_layer',
               'training.volumetric_rendering.renderer', 'training.volumetric_rendering.ray_sampler', 'diagnostics'):
         try:
             importlib.import_module('pix2pix3d_amd.' + m)          # op modules register their entry points on import

@@ -139,3 +139,34 @@ def test_one_launch_fully_connected_layer_matches_the_unfused_formulation(hip_li
     assert set(a) == set(b)
     errs = {key: rel(a[key], b[key]) for key in a}
     assert all(e < 2e-5 for e in errs.values()), errs
+
+
+@pytest.mark.parametrize('shape', [(512, 512, 3, 4), (96, 256, 1, 4), (64, 128, 3, 2), (33, 40, 3, 3)], ids=['backbone', 'torgb_like', 'sr', 'odd'])
+def test_demodulation_coefficients_and_their_gradient(hip_lib, shape):
+    """conv_layer.demod (one kernel; two for the gradient) against the tensor-operator formulation of networks_stylegan2.py:57-63, and — with create_graph — its
+    second-order path against the same formulation differentiated twice."""
+    from pix2pix3d_amd.torch_utils.ops import conv_layer, conv2d_gradfix
+    co, ci, k, n = shape
+    g = torch.Generator(device='cuda').manual_seed(co + ci)
+    weight = torch.nn.Parameter(torch.randn(co, ci, k, k, device='cuda', generator=g))
+    s0 = torch.randn(n, ci, device='cuda', generator=g) + 1.0
+    probe = torch.randn(n, co, device='cuda', generator=g)
+    prev, conv2d_gradfix.enabled = conv2d_gradfix.enabled, True
+    try:
+        assert conv_layer.demod_supported(weight, s0.requires_grad_(True))
+        out = {}
+        for name, fn in (('native', conv_layer.demod), ('ref', conv_layer.demod_reference)):
+            weight.grad = None
+            s = s0.detach().clone().requires_grad_(True)
+            d = fn(weight, s)
+            (d * probe).sum().backward()
+            out[name] = (d.detach(), s.grad.clone(), weight.grad.clone())
+            weight.grad = None
+            s = s0.detach().clone().requires_grad_(True)
+            gs, = torch.autograd.grad((fn(weight, s) * probe).sum(), [s], create_graph=True)
+            gs.square().sum().backward()
+            out[name] += (gs.detach(), s.grad.clone(), weight.grad.clone())
+    finally:
+        conv2d_gradfix.enabled = prev
+    errs = [rel(a, b) for a, b in zip(out['native'], out['ref'])]
+    assert all(e < 2e-5 for e in errs), errs
