@@ -17,11 +17,15 @@ front of the convolution that conv2d_resample.py:108-118 makes it.
 Not taken (the caller falls back to the unfused formulation): CPU tensors, up-sampling layers, channel counts that are not whole K
 rows of the matrix-core kernels (the 6 / 18-channel fromrgb layers), activations other than linear / lrelu.
 """
+import ctypes
 import os
 
 import torch
 
+from ... import _lib
 from . import bias_act, conv2d_gradfix, modconv, upfirdn2d
+
+_lib.register('p3d_demod_coefs_backward', ctypes.c_int, [ctypes.c_void_p] * 7 + [ctypes.c_int32] * 4 + [ctypes.c_void_p])
 
 enabled = os.environ.get('P3D_CONV_LAYER', '1') != '0'      # off: Conv2dLayer keeps the unfused formulation in training passes (tests / A-B measurements)
 calls = {'forward': 0, 'backward': 0}
@@ -166,12 +170,6 @@ class _Fc(torch.autograd.Function):
 # rsqrt(sum_{i,taps} (w * s)^2 + 1e-8) as [N, Co]: written with tensor operators that is square / tap sum / square / broadcast product / sum / add / rsqrt and their
 # gradients — ~15 launches for a [4, 512] result, ~55 calls per iteration.  Forward: the kernel inference uses (tap sums of w^2 kept per weight version); backward: two
 # kernels (p3d_demod_coefs_backward).  When the backward is itself being recorded (create_graph) the tensor-operator formulation is differentiated instead.
-
-import ctypes as _ct
-
-_lib = modconv._lib
-_lib.register('p3d_demod_coefs_backward', _ct.c_int, [_ct.c_void_p] * 7 + [_ct.c_int32] * 4 + [_ct.c_void_p])
-
 
 def demod_supported(weight, styles):
     if not (enabled and conv2d_gradfix.enabled and conv2d_gradfix.native and modconv.enabled and torch.is_grad_enabled()):

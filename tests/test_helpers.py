@@ -107,3 +107,30 @@ def test_filtered_resizing_upsizes_on_the_native_kernels(hip_lib):
         assert _lib.launch_count('upfirdn2d') == n0
     finally:
         dd.native_upsize = prev
+
+
+def test_one_launch_training_layers_leave_the_cpu_path_alone():
+    """torch_utils/ops/conv_layer.py is a device-only route: on CPU tensors its predicates decline and Conv2dLayer / FullyConnectedLayer / the demodulation
+    coefficients run the operator-by-operator formulation; the tensor-operator demodulation it falls back to equals the reference's [N, O, I, k, k] product form
+    (networks_stylegan2.py:57-63)."""
+    from pix2pix3d_amd.torch_utils.ops import conv_layer, conv2d_gradfix
+    from pix2pix3d_amd.training.networks_stylegan2 import Conv2dLayer, FullyConnectedLayer, _demod_coefficients
+    g = torch.Generator().manual_seed(2)
+    prev, conv2d_gradfix.enabled = conv2d_gradfix.enabled, True
+    try:
+        conv = Conv2dLayer(32, 64, 3, activation='lrelu', down=2)
+        x = torch.randn(2, 32, 16, 16, generator=g, requires_grad=True)
+        assert not conv_layer.supported(x, conv.weight, conv.bias, 1, 2, 'lrelu')
+        fc = FullyConnectedLayer(64, 32, activation='lrelu')
+        z = torch.randn(3, 64, generator=g, requires_grad=True)
+        assert not conv_layer.fc_supported(z, fc.weight, fc.bias, 'lrelu')
+        w = torch.nn.Parameter(torch.randn(8, 6, 3, 3, generator=g)); s = torch.randn(2, 6, generator=g, requires_grad=True)
+        assert not conv_layer.demod_supported(w, s)
+        c0 = dict(conv_layer.calls)
+        conv(x).sum().backward(); fc(z).sum().backward()
+        d = _demod_coefficients(w, s)
+        assert conv_layer.calls == c0 and conv.weight.grad is not None and fc.weight.grad is not None
+    finally:
+        conv2d_gradfix.enabled = prev
+    ref = ((w.unsqueeze(0) * s.reshape(2, 1, 6, 1, 1)).square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt()
+    assert float((d - ref).abs().max()) < 1e-6
