@@ -323,6 +323,162 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
         }
 }
 
+// ---- fp16 weight gradient with the operands left as they arrive: pixel-major rows in LDS, fragments by the transposing LDS read -------------------------------
+// The contraction runs over PIXELS and both images are stored pixel-major, so an MFMA fragment (8 consecutive k for one channel per lane) is a strided gather.
+// conv_wgrad_kernel<__half> transposes 4 x 8 blocks in registers on the way into LDS (byte permutes: VALU 0.25-0.38 busy against 0.12-0.19 for the matrix pipe).
+// gfx950's ds_read_b64_tr_b16 does that transposition in the LDS read: within a 16-lane group, lane 4 r + q passes the address of row r, columns 4 q .. 4 q + 3 of a
+// 4 x 16 matrix of 16-bit elements and lane i receives column i (tests/probes/tr_b16_probe.hip establishes exactly this on the device).  So the 16-byte global
+// loads go to LDS as they are — row p of an operand image is pixel p's 128 channels, 256 bytes, rotated by 64 bytes x (p & 3) so that the four rows one read
+// touches sit in four different quarters of the 64 banks — and a fragment is two such reads (k 0..3 and 4..7 of the lane's k-group).  Same work decomposition,
+// roles and partial-tile layout as conv_wgrad_kernel; FAST geometries, psplit 1 or 2.
+typedef __fp16 tr_f16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+// ROW64: image rows are a multiple of 64 pixels wide, so a chunk lies inside ONE row and a thread's four pixels (16 apart) share one position, one row test.
+template <bool ROW64>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_tr_f16_kernel(WgradArgs a)
+{
+    constexpr int KP = 64, ROW = 256, IMG = KP * ROW;                          // pixels per chunk, bytes per pixel row, bytes per operand image
+    __shared__ __attribute__((aligned(16))) char lds[2][2][IMG];               // [buffer][S | B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = a.psplit == 1 ? wave >> 1 : (a.narrow_b ? wave & 1 : 0);
+    const int wn = a.psplit == 1 ? wave & 1 : (!a.narrow_b ? wave & 1 : 0);
+    const int part = a.psplit == 1 ? 0 : wave >> 1, pmask = a.psplit - 1;
+    const int taps = a.k * a.k;
+    const int groups = a.ksplit * a.tiles_s * a.tiles_b;
+    int L = blockIdx.x, g, tap;
+    if (a.xcd_pad)              { g = (L & 7) + 8 * ((L >> 3) / taps); tap = (L >> 3) % taps; if (g >= groups) return; }
+    else if ((groups & 7) == 0) { g = (L & 7) + 8 * ((L >> 3) / taps); tap = (L >> 3) % taps; }
+    else                        { g = L / taps; tap = L - g * taps; }
+    const int tile = g % (a.tiles_s * a.tiles_b), split = g / (a.tiles_s * a.tiles_b);
+    const int cs0 = (tile / a.tiles_b) * 128, cb0 = (tile % a.tiles_b) * 128;
+    const int ky = tap / a.k, kx = tap - ky * a.k;
+    const int dy = ky - a.pad, dx = kx - a.pad;
+    const int c_begin = split * a.chunks_per_split;
+    int c_end = c_begin + a.chunks_per_split;
+    if (c_end > a.chunks) c_end = a.chunks;
+    const int64_t Mtot = (int64_t)a.N * a.HS * a.WS;
+    const int m_end = (int)((int64_t)c_end * KP < Mtot ? (int64_t)c_end * KP : Mtot);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // loader: 16 threads cover one pixel's 128 channels (256 contiguous bytes of global memory), 16 pixels per pass, four passes per chunk
+    const int lc = (tid & 15) * 8;
+    int lp[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lp[q] = (tid >> 4) + 16 * q;
+    const int wrow = ((lc * 2 + 64 * ((tid >> 4) & 3)) & 255);                  // byte position of this thread's 16 bytes inside its (rotated) LDS rows
+    PixPos pos[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t m = (int64_t)c_begin * KP + lp[q];
+        const int64_t per = (int64_t)a.HS * a.WS;
+        pos[q].n = (int)(m / per);
+        const int rem = (int)(m - (int64_t)pos[q].n * per);
+        pos[q].i = rem / a.WS; pos[q].j = rem - pos[q].i * a.WS;
+    }
+    const bool s_ok = cs0 + lc < a.Cs, b_ok = cb0 + lc < a.Cb;
+    const char* const Sb = (const char*)a.s;
+    const char* const Bb = (const char*)a.b;
+    f32x4 rs[4], rb[4];
+    auto fetch = [&](int chunk) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (ROW64) {
+            const int m0 = chunk * KP + lp[0];
+            const bool live = m0 < m_end;                                           // (whole rows of 64: the four pixels are live together)
+            const int bi = pos[0].i * a.stride + dy, bj0 = pos[0].j * a.stride + dx;
+            const bool row_ok = live && b_ok && bi >= 0 && bi < a.HB;
+            const unsigned so = (unsigned)(m0 * a.Cs + cs0 + lc) * 2u;
+            const unsigned bo = (unsigned)(((pos[0].n * a.HB + bi) * a.WB + bj0) * a.Cb + cb0 + lc) * 2u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int bj = bj0 + 16 * q * a.stride;
+                rs[q] = (live && s_ok) ? *(const f32x4*)(Sb + (so + (unsigned)(16 * q * a.Cs) * 2u)) : zero;
+                rb[q] = (row_ok && bj >= 0 && bj < a.WB) ? *(const f32x4*)(Bb + (bo + (unsigned)(16 * q * a.stride * a.Cb) * 2u)) : zero;
+            }
+            pix_advance(pos[0], KP, a.HS, a.WS);
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = chunk * KP + lp[q];
+            const bool live = m < m_end;
+            const int bi = pos[q].i * a.stride + dy, bj = pos[q].j * a.stride + dx;
+            const unsigned so = (unsigned)(m * a.Cs + cs0 + lc) * 2u;
+            const unsigned bo = (unsigned)(((pos[q].n * a.HB + bi) * a.WB + bj) * a.Cb + cb0 + lc) * 2u;
+            rs[q] = (live && s_ok) ? *(const f32x4*)(Sb + so) : zero;
+            rb[q] = (live && b_ok && bi >= 0 && bi < a.HB && bj >= 0 && bj < a.WB) ? *(const f32x4*)(Bb + bo) : zero;
+            pix_advance(pos[q], KP, a.HS, a.WS);
+        }
+    };
+    auto deposit = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *(f32x4*)(lds[buf][0] + lp[q] * ROW + wrow) = rs[q];
+            *(f32x4*)(lds[buf][1] + lp[q] * ROW + wrow) = rb[q];
+        }
+    };
+    // fragment reads: lane = (group gq = lane >> 4, i16 = lane & 15): channel (gq & 1) * 16 + i16 = lane & 31 of its 32-channel tile, k-group gq >> 1 = lane >> 5 —
+    // the MFMA operand layout; the lane's ADDRESS is row (i16 >> 2) of the group's 4 x 16 matrix (= pixel), columns 4 (i16 & 3) .. (= channels)
+    const int gq = lane >> 4, i16 = lane & 15;
+    int preA[2], preB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int prow = (gq >> 1) * 8 + (i16 >> 2);
+        preA[i] = prow * ROW + ((((wm * 64 + i * 32 + (gq & 1) * 16) * 2) + (i16 & 3) * 8 + 64 * (i16 >> 2)) & 255);
+        preB[i] = prow * ROW + ((((wn * 64 + i * 32 + (gq & 1) * 16) * 2) + (i16 & 3) * 8 + 64 * (i16 >> 2)) & 255);
+    }
+    typedef __attribute__((address_space(3))) tr_f16x4* lds_tr;
+    auto frag = [&](const char* img, int pre, int kk) -> h8 {
+        const tr_f16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr)(img + pre + kk * 16 * ROW));
+        const tr_f16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr)(img + pre + kk * 16 * ROW + 4 * ROW));
+        h8 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = (_Float16)lo[e]; v[4 + e] = (_Float16)hi[e]; }
+        return v;
+    };
+    const int frow = lane & 31, fk = lane >> 5;
+
+    if (c_begin < c_end) fetch(c_begin);
+    int buf = 0;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        deposit(buf);
+        __syncthreads();
+        if (chunk + 1 < c_end) fetch(chunk + 1);
+#pragma unroll
+        for (int kk = 0; kk < KP / 16; ++kk) {
+            if ((kk & pmask) != part) continue;                                 // (wave-uniform)
+            h8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { fa[i] = frag(lds[buf][0], preA[i], kk); fb[i] = frag(lds[buf][1], preB[i], kk); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+
+    float* out = a.ws + ((int64_t)(split * a.psplit + part) * taps + tap) * a.CsP * a.CbP;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = cb0 + wn * 64 + j * 32 + frow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = cs0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                out[(int64_t)row * a.CbP + col] = acc[i][j][r];
+            }
+        }
+}
+
 // sum the splits, cast, and write torch's layout gw[cs][cb][taps].  One thread = four consecutive cb of one (tap, cs): 16-byte loads
 // along the workspace's fastest axis, four splits in flight at a time (the first version walked taps x splits with scalar loads from
 // 16 K threads and took 100-200 us for 50 MB).
@@ -787,8 +943,14 @@ static int bwd_weight_impl(const void* small_img, const void* big_img, void* gw,
                       && (int64_t)n_img * small_h * small_w * c_small * esz < (1ll << 31) && (int64_t)n_img * big_h * big_w * c_big * esz < (1ll << 31)
                       && (dtype != P3D_F16 || small_w % 4 == 0);
     const bool small64 = fast && !no_small && a.psplit == 4;
+    static const bool no_tr = getenv("P3D_WGRAD_NO_TR") != nullptr;
+    // (the transposing-read kernel handles its pixels one by one: no rows-of-four requirement)
+    const bool fast_tr = !no_fast && !no_tr && dtype == P3D_F16 && a.psplit != 4 && c_small % 8 == 0 && c_big % 8 == 0 && ((((uintptr_t)small_img) | ((uintptr_t)big_img)) & 15u) == 0
+                         && (int64_t)n_img * small_h * small_w * c_small * 2 < (1ll << 31) && (int64_t)n_img * big_h * big_w * c_big * 2 < (1ll << 31);
     if (dtype == P3D_F16) {
-        if (small64)   hipLaunchKernelGGL((conv_wgrad_kernel<__half, 128, true, true>), dim3(blocks), dim3(256), 0, s, a);
+        if (small64)      hipLaunchKernelGGL((conv_wgrad_kernel<__half, 128, true, true>), dim3(blocks), dim3(256), 0, s, a);
+        else if (fast_tr && small_w % 64 == 0) hipLaunchKernelGGL(conv_wgrad_tr_f16_kernel<true>, dim3(blocks), dim3(256), 0, s, a);
+        else if (fast_tr) hipLaunchKernelGGL(conv_wgrad_tr_f16_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
         else if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<__half, 64, true>), dim3(blocks), dim3(256), 0, s, a);
         else           hipLaunchKernelGGL((conv_wgrad_kernel<__half, 64, false>), dim3(blocks), dim3(256), 0, s, a);
     } else {

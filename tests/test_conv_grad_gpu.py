@@ -34,6 +34,9 @@ GEOM = [
     ('small64_mid', False, 3, 1, 64, 64, 40, 44, 3, 0),              # weight gradient: the 64-channel form over several double chunks, an odd count per split, a half-filled last one
     ('half_tile_b', False, 3, 1, 128, 64, 40, 44, 3, 0),             # weight gradient: waves pair up on pixels when one side holds <= 64 channels ...
     ('half_tile_s', False, 3, 1, 64, 128, 40, 44, 3, 0),             # ... either side
+    ('row64', False, 3, 1, 128, 128, 64, 64, 2, 0),                  # fp16 weight gradient: transposing LDS reads, rows of 64 pixels (one position per thread)
+    ('row64_down', False, 3, 2, 64, 128, 129, 129, 2, 0),            # ... against the big image at stride 2 (gradient image 64 x 64)
+    ('row64_up', True, 3, 2, 128, 64, 64, 64, 2, 0),                 # ... and with the roles swapped (transposed op)
 ]
 
 
