@@ -88,7 +88,7 @@ class _ConvBiasAct(torch.autograd.Function):
         ci = weight.shape[1]
         wdt = modconv.BF16X3 if geo.split else x.dtype
         wmod = modconv._cached_weight(weight, ('mfma', wdt, geo.wgain),
-                                      lambda: modconv.modulate_weights(weight.detach(), torch.ones([1, ci], dtype=torch.float32, device=weight.device), demodulate=False,
+                                      lambda: modconv.modulate_weights(weight, torch.ones([1, ci], dtype=torch.float32, device=weight.device), demodulate=False,
                                                                        pre_scale=geo.wgain, dtype=wdt))
         y = modconv.conv2d(x, wmod, bias=bias, act=geo.act_idx, gain=geo.spec.gain, clamp=geo.spec.clamp, down=geo.stride, split=geo.split)
         ctx.save_for_backward(x, weight, y if 'y' in geo.spec.ref else None)           # what bias_act keeps for its gradient (bias_act.py:143-146)
