@@ -333,16 +333,20 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
 // roles and partial-tile layout as conv_wgrad_kernel; FAST geometries, psplit 1 or 2.
 typedef __fp16 tr_f16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
-// ROW64: image rows are a multiple of 64 pixels wide, so a chunk lies inside ONE row and a thread's four pixels (16 apart) share one position, one row test.
-template <bool ROW64>
+// ROWK: image rows are a multiple of the chunk's pixels wide, so a chunk lies inside ONE row and a thread's four pixels share one position, one row test.
+// SMALL64 (psplit == 4: both sides <= 64 channels): rows of 64 channels (128 bytes, rotated by 64 bytes x ((p >> 1) & 1)), 128 pixels a chunk (two chunks of the
+// split plan), every thread loads, each wave takes two of the chunk's eight 16-pixel steps — the transposing-read form of conv_wgrad_kernel's SMALL loader.
+template <bool ROWK, bool SMALL64>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_f16_kernel(WgradArgs a)
 {
-    constexpr int KP = 64, ROW = 256, IMG = KP * ROW;                          // pixels per chunk, bytes per pixel row, bytes per operand image
+    constexpr int KPB = 64, KP = SMALL64 ? 128 : 64, STEP = KP / KPB;          // pixels per chunk of the split plan / per iteration
+    constexpr int ROW = SMALL64 ? 128 : 256, IMG = KP * ROW;                   // bytes per pixel row, bytes per operand image
+    constexpr int TPR = ROW / 16, PASS = 256 / TPR;                            // threads per pixel row, pixels per loading pass (four passes per iteration)
     __shared__ __attribute__((aligned(16))) char lds[2][2][IMG];               // [buffer][S | B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = a.psplit == 1 ? wave >> 1 : (a.narrow_b ? wave & 1 : 0);
-    const int wn = a.psplit == 1 ? wave & 1 : (!a.narrow_b ? wave & 1 : 0);
-    const int part = a.psplit == 1 ? 0 : wave >> 1, pmask = a.psplit - 1;
+    const int wm = SMALL64 ? 0 : (a.psplit == 1 ? wave >> 1 : (a.narrow_b ? wave & 1 : 0));
+    const int wn = SMALL64 ? 0 : (a.psplit == 1 ? wave & 1 : (!a.narrow_b ? wave & 1 : 0));
+    const int part = SMALL64 ? wave : (a.psplit == 1 ? 0 : wave >> 1), pmask = a.psplit - 1;
     const int taps = a.k * a.k;
     const int groups = a.ksplit * a.tiles_s * a.tiles_b;
     int L = blockIdx.x, g, tap;
@@ -357,7 +361,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_f16_kernel(WgradArgs a)
     int c_end = c_begin + a.chunks_per_split;
     if (c_end > a.chunks) c_end = a.chunks;
     const int64_t Mtot = (int64_t)a.N * a.HS * a.WS;
-    const int m_end = (int)((int64_t)c_end * KP < Mtot ? (int64_t)c_end * KP : Mtot);
+    const int m_end = (int)((int64_t)c_end * KPB < Mtot ? (int64_t)c_end * KPB : Mtot);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -367,16 +371,17 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_f16_kernel(WgradArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // loader: 16 threads cover one pixel's 128 channels (256 contiguous bytes of global memory), 16 pixels per pass, four passes per chunk
-    const int lc = (tid & 15) * 8;
+    // loader: TPR threads cover one pixel's channels (contiguous bytes of global memory), PASS pixels per pass, four passes per iteration
+    const int lc = (tid % TPR) * 8;
     int lp[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) lp[q] = (tid >> 4) + 16 * q;
-    const int wrow = ((lc * 2 + 64 * ((tid >> 4) & 3)) & 255);                  // byte position of this thread's 16 bytes inside its (rotated) LDS rows
+    for (int q = 0; q < 4; ++q) lp[q] = tid / TPR + PASS * q;
+    auto rot = [](int p) { return SMALL64 ? 64 * ((p >> 1) & 1) : 64 * (p & 3); };      // bytes an LDS row is rotated by (PASS is a multiple of 4: the same for a thread's four pixels)
+    const int wrow = (lc * 2 + rot(tid / TPR)) & (ROW - 1);                     // byte position of this thread's 16 bytes inside its LDS rows
     PixPos pos[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int64_t m = (int64_t)c_begin * KP + lp[q];
+        const int64_t m = (int64_t)c_begin * KPB + lp[q];
         const int64_t per = (int64_t)a.HS * a.WS;
         pos[q].n = (int)(m / per);
         const int rem = (int)(m - (int64_t)pos[q].n * per);
@@ -388,25 +393,25 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_f16_kernel(WgradArgs a)
     f32x4 rs[4], rb[4];
     auto fetch = [&](int chunk) {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (ROW64) {
-            const int m0 = chunk * KP + lp[0];
-            const bool live = m0 < m_end;                                           // (whole rows of 64: the four pixels are live together)
+        if constexpr (ROWK) {
+            const int m0 = chunk * KPB + lp[0];
             const int bi = pos[0].i * a.stride + dy, bj0 = pos[0].j * a.stride + dx;
-            const bool row_ok = live && b_ok && bi >= 0 && bi < a.HB;
+            const bool row_b = b_ok && bi >= 0 && bi < a.HB;
             const unsigned so = (unsigned)(m0 * a.Cs + cs0 + lc) * 2u;
             const unsigned bo = (unsigned)(((pos[0].n * a.HB + bi) * a.WB + bj0) * a.Cb + cb0 + lc) * 2u;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int bj = bj0 + 16 * q * a.stride;
-                rs[q] = (live && s_ok) ? *(const f32x4*)(Sb + (so + (unsigned)(16 * q * a.Cs) * 2u)) : zero;
-                rb[q] = (row_ok && bj >= 0 && bj < a.WB) ? *(const f32x4*)(Bb + (bo + (unsigned)(16 * q * a.stride * a.Cb) * 2u)) : zero;
+                const bool live = m0 + PASS * q < m_end;                            // (SMALL64: the second half of a double chunk may lie past this work-group's pixels)
+                const int bj = bj0 + PASS * q * a.stride;
+                rs[q] = (live && s_ok) ? *(const f32x4*)(Sb + (so + (unsigned)(PASS * q * a.Cs) * 2u)) : zero;
+                rb[q] = (live && row_b && bj >= 0 && bj < a.WB) ? *(const f32x4*)(Bb + (bo + (unsigned)(PASS * q * a.stride * a.Cb) * 2u)) : zero;
             }
             pix_advance(pos[0], KP, a.HS, a.WS);
             return;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int m = chunk * KP + lp[q];
+            const int m = chunk * KPB + lp[q];
             const bool live = m < m_end;
             const int bi = pos[q].i * a.stride + dy, bj = pos[q].j * a.stride + dx;
             const unsigned so = (unsigned)(m * a.Cs + cs0 + lc) * 2u;
@@ -430,11 +435,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_f16_kernel(WgradArgs a)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int prow = (gq >> 1) * 8 + (i16 >> 2);
-        preA[i] = prow * ROW + ((((wm * 64 + i * 32 + (gq & 1) * 16) * 2) + (i16 & 3) * 8 + 64 * (i16 >> 2)) & 255);
-        preB[i] = prow * ROW + ((((wn * 64 + i * 32 + (gq & 1) * 16) * 2) + (i16 & 3) * 8 + 64 * (i16 >> 2)) & 255);
+        preA[i] = prow * ROW + ((((wm * 64 + i * 32 + (gq & 1) * 16) * 2) + (i16 & 3) * 8 + rot(prow)) & (ROW - 1));
+        preB[i] = prow * ROW + ((((wn * 64 + i * 32 + (gq & 1) * 16) * 2) + (i16 & 3) * 8 + rot(prow)) & (ROW - 1));
     }
     typedef __attribute__((address_space(3))) tr_f16x4* lds_tr;
-    auto frag = [&](const char* img, int pre, int kk) -> h8 {
+    auto frag = [&](const char* img, int pre, int kk) -> h8 {                  // (+ 16 kk and + 4 pixels leave the rotation of the lane's row unchanged)
         const tr_f16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr)(img + pre + kk * 16 * ROW));
         const tr_f16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr)(img + pre + kk * 16 * ROW + 4 * ROW));
         h8 v;
@@ -446,10 +451,10 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_f16_kernel(WgradArgs a)
 
     if (c_begin < c_end) fetch(c_begin);
     int buf = 0;
-    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    for (int chunk = c_begin; chunk < c_end; chunk += STEP) {
         deposit(buf);
         __syncthreads();
-        if (chunk + 1 < c_end) fetch(chunk + 1);
+        if (chunk + STEP < c_end) fetch(chunk + STEP);
 #pragma unroll
         for (int kk = 0; kk < KP / 16; ++kk) {
             if ((kk & pmask) != part) continue;                                 // (wave-uniform)
@@ -765,7 +770,8 @@ static int wgrad_plan(int dtype, int64_t pixels, int cs, int cb, int k, int* ksp
         if (want > nchunks) want = nchunks;
         if (want > 1024) want = 1024;
         per = (nchunks + want - 1) / want;
-        split = (nchunks + per - 1) / per;
+        if (cs <= 64 && cb <= 64 && per > 1) per = (per + 1) & ~(int64_t)1;       // the 64-channel kernels take two chunks an iteration: whole iterations per split, each
+        split = (nchunks + per - 1) / per;                                      // starting on a multiple of its 2 x KP pixels (what lets a row-aligned image share one position)
     }
     *ksplit = (int)split; *chunks = (int)nchunks; *cps = (int)per;
     return taps;
@@ -945,12 +951,17 @@ static int bwd_weight_impl(const void* small_img, const void* big_img, void* gw,
     const bool small64 = fast && !no_small && a.psplit == 4;
     static const bool no_tr = getenv("P3D_WGRAD_NO_TR") != nullptr;
     // (the transposing-read kernel handles its pixels one by one: no rows-of-four requirement)
-    const bool fast_tr = !no_fast && !no_tr && dtype == P3D_F16 && a.psplit != 4 && c_small % 8 == 0 && c_big % 8 == 0 && ((((uintptr_t)small_img) | ((uintptr_t)big_img)) & 15u) == 0
+    const bool fast_tr = !no_fast && !no_tr && dtype == P3D_F16 && c_small % 8 == 0 && c_big % 8 == 0 && ((((uintptr_t)small_img) | ((uintptr_t)big_img)) & 15u) == 0
                          && (int64_t)n_img * small_h * small_w * c_small * 2 < (1ll << 31) && (int64_t)n_img * big_h * big_w * c_big * 2 < (1ll << 31);
+    static const bool no_tr_small = getenv("P3D_WGRAD_NO_TR_SMALL") != nullptr;
     if (dtype == P3D_F16) {
-        if (small64)      hipLaunchKernelGGL((conv_wgrad_kernel<__half, 128, true, true>), dim3(blocks), dim3(256), 0, s, a);
-        else if (fast_tr && small_w % 64 == 0) hipLaunchKernelGGL(conv_wgrad_tr_f16_kernel<true>, dim3(blocks), dim3(256), 0, s, a);
-        else if (fast_tr) hipLaunchKernelGGL(conv_wgrad_tr_f16_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
+        if (fast_tr && a.psplit == 4 && !no_small && !no_tr_small) {
+            if (small_w % 128 == 0) hipLaunchKernelGGL((conv_wgrad_tr_f16_kernel<true, true>), dim3(blocks), dim3(256), 0, s, a);
+            else                    hipLaunchKernelGGL((conv_wgrad_tr_f16_kernel<false, true>), dim3(blocks), dim3(256), 0, s, a);
+        }
+        else if (small64) hipLaunchKernelGGL((conv_wgrad_kernel<__half, 128, true, true>), dim3(blocks), dim3(256), 0, s, a);
+        else if (fast_tr && a.psplit != 4 && small_w % 64 == 0) hipLaunchKernelGGL((conv_wgrad_tr_f16_kernel<true, false>), dim3(blocks), dim3(256), 0, s, a);
+        else if (fast_tr && a.psplit != 4) hipLaunchKernelGGL((conv_wgrad_tr_f16_kernel<false, false>), dim3(blocks), dim3(256), 0, s, a);
         else if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<__half, 64, true>), dim3(blocks), dim3(256), 0, s, a);
         else           hipLaunchKernelGGL((conv_wgrad_kernel<__half, 64, false>), dim3(blocks), dim3(256), 0, s, a);
     } else {

@@ -37,6 +37,8 @@ GEOM = [
     ('row64', False, 3, 1, 128, 128, 64, 64, 2, 0),                  # fp16 weight gradient: transposing LDS reads, rows of 64 pixels (one position per thread)
     ('row64_down', False, 3, 2, 64, 128, 129, 129, 2, 0),            # ... against the big image at stride 2 (gradient image 64 x 64)
     ('row64_up', True, 3, 2, 128, 64, 64, 64, 2, 0),                 # ... and with the roles swapped (transposed op)
+    ('small64_row128', False, 3, 1, 64, 64, 24, 128, 2, 0),          # ... the 64-channel form of it on rows of 128 pixels (double chunks, one position per thread)
+    ('small64_narrow', False, 3, 1, 32, 64, 20, 36, 3, 0),           # ... and with a 32-channel side, rows that are no multiple of anything
 ]
 
 
