@@ -956,7 +956,8 @@ static int bwd_weight_impl(const void* small_img, const void* big_img, void* gw,
     static const bool no_tr_small = getenv("P3D_WGRAD_NO_TR_SMALL") != nullptr;
     if (dtype == P3D_F16) {
         if (fast_tr && a.psplit == 4 && !no_small && !no_tr_small) {
-            if (small_w % 128 == 0) hipLaunchKernelGGL((conv_wgrad_tr_f16_kernel<true, true>), dim3(blocks), dim3(256), 0, s, a);
+            // (one position per thread needs every iteration to start on a multiple of its 128 pixels: whole double chunks per split — what wgrad_plan hands out)
+            if (small_w % 128 == 0 && (a.chunks_per_split % 2 == 0 || a.ksplit == 1)) hipLaunchKernelGGL((conv_wgrad_tr_f16_kernel<true, true>), dim3(blocks), dim3(256), 0, s, a);
             else                    hipLaunchKernelGGL((conv_wgrad_tr_f16_kernel<false, true>), dim3(blocks), dim3(256), 0, s, a);
         }
         else if (small64) hipLaunchKernelGGL((conv_wgrad_kernel<__half, 128, true, true>), dim3(blocks), dim3(256), 0, s, a);
