@@ -20,6 +20,9 @@ def _worker(rank, world, port, out_dir):
     from pix2pix3d_amd.training.networks_stylegan2 import SynthesisNetwork
     torch.manual_seed(0)                                       # same init everywhere, then perturb rank 1 to test the broadcast
     net = SynthesisNetwork(w_dim=32, img_resolution=16, img_channels=3, channel_base=256, channel_max=16, num_fp16_res=0)
+    for p in net.parameters():                                 # the 3x3 weights channels-last, as fp16_channels_last lays out the fp16 blocks' (networks_stylegan2.py:403-409)
+        if p.ndim == 4 and p.shape[2] == 3:
+            p.data = p.data.contiguous(memory_format=torch.channels_last)
     if rank == 1:
         with torch.no_grad():
             for p in net.parameters():
@@ -35,6 +38,8 @@ def _worker(rank, world, port, out_dir):
     loss.backward()
     flat = dp.allreduce_gradients(net)
     assert flat is not None and flat.ndim == 1
+    assert all(p.grad.stride() == p.stride() for p in net.parameters() if p.grad is not None)      # pieces of the flat vector in each parameter's own memory order
+    assert any(not p.is_contiguous() for p in net.parameters())
     grads = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
     # sharded inference: every rank renders its own images; nothing is exchanged
     net.eval()
