@@ -329,7 +329,7 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
-    local = local % torch.cuda.device_count()                      # (ranks > devices only in the one-GPU RCCL smoke run, tests/gpu_rccl_smoke.sh)
+    local = local % torch.cuda.device_count()                      # (ranks > devices only in the one-GPU RCCL smoke run, tools/sessions/gpu_rccl_smoke.sh)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     dist = None

@@ -14,6 +14,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, 'csrc')
 OBJ_DIR = os.path.join(CSRC, '_obj')
 LIB_PATH = os.path.join(PKG_DIR, 'libp3d_hip.so')
+PROBES_DIR = os.path.join(CSRC, 'probes')
+PROBES_LIB_PATH = os.path.join(PKG_DIR, 'libp3d_probes.so')      # hardware probes: a library of its own, never part of the product ABI
 ARCH = 'gfx950'
 CXXFLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function',
             '-fno-gpu-rdc', '-DNDEBUG']
@@ -37,18 +39,23 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
 
 
+def probe_sources():
+    return sorted(os.path.join(PROBES_DIR, f) for f in os.listdir(PROBES_DIR) if f.endswith('.hip'))
+
+
 def headers():
     inc = os.path.join(os.path.dirname(PKG_DIR), 'include')
     hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    hs += [os.path.join(PROBES_DIR, f) for f in os.listdir(PROBES_DIR) if f.endswith('.h')]
     hs += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith('.h')]
     return sorted(hs)
 
 
-def _compile(src, verbose):
+def _compile(src, verbose, extra=()):
     obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + '.o')
     if _newer(obj, [src] + headers()):
         return obj, False
-    cmd = [_hipcc()] + CXXFLAGS + ['-c', src, '-o', obj]
+    cmd = [_hipcc()] + CXXFLAGS + list(extra) + ['-c', src, '-o', obj]
     if verbose:
         print(' '.join(cmd), flush=True)
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -76,7 +83,26 @@ def build_library(force=False, verbose=False):
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'link failed:\n{r.stdout}')
+    build_probes(verbose=verbose)
     return LIB_PATH
+
+
+def build_probes(verbose=False):
+    """libp3d_probes.so (csrc/probes/*.hip, -DP3D_BUILD_PROBES): the hardware probes the tests and the kernel studies use, with their own
+    copy of the library services (p3d_common.hip) so that nothing of them is exported through libp3d_hip.so."""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    srcs = probe_sources()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(8, len(srcs)))) as ex:
+        results = list(ex.map(lambda s: _compile(s, verbose, ('-DP3D_BUILD_PROBES',)), srcs))
+    objs = [o for o, _ in results] + [os.path.join(OBJ_DIR, 'p3d_common.o')]
+    if any(changed for _, changed in results) or not _newer(PROBES_LIB_PATH, objs):
+        cmd = [_hipcc(), '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', PROBES_LIB_PATH] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'link failed:\n{r.stdout}')
+    return PROBES_LIB_PATH
 
 
 if __name__ == '__main__':

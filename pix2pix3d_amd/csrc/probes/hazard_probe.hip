@@ -7,7 +7,8 @@
 // VGPRs as SrcB — once at the distance under test and once behind 16 wait states (the reference), into two accumulators that must end
 // up bit-identical.  A lane whose accumulators differ saw stale SrcB data.  Launch shape = the ray-marcher's: 8 waves per block, two
 // waves per SIMD, every CU busy.
-#include "p3d_common.h"
+#include "../p3d_common.h"
+#include "p3d_probes.h"
 
 namespace p3d {
 

@@ -1,14 +1,42 @@
-"""Hardware regression probes of libp3d_hip.so (not part of the reference's interface).
+"""Hardware probes of gfx950 (libp3d_probes.so: csrc/probes/*.hip, declared in csrc/probes/p3d_probes.h).  A library of its own — the
+product ABI (include/p3d_hip.h, libp3d_hip.so) exports none of this and no op of the package loads it.
 
 ``cvt_mfma_hazard``: the gfx950 hazard behind the ``s_nop 4`` of the bf16x3 kernels — an MFMA reading, as SrcB, registers that
-``v_cvt_pk_bf16_f32`` wrote a few wait states earlier (csrc/hazard_probe.hip)."""
+``v_cvt_pk_bf16_f32`` wrote a few wait states earlier (csrc/probes/hazard_probe.hip).
+``mfma_rate``: what the matrix pipe sustains with nothing but ``v_mfma_f32_32x32x16_f16`` in the loop, in the fp16 3x3 kernel's register
+blocking, and the clock the chip holds meanwhile (csrc/probes/mfma_rate_probe.hip)."""
 import ctypes
+import os
 
 import torch
 
 from . import _lib
 
-_lib.register('p3d_probe_cvt_mfma_hazard', ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p])
+PROBES_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libp3d_probes.so')
+_handle = None
+
+
+def probes():
+    """The probe library, or RuntimeError (built by ``pix2pix3d_amd.build.build_probes`` / ``__graft_entry__.build``)."""
+    global _handle
+    if _handle is None:
+        _lib.lib()                                                  # maps the HIP runtime torch uses first
+        try:
+            h = ctypes.CDLL(PROBES_LIB_PATH)
+        except OSError as e:
+            raise RuntimeError(f'pix2pix3d_amd: {PROBES_LIB_PATH} could not be loaded ({e}); build it with `python -m pix2pix3d_amd.build`')
+        h.p3d_last_error.restype = ctypes.c_char_p
+        h.p3d_probe_cvt_mfma_hazard.restype = ctypes.c_int
+        h.p3d_probe_cvt_mfma_hazard.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+        h.p3d_probe_mfma_rate.restype = ctypes.c_int
+        h.p3d_probe_mfma_rate.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 4 + [ctypes.c_void_p]
+        _handle = h
+    return _handle
+
+
+def _check(code, what):
+    if code != 0:
+        raise RuntimeError(f'{what}: {probes().p3d_last_error().decode()} (code {code})')
 
 
 def cvt_mfma_hazard(wait_states, iters=4000, device='cuda', src_a=False, war=False):
@@ -16,6 +44,46 @@ def cvt_mfma_hazard(wait_states, iters=4000, device='cuda', src_a=False, war=Fal
     the converted registers being the MFMA's SrcB (default) or SrcA; ``war``: the opposite order — the MFMA reads the registers (SrcB) and a
     conversion overwrites them ``wait_states`` later; (0, 0) = clean."""
     counts = torch.zeros([2], dtype=torch.int32, device=device)
-    _lib.check(_lib.lib().p3d_probe_cvt_mfma_hazard(int(wait_states), 2 if war else int(bool(src_a)), int(iters), _lib.ptr(counts), _lib.stream_of(counts)), 'probe_cvt_mfma_hazard')
+    with torch.cuda.device(counts.device):
+        _check(probes().p3d_probe_cvt_mfma_hazard(int(wait_states), 2 if war else int(bool(src_a)), int(iters), counts.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream), 'probe_cvt_mfma_hazard')
     lanes, regs = counts.cpu().tolist()
     return int(lanes), int(regs)
+
+
+def mfma_rate(operands, chains=8, waves_per_simd=2, blocks=None, iters=2000, launches=40):
+    """Time ``launches`` back-to-back launches of the MFMA-only loop (16 ``v_mfma_f32_32x32x16_f16`` per iteration and wave) and return
+    a dict: TFLOP/s over the wall time of the launches (HIP events), cycles per MFMA and SIMD from the waves' own ``s_memtime`` stamps,
+    and the shader clock they imply against ``s_memrealtime`` (100 MHz).  ``operands``: fp16 tensor of 8 x 2 x 6 x 64 x 8 values
+    (eight wave slots x two K sub-steps x (2 A + 4 B fragments) x 64 lanes x 8 halfs), on the device."""
+    assert operands.dtype == torch.float16 and operands.numel() == 8 * 2 * 6 * 64 * 8 and operands.is_cuda
+    blocks = int(blocks) if blocks else 256 * int(waves_per_simd) * 4
+    dev = operands.device
+    sink = torch.empty([blocks * 256], dtype=torch.float32, device=dev)
+    stamps = torch.zeros([blocks * 4, 2], dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def go():
+            _check(probes().p3d_probe_mfma_rate(operands.data_ptr(), sink.data_ptr(), stamps.data_ptr(), int(chains), int(waves_per_simd), blocks,
+                                                int(iters), stream), 'probe_mfma_rate')
+        for _ in range(max(3, launches // 4)):
+            go()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            go()
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / launches
+    st = stamps.cpu().double()
+    ticks, real = st[:, 0], st[:, 1]
+    mfmas_per_wave = 16 * iters
+    flop = 2.0 * 32 * 32 * 16 * mfmas_per_wave * blocks * 4
+    clock_ghz = float((ticks / real.clamp(min=1)).median()) * 0.1
+    return {'chains': int(chains), 'waves_per_simd': int(waves_per_simd), 'blocks': blocks, 'iters': int(iters), 'us_per_launch': ms * 1e3,
+            'tflops': flop / (ms * 1e-3) / 1e12, 'frac_of_2p5pf': flop / (ms * 1e-3) / 2.5e15,
+            'cycles_per_mfma_per_simd': float(ticks.median()) / mfmas_per_wave / int(waves_per_simd),
+            'wave_cycles_median': float(ticks.median()), 'clock_ghz': clock_ghz,
+            'tflops_peak_at_that_clock': 1024 * 1024 * clock_ghz * 1e9 / 1e12}

@@ -1,5 +1,5 @@
 """The RCCL leg of the gradient exchange on the one GPU a test box has.  RCCL refuses two ranks on one device ("Duplicate GPU
-detected", tests/gpu_rccl_smoke.sh records it), so what can be proven here is that `backend='nccl'` (= RCCL on ROCm) initialises
+detected", tools/sessions/gpu_rccl_smoke.sh records it), so what can be proven here is that `backend='nccl'` (= RCCL on ROCm) initialises
 from this package's entry points and that dp.allreduce_gradients drives it on a flat buffer of the real size class; the world-size-2
 arithmetic is covered by tests/test_dp_gloo.py and the 8-GPU timing by bench.py --gpus N (--train-step)."""
 import os

@@ -1,5 +1,5 @@
 # End-of-round GPU pass: [full -m gpu suite,] smoke, the bench line (hipGraph, with roofline + cpu_baseline), the eager rocprofv3 profile.
-# usage: bash tests/gpu_final_pass.sh [nosuite]
+# usage: bash tools/sessions/gpu_final_pass.sh [nosuite]
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
 if [ "$1" != "nosuite" ]; then ( timeout 900 python -m pytest tests -q -m gpu -x 2>&1 | tail -8 ) > gpurun_out/final/pytest.log 2>&1; fi

@@ -1,6 +1,6 @@
 #!/bin/bash
 # where the renderer's point-wise backward spends its time: ablation builds of csrc/render_bwd.hip (-DP3D_RBWD_DEBUG=<bits>, see the file), same box.
-# Build the variants first: bash tests/build_rbwd_variants.sh 16 1
+# Build the variants first: bash tools/sessions/build_rbwd_variants.sh 16 1
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
 for d in "" 16 1 ""; do
   if [ -z "$d" ]; then timeout 120 python tests/gpu_time_render_bwd.py 2>&1 | grep "^render backward"

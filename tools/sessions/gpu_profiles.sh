@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 summaries for profiles/: the benchmark step (eager launches, every kernel visible by name) and the two training passes.
-# usage: bash tests/gpu_profiles.sh <tag>     -> gpurun_out/<tag>_*
+# usage: bash tools/sessions/gpu_profiles.sh <tag>     -> gpurun_out/<tag>_*
 tag=${1:-round2}
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-graph --no-train-step --no-exact-fp32 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_bench_line_eager.json 2> /tmp/prof_bench.err)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4, first session: the new parity tests (verbose), the whole -m gpu suite, smoke(), the default benchmark line (now with the six-phase training
 # step), the steps-in-flight variants, the rocprofv3 kernel statistics of the training iteration, and the counter passes of the ray-marcher (re-taken:
-# the kernel sources changed by a codegen-neutral refactor, the committed passes are bound to the source hash).   usage: bash tests/gpu_round4_a.sh <tag>
+# the kernel sources changed by a codegen-neutral refactor, the committed passes are bound to the source hash).   usage: bash tools/sessions/gpu_round4_a.sh <tag>
 tag=${1:-round4_a}
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
 echo "== new tests"

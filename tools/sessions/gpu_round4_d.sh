@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, session d: the whole -m gpu suite, smoke(), the default benchmark line, the rocprofv3 kernel statistics of the same step launched eagerly,
-# the step trace, and the per-kernel counter passes of the six-phase training iteration.   usage: bash tests/gpu_round4_d.sh <tag>
+# the step trace, and the per-kernel counter passes of the six-phase training iteration.   usage: bash tools/sessions/gpu_round4_d.sh <tag>
 tag=${1:-round4_d}
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
 echo "== suite"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, closing session: the whole -m gpu suite, smoke(), the default benchmark line, the eager step under rocprofv3, the training iteration under rocprofv3,
-# and the per-kernel counter passes of the training iteration.   usage: bash tests/gpu_round4_k.sh <tag>
+# and the per-kernel counter passes of the training iteration.   usage: bash tools/sessions/gpu_round4_k.sh <tag>
 tag=${1:-round4_k}
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
 timeout 900 python -m pytest tests -m gpu -q --tb=short -rf -p no:cacheprovider > gpurun_out/${tag}_gputest.log 2>&1; tail -n 6 gpurun_out/${tag}_gputest.log | cut -c1-500

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4, closing session: the whole -m gpu suite, smoke(), the default benchmark line, the eager step under rocprofv3, the training iteration under rocprofv3,
-# and the per-kernel counter passes of the training iteration.   usage: bash tests/gpu_round4_s.sh <tag>
-tag=${1:-round4_s}
+# and the per-kernel counter passes of the training iteration.   usage: bash tools/sessions/gpu_round4_p.sh <tag>
+tag=${1:-round4_p}
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
 timeout 900 python -m pytest tests -m gpu -q --tb=short -rf -p no:cacheprovider > gpurun_out/${tag}_gputest.log 2>&1; tail -n 6 gpurun_out/${tag}_gputest.log | cut -c1-500
 grep -E "^E  " gpurun_out/${tag}_gputest.log | head -12 | cut -c1-1500

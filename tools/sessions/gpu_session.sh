@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: new-kernel tests first (verbose output kept), then the whole gpu suite, the training census and a bench line.
-# usage: bash tests/gpu_session.sh <tag>
+# usage: bash tools/sessions/gpu_session.sh <tag>
 tag=${1:-s}
 out=gpurun_out/$tag
 mkdir -p $out
