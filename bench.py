@@ -59,6 +59,7 @@ def parse():
     p.add_argument('--train-step', action='store_true', help='time training iterations of BASELINE config 3 (all six phases of training_loop.py, gradient all-reduce + Adam per phase) instead of inference')
     p.add_argument('--no-train-step', action='store_true', help='skip the short train_step extra of the default run')
     p.add_argument('--no-exact-fp32', action='store_true', help='skip the second timed loop with the bf16x3 switches off')
+    p.add_argument('--no-configs', action='store_true', help="skip the short timed loops of BASELINE.json's other single-GPU configurations")
     p.add_argument('--train-nrr', type=int, default=128, help='neural rendering resolution of the training passes (train.py: 128 for the 512^2 configs)')
     return p.parse_args()
 
@@ -323,6 +324,55 @@ def run_train(args, device, world, dist, iters, warm):
     return summary, elapsed
 
 
+XGMI_LINKS, XGMI_LINK_GBS = 7, 153.0                # per GPU: 7 point-to-point links x ~153 GB/s (MI355X_MICROARCH.md / the task statement)
+
+
+def collective_info(dist, world, rank, device, sizes=(336402180, 125438976), reps=5):
+    """N > 1 only: what the collective library saw, so that a multi-GPU line is self-evidencing — backend and RCCL version, every rank's device
+    (index, name, PCI bus id: N distinct devices or the line is not a scaling measurement), the environment knobs that change the transport
+    (the reference's scripts export NCCL_P2P_DISABLE=1, train_scripts/afhq_seg.sh:2: refused here, it would take the exchange off xGMI), and the flat
+    fp32 all-reduce ALONE at the two message sizes of the training phases (G: 336 MB, D / D_semantic: 125 MB) with its bus bandwidth
+    (2 (N-1)/N x bytes / time) next to the xGMI figures."""
+    p2p_off = os.environ.get('NCCL_P2P_DISABLE', '0').strip()
+    assert p2p_off in ('', '0'), 'NCCL_P2P_DISABLE is set: RCCL would route the gradient exchange through host memory instead of xGMI (unset it; the reference scripts set it for their own hardware)'
+    from pix2pix3d_amd import dp
+    backend = dist.get_backend()
+    props = torch.cuda.get_device_properties(device)
+    mine = {'rank': rank, 'device_index': device.index, 'name': props.name, 'pci_bus_id': getattr(props, 'pci_bus_id', None), 'pci_device_id': getattr(props, 'pci_device_id', None),
+            'uuid': str(getattr(props, 'uuid', '')) or None, 'host': os.uname().nodename}
+    devices = [None] * world
+    dist.all_gather_object(devices, mine)
+    version = None
+    if backend == 'nccl':
+        try:
+            version = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:                                          # noqa: BLE001
+            version = None
+    timed = {}
+    for nbytes in sizes:
+        flat = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
+        dp._all_reduce(flat, None)                                 # warm-up (communicator set-up, buffer registration)
+        torch.cuda.synchronize(); dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            dp._all_reduce(flat, None)
+        e1.record(); torch.cuda.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) / reps], dtype=torch.float64, device=device)
+        if backend == 'nccl':
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item())
+        timed[str(nbytes)] = {'ms': round(ms, 3), 'bus_GBps': round(2 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 1)}
+        del flat
+    return {'backend': backend + (' (= RCCL on ROCm)' if backend == 'nccl' else ' (staged through host memory: the one-GPU test configuration, not a measurement)'),
+            'version': version, 'ranks': world, 'devices': devices, 'distinct_devices': len({(d['host'], d['pci_bus_id'], d['device_index']) for d in devices}),
+            'env': {k: os.environ.get(k) for k in ('NCCL_P2P_DISABLE', 'NCCL_DEBUG', 'NCCL_ALGO', 'NCCL_PROTO', 'NCCL_IB_DISABLE', 'NCCL_SOCKET_IFNAME', 'RCCL_MSCCL_ENABLE',
+                                                   'HSA_ENABLE_IPC_MODE_LEGACY', 'HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES')},
+            'allreduce_alone': timed,
+            'xgmi': {'links_per_gpu': XGMI_LINKS, 'GBps_per_link': XGMI_LINK_GBS, 'ring_bound_GBps': XGMI_LINK_GBS, 'all_links_GBps': XGMI_LINKS * XGMI_LINK_GBS,
+                     'note': 'a ring all-reduce is bound by ONE link per direction (bus bandwidth <= ~153 GB/s); direct all-to-all algorithms can use all seven (<= ~1071 GB/s)'}}
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -346,6 +396,8 @@ def main():
     rmod.fused_policy = 'require'
     torch.backends.cudnn.benchmark = bool(args.miopen_find)         # training_loop.py:280 sets True; find-mode costs ~100 s of warm-up per fresh box
 
+    rccl = collective_info(dist, world, rank, device) if world > 1 else None
+
     if args.train_step:                                              # BASELINE config 3 as the timed workload
         summary, elapsed = run_train(args, device, world, dist, args.steps, max(args.warmup, 1))
         if rank == 0:
@@ -354,7 +406,7 @@ def main():
                     'ms_per_step': summary['ms_per_iteration'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                     'dtype': 'f32 (backbone, ray-marcher) + f16/f32-acc (super-resolution, discriminator top blocks), as train.py configures', 'data': 'synthetic',
                     'config': {'workload': summary['what'], 'launch': 'eager', 'parallelism': f'dp{world} (batch sharded, flat fp32 gradient all-reduce per phase)'},
-                    'train_step': summary}
+                    'train_step': summary, 'rccl': rccl}
             print(json.dumps(line), flush=True)
         if dist is not None:
             dist.destroy_process_group()
@@ -370,11 +422,14 @@ def main():
     syn_kw = dict(noise_mode='const', neural_rendering_resolution=nrr, force_fp32=args.force_fp32)
     from pix2pix3d_amd.torch_utils.ops import modconv as _mc
 
-    def step():
-        with torch.no_grad():
-            return G.synthesis(ws, c, **syn_kw)
+    def make_step(G_, ws_, c_, kw_):
+        def step_():
+            with torch.no_grad():
+                return G_.synthesis(ws_, c_, **kw_)
+        return step_
+    step = make_step(G, ws, c, syn_kw)
 
-    def measure(settle_s):
+    def measure(settle_s, step=step, G=G, batch=args.batch, res=info['res']):
         """Warm up, capture the step as one hipGraph, settle, time K steps (barrier + synchronize on both sides, MAX over ranks); then an
         eager pass of the same steps with HIP events around the stages and the instrumented kernels."""
         for _ in range(max(args.warmup, 1)):
@@ -387,7 +442,7 @@ def main():
             t0 = time.perf_counter(); step(); torch.cuda.synchronize(); hist.append(time.perf_counter() - t0)
             if len(hist) >= 3 and max(hist[-3:]) < 1.05 * min(hist[-3:]):
                 break
-        assert out['image'].shape == (args.batch, 3, info['res'], info['res'])
+        assert out['image'].shape == (batch, 3, res, res)
         launch, graph = 'eager', None
         if not args.no_graph:
             try:                                                         # replay the whole step as one hipGraph
@@ -521,6 +576,37 @@ def main():
         finally:
             _mc.split_bf16, rmod.mlp_bf16x3 = prev
 
+    # BASELINE.json's other single-GPU shapes, each timed the same way (own warm-up, own hipGraph, short settling): configs[1] at its own 48+48
+    # samples, configs[3]'s per-GPU share (edge2car, batch 16 over 2 GPUs: train.py:451-461) and configs[4]'s (seg2face, batch 8 over 4 GPUs:
+    # train.py:425-437).  configs[0] is the reference's CPU case (cpu_baseline), configs[2] the training iteration (train_step).
+    other = None
+    if not args.no_configs and args.dataset == 'seg2cat' and args.batch == 4 and args.depth == 128 and not args.force_fp32:
+        import copy as _copy
+        other = {}
+        G = G.cpu()
+        for key, ds_name, nb, depth in (('configs[1] seg2cat 512^2, 48+48 samples, batch 4', 'seg2cat', 4, 96),
+                                        ('configs[3] edge2car 128^2, 64^2 rays x 64+64 samples, batch 8 per GPU (16 over 2 GPUs)', 'edge2car', 8, 128),
+                                        ('configs[4] seg2face 512^2 (19 label channels), 48+48 samples, batch 2 per GPU (8 over 4 GPUs)', 'seg2face', 2, 96)):
+            try:
+                torch.cuda.empty_cache()
+                a2 = _copy.copy(args)
+                a2.dataset, a2.batch, a2.depth = ds_name, nb, depth
+                G2_cpu, kw2, info2, ws2, c2 = build(a2, device)
+                G2 = G2_cpu.to(device)
+                nrr2 = info2['nrr']
+                m2 = measure(2.0, step=make_step(G2, ws2.to(device), c2.to(device), dict(noise_mode='const', neural_rendering_resolution=nrr2, force_fp32=False)),
+                             G=G2, batch=nb, res=info2['res'])
+                spl = nb * nrr2 * nrr2 * depth
+                other[key] = {'value': round(nb * world * args.steps / m2['elapsed'], 2), 'unit': 'img/s', 'ms_per_step': round(m2['elapsed'] / args.steps * 1e3, 3), 'launch': m2['launch'],
+                              'stage_ms': {k: round(v, 3) for k, v in m2['stage_ms'].items()},
+                              'ray_marcher': {'ms_per_launch': round(m2['render_kernel_ms'], 4), 'ray_samples_per_launch': spl,
+                                              'ray_samples_per_s': round(spl / (m2['render_kernel_ms'] * 1e-3), 1) if m2['render_kernel_ms'] > 0 else None},
+                              'mfma_conv': m2['mfma_conv']}
+                del G2, G2_cpu, m2
+            except Exception as e:                                   # noqa: BLE001 - the headline line must still be printed
+                other[key] = {'error': f'{type(e).__name__}: {e}'[:300]}
+        G = G.to(device)
+
     train = None
     if not args.no_train_step:                                       # short: 2 warm-up + 3 timed iterations
         G = G.cpu()
@@ -567,8 +653,10 @@ def main():
             'roofline': roofline(main_m, bool(rmod.mlp_bf16x3)),
             'mfma_conv': main_m['mfma_conv'],
             'exact_fp32': exact,
+            'configs': other,
             'cpu_baseline': cpu,
             'train_step': train,
+            'rccl': rccl,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

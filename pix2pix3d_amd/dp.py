@@ -38,9 +38,10 @@ def allreduce_gradients(module_or_params, world_size=None, group=None, out=None)
 
     Parameters without a gradient are skipped, exactly like the reference's ``if param.grad is not None`` filter, so
     every rank must have the same set of parameters with gradients (true when all ranks run the same phase).
-    ``out``: a dict the caller keeps between phases — the flat vector of each size is then allocated once and reused (the gradients
-    are views of it after the call, so it must not be handed to a second module of the same size before that module's optimizer
-    step; the training loop steps right after every exchange)."""
+    ``out``: a dict the caller keeps between phases — the flat vector of each (module, size) is then allocated once and reused; the
+    gradients are views of it after the call (a second exchange of the same module without a backward in between is detected by
+    storage and copied through a temporary).  All gradients of one exchange must share one dtype (the reference's are fp32)."""
+    owner = id(module_or_params) if isinstance(module_or_params, torch.nn.Module) else None
     params = module_or_params.parameters() if isinstance(module_or_params, torch.nn.Module) else module_or_params
     params = [p for p in params if p.grad is not None]
     if not params:
@@ -51,17 +52,19 @@ def allreduce_gradients(module_or_params, world_size=None, group=None, out=None)
     # per-tensor lerp_ / addcmul_ launches
     orders = [_memory_order(p) for p in params]
     grads = [(p.grad if o is None else p.grad.permute(o)).reshape(-1) for p, o in zip(params, orders)]
+    assert all(g.dtype == grads[0].dtype and g.device == grads[0].device for g in grads), 'allreduce_gradients: gradients of one exchange must share dtype and device'
     if out is None:
         flat = torch.cat(grads)
     else:
-        key = (sum(g.numel() for g in grads), grads[0].dtype, grads[0].device)
+        key = (owner, sum(g.numel() for g in grads), grads[0].dtype, grads[0].device)
         flat = out.get(key)
         if flat is None:
-            flat = out[key] = torch.empty(key[0], dtype=key[1], device=key[2])
-        try:
-            torch.cat(grads, out=flat)
-        except RuntimeError:                             # some gradient still is a view of this buffer (two exchanges without a backward in between)
+            flat = out[key] = torch.empty(key[1], dtype=key[2], device=key[3])
+        base = flat.untyped_storage().data_ptr()
+        if any(g.untyped_storage().data_ptr() == base for g in grads):      # some gradient still is a view of this buffer (two exchanges without a backward in between)
             flat.copy_(torch.cat(grads))
+        else:
+            torch.cat(grads, out=flat)
     if world_size is None:
         world_size = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     if world_size > 1:

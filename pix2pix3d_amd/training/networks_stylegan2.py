@@ -601,10 +601,14 @@ class SynthesisNetwork(torch.nn.Module):
         planned = self._prefetch(block_ws, block_kwargs)
         x = img = None
         try:
-            hooked = bool(torch.nn.modules.module._global_forward_hooks)
-            for res, cur in zip(self.block_resolutions, block_ws):
-                block = getattr(self, f'b{res}')              # x is private to this loop unless somebody hooked a block: then it stays a tensor
-                x, img = block(x, img, cur, _split_ok=not (hooked or block._forward_hooks), **block_kwargs)
+            _m = torch.nn.modules.module
+            blocks = [getattr(self, f'b{res}') for res in self.block_resolutions]
+            for i, (block, cur) in enumerate(zip(blocks, block_ws)):
+                # x is private to this loop unless somebody can observe it: a forward hook on the producing block (its output), a forward PRE-hook on
+                # the consuming block (its input), or a global hook of either kind — then it stays a tensor.  Sampled per block, not per pass.
+                nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+                hooked = bool(_m._global_forward_hooks or _m._global_forward_pre_hooks or block._forward_hooks or (nxt is not None and nxt._forward_pre_hooks))
+                x, img = block(x, img, cur, _split_ok=not hooked, **block_kwargs)
         finally:
             if planned:
                 finish_prefetch(ws.device)

@@ -15,6 +15,7 @@ from .volumetric_rendering.ray_sampler import RaySampler
 
 
 frozen_passes_without_graph = os.environ.get('P3D_FROZEN_NO_GRAD', '1') != '0'
+frozen_passes_exact_fp32 = os.environ.get('P3D_FROZEN_EXACT_FP32', '1') != '0'      # graph-less passes of a generator in TRAINING mode keep the arithmetic of its differentiated passes
 train_products_bf16x3 = os.environ.get('P3D_TRAIN_G_BF16X3', '0') == '1'     # opt-in: the GENERATOR's fp32 training convolutions (forward + data gradient; the label-map
                                                                              # Encoder included) as bf16x3 — the arithmetic its inference passes use — while the
                                                                              # discriminators keep exact fp32 products (conv2d_gradfix.products)
@@ -28,18 +29,36 @@ def _tensors_of(values):
             yield from _tensors_of(v.values())
 
 
+def _with_exact_products(method, self, args, kwargs):
+    from ..torch_utils.ops import modconv
+    from .volumetric_rendering import renderer as rmod
+    prev = (modconv.split_bf16, rmod.mlp_bf16x3)
+    modconv.split_bf16, rmod.mlp_bf16x3 = False, False
+    try:
+        return method(self, *args, **kwargs)
+    finally:
+        modconv.split_bf16, rmod.mlp_bf16x3 = prev
+
+
 def frozen_pass(method):
     """Device passes through a generator that CANNOT record a graph — grad mode is on, but neither an argument nor a parameter requires a gradient: the
     generator passes of the discriminator phases (training_loop.py:516 leaves ``requires_grad`` on for the phase's own network only; loss.py:834-836,
     903-905 call run_G without no_grad) — run under ``torch.no_grad()``.  Same values and the same (graph-less) outputs; what changes is that the layers
-    below see what they key their inference kernels on."""
+    below see what they key their inference kernels on.  Those kernels default to bf16x3 products (three bf16 MFMAs per fp32 product) while the
+    differentiated passes of training form exact fp32 products (training_loop.py:278-280): a generator in TRAINING mode therefore runs its frozen passes
+    with the bf16x3 switches off — the discriminators are trained on fakes from the same function the generator is optimised through — unless the
+    generator's training products are bf16x3 themselves (``train_products_bf16x3``).  (The parameter scan below is per call on purpose: a cached answer
+    would go stale under ``p.requires_grad_()`` on a single parameter and silently drop that parameter's gradient.)"""
     @functools.wraps(method)
     def wrapper(self, *args, **kwargs):
+        exact = self.training and frozen_passes_exact_fp32 and not train_products_bf16x3
         if frozen_passes_without_graph and torch.is_grad_enabled():
             tensors = list(_tensors_of(list(args) + list(kwargs.values())))
             if tensors and all(t.is_cuda for t in tensors) and not any(t.requires_grad for t in tensors) and not any(p.requires_grad for p in self.parameters()):
                 with torch.no_grad():
-                    return method(self, *args, **kwargs)
+                    return _with_exact_products(method, self, args, kwargs) if exact else method(self, *args, **kwargs)
+        elif exact and not torch.is_grad_enabled():                  # the loss's own no_grad passes of a training-mode generator (the cross-view block, loss.py:690-741)
+            return _with_exact_products(method, self, args, kwargs)
         if train_products_bf16x3 and torch.is_grad_enabled():
             from ..torch_utils.ops import conv2d_gradfix
             with conv2d_gradfix.products(True):

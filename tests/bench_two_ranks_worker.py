@@ -45,6 +45,11 @@ def main():
     seen = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(seen, data)
     assert float(seen[0]) != float(seen[1]), 'the ranks were supposed to see different data'
+    # the N > 1 line's self-evidence object (bench.collective_info; backend gloo here, so the bandwidth is host staging and says so)
+    info = bench.collective_info(dist, world, rank, dev, sizes=(8 << 20,), reps=2)
+    assert info['ranks'] == world and len(info['devices']) == world and {d['rank'] for d in info['devices']} == set(range(world)), info
+    assert info['distinct_devices'] == 1 and 'gloo' in info['backend'] and info['env']['NCCL_P2P_DISABLE'] in (None, '', '0'), info       # two ranks on ONE device: visible in the record
+    assert info['allreduce_alone'][str(8 << 20)]['bus_GBps'] > 0 and info['xgmi']['links_per_gpu'] == 7
     dist.barrier()
     if rank == 0:
         print('BENCH_TWO_RANKS_OK', {k: int(v) for k, v in sizes.items()}, flush=True)

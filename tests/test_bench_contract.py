@@ -58,3 +58,14 @@ def test_bench_argument_surface():
     assert r.returncode == 0
     for flag in ('--gpus', '--steps', '--warmup', '--train-step', '--no-exact-fp32', '--no-cpu-baseline', '--cpu-reps'):
         assert flag in r.stdout, flag
+
+
+def test_multi_gpu_line_refuses_the_reference_scripts_p2p_switch(monkeypatch):
+    """train_scripts/afhq_seg.sh:2 exports NCCL_P2P_DISABLE=1; with it RCCL leaves xGMI.  bench.collective_info (the `rccl` object of every N > 1
+    line) refuses to measure in that state — before touching a device or the process group."""
+    import pytest
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setenv('NCCL_P2P_DISABLE', '1')
+    with pytest.raises(AssertionError, match='NCCL_P2P_DISABLE'):
+        bench.collective_info(None, 2, 0, None)

@@ -93,3 +93,41 @@ print('ok')
 ''' % (ROOT, ref, str(blob))
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-3000:]
+
+
+def test_a_registered_checkout_never_shadows_the_packages_own_modules():
+    """After install(reference_root=...) the reference's names that this package only restates as a fallback (training.loss) resolve to the
+    checkout's file — and `pix2pix3d_amd.training.loss` stays this package's file in every import form and order (the aliases of the packages
+    are objects of their own: nothing the checkout serves is registered under or attached to pix2pix3d_amd.*)."""
+    import os
+    import pytest
+    ref = os.environ.get('P3D_REFERENCE', '/root/reference')
+    if not os.path.isfile(os.path.join(ref, 'training', 'loss.py')):
+        pytest.skip('no reference checkout here')
+    code = r'''
+import sys, os, types
+sys.path.insert(0, %(root)r)
+from pix2pix3d_amd import dropin
+dropin.install()                                                  # first without a checkout: the restatement serves the name
+import training.loss
+assert training.loss.__name__ == 'pix2pix3d_amd.training.loss'
+dropin.install(reference_root=%(ref)r)
+sys.modules['lpips'] = types.ModuleType('lpips')                  # the checkout's loss.py imports it at module level; not installed here
+import pix2pix3d_amd.training.loss as own
+from pix2pix3d_amd.training import loss as own2
+assert own is own2 and own.__name__ == 'pix2pix3d_amd.training.loss' and own.__file__.startswith(%(root)r), own.__file__
+from training import loss as theirs                               # the checkout's file, under the reference's name
+import training.loss as theirs2
+assert theirs is theirs2 and theirs.__name__ == 'training.loss' and os.path.samefile(theirs.__file__, os.path.join(%(ref)r, 'training', 'loss.py'))
+import pix2pix3d_amd.training
+assert pix2pix3d_amd.training.loss is own and sys.modules['pix2pix3d_amd.training.loss'] is own     # still, after the checkout's module was loaded
+import training, torch_utils
+from torch_utils import training_stats, misc                      # un-mirrored -> checkout; mirrored -> this package
+assert training_stats.__name__ == 'torch_utils.training_stats' and misc.__name__ == 'pix2pix3d_amd.torch_utils.misc'
+assert 'pix2pix3d_amd.torch_utils.training_stats' not in sys.modules and not hasattr(pix2pix3d_amd.torch_utils, 'training_stats')
+import training.triplane_cond, pix2pix3d_amd.training.triplane_cond
+assert training.triplane_cond is pix2pix3d_amd.training.triplane_cond       # leaf mirrors: one module object, one set of classes
+print('ok')
+''' % dict(root=ROOT, ref=ref)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300, cwd='/tmp')
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-3000:]
