@@ -173,6 +173,13 @@ int p3d_render_forward(const float* planes_cl, const float* decoder, const float
                        const float* u_coarse, const float* u_fine, const float* t_start, const float* t_end,
                        const p3d_render_desc* desc, float* feat, float* depth, float* wsum, uint32_t* minmax_ws,
                        float* dbg_fine, float* dbg_wcoarse, p3d_stream_t stream);
+/* The same launch (same kernel instantiation) with one more optional record: dbg_bins [N*M][S_f] <- for every importance draw, in draw order,
+ * the index torch.searchsorted(cdf, u, right=True) returns in sample_pdf (renderer.py:221-253) — the integers behind dbg_fine, so that the index
+ * work of the FUSED launch can be compared exactly (tests/test_render_gpu.py), not only that of the stand-alone p3d_importance_sample_index. */
+int p3d_render_forward_debug(const float* planes_cl, const float* decoder, const float* ray_o, const float* ray_d,
+                             const float* u_coarse, const float* u_fine, const float* t_start, const float* t_end,
+                             const p3d_render_desc* desc, float* feat, float* depth, float* wsum, uint32_t* minmax_ws,
+                             float* dbg_fine, float* dbg_wcoarse, int32_t* dbg_bins, p3d_stream_t stream);
 
 /* ---- two plane sets: ImportanceSemanticRenderer (training/volumetric_rendering/renderer.py:256-438) --------------------------------
  * The renderer of TriPlaneSemanticGenerator (training/triplane_cond.py:746-758): a texture and a semantic tri-plane set of the same

@@ -298,7 +298,7 @@ static void fill_args(RenderArgs& a, const p3d_render_desc* d)
 static int render_forward_impl(const float* planes_cl, const float* planes_sem_cl, const float* decoder, const float* ray_o, const float* ray_d,
                                const float* u_coarse, const float* u_fine, const float* t_start, const float* t_end,
                                const p3d_render_desc* d, float* feat, float* depth, float* wsum, uint32_t* minmax_ws,
-                               float* dbg_fine, float* dbg_wcoarse, p3d_stream_t stream)
+                               float* dbg_fine, float* dbg_wcoarse, p3d_stream_t stream, int32_t* dbg_bins = nullptr)
 {
     const bool dual = planes_sem_cl != nullptr;
     int rc = check_render_common(d);
@@ -318,7 +318,7 @@ static int render_forward_impl(const float* planes_cl, const float* planes_sem_c
     fill_args(a, d);
     a.planes = planes_cl; a.planes2 = planes_sem_cl; a.decoder = decoder; a.ray_o = ray_o; a.ray_d = ray_d; a.u_coarse = u_coarse; a.u_fine = u_fine;
     a.t_start = t_start; a.t_end = t_end; a.feat = feat; a.depth = depth; a.wsum = wsum;
-    a.dbg_fine = dbg_fine; a.dbg_wcoarse = dbg_wcoarse; a.minmax = minmax_ws;
+    a.dbg_fine = dbg_fine; a.dbg_wcoarse = dbg_wcoarse; a.dbg_bins = dbg_bins; a.minmax = minmax_ws;
     a.total_rays = (int)total; a.rays_per_img = d->rays_per_img;
     { int r = 1; while (r * r < d->rays_per_img) ++r; a.res = (r * r == d->rays_per_img && d->raster_order) ? r : 0; }
     hipStream_t s = (hipStream_t)stream;
@@ -366,6 +366,14 @@ extern "C" int p3d_render_forward(const float* planes_cl, const float* decoder, 
                                   float* dbg_fine, float* dbg_wcoarse, p3d_stream_t stream)
 {
     return render_forward_impl(planes_cl, nullptr, decoder, ray_o, ray_d, u_coarse, u_fine, t_start, t_end, d, feat, depth, wsum, minmax_ws, dbg_fine, dbg_wcoarse, stream);
+}
+
+extern "C" int p3d_render_forward_debug(const float* planes_cl, const float* decoder, const float* ray_o, const float* ray_d,
+                                        const float* u_coarse, const float* u_fine, const float* t_start, const float* t_end,
+                                        const p3d_render_desc* d, float* feat, float* depth, float* wsum, uint32_t* minmax_ws,
+                                        float* dbg_fine, float* dbg_wcoarse, int32_t* dbg_bins, p3d_stream_t stream)
+{
+    return render_forward_impl(planes_cl, nullptr, decoder, ray_o, ray_d, u_coarse, u_fine, t_start, t_end, d, feat, depth, wsum, minmax_ws, dbg_fine, dbg_wcoarse, stream, dbg_bins);
 }
 
 extern "C" int p3d_render_forward_dual(const float* planes_tex_cl, const float* planes_sem_cl, const float* decoder_dual, const float* ray_o, const float* ray_d,

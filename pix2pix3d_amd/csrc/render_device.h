@@ -42,6 +42,7 @@ struct RenderArgs {
     float* wsum;              // [N*M]
     float* dbg_fine;          // optional [N*M][Sf] sorted fine depths
     float* dbg_wcoarse;       // optional [N*M][Sc-1] coarse weights
+    int*   dbg_bins;          // optional [N*M][Sf] searchsorted index of every importance draw, in draw order (p3d_render_forward_debug: the integer test)
     // training tape (render_bwd.hip): upstream gradients in, per-interval / per-sample records out
     const float* g_feat;      // [N*M][n_nets*32] dL/dfeat
     const float* g_wsum;      // optional [N*M] dL/dwsum
@@ -698,7 +699,13 @@ render_forward_kernel(RenderArgs a)
             u[q]   = (lane < Sf) ? a.u_fine[(size_t)gr[q] * Sf + lane] : 2.f;
             if (a.dbg_wcoarse && lane < Sc - 1 && r_live[q]) a.dbg_wcoarse[(size_t)gr[q] * (Sc - 1) + lane] = w_i[q];
         }
-        importance_depth<kRaysB>(Sc, Sf, lane, w_i, z_i, u, zf);
+        int bins[kRaysB];
+        importance_depth<kRaysB>(Sc, Sf, lane, w_i, z_i, u, zf, &bins);
+        if (a.dbg_bins) {
+#pragma unroll
+            for (int q = 0; q < kRaysB; ++q)
+                if (lane < Sf && r_live[q]) a.dbg_bins[(size_t)gr[q] * Sf + lane] = bins[q];
+        }
         bitonic_sort64<kRaysB>(zf, lane);
         wave_sync();
 #pragma unroll

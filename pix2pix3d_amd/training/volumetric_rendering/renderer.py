@@ -56,6 +56,7 @@ _lib.register('p3d_render_grad_decoder_floats', ctypes.c_int, [])
 _lib.register('p3d_pack_decoder_bwd', ctypes.c_int, [_vp] * 4 + [ctypes.c_int32, ctypes.c_float, _vp, _vp])
 _lib.register('p3d_render_backward', ctypes.c_int, [_vp] * 9 + [ctypes.POINTER(_RenderDesc)] + [_vp] * 6 + [_vp])
 _lib.register('p3d_render_forward', ctypes.c_int, [_vp] * 8 + [ctypes.POINTER(_RenderDesc)] + [_vp] * 6 + [_vp])
+_lib.register('p3d_render_forward_debug', ctypes.c_int, [_vp] * 8 + [ctypes.POINTER(_RenderDesc)] + [_vp] * 7 + [_vp])
 _lib.register('p3d_sample_points', ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(_RenderDesc), _i32, _vp, _vp, _vp])
 _lib.register('p3d_sample_points_backward', ctypes.c_int, [_vp] * 4 + [ctypes.POINTER(_RenderDesc), _i32] + [_vp] * 4 + [_vp])
 _lib.register('p3d_importance_sample', ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp])
@@ -749,7 +750,7 @@ def fused_render_backward(planes, decoder, ray_origins, ray_directions, opt, u_c
 def fused_render(planes, decoder, ray_origins, ray_directions, opt, u_coarse, u_fine, t_start=None, t_end=None, debug=False, exact_fp32=False, packed=None):
     """One launch of the fused ray-marcher with explicit uniforms (u_coarse [N,M,Sc(,1)], u_fine [N*M,Sf]).
     Returns (feat [N,M,C], depth [N,M,1], wsum [N,M,1]) and, with debug, the sorted fine depths [N*M,Sf] and the
-    coarse weights [N*M,Sc-1] the kernel used."""
+    coarse weights [N*M,Sc-1] the kernel used; with debug='bins' also the searchsorted index of every draw [N*M,Sf] (int32, draw order)."""
     info = _decoder_nets(decoder)
     if info is None:
         raise RuntimeError(f'fused_render: unsupported decoder {type(decoder).__name__}')
@@ -768,13 +769,21 @@ def fused_render(planes, decoder, ray_origins, ray_directions, opt, u_coarse, u_
     mm = torch.empty([2], device=dev, dtype=torch.int32)
     dbg_f = torch.empty([n * m, sf], device=dev, dtype=torch.float32) if debug else None
     dbg_w = torch.empty([n * m, sc - 1], device=dev, dtype=torch.float32) if debug else None
+    dbg_b = torch.empty([n * m, sf], device=dev, dtype=torch.int32) if debug == 'bins' else None
     # raster=True is a pure scheduling hint (which wave takes which ray); results never depend on it
     d = ctx.desc(opt, rays_per_img=m, start=0.0 if auto else opt['ray_start'], end=0.0 if auto else opt['ray_end'], raster=True)
     with _lib.kernel_timer('render_forward', feat):
-        code = _lib.lib().p3d_render_forward(_lib.ptr(ctx.planes_cl), _lib.ptr(ctx.packed), _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(uc), _lib.ptr(uf),
-                                             _lib.ptr(t0), _lib.ptr(t1), ctypes.byref(d), _lib.ptr(feat), _lib.ptr(depth), _lib.ptr(wsum),
-                                             _lib.ptr(mm), _lib.ptr(dbg_f), _lib.ptr(dbg_w), _lib.stream_of(feat))
+        if dbg_b is not None:
+            code = _lib.lib().p3d_render_forward_debug(_lib.ptr(ctx.planes_cl), _lib.ptr(ctx.packed), _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(uc), _lib.ptr(uf),
+                                                       _lib.ptr(t0), _lib.ptr(t1), ctypes.byref(d), _lib.ptr(feat), _lib.ptr(depth), _lib.ptr(wsum),
+                                                       _lib.ptr(mm), _lib.ptr(dbg_f), _lib.ptr(dbg_w), _lib.ptr(dbg_b), _lib.stream_of(feat))
+        else:
+            code = _lib.lib().p3d_render_forward(_lib.ptr(ctx.planes_cl), _lib.ptr(ctx.packed), _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(uc), _lib.ptr(uf),
+                                                 _lib.ptr(t0), _lib.ptr(t1), ctypes.byref(d), _lib.ptr(feat), _lib.ptr(depth), _lib.ptr(wsum),
+                                                 _lib.ptr(mm), _lib.ptr(dbg_f), _lib.ptr(dbg_w), _lib.stream_of(feat))
     if code == _lib.P3D_ERR_UNSUPPORTED:
         return None
     _lib.check(code, 'render_forward')
+    if dbg_b is not None:
+        return feat, depth, wsum, dbg_f, dbg_w, dbg_b
     return (feat, depth, wsum, dbg_f, dbg_w) if debug else (feat, depth, wsum)

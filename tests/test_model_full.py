@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_err
+from conftest import load_golden, rel_err, record_error
 from model_cases import build_generator, uniforms, replay_uniforms
 
 FULL = {'seg2cat_96': 'seg2cat', 'seg2cat_128': 'seg2cat', 'seg2face_96': 'seg2face'}
@@ -92,6 +92,7 @@ def test_synthesis_at_baseline_size_matches_reference(hip_lib, tag, force_fp32):
     assert _lib.launch_count('render') > n0
     errs = compare_full(out, g, tol_raw=1e-3, tol_sr=1e-3 if force_fp32 else 3e-2)
     print(tag, 'fp32' if force_fp32 else 'fp16-sr', errs)
+    record_error(f'model_full.{tag}.' + ('fp32' if force_fp32 else 'fp16-sr'), errs)
 
 
 @pytest.mark.gpu

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_err
+from conftest import load_golden, rel_err, record_error
 from model_cases import build_generator, uniforms, replay_uniforms, compare_outputs
 
 pytestmark = pytest.mark.gpu
@@ -41,6 +41,7 @@ def test_synthesis_on_gpu_matches_reference(hip_lib, name, force_fp32):
     tol_raw = 3e-2 if (name == 'edge2car' and not force_fp32) else 1e-3
     errs = compare_outputs(out, g, tol_raw=tol_raw, tol_sr=1e-3 if force_fp32 else 3e-2)
     print(name, 'fp32' if force_fp32 else 'fp16-sr', errs)
+    record_error(f'model.{name}.' + ('fp32' if force_fp32 else 'fp16-sr'), errs)
 
 
 @pytest.mark.parametrize('name', ['seg2cat', 'edge2car'])

@@ -150,7 +150,7 @@ def test_index_work_at_bench_size(hip_lib):
         planes = G.backbone.synthesis(ws, noise_mode='const')
         planes = planes.view(planes.shape[0], 3, 32, planes.shape[-2], planes.shape[-1])
         o, d = G.ray_sampler(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), nrr)
-        _, _, _, zf_fused, w_coarse = rmod.fused_render(planes, G.decoder, o, d, rk, u_c.to('cuda'), u_f.to('cuda'), debug=True)
+        _, _, _, zf_fused, w_coarse, bins_fused = rmod.fused_render(planes, G.decoder, o, d, rk, u_c.to('cuda'), u_f.to('cuda'), debug='bins')
     n, m, sc = u_c.shape[0], u_c.shape[1], u_c.shape[2]
     z_c = R.sample_stratified(u_c.numpy().reshape(n, m, sc), rk['ray_start'], rk['ray_end']).reshape(n * m, sc)
     n_diff, total = _check_index_work(rmod, z_c, w_coarse.cpu().numpy(), u_f.numpy(), allow_ties=True)
@@ -159,6 +159,15 @@ def test_index_work_at_bench_size(hip_lib):
     # coarse depths' last ulp, which only enter the final interpolation)
     zf_alone = rmod.importance_sample_native(torch.tensor(z_c, device='cuda'), w_coarse, u_f.to('cuda'), sort=True)
     assert float((zf_alone - zf_fused).abs().max()) <= 5e-7
+    # ... and the FUSED launch's own integers (p3d_render_forward_debug: the bin index of every draw, written by the kernel that rendered): equal to the
+    # stand-alone entry point's on every one of the 4.2 M draws, and to the oracle's searchsorted up to the cdf ties counted above
+    _, bins_alone, _ = rmod.importance_sample_index_native(torch.tensor(z_c, device='cuda'), w_coarse, u_f.to('cuda'))
+    assert bins_fused.shape == bins_alone.shape and torch.equal(bins_fused.to(bins_alone.dtype), bins_alone)
+    bins_o, wp_o = R.importance_bins(z_c, w_coarse.cpu().numpy())
+    _, inds_o = R.sample_pdf(bins_o, wp_o, u_f.numpy(), return_index=True)
+    n_fused_diff = int((bins_fused.cpu().numpy().astype(np.int64) != inds_o).sum())
+    assert n_fused_diff == n_diff, (n_fused_diff, n_diff)
+    print(f'fused launch: bin indices of {bins_fused.numel()} draws == the stand-alone sampler, {n_fused_diff} cdf ties vs the oracle')
 
 
 def test_edge_cases_empty_space_tail_tile_and_oob(hip_lib):

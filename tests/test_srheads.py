@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, load_golden
+from conftest import GOLDEN, load_golden, record_error
 from model_cases import weights
 
 _spec = importlib.util.spec_from_file_location('p3d_make_golden_cases', os.path.join(GOLDEN, 'make_golden.py'))
@@ -47,6 +47,8 @@ def _run(i, device, tol, **kw):
     step, c0 = res // 32, res // 2 - 16
     scale = np.abs(g[f'{i}.thumb']).max()
     err = max(np.abs(y[..., ::step, ::step].numpy() - g[f'{i}.thumb']).max(), np.abs(y[..., c0:c0 + 32, c0:c0 + 32].numpy() - g[f'{i}.crop']).max()) / scale
+    if device != 'cpu':
+        record_error(f'srheads.{i}.{cls}.{side}.' + ('fp32' if kw.get('force_fp32') else 'fp16'), float(err))
     assert err < tol, (cls, side, aa, err)
 
 
