@@ -811,13 +811,15 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
             }
     }
     __syncthreads();
-    __half* const yout = (__half*)a.y + (int64_t)n * a.H * a.W * a.Co;
+    if (a.y) {                                                                   // (null: p3d_conv3x3_torgb_f16 on a block whose x nobody reads — the tile only feeds the ToRGB below)
+        __half* const yout = (__half*)a.y + (int64_t)n * a.H * a.W * a.Co;
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int idx = it * 256 + tid, p = idx >> 4, ch = idx & 15;
-        const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15), co = co0 + ch * 8;
-        if (oy < a.H && ox < a.W && co < a.Co)
-            *(f32x4*)(yout + ((int64_t)oy * a.W + ox) * a.Co + co) = *(const f32x4*)(ot + p * OP + ch * 8);
+        for (int it = 0; it < 16; ++it) {
+            const int idx = it * 256 + tid, p = idx >> 4, ch = idx & 15;
+            const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15), co = co0 + ch * 8;
+            if (oy < a.H && ox < a.W && co < a.Co)
+                *(f32x4*)(yout + ((int64_t)oy * a.W + ox) * a.Co + co) = *(const f32x4*)(ot + p * OP + ch * 8);
+        }
     }
     if (a.rgb_out) {                                                             // (host: Co == 128, one channel block, no noise)
         // ToRGB of the finished tile on the matrix cores, as torgb_nhwc_kernel does it: A = the tile's pixels (rows of `ot`), B = the image's
@@ -1507,7 +1509,7 @@ extern "C" int p3d_conv3x3_torgb_f16(const void* x, const void* w, void* y, cons
                                      int64_t w_img_stride, int32_t act, float gain, float clamp, p3d_stream_t stream)
 {
     using namespace p3d;
-    P3D_REQUIRE(x && w && y && zeros128 && rgb_w && rgb_out, "conv3x3_torgb_f16: null pointer");
+    P3D_REQUIRE(x && w && zeros128 && rgb_w && rgb_out, "conv3x3_torgb_f16: null pointer");      // y may be null: the layer's activations have no other consumer
     P3D_REQUIRE(rgb_co >= 1 && rgb_co <= 8, "conv3x3_torgb_f16: 1 .. 8 image channels");
     P3D_REQUIRE(act == 0 || act == 1, "conv3x3_torgb_f16: act must be 0 (linear) or 1 (lrelu)");
     if (co != BN || ci % 64 != 0 || h < 32 || wdt < 32 || ((uintptr_t)y & 15u))

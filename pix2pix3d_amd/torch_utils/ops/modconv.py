@@ -596,10 +596,10 @@ def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=No
             y = y.add_((noise_const * noise_strength).to(y.dtype))
         return bias_act.bias_act(y, (None if bias is None else bias.to(y.dtype)), act=act, gain=act_gain, clamp=clamp)
     wmod = wpre if wpre is not None else modulate_weights(weight, styles, demodulate=True, dtype=wtag)
-    if rgb is not None:                                    # (rgb_weight, rgb_styles, rgb_bias, rgb_clamp, img): checked by torgb_fusable
-        rgb_w, rgb_s, rgb_b, rgb_c, img = rgb
+    if rgb is not None:                                    # (rgb_weight, rgb_styles, rgb_bias, rgb_clamp, img[, x_dead]): checked by torgb_fusable
+        rgb_w, rgb_s, rgb_b, rgb_c, img = rgb[:5]
         rgb_wmod = modulate_weights(rgb_w, rgb_s, demodulate=False, dtype=torch.float32)
-        return conv3x3_torgb(x, wmod, bias, act_idx, act_gain, clampv, rgb_wmod, rgb_b, rgb_c, img)
+        return conv3x3_torgb(x, wmod, bias, act_idx, act_gain, clampv, rgb_wmod, rgb_b, rgb_c, img, store_y=not (len(rgb) > 5 and rgb[5]))
     if up == 1 and act_idx is not None:
         return conv2d(x, wmod, bias=bias, noise=noise_const, noise_strength=noise_strength, act=act_idx, gain=act_gain, clamp=clampv, split=split, out_split=out_split)
     if up == 1:
@@ -699,11 +699,13 @@ def torgb_fusable(x, conv_weight, rgb_weight, img, up, noise_const, act):
             and not img.requires_grad and _no_grad_needed(x, conv_weight, rgb_weight))
 
 
-def conv3x3_torgb(x, wmod, bias, act, gain, clamp, rgb_wmod, rgb_bias, rgb_clamp, img):
-    """3x3 'same' modulated conv (fp16 NHWC, Co = 128) + epilogue, and img += clamp(ToRGB(y) + rgb_bias) from the same launch."""
+def conv3x3_torgb(x, wmod, bias, act, gain, clamp, rgb_wmod, rgb_bias, rgb_clamp, img, store_y=True):
+    """3x3 'same' modulated conv (fp16 NHWC, Co = 128) + epilogue, and img += clamp(ToRGB(y) + rgb_bias) from the same launch.
+    ``store_y=False``: the layer's activations have no reader but this ToRGB (the last block of a super-resolution head) — they are not written
+    (268 MB per launch at 512^2, batch 4) and None is returned."""
     n, ci, h, w = x.shape
     co = wmod.shape[1]
-    y = torch.empty([n, co, h, w], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    y = torch.empty([n, co, h, w], dtype=x.dtype, device=x.device, memory_format=torch.channels_last) if store_y else None
     stride = 0 if wmod.shape[0] == 1 else co * 9 * ci
     b32 = None if bias is None else bias.detach().float().contiguous()
     rb32 = None if rgb_bias is None else rgb_bias.detach().float().contiguous()

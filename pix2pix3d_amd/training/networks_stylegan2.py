@@ -293,11 +293,11 @@ class SynthesisLayer(torch.nn.Module):
             const_noise = self.use_noise and noise_mode == 'const'
             fused_rgb = None
             if rgb is not None:
-                torgb, w_rgb, img = rgb
+                torgb, w_rgb, img = rgb[:3]
                 if modconv.torgb_fusable(x, self.weight, torgb.weight, img, self.up, self.noise_const if const_noise else None, self.activation):
                     planned_rgb = modconv.take_plan(torgb) if modconv._plan else None
                     s_rgb = planned_rgb[0] if planned_rgb is not None else torgb.affine(w_rgb, out_scale=torgb.weight_gain)
-                    fused_rgb = (torgb.weight, s_rgb, torgb.bias, torgb.conv_clamp, img)
+                    fused_rgb = (torgb.weight, s_rgb, torgb.bias, torgb.conv_clamp, img, len(rgb) > 3 and bool(rgb[3]))      # [5]: x has no other reader
             y = modconv.synthesis_layer(x, self.weight, styles, self.bias, self.up, self.resample_filter,
                                         noise_const=self.noise_const if const_noise else None,
                                         noise_strength=self.noise_strength if const_noise else None,
@@ -417,7 +417,7 @@ class SynthesisBlock(torch.nn.Module):
 
     _in_div = 2          # input resolution = resolution // _in_div (the NoUp variant in superresolution.py uses 1)
 
-    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, _split_ok=False, **layer_kwargs):
+    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, _split_ok=False, _x_dead=False, **layer_kwargs):
         """``_split_ok`` (private, set by SynthesisNetwork.forward only): the returned ``x`` may be a modconv.SplitActs that only the next block of the
         same network reads.  Every other caller — a feature extractor stepping through the blocks, a forward hook — gets the reference's contract: a
         tensor."""
@@ -449,7 +449,9 @@ class SynthesisBlock(torch.nn.Module):
                 img_carried = False
             elif wants_rgb and img is not None and self.img_channels <= 8 and x.is_cuda and not torch.is_grad_enabled():
                 img = self._carry_image(img)                     # (independent of the convolutions: done first so that conv1 can add into it)
-                x, rgb_done = self.conv1(x, per_layer[1], rgb=(self.torgb, per_layer[self.num_conv], img), **conv_kwargs)
+                # _x_dead (private, set by the super-resolution heads for their last block): the caller drops the returned x, so when conv1 also produces
+                # the ToRGB contribution its activations are never stored and x comes back as None
+                x, rgb_done = self.conv1(x, per_layer[1], rgb=(self.torgb, per_layer[self.num_conv], img, _x_dead), **conv_kwargs)
                 img_carried = True
             else:
                 x = self.conv1(x, per_layer[1], **conv_kwargs)
@@ -481,7 +483,8 @@ class SynthesisBlock(torch.nn.Module):
             y = self.torgb(x, per_layer[self.num_conv], fused_modconv=fused_modconv, accumulate_into=img)
             img = img if y is img else self._accumulate_image(img, y, fmt)
 
-        assert x.dtype == dtype and (img is None or img.dtype == torch.float32)
+        assert (x is None and _x_dead and rgb_done) or x.dtype == dtype
+        assert img is None or img.dtype == torch.float32
         return x, img
 
     def _carry_image(self, img):

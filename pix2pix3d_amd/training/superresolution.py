@@ -36,7 +36,10 @@ class _SuperresolutionBase(torch.nn.Module):
         planned = prefetch_styles([self.block0, self.block1], [ws, ws], block_kwargs)
         try:
             x, rgb = self.block0(x, rgb, ws, **block_kwargs)
-            x, rgb = self.block1(x, rgb, ws, **block_kwargs)
+            # block1's x is returned to nobody (:297-354 of the reference return rgb only): unless somebody hooked the block to look at it, its last
+            # layer need not store it (networks_stylegan2.SynthesisBlock.forward: _x_dead)
+            hooked = bool(torch.nn.modules.module._global_forward_hooks or self.block1._forward_hooks)
+            x, rgb = self.block1(x, rgb, ws, _x_dead=not hooked, **block_kwargs)
         finally:
             if planned:
                 finish_prefetch(ws.device)

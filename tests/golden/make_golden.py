@@ -357,17 +357,22 @@ def group_model_full():
     weights = _load_by_path('p3d_weights', os.path.join(HERE, 'weights.py'))
     runs = [dict(tag='seg2cat_96', name='seg2cat', n=4, depth=(48, 48), frames=[3, 10, 17, 24]),
             dict(tag='seg2cat_128', name='seg2cat', n=4, depth=(64, 64), frames=[3, 10, 17, 24]),
-            dict(tag='seg2face_96', name='seg2face', n=2, depth=(48, 48), frames=[5, 70])]
+            dict(tag='seg2face_96', name='seg2face', n=2, depth=(48, 48), frames=[5, 70]),
+            # BASELINE configs[3] per GPU (train.py:451-461): edge2car, 64^2 rays x 64+64, batch 8, Hybrid2X heads -> 128^2, white background, sigmoid labels
+            dict(tag='edge2car_128', name='edge2car', n=8, depth=(64, 64), nrr=64, focal=1.7074, frames=[3, 18, 33, 48, 63, 78, 93, 108])]
+    only = os.environ.get('P3D_GOLDEN_ONLY')                   # e.g. P3D_GOLDEN_ONLY=edge2car_128: record just that run (the others are unchanged)
     for run in runs:
+        if only and run['tag'] not in only.split(','):
+            continue
         kw = configs.generator_kwargs(run['name'], depth=run['depth'])
         torch.manual_seed(0)
         G = dnnlib.util.construct_class_by_name(**kw).eval().requires_grad_(False)
         weights.seed_module(G, seed=1)
-        n, nrr = run['n'], 128
+        n, nrr = run['n'], run.get('nrr', 128)
         gz = torch.Generator().manual_seed(5)
         ws = torch.randn(n, G.backbone.num_ws, 512, generator=gz)
         rk = kw['rendering_kwargs']
-        c = torch.tensor(np.stack([configs.orbit_camera(k, radius=rk['avg_camera_radius'], pivot=rk['avg_camera_pivot']) for k in run['frames']]))
+        c = torch.tensor(np.stack([configs.orbit_camera(k, radius=rk['avg_camera_radius'], focal=run.get('focal', 4.2647), pivot=rk['avg_camera_pivot']) for k in run['frames']]))
         torch.manual_seed(4321)
         with _RandTape() as tape, torch.no_grad():
             out = G.synthesis(ws, c, neural_rendering_resolution=nrr, noise_mode='const')

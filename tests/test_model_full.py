@@ -16,7 +16,7 @@ import torch
 from conftest import load_golden, rel_err, record_error
 from model_cases import build_generator, uniforms, replay_uniforms
 
-FULL = {'seg2cat_96': 'seg2cat', 'seg2cat_128': 'seg2cat', 'seg2face_96': 'seg2face'}
+FULL = {'seg2cat_96': 'seg2cat', 'seg2cat_128': 'seg2cat', 'seg2face_96': 'seg2face', 'edge2car_128': 'edge2car'}
 
 
 def compare_full(out, g, tol_raw, tol_sr, tol_depth=1e-4):
@@ -65,6 +65,18 @@ def test_oracle_matches_reference_at_seg2face_size():
     print(compare_full(out, g, tol_raw=2e-4, tol_sr=2e-4))
 
 
+def test_oracle_matches_reference_at_edge2car_size():
+    """BASELINE configs[3] per GPU: edge2car (edge maps, white background, sigmoid label channel, Hybrid2X heads), 64^2 rays x 64+64, batch 8 -> 128^2."""
+    from oracle import model_oracle as M
+    from pix2pix3d_amd import configs
+    g, G, ws, c, nrr, u_c, u_f = _inputs('edge2car_128', 'cpu')
+    sd = {k: v.float() for k, v in G.state_dict().items()}
+    with torch.no_grad():
+        out = M.synthesis(sd, configs.oracle_cfg('edge2car', depth=(64, 64)), ws, c, u_c, u_f, nrr=nrr, noise_mode='const')
+    assert out['image'].shape == (8, 3, 128, 128) and out['semantic'].shape == (8, 1, 128, 128)
+    print(compare_full(out, g, tol_raw=2e-4, tol_sr=2e-4))
+
+
 def test_product_cpu_path_matches_reference_at_seg2face_size():
     g, G, ws, c, nrr, u_c, u_f = _inputs('seg2face_96', 'cpu')
     with replay_uniforms(u_c, u_f), torch.no_grad():
@@ -90,7 +102,12 @@ def test_synthesis_at_baseline_size_matches_reference(hip_lib, tag, force_fp32):
     finally:
         rmod.fused_policy, conv2d_gradfix.enabled = prev_pol, prev_en
     assert _lib.launch_count('render') > n0
-    errs = compare_full(out, g, tol_raw=1e-3, tol_sr=1e-3 if force_fp32 else 3e-2)
+    # Bounds = 3 x the worst value this suite has measured on an MI355X (profiles/round5_a_parity_errors.json: fp32 legs <= 1.3e-5, fp16-SR legs
+    # <= 9.4e-4 of the range on every record, tile records included) — a 1 %-level defect of an fp16 kernel (conv3x3_h2_f16 / up2_fir_f16) fails here.
+    # edge2car + fp16 heads: the no-upsampling SR block adds its fp16 ToRGB output into 'image_raw' IN PLACE (reference quirk, superresolution.py:281),
+    # so the "raw" images carry fp16 rounding there.
+    fp16_raw = tag.startswith('edge2car') and not force_fp32
+    errs = compare_full(out, g, tol_raw=5e-3 if fp16_raw else 1e-4, tol_sr=1e-4 if force_fp32 else (8e-3 if fp16_raw else 3e-3))
     print(tag, 'fp32' if force_fp32 else 'fp16-sr', errs)
     record_error(f'model_full.{tag}.' + ('fp32' if force_fp32 else 'fp16-sr'), errs)
 

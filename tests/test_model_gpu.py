@@ -3,7 +3,7 @@ reference generator (same name-seeded weights, latents, cameras, uniforms).
 
 Tolerances: all-fp32 run (force_fp32): rendered pixels (image_raw / semantic_raw) and SR images <= 1e-3
 relative-to-max, depth <= 1e-4; default precision (fp16 super-resolution blocks with fp32 accumulation, as the
-reference runs on a GPU): SR images <= 3e-2, rendered pixels unchanged (the renderer is always fp32)."""
+reference runs on a GPU): SR images <= 8e-3 (3 x the worst measured), rendered pixels unchanged (the renderer is always fp32)."""
 import numpy as np
 import pytest
 import torch
@@ -38,8 +38,9 @@ def test_synthesis_on_gpu_matches_reference(hip_lib, name, force_fp32):
     assert out['image'].dtype == torch.float32
     # edge2car + fp16 heads: the no-upsampling SR block adds its fp16 ToRGB output into 'image_raw' IN PLACE (reference
     # quirk, superresolution.py:281), so the "raw" images inherit fp16 rounding there; everywhere else they are pure fp32
-    tol_raw = 3e-2 if (name == 'edge2car' and not force_fp32) else 1e-3
-    errs = compare_outputs(out, g, tol_raw=tol_raw, tol_sr=1e-3 if force_fp32 else 3e-2)
+    # bounds = 3 x the worst value measured on an MI355X (profiles/round5_a_parity_errors.json: fp32 <= 2.9e-5; fp16 heads: images <= 2.5e-3, edge2car's raw <= 1.5e-3)
+    tol_raw = 5e-3 if (name == 'edge2car' and not force_fp32) else 1e-4
+    errs = compare_outputs(out, g, tol_raw=tol_raw, tol_sr=1e-4 if force_fp32 else 8e-3)
     print(name, 'fp32' if force_fp32 else 'fp16-sr', errs)
     record_error(f'model.{name}.' + ('fp32' if force_fp32 else 'fp16-sr'), errs)
 

@@ -68,5 +68,5 @@ def test_4x_head_refuses_larger_inputs_like_the_reference():
 @pytest.mark.gpu
 @pytest.mark.parametrize('i', range(len(SR_CASES)))
 def test_sr_head_device_path_matches_reference(i):
-    _run(i, 'cuda', 1e-3, force_fp32=True)
-    _run(i, 'cuda', 3e-2)
+    _run(i, 'cuda', 1e-4, force_fp32=True)         # measured <= 1.2e-5 (profiles/round5_a_parity_errors.json)
+    _run(i, 'cuda', 3e-3)                          # fp16 blocks: measured <= 8.6e-4 of the range; 3 x that
