@@ -640,6 +640,13 @@ constexpr int H2_WT_BYTES = BN * 64;                            // 8192
 constexpr int H2_WT_BASE = 2 * H2_SLAB_BUF;                     // 47104
 constexpr int H2_LDS = H2_WT_BASE + 3 * H2_WT_BYTES;            // 71680 (>= the 69632-byte epilogue stage)
 
+// TR (p3d_conv3x3_torgb_f16 with y == null: the last block of a super-resolution head, whose activations only its ToRGB reads): the MFMA operands
+// are SWAPPED — weights as A, pixels as B — so an accumulator tile is y^T: a lane holds 16 channels of ONE pixel ((r & 3) + 8 (r >> 2) + 4 fk of its
+// 32-channel group).  After bias / activation / clamp and the fp16 rounding those registers ARE the B fragments of the ToRGB contraction over
+// channels (the k <-> channel permutation is put into the ToRGB weights' A fragments), and its result tile has the pixel in the lane again: the
+// epilogue needs no LDS image, no rendezvous and no store of y — 128 two-byte LDS stores, 16 LDS reads, 16 global stores and three block-wide
+// barriers per thread become 16 MFMAs and a handful of read-modify-writes of the skip image.
+template <bool TR>
 __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
 {
     // ONE __shared__ object on purpose: with two, hipcc drains vmcnt to 0 before the first ds_read of every step and the counted
@@ -772,11 +779,76 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, fa[cur][i]), __builtin_bit_cast(h8, fb[cur][j]), acc[i][j], 0, 0, 0);
+                            acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, fb[cur][j]), __builtin_bit_cast(h8, fa[cur][i]), acc[i][j], 0, 0, 0)
+                                           : __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, fa[cur][i]), __builtin_bit_cast(h8, fb[cur][j]), acc[i][j], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
+    }
+    if constexpr (TR) {
+        // acc[i][j][r] = y^T: channel 32 j + (r & 3) + 8 (r >> 2) + 4 fk of pixel wave * 64 + i * 32 + frow.  (host: Co == 128, one channel block, no noise)
+        // ToRGB weights as A fragments: lane (row o = frow, k group fk) of k-step (j, half) holds w[o][32 j + 16 half + (e & 3) + 8 (e >> 2) + 4 fk], e = 0 .. 7 —
+        // the channels the pixel lanes' registers 8 half + e carry — rounded to fp16 like the reference's fp16 layer does
+        h8 bw[8];
+#pragma unroll
+        for (int sidx = 0; sidx < 8; ++sidx) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bw[sidx][e] = (_Float16)0.f;
+            if (frow < a.rgb_co) {
+                const float* wp = a.rgb_w + ((int64_t)n * a.rgb_co + frow) * 128 + sidx * 16 + fk * 4;
+                const f32x4 w0 = *(const f32x4*)wp, w1 = *(const f32x4*)(wp + 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bw[sidx][e] = (_Float16)w0[e]; bw[sidx][4 + e] = (_Float16)w1[e]; }
+            }
+        }
+        f32x16 rr[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) rr[i][e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float b[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = a.bias ? *(const f32x4*)(a.bias + co0 + j * 32 + 8 * q + 4 * fk) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[q * 4 + e] = b4[e];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                h8 yb[2];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] + b[r];
+                    if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
+                    v *= a.gain;
+                    if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
+                    yb[r >> 3][r & 7] = (_Float16)v;
+                }
+                rr[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[j * 2], yb[0], rr[i], 0, 0, 0);
+                rr[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[j * 2 + 1], yb[1], rr[i], 0, 0, 0);
+            }
+        }
+        // rr[i][r]: image channel (r & 3) + 8 (r >> 2) + 4 fk of pixel (wave * 4 + 2 i + (frow >> 4), frow & 15) of the patch: channels 0 .. 7 are r = 0 .. 3 of the two halves
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int oy = oy0 + wave * 4 + 2 * i + (frow >> 4), ox = ox0 + (frow & 15);
+            if (oy < a.H && ox < a.W) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = r + 4 * fk;
+                    if (o < a.rgb_co) {
+                        float v = rr[i][r] + (a.rgb_bias ? a.rgb_bias[o] : 0.f);
+                        if (a.rgb_clamp >= 0.f) v = fminf(fmaxf(v, -a.rgb_clamp), a.rgb_clamp);
+                        float* dst = a.rgb_out + (((int64_t)n * a.rgb_co + o) * a.H + oy) * a.W + ox;
+                        *dst += v;
+                    }
+                }
+            }
+        }
+        return;
     }
     __syncthreads();                                                            // every wave is done with the slabs and tiles
 
@@ -1512,7 +1584,7 @@ extern "C" int p3d_conv3x3_torgb_f16(const void* x, const void* w, void* y, cons
     P3D_REQUIRE(x && w && zeros128 && rgb_w && rgb_out, "conv3x3_torgb_f16: null pointer");      // y may be null: the layer's activations have no other consumer
     P3D_REQUIRE(rgb_co >= 1 && rgb_co <= 8, "conv3x3_torgb_f16: 1 .. 8 image channels");
     P3D_REQUIRE(act == 0 || act == 1, "conv3x3_torgb_f16: act must be 0 (linear) or 1 (lrelu)");
-    if (co != BN || ci % 64 != 0 || h < 32 || wdt < 32 || ((uintptr_t)y & 15u))
+    if (co != BN || ci % 64 != 0 || h < 32 || wdt < 32 || ((uintptr_t)y & 15u) || ((uintptr_t)rgb_w & 15u) || (bias && ((uintptr_t)bias & 15u)))
         return fail(P3D_ERR_UNSUPPORTED, "conv3x3_torgb_f16: needs Co = 128, Ci %% 64 = 0, an image of 32 x 32 or more (got %d, %d, %d x %d)", co, ci, h, wdt);
     P3D_REQUIRE((((uintptr_t)x) & 15u) == 0 && (((uintptr_t)w) & 15u) == 0 && (((uintptr_t)zeros128) & 15u) == 0, "conv3x3_torgb_f16: x, w and zeros128 must be 16-byte aligned");
     ConvArgs a{};
@@ -1523,7 +1595,9 @@ extern "C" int p3d_conv3x3_torgb_f16(const void* x, const void* w, void* y, cons
     for (int t = 0; t < 9; ++t) a.cls[0].taps[t] = ConvTap{t / 3 - 1, t % 3 - 1, t};
     a.rgb_w = rgb_w; a.rgb_bias = rgb_bias; a.rgb_out = rgb_out; a.rgb_co = rgb_co; a.rgb_clamp = rgb_clamp;
     dim3 grid(((h + QH - 1) / QH) * ((wdt + QW - 1) / QW), 1, n_img);
-    hipLaunchKernelGGL(conv3x3_h2_f16_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    static const bool no_tr = [] { const char* d = getenv("P3D_TORGB_NO_TR"); return d && atoi(d) != 0; }();      // A/B switch: the LDS-image epilogue without the store
+    if (!y && !no_tr) hipLaunchKernelGGL(conv3x3_h2_f16_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else              hipLaunchKernelGGL(conv3x3_h2_f16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
     count_launch(FAM_CONV);
     return check_launch("conv3x3_torgb_f16");
 }
@@ -1641,7 +1715,7 @@ int p3d::conv2d_nhwc_run_io(const void* x, const void* w, void* y, int dtype, co
         if (h2_ok && !prefer_split) {
             if (dry) return P3D_OK;
             dim3 grid(((h + QH - 1) / QH) * ((wdt + QW - 1) / QW), co / BN, n_img);
-            hipLaunchKernelGGL(conv3x3_h2_f16_kernel, grid, dim3(256), 0, s, a);
+            hipLaunchKernelGGL(conv3x3_h2_f16_kernel<false>, grid, dim3(256), 0, s, a);
             count_launch(FAM_CONV);
             return check_launch("conv3x3_h2_f16");
         }

@@ -1,6 +1,8 @@
 """Super-resolution heads: two StyleGAN2 synthesis blocks that lift the 128^2 (or 64^2) neural rendering to the
 output resolution.  Mirror of training/superresolution.py (line refs are to that file); same class and
 parameter names."""
+import os
+
 import torch
 
 from ..torch_utils import persistence
@@ -16,6 +18,9 @@ class SynthesisBlockNoUp(SynthesisBlock):
         super().__init__(in_channels, out_channels, w_dim, resolution, img_channels, is_last, **kwargs)
         if in_channels != 0:
             self.conv0.up = 1                      # same weights/shapes as the x2 layer, no resampling
+
+
+skip_dead_x = os.environ.get('P3D_SR_SKIP_DEAD_X', '1') != '0'      # the last block's activations are not stored when only its fused ToRGB reads them (0: A/B runs)
 
 
 class _SuperresolutionBase(torch.nn.Module):
@@ -39,7 +44,7 @@ class _SuperresolutionBase(torch.nn.Module):
             # block1's x is returned to nobody (:297-354 of the reference return rgb only): unless somebody hooked the block to look at it, its last
             # layer need not store it (networks_stylegan2.SynthesisBlock.forward: _x_dead)
             hooked = bool(torch.nn.modules.module._global_forward_hooks or self.block1._forward_hooks)
-            x, rgb = self.block1(x, rgb, ws, _x_dead=not hooked, **block_kwargs)
+            x, rgb = self.block1(x, rgb, ws, _x_dead=skip_dead_x and not hooked, **block_kwargs)
         finally:
             if planned:
                 finish_prefetch(ws.device)

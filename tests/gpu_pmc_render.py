@@ -127,9 +127,13 @@ BUSY_OF = {   # resource -> (counter, busy-cycle scale, peak units per second, u
 
 
 def main():
-    out_root = os.path.join(ROOT, 'gpurun_out', 'rpmc' + ('_exact' if os.environ.get('P3D_MLP_BF16X3', '1') == '0' else ''))
+    dataset = os.environ.get('P3D_PMC_DATASET', 'seg2cat')         # another BASELINE configuration's launch (tests/gpu_profile_render.py): file names get the suffix
+    only = os.environ.get('P3D_PMC_GROUPS')                         # e.g. "0,1,2,3,4": a subset of the passes
+    out_root = os.path.join(ROOT, 'gpurun_out', 'rpmc' + ('_exact' if os.environ.get('P3D_MLP_BF16X3', '1') == '0' else '') + ('' if dataset == 'seg2cat' else '_' + dataset))
     counters, ms, errors = {}, {}, {}
     for i, grp in enumerate(GROUPS):
+        if only and str(i) not in only.split(','):
+            continue
         vals, dur, err = one_pass(i, grp, out_root)
         if vals is None:
             errors[' '.join(grp)] = err
@@ -140,7 +144,9 @@ def main():
     derived, best = derive(counters, ms)
     rec = {
         'kernel': 'p3d::render_forward_kernel<2, false, false, true> (bf16x3 decoder)' if os.environ.get('P3D_MLP_BF16X3', '1') != '0' else 'p3d::render_forward_kernel<2, false> (exact fp32 decoder)',
-        'workload': "bench.py's: seg2cat generator, 4 img x 128^2 rays x 64+64 samples on the backbone's own 256^2 x 96 channels-last planes (tests/gpu_profile_render.py)",
+        'workload': ("bench.py's: seg2cat generator, 4 img x 128^2 rays x 64+64 samples" if dataset == 'seg2cat' else
+                     f"BASELINE configs[3] per GPU: {dataset} generator, 8 img x 64^2 rays x 64+64 samples (white background, sigmoid labels)")
+                    + " on the backbone's own 256^2 x 96 channels-last planes (tests/gpu_profile_render.py)",
         'source': 'rocprofv3 --kernel-trace --pmc <group>, one pass per group (tests/gpu_pmc_render.py); averages per launch of the kernel',
         'counters': counters, 'kernel_ms_in_pass': ms, 'derived': derived,
         'binding': None if best is None else {
@@ -154,7 +160,7 @@ def main():
         'kernel_src_sha16': kernel_source_hash(), 'errors': errors,
     }
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-    tag = '_exact_fp32' if os.environ.get('P3D_MLP_BF16X3', '1') == '0' else ''
+    tag = ('_exact_fp32' if os.environ.get('P3D_MLP_BF16X3', '1') == '0' else '') + ('' if dataset == 'seg2cat' else '_' + dataset)
     json.dump(rec, open(os.path.join(ROOT, 'gpurun_out', f'render_pmc{tag}.json'), 'w'), indent=1)
     with open(os.path.join(ROOT, 'gpurun_out', f'render_sq_pmc{tag}.txt'), 'w') as f:
         f.write(f"# {rec['kernel']}\n# {rec['workload']}\n# kernel sources sha16 {rec['kernel_src_sha16']}\n")

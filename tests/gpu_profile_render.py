@@ -14,7 +14,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pix2pix3d_amd import configs                                                              # noqa: E402
 from pix2pix3d_amd.training.volumetric_rendering import renderer as rmod                       # noqa: E402
 
-N, R, S = 4, 128, int(os.environ.get('S', 64))
+DATASET = os.environ.get('P3D_PMC_DATASET', 'seg2cat')        # edge2car: BASELINE configs[3] per GPU (batch 8, 64^2 rays x 64+64, white background, sigmoid labels)
+N = int(os.environ.get('P3D_PMC_BATCH', 8 if DATASET == 'edge2car' else 4))
+R, S = configs.dataset_info(DATASET)['nrr'], int(os.environ.get('S', 64))
 torch.manual_seed(0)
 if os.environ.get('PLANES', 'model') == 'random':
     from pix2pix3d_amd.training.triplane_cond import OSGDecoder_semantic_lateSeparate
@@ -26,7 +28,7 @@ if os.environ.get('PLANES', 'model') == 'random':
     opt = dict(depth_resolution=S, depth_resolution_importance=S, ray_start=2.25, ray_end=3.3, box_warp=1, disparity_space_sampling=False, clamp_mode='softplus')
 else:
     import bench
-    args = argparse.Namespace(dataset='seg2cat', depth=2 * S, batch=N)
+    args = argparse.Namespace(dataset=DATASET, depth=2 * S, batch=N)
     G, kw, info, ws, c = bench.build(args, 'cuda')
     G = G.cuda()
     ws, c = ws.cuda(), c.cuda()

@@ -424,6 +424,15 @@ def test_last_conv_and_torgb_in_one_launch(hip_lib, img_channels, in_ch, res):
     assert torch.equal(x1, x0)                                                 # same kernel, same K order
     # both contract fp16 activations with the modulated weights rounded to fp16 (as the reference's fp16 layer does); fp32 summation order differs
     assert rel_err(i1.cpu().numpy(), i0.cpu().numpy()) < 1e-5
+    # the form the super-resolution heads use for their last block (SynthesisBlock.forward(_x_dead=True)): x is returned to nobody, so the launch stores
+    # no activations at all — swapped MFMA operands, the ToRGB contracted straight from the accumulator registers (conv3x3_h2_f16_kernel<true>) —
+    # and the skip image must come out the same: the same fp16-rounded activations times the same fp16-rounded weights, another fp32 summation order
+    c0 = modconv.fused_torgb_calls
+    with torch.no_grad():
+        xd, idd = blk(x, img.clone(), ws, noise_mode='none', _x_dead=True)
+    assert xd is None and modconv.fused_torgb_calls == c0 + 1
+    assert rel_err(idd.cpu().numpy(), i1.cpu().numpy()) < 1e-5 and rel_err(idd.cpu().numpy(), i0.cpu().numpy()) < 1e-5
+    assert torch.isfinite(idd).all() and idd.shape == i1.shape
 
 
 @pytest.mark.parametrize('ci,co,h,w,n,noise,act,clamp', [
