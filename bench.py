@@ -135,6 +135,21 @@ def cpu_baseline(args, G_cpu, kw, info, ws, c):
                       f'faster of {all_threads} / {min(all_threads, 32)} threads ({t:.2f} s/img; host has {os.cpu_count()} logical cores)'}
 
 
+def mfma_real_data_ceiling():
+    """What an MFMA-only loop sustains on this part with the operands the SR heads multiply (profiles/round5_a_mfma_rate_probe.json, taken by
+    tools/probe_mfma_rate.py on csrc/probes/mfma_rate_probe.hip): the pipe issues every 32 cycles, the chip holds ~1.69 GHz instead of 2.4 — the ceiling of
+    ANY fp16 / bf16 kernel on non-zero data, printed beside the fractions of the quoted 2.5 PFLOP/s."""
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'round5_a_mfma_rate_probe.json')))
+        rows = [r for r in d['rows'] if r['data'] == 'sr_layer' and r['chains'] == 8 and r['waves_per_simd'] == 2 and r['iters'] >= 500 and r['blocks'] % 256 == 0]
+        tf = float(np.median([r['tflops'] for r in rows]))
+        return {'tflops': round(tf, 1), 'frac_of_2p5pf': round(tf / 2500.0, 3), 'clock_ghz': round(float(np.median([r['clock_ghz'] for r in rows])), 3),
+                'zero_operands_tflops': round(float(np.median([r['tflops'] for r in d['rows'] if r['data'] == 'zeros' and r['chains'] == 8])), 1),
+                'source': 'profiles/round5_a_mfma_rate_probe.json: MFMA-only loop in conv3x3_h2_f16_kernel\'s register blocking, operands distributed like the SR heads\' (DESIGN.md section 2.4)'}
+    except (OSError, KeyError, ValueError, IndexError):
+        return None
+
+
 def _kernel_source_hash():
     import hashlib
     h = hashlib.sha256()
@@ -207,7 +222,7 @@ def _finish_phase(st, ph):
     return flat.numel() * 4 if flat is not None else 0
 
 
-def train_iteration(st, timers, only=None):
+def train_iteration(st, timers, only=None, on_phase=None):
     """One iteration with EVERY phase of training_loop.py:487-543 (what the loop does on an iteration where both lazy regularisers fire), driven exactly
     as the loop drives them: zero_grad, requires_grad_(True), ``loss.accumulate_gradients(phase, batch, gen_z, gen_c, gain = interval, cur_nimg)``
     (pix2pix3d_amd/training/loss.py, the restatement of loss.py:509-1003 pinned by tests/test_loss_phases.py), requires_grad_(False), flat gradient
@@ -227,6 +242,8 @@ def train_iteration(st, timers, only=None):
             ph['module'].requires_grad_(False)
             sizes[ph['name']] = _finish_phase(st, ph)
         mark(ph['name'])
+        if on_phase is not None:
+            on_phase(ph['name'])
     with torch.no_grad():                                                  # G_ema (training_loop.py:545-557), beta for batch 4 x world / ema_kimg = batch * 10 / 32
         batch_size = st['batch']['image'].shape[0] * st['world']
         beta = 0.5 ** (batch_size / max(batch_size * 10 / 32 * 1000, 1e-8))
@@ -282,6 +299,55 @@ def train_roofline():
             'dominant': out[0] if out else None, 'next': out[1:]}
 
 
+def train_arithmetic_floor(st, args, phase_ms):
+    """One more (untimed) iteration with every native convolution logging its multiply-add FLOPs and arithmetic class, cut per phase: what the phase would
+    take if its matrix work ran at the quoted peaks — exact-fp32 MFMA 157.3 TFLOP/s, fp16 / bf16 MFMA 2.5 PFLOP/s (each bf16x3 product = three bf16 MFMAs) — and at
+    what the matrix pipe sustains on real operands (mfma_real_data_ceiling).  The decoder MLPs of the fused renderer (exact fp32 MFMA in training: forward, and
+    in the backward the recomputation + data gradient + weight gradient) are added from the sample counts; element-wise work, the gathers and the optimizer are
+    not arithmetic the matrix pipes do and are left out: a FLOOR, to read the measured phase times against."""
+    from pix2pix3d_amd import _lib
+    from pix2pix3d_amd.training.volumetric_rendering import renderer as rmod
+    cuts, log, fwd = {}, [], []
+    _lib.kernel_events['conv_flops'] = log
+    _lib.kernel_events['render_forward'] = fwd                        # one event pair per fused forward launch (inference and training forwards alike)
+    marks = [(0, dict(rmod.backward_calls), 0)]
+
+    def on_phase(name):
+        marks.append((len(log), dict(rmod.backward_calls), len(fwd)))
+        cuts[name] = (marks[-2], marks[-1])
+    try:
+        train_iteration(st, {}, on_phase=on_phase)
+        torch.cuda.synchronize()
+    finally:
+        _lib.kernel_events.pop('conv_flops', None)
+        _lib.kernel_events.pop('render_forward', None)
+    ceiling = mfma_real_data_ceiling()
+    ceil_tf = ceiling['tflops'] if ceiling else None
+    samples = args.batch * args.train_nrr * args.train_nrr * 96          # config 3: 48 + 48 samples per ray
+    out = {}
+    for name, ((i0, b0, l0), (i1, b1, l1)) in cuts.items():
+        fl = {'float32': 0.0, 'float16': 0.0, 'bf16x3': 0.0}
+        for d, f in log[i0:i1]:
+            key = 'bf16x3' if d == 'bf16x3' else ('float16' if 'float16' in d else 'float32')
+            fl[key] += f
+        n_bwd = b1.get('fused', 0) - b0.get('fused', 0)
+        n_fwd = l1 - l0                                                  # (the density regularisation's point queries are 2 x 1000 points per image: not counted)
+        mlp = samples * MLP_FLOP_PER_SAMPLE * (COARSE_FACTOR * n_fwd + 3.0 * n_bwd)
+        f32 = fl['float32'] + mlp
+        half = fl['float16'] + 3.0 * fl['bf16x3']
+        floor_ms = (f32 / (F32_MFMA_PEAK_TF * 1e12) + half / 2.5e15) * 1e3
+        rec = {'tflop': {'f32_convs': round(fl['float32'] / 1e12, 3), 'f32_decoder_mlps': round(mlp / 1e12, 3), 'f16_convs': round(fl['float16'] / 1e12, 3),
+                         'bf16x3_convs_fp32_equivalent': round(fl['bf16x3'] / 1e12, 3)},
+               'floor_ms_at_quoted_peaks': round(floor_ms, 2), 'measured_ms': phase_ms.get(name),
+               'measured_over_floor': round(phase_ms[name] / floor_ms, 2) if phase_ms.get(name) and floor_ms > 0 else None}
+        if ceil_tf:
+            rec['floor_ms_half_precision_at_real_data_ceiling'] = round((f32 / (F32_MFMA_PEAK_TF * 1e12) + half / (ceil_tf * 1e12)) * 1e3, 2)
+        out[name] = rec
+    return {'what': 'matrix-pipe floor per phase: FLOPs of every native convolution (forward, data gradient, weight gradient) and of the renderer\'s decoder MLPs by arithmetic '
+                    'class / the pipe\'s rate for that class; exact fp32 MFMA 157.3 TFLOP/s, fp16 / bf16 MFMA 2.5 PFLOP/s quoted (' + (f'{ceil_tf:.0f} TFLOP/s on real operands' if ceil_tf else 'no probe record') + ')',
+            'phases': out}
+
+
 def run_train(args, device, world, dist, iters, warm):
     st = train_setup(args, device, world)
     timers = {}
@@ -305,6 +371,10 @@ def run_train(args, device, world, dist, iters, warm):
         elapsed = float(t.item())
     summary = train_summary(timers, sizes, world, args.batch, elapsed / iters * 1e3)
     summary['roofline'] = train_roofline()
+    try:
+        summary['arithmetic_floor'] = train_arithmetic_floor(st, args, summary['phase_ms'])
+    except Exception as e:                                           # noqa: BLE001 - an accounting extra must not cost the line
+        summary['arithmetic_floor'] = {'error': f'{type(e).__name__}: {e}'[:200]}
     if world > 1:                                                        # the exchange alone: one more all-reduce of each flat vector, timed
         from pix2pix3d_amd import dp
         bus = {}
@@ -630,6 +700,10 @@ def main():
                 _tp.train_products_bf16x3 = prev_tp
 
     if rank == 0:
+        ceiling = mfma_real_data_ceiling()
+        if ceiling:                                                  # the same classes against what the pipe can do on real data at the clock it then holds
+            ceiling['frac_of_it'] = {k: (round(v['tflops'] * (3.0 if k == 'conv_bf16x3' else 1.0) / ceiling['tflops'], 3) if v.get('tflops') else None)
+                                     for k, v in main_m['mfma_conv'].items() if k != 'conv_f32'}
         bb = ('f32 tensors + f32 accumulation; the backbone convolutions (3x3 and the 1x1 ToRGB) form each product as 3 bf16 MFMAs of (hi, lo) splits ("bf16x3", <= 5e-6 of the '
               'output range vs fp64 per layer; P3D_BF16X3=0 = exact f32 MFMA, timed as `exact_fp32`)') if _mc.split_bf16 else 'f32 (exact f32 MFMA)'
         rm = 'f32 gather / sampling / compositing, decoder MLPs as bf16x3 (P3D_MLP_BF16X3=0 = exact f32 MFMA)' if rmod.mlp_bf16x3 else 'f32'
@@ -652,6 +726,7 @@ def main():
             'conv_tflops': round(FLOP_PER_IMG * args.batch / ((stage_ms['backbone'] + stage_ms['sr']) * 1e-3) / 1e12, 2) if stage_ms['backbone'] + stage_ms['sr'] > 0 else None,
             'roofline': roofline(main_m, bool(rmod.mlp_bf16x3)),
             'mfma_conv': main_m['mfma_conv'],
+            'mfma_real_data_ceiling': ceiling,
             'exact_fp32': exact,
             'configs': other,
             'cpu_baseline': cpu,

@@ -201,6 +201,9 @@ def _native_conv(x, w, cfg, k, stride):
                                          _lib.ptr(work), nbytes, _lib.stream_of(x))
     _lib.check(code, 'conv2d_forward')
     native_calls['forward'] += 1
+    log = _lib.kernel_events.get('conv_flops')               # bench.py's arithmetic floor: (arithmetic class, multiply-add FLOPs) of every native convolution
+    if log is not None:
+        log.append(('bf16x3' if code_dtype == 3 else str(x.dtype), 2.0 * n * ci * co * k * k * (h * wd if (tr and stride == 2) else oh * ow)))
     return y
 
 
@@ -241,6 +244,9 @@ def _native_weight_grad(grad_output, x, cfg, k, stride, scale=None):
                                                        k, stride, cfg.padding[0], float(scale), _lib.stream_of(gw))
     _lib.check(code, 'conv2d_bwd_weight')
     native_calls['weight_grad'] += 1
+    log = _lib.kernel_events.get('conv_flops')
+    if log is not None:
+        log.append((str(x.dtype), 2.0 * n * cs * cb * k * k * hs * ws_))
     return gw
 
 
