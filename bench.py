@@ -397,14 +397,14 @@ def run_train(args, device, world, dist, iters, warm):
 XGMI_LINKS, XGMI_LINK_GBS = 7, 153.0                # per GPU: 7 point-to-point links x ~153 GB/s (MI355X_MICROARCH.md / the task statement)
 
 
-def collective_info(dist, world, rank, device, sizes=(336402180, 125438976), reps=5):
+def collective_info(dist, world, rank, device, sizes=(336402180, 125438976), reps=5, strict=True):
     """N > 1 only: what the collective library saw, so that a multi-GPU line is self-evidencing — backend and RCCL version, every rank's device
     (index, name, PCI bus id: N distinct devices or the line is not a scaling measurement), the environment knobs that change the transport
     (the reference's scripts export NCCL_P2P_DISABLE=1, train_scripts/afhq_seg.sh:2: refused here, it would take the exchange off xGMI), and the flat
     fp32 all-reduce ALONE at the two message sizes of the training phases (G: 336 MB, D / D_semantic: 125 MB) with its bus bandwidth
     (2 (N-1)/N x bytes / time) next to the xGMI figures."""
     p2p_off = os.environ.get('NCCL_P2P_DISABLE', '0').strip()
-    assert p2p_off in ('', '0'), 'NCCL_P2P_DISABLE is set: RCCL would route the gradient exchange through host memory instead of xGMI (unset it; the reference scripts set it for their own hardware)'
+    assert not strict or p2p_off in ('', '0'), 'NCCL_P2P_DISABLE is set: RCCL would route the gradient exchange through host memory instead of xGMI (unset it; the reference scripts set it for their own hardware)'
     from pix2pix3d_amd import dp
     backend = dist.get_backend()
     props = torch.cuda.get_device_properties(device)
@@ -434,7 +434,8 @@ def collective_info(dist, world, rank, device, sizes=(336402180, 125438976), rep
         ms = float(t.item())
         timed[str(nbytes)] = {'ms': round(ms, 3), 'bus_GBps': round(2 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 1)}
         del flat
-    return {'backend': backend + (' (= RCCL on ROCm)' if backend == 'nccl' else ' (staged through host memory: the one-GPU test configuration, not a measurement)'),
+    return {'p2p_disabled': p2p_off not in ('', '0'),
+            'backend': backend + (' (= RCCL on ROCm)' if backend == 'nccl' else ' (staged through host memory: the one-GPU test configuration, not a measurement)'),
             'version': version, 'ranks': world, 'devices': devices, 'distinct_devices': len({(d['host'], d['pci_bus_id'], d['device_index']) for d in devices}),
             'env': {k: os.environ.get(k) for k in ('NCCL_P2P_DISABLE', 'NCCL_DEBUG', 'NCCL_ALGO', 'NCCL_PROTO', 'NCCL_IB_DISABLE', 'NCCL_SOCKET_IFNAME', 'RCCL_MSCCL_ENABLE',
                                                    'HSA_ENABLE_IPC_MODE_LEGACY', 'HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES')},
@@ -466,7 +467,17 @@ def main():
     rmod.fused_policy = 'require'
     torch.backends.cudnn.benchmark = bool(args.miopen_find)         # training_loop.py:280 sets True; find-mode costs ~100 s of warm-up per fresh box
 
-    rccl = collective_info(dist, world, rank, device) if world > 1 else None
+    rccl = None
+    if world > 1:
+        # the training exchange must run over xGMI (strict: refuses NCCL_P2P_DISABLE); the inference line has no data-path collective, so there the switch is
+        # recorded (rccl.p2p_disabled) instead of refused, and nothing in this object may cost the line itself
+        if args.train_step:
+            rccl = collective_info(dist, world, rank, device, strict=True)
+        else:
+            try:
+                rccl = collective_info(dist, world, rank, device, strict=False)
+            except Exception as e:                                   # noqa: BLE001
+                rccl = {'error': f'{type(e).__name__}: {e}'[:300]}
 
     if args.train_step:                                              # BASELINE config 3 as the timed workload
         summary, elapsed = run_train(args, device, world, dist, args.steps, max(args.warmup, 1))

@@ -472,6 +472,9 @@ int p3d_noise_bias_act(const float* x, float* y, const float* noise, const float
  * directions unit length (norm clamped at 1e-12 like F.normalize).                                                        */
 int p3d_ray_sample(const float* cam2world, const float* intrinsics, float* origins, float* dirs, int32_t n_cam, int32_t resolution,
                    p3d_stream_t stream);
+/* The same straight from the 25-float camera labels the generators take (training/triplane.py:57-60: c[:, :16] is cam2world, c[:, 16:25] the
+ * intrinsics): labels [n_cam][label_stride] fp32, label_stride >= 25 floats between rows — no contiguous copies of the two slices.       */
+int p3d_ray_sample_labels(const float* labels, int64_t label_stride, float* origins, float* dirs, int32_t n_cam, int32_t resolution, p3d_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -220,15 +220,15 @@ __global__ void __launch_bounds__(256) noise_bias_act_kernel(const float* __rest
 // Pixel (row i, col j) -> image coords ((j+.5)/R, (i+.5)/R) -> camera-frame point at z = 1 (OpenCV intrinsics with skew)
 // -> world space through cam2world -> unit direction from the camera origin.  Same operation order as the tensor-op form.
 __global__ void __launch_bounds__(256) ray_sample_kernel(const float* __restrict__ c2w, const float* __restrict__ intr, float* __restrict__ origins,
-                                                         float* __restrict__ dirs, int N, int R)
+                                                         float* __restrict__ dirs, int N, int R, int64_t c2w_stride, int64_t intr_stride)
 {
     const int M = R * R;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= N * M) return;
     const int n = e / M, m = e - n * M;
     const int i = m / R, j = m - i * R;
-    const float* K = intr + n * 9;
-    const float* C = c2w + n * 16;
+    const float* K = intr + n * intr_stride;
+    const float* C = c2w + n * c2w_stride;
     const float fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
     const float inv = 1.f / (float)R, half = 0.5f / (float)R;
     const float x_img = (float)j * inv + half, y_img = (float)i * inv + half;
@@ -258,9 +258,21 @@ extern "C" int p3d_ray_sample(const float* cam2world, const float* intrinsics, f
     P3D_REQUIRE(n_cam >= 1 && resolution >= 1 && (int64_t)n_cam * resolution * resolution < (1ll << 31), "ray_sample: bad sizes");
     const int total = n_cam * resolution * resolution;
     hipLaunchKernelGGL(ray_sample_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, cam2world, intrinsics, origins, dirs,
-                       n_cam, resolution);
+                       n_cam, resolution, (int64_t)16, (int64_t)9);
     count_launch(FAM_AUX);
     return check_launch("ray_sample");
+}
+
+extern "C" int p3d_ray_sample_labels(const float* labels, int64_t label_stride, float* origins, float* dirs, int32_t n_cam, int32_t resolution, p3d_stream_t stream)
+{
+    using namespace p3d;
+    P3D_REQUIRE(labels && origins && dirs, "ray_sample_labels: null pointer");
+    P3D_REQUIRE(n_cam >= 1 && resolution >= 1 && label_stride >= 25 && (int64_t)n_cam * resolution * resolution < (1ll << 31), "ray_sample_labels: bad sizes");
+    const int total = n_cam * resolution * resolution;
+    hipLaunchKernelGGL(ray_sample_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, labels, labels + 16, origins, dirs,
+                       n_cam, resolution, label_stride, label_stride);
+    count_launch(FAM_AUX);
+    return check_launch("ray_sample_labels");
 }
 
 extern "C" int p3d_fc_forward(const float* x, const float* w, const float* b, float* y, int32_t n_rows, int32_t in_features,

@@ -499,6 +499,15 @@ class SynthesisBlock(torch.nn.Module):
     def _entry_features(self, x, batch, dtype, fmt):
         """The block's input activations in its working dtype / layout: the learned constant for b4, else the previous block's x."""
         if self.in_channels == 0:
+            if self.const.is_cuda and not torch.is_grad_enabled():
+                # device inference: the batch of constants is the same tensor every pass — built once per (batch, dtype, layout, version of the parameter);
+                # nothing writes into a block's input in place (conv1 returns a new tensor), so the copy can be handed out again
+                key = (batch, dtype, fmt, self.const._version, self.const.data_ptr())
+                hit = getattr(self, '_const_batch', None)
+                if hit is None or hit[0] != key:
+                    hit = (key, self.const.detach().to(dtype=dtype).unsqueeze(0).repeat([batch, 1, 1, 1]).contiguous(memory_format=fmt))
+                    object.__setattr__(self, '_const_batch', hit)
+                return hit[1]
             return self.const.to(dtype=dtype).unsqueeze(0).repeat([batch, 1, 1, 1]).contiguous(memory_format=fmt)
         in_res = self.resolution // self._in_div
         misc.assert_shape(x, [None, self.in_channels, in_res, in_res])

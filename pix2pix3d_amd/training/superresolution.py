@@ -36,7 +36,10 @@ class _SuperresolutionBase(torch.nn.Module):
         return rgb, x
 
     def forward(self, rgb, x, ws, **block_kwargs):
-        ws = ws[:, -1:, :].repeat(1, 3, 1)
+        if ws.is_cuda and not torch.is_grad_enabled():
+            ws = ws[:, -1:, :].expand(-1, 3, -1)                  # device inference: the three layers read the SAME row in place (a stride-0 view; repeat() is three launches per head)
+        else:
+            ws = ws[:, -1:, :].repeat(1, 3, 1)
         rgb, x = self._prep(rgb, x)
         planned = prefetch_styles([self.block0, self.block1], [ws, ws], block_kwargs)
         try:

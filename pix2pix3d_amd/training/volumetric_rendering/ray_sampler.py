@@ -6,6 +6,7 @@ import torch
 from ... import _lib
 
 _lib.register('p3d_ray_sample', ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int32] * 2 + [ctypes.c_void_p])
+_lib.register('p3d_ray_sample_labels', ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 2 + [ctypes.c_void_p])
 native = True        # device inference: one launch instead of ~20 tensor ops (csrc/small_ops.hip)
 
 
@@ -23,9 +24,15 @@ class RaySampler(torch.nn.Module):
         r = int(resolution)
         if native and cam2world_matrix.is_cuda and cam2world_matrix.dtype == torch.float32 and intrinsics.dtype == torch.float32 \
                 and not (torch.is_grad_enabled() and (cam2world_matrix.requires_grad or intrinsics.requires_grad)):
-            c2w, k = cam2world_matrix.detach().contiguous(), intrinsics.detach().contiguous()
             origins = torch.empty([n, r * r, 3], dtype=torch.float32, device=dev)
             dirs = torch.empty_like(origins)
+            c2w0, k0 = cam2world_matrix.detach(), intrinsics.detach()
+            if (c2w0.stride() == (c2w0.stride(0), 4, 1) and k0.stride() == (c2w0.stride(0), 3, 1) and c2w0.stride(0) >= 25 and c2w0.untyped_storage().data_ptr() == k0.untyped_storage().data_ptr()
+                    and k0.storage_offset() == c2w0.storage_offset() + 16):
+                # the two views of ONE [N, >= 25] camera-label tensor (triplane.py: c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3)): read in place
+                _lib.check(_lib.lib().p3d_ray_sample_labels(_lib.ptr(c2w0), c2w0.stride(0), _lib.ptr(origins), _lib.ptr(dirs), n, r, _lib.stream_of(origins)), 'ray_sample_labels')
+                return origins, dirs
+            c2w, k = c2w0.contiguous(), k0.contiguous()
             _lib.check(_lib.lib().p3d_ray_sample(_lib.ptr(c2w), _lib.ptr(k), _lib.ptr(origins), _lib.ptr(dirs), n, r, _lib.stream_of(origins)), 'ray_sample')
             return origins, dirs
         fx, fy = intrinsics[:, 0, 0, None], intrinsics[:, 1, 1, None]
