@@ -4,7 +4,7 @@ import csv, glob, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = '/tmp/step_trace'
 cmd = ['rocprofv3', '--kernel-trace', '--output-format', 'csv', '-d', out_dir, '-o', 't', '--', sys.executable, os.path.join(ROOT, 'bench.py'),
-       '--no-cpu-baseline', '--no-train-step', '--no-exact-fp32', '--steps', '4', '--warmup', '2'] + sys.argv[1:]
+       '--no-cpu-baseline', '--no-train-step', '--no-exact-fp32', '--no-configs', '--steps', '4', '--warmup', '2'] + sys.argv[1:]
 subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=400)
 rows = []
 for f in glob.glob(os.path.join(out_dir, '**', '*kernel_trace.csv'), recursive=True):
