@@ -339,6 +339,14 @@ int p3d_conv2d_nhwc_scaled(const void* x, const void* w, void* y, int dtype, con
                            const float* noise_strength, const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co,
                            int64_t w_img_stride, int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, void* workspace,
                            int64_t workspace_bytes, p3d_stream_t stream);
+/* ... and with the style modulation of that form applied on the way INTO the matrix cores: in_scale fp32 [N][Ci] multiplies every activation as it is
+ * split for the MFMAs (the same fp32 product `x * styles` a separate pass would have stored: results are bit-identical to p3d_bcast_fma followed by
+ * p3d_conv2d_nhwc_scaled), so the low-resolution layers lose one launch each.  dtype P3D_F32_BF16X3 only; P3D_ERR_UNSUPPORTED when the images one
+ * 128-row tile touches times Ci exceed the kernel's 2048-float table (the caller then scales x itself).                                          */
+int p3d_conv2d_nhwc_scaled_in(const void* x, const void* w, void* y, int dtype, const float* in_scale, const float* out_scale, const float* bias,
+                              const float* noise, const float* noise_strength, const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci,
+                              int32_t co, int64_t w_img_stride, int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp,
+                              void* workspace, int64_t workspace_bytes, p3d_stream_t stream);
 /* Activations that stay split between the bf16x3 layers of an inference pass (training/networks_stylegan2.py:436-459: conv0 -> conv1 -> ToRGB /
  * the next block, each a modulated_conv2d :26-105 whose fp32 products this library forms as three bf16 MFMAs).  x_split != 0: x is NOT fp32 but,
  * per pixel and 32 channels, [32 x bf16 hi | 32 x bf16 lo] in the same 128 bytes (hi = bf16(v), lo = bf16(v - hi): exactly what the kernels

@@ -92,9 +92,14 @@ struct ConvArgs {
     float rgb_clamp;       // on (sum + bias) before the accumulation; < 0: off
     const float* oscale;   // [N][Co] or null (generic kernel, fp32 tensors): the accumulator is multiplied by oscale[image][channel] before the
                            // rest of the epilogue — the demodulation coefficient of the SHARED-weight form of the modulated convolution
+    const float* iscale;   // [N][Ci] or null (generic kernel, bf16x3 on plain fp32 activations: conv2d_nhwc_kernel<float, true, false, false, true>): every activation is
+                           // multiplied by iscale[image][channel] on its way from LDS into the MFMA fragments — the style modulation of the SHARED-weight form
+                           // (networks_stylegan2.py:70-79: x * styles), without a pass over x of its own
     int y_split;           // != 0 (conv3x3_halo_kernel<float, true, .>): y leaves in the bf16x3 K-row layout — per 32 channels [32 x bf16 hi | 32 x bf16 lo],
                            // the same 128 bytes as 32 floats — which the next bf16x3 layer reads without splitting anything (XS below)
 };
+
+static thread_local const float* tl_in_scale = nullptr;      // ConvArgs::iscale of the call in flight on this thread (p3d_conv2d_nhwc_scaled_in)
 
 // 16-B slot of (row, chunk).  Two 128-byte tile rows share one 256-byte LDS bank row, so the XOR key is (row >> 1) & 7:
 // the 16 rows a ds_read_b128 lane group touches then land on 16 distinct slots (row & 7 would leave a 2-way conflict).
@@ -111,9 +116,13 @@ template <> struct ConvTraits<float>  { static constexpr int BK = 32; };
 // CO64: the launch has at most 64 output channels (one column block, half of its weight tile zeros).  The four waves then take 32 GEMM rows each against both
 // 32-column tiles instead of a 64 x 64 quadrant each — two of which would multiply the zero half (the 128 -> 64 channel transposed convolutions of the
 // discriminators' data gradient ran at 47 TFLOP/s in fp32 where their 128-column neighbours run at 90).
-template <class T, bool BF3 = false, bool XS = false, bool CO64 = false>
+// ISC: ConvArgs::iscale.  The scales a tile can need — its image's row, or with the batch folded into the GEMM rows the rows of the (few) images its 128 GEMM rows
+// belong to — sit in an 8 KB LDS table (host: images per tile x Ci <= kIscaleFloats), read 32 bytes per fragment piece next to the activation itself.
+constexpr int kIscaleFloats = 2048;
+template <class T, bool BF3 = false, bool XS = false, bool CO64 = false, bool ISC = false>
 __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
 {
+    static_assert(!ISC || (BF3 && !XS && !CO64), "the input scale rides on the in-register split of plain fp32 activations");
     static_assert(!BF3 || sizeof(T) == 4, "bf16x3 is a formulation of the fp32 convolution");
     static_assert(!XS || BF3, "pre-split activations are the bf16x3 kernels' input format");
     constexpr int BK = ConvTraits<T>::BK;
@@ -207,6 +216,19 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
     if (s_begin < s_end) stage(cc, t, 0);
     __syncthreads();
     const int frow = lane & 31, fk = lane >> 5;                                 // fragment row / k-group of this lane
+    __shared__ __attribute__((aligned(16))) float isc_tab[ISC ? kIscaleFloats : 4];
+    int isc_off[2] = {0, 0};                                                    // table offset of the image of this lane's fragment rows (i = 0, 1)
+    if constexpr (ISC) {
+        const int img0 = a.fold ? m0 / MI : n;
+        const int img1 = a.fold ? min((min(m0 + BM, M) - 1) / MI, a.N - 1) : n;
+        for (int e = tid; e < (img1 - img0 + 1) * a.Ci; e += 256) isc_tab[e] = a.iscale[(int64_t)img0 * a.Ci + e];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = min(m0 + rbase + i * 32 + frow, M - 1);
+            isc_off[i] = (a.fold ? m / MI - img0 : 0) * a.Ci + 8 * fk;
+        }
+        __syncthreads();
+    }
     int pa[NI][4], pb[2][4];                                                    // fragment slots of this lane (buffer 0)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -217,6 +239,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
         }
     int buf = 0;
     for (int s = s_begin; s < s_end; ++s) {
+            const int cc_cur = cc;                                              // the channel chunk of THIS step's tile (ISC)
             {                                                                   // next tile streams into the other buffer under the MFMAs
                 if (++t == ntaps) { t = 0; ++cc; }
                 if (s + 1 < s_end) stage(cc, t, buf ^ 1);
@@ -231,6 +254,11 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
                         if constexpr (XS) {
                             ah[i] = __builtin_bit_cast(bf8, lds[buf][0][swz(ra, 2 * m + fk)]);
                             al[i] = __builtin_bit_cast(bf8, lds[buf][0][swz(ra, 4 + 2 * m + fk)]);
+                        } else if constexpr (ISC) {                             // x * styles in registers: the same fp32 product scale_input() would have stored
+                            const float* sp = isc_tab + isc_off[i] + cc_cur * 32 + 16 * m;
+                            f32x4 p0 = lds[buf][0][swz(ra, 4 * m + 2 * fk)] * *(const f32x4*)sp, p1 = lds[buf][0][swz(ra, 4 * m + 2 * fk + 1)] * *(const f32x4*)(sp + 4);
+                            asm volatile("" : "+v"(p0), "+v"(p1));              // the ROUNDED product is what gets split (no contraction into the split's subtraction)
+                            split_bf16x8(p0, p1, ah[i], al[i]);
                         } else
                         split_bf16x8(lds[buf][0][swz(ra, 4 * m + 2 * fk)], lds[buf][0][swz(ra, 4 * m + 2 * fk + 1)], ah[i], al[i]);
                         bh[i] = __builtin_bit_cast(bf8, lds[buf][1][swz(rb, 2 * m + fk)]);          // weight row = [32 hi | 32 lo] bf16
@@ -1542,10 +1570,25 @@ static int launch_conv(ConvArgs& a, int dtype, hipStream_t s, void* workspace, i
     dim3 grid(gx, gy, z * a.ksplit);
     static const bool no_co64 = getenv("P3D_CONV_NO_CO64") != nullptr;          // (A/B switch of the measurement scripts)
     const bool co64 = !no_co64 && a.Co <= 64;
+    if (a.iscale) {                                                             // the table of conv2d_nhwc_kernel<.., ISC>: the scale rows of every image a 128-row tile touches
+        if (dtype != P3D_F32_BF16X3 || x_split) return fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc: the input scale is implemented for bf16x3 on plain fp32 activations");
+        int worst = 1;
+        if (a.fold) {
+            const int MI = a.cls[0].SH * a.cls[0].SW;
+            for (int tile = 0; tile < gx; ++tile) {
+                const int m0 = tile * BM, m1 = (m0 + BM < M ? m0 + BM : M) - 1;
+                int i1 = m1 / MI; if (i1 > a.N - 1) i1 = a.N - 1;
+                const int cnt = i1 - m0 / MI + 1;
+                if (cnt > worst) worst = cnt;
+            }
+        }
+        if ((int64_t)worst * a.Ci > kIscaleFloats) return fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc: %d images x %d channels of input scales exceed the kernel's table", worst, a.Ci);
+    }
     if (dtype == P3D_F16 && co64)     hipLaunchKernelGGL((conv2d_nhwc_kernel<__half, false, false, true>), grid, dim3(256), 0, s, a);
     else if (dtype == P3D_F32 && co64) hipLaunchKernelGGL((conv2d_nhwc_kernel<float, false, false, true>), grid, dim3(256), 0, s, a);
     else if (dtype == P3D_F16)        hipLaunchKernelGGL(conv2d_nhwc_kernel<__half>, grid, dim3(256), 0, s, a);
     else if (dtype == P3D_F32_BF16X3 && x_split) hipLaunchKernelGGL((conv2d_nhwc_kernel<float, true, true>), grid, dim3(256), 0, s, a);
+    else if (dtype == P3D_F32_BF16X3 && a.iscale) hipLaunchKernelGGL((conv2d_nhwc_kernel<float, true, false, false, true>), grid, dim3(256), 0, s, a);
     else if (dtype == P3D_F32_BF16X3) hipLaunchKernelGGL((conv2d_nhwc_kernel<float, true>), grid, dim3(256), 0, s, a);
     else                              hipLaunchKernelGGL(conv2d_nhwc_kernel<float>, grid, dim3(256), 0, s, a);
     count_launch(FAM_CONV);
@@ -1637,6 +1680,22 @@ extern "C" int p3d_conv2d_nhwc_scaled(const void* x, const void* w, void* y, int
                                 0, 0, workspace, workspace_bytes, nullptr, out_scale, stream);
 }
 
+extern "C" int p3d_conv2d_nhwc_scaled_in(const void* x, const void* w, void* y, int dtype, const float* in_scale, const float* out_scale, const float* bias,
+                                         const float* noise, const float* noise_strength, const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci,
+                                         int32_t co, int64_t w_img_stride, int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp,
+                                         void* workspace, int64_t workspace_bytes, p3d_stream_t stream)
+{
+    using namespace p3d;
+    P3D_REQUIRE(in_scale && out_scale, "conv2d_nhwc_scaled_in: both scales are required (the shared-weight form of the modulated convolution)");
+    if (dtype != P3D_F32_BF16X3) return fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc_scaled_in: implemented for dtype P3D_F32_BF16X3");
+    P3D_REQUIRE((((uintptr_t)in_scale) & 15u) == 0, "conv2d_nhwc_scaled_in: in_scale must be 16-byte aligned");
+    tl_in_scale = in_scale;
+    const int rc = conv2d_nhwc_run(x, w, y, dtype, bias, noise, noise_strength, zeros128, n_img, h, wdt, ci, co, w_img_stride, kernel_size, resample, act, gain, clamp,
+                                   0, 0, workspace, workspace_bytes, nullptr, out_scale, stream);
+    tl_in_scale = nullptr;
+    return rc;
+}
+
 extern "C" int64_t p3d_conv2d_nhwc_workspace(int dtype, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride, int32_t kernel_size,
                                              int32_t resample)
 {
@@ -1687,6 +1746,7 @@ int p3d::conv2d_nhwc_run_io(const void* x, const void* w, void* y, int dtype, co
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.noise = noise; a.noise_strength = noise_strength; a.zeros = zeros128;
     a.N = n_img; a.H = h; a.W = wdt; a.Ci = ci; a.Co = co; a.KT = kernel_size * kernel_size; a.w_img_stride = w_img_stride;
     a.act = act; a.gain = gain; a.clamp = clamp; a.isy = a.isx = 1; a.oscale = out_scale;
+    a.iscale = tl_in_scale;                                          // (set by p3d_conv2d_nhwc_scaled_in for the duration of its call)
     hipStream_t s = (hipStream_t)stream;
     if (down2) {                                                     // valid (unpadded) correlation at stride 2: conv2d_resample.py:108-111 after its FIR
         P3D_REQUIRE(h >= kernel_size && wdt >= kernel_size, "conv2d_nhwc: image smaller than the kernel");
@@ -1707,7 +1767,7 @@ int p3d::conv2d_nhwc_run_io(const void* x, const void* w, void* y, int dtype, co
         // no scratch); a 512-channel layer at 16^2 / 32^2 is 32 / 128 work-groups with a 144-step K loop — that goes to the generic
         // kernel with its K steps dealt out
         const bool h2_ok = !no_h2 && !no_halo && kernel_size == 3 && dtype == P3D_F16 && h >= 32 && wdt >= 32 && ci % 64 == 0 && co % BN == 0 && (((uintptr_t)y) & 15u) == 0;
-        const bool halo_ok = kernel_size == 3 && h >= PH && wdt >= PW && !no_halo && !out_scale;      // (the per-image output scale lives in the generic kernel's epilogue)
+        const bool halo_ok = kernel_size == 3 && h >= PH && wdt >= PW && !no_halo && !out_scale && !a.iscale;      // (the per-image scales live in the generic kernel)
         const int64_t own_blocks = h2_ok ? (int64_t)((h + QH - 1) / QH) * ((wdt + QW - 1) / QW) * (co / BN) * n_img
                                          : (int64_t)((h + PH - 1) / PH) * ((wdt + PW - 1) / PW) * ((co + BN - 1) / BN) * n_img;
         const bool have_ws = dry || (workspace != nullptr && workspace_bytes > 0);

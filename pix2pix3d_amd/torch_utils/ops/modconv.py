@@ -46,6 +46,7 @@ _lib.register('p3d_conv2d_nhwc_workspace', _i64, [ctypes.c_int] + [_i32] * 5 + [
 _lib.register('p3d_conv3x3_torgb_f16', ctypes.c_int, [_vp] * 8 + [_i32, _f32] + [_i32] * 5 + [ctypes.c_int64, _i32, _f32, _f32, _vp])
 _lib.register('p3d_conv2d_nhwc_scaled', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp] + [_i32] * 5 + [ctypes.c_int64] + [_i32] * 3 + [_f32, _f32, _vp, ctypes.c_int64, _vp])
 _lib.register('p3d_demod_coefs', ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp])
+_lib.register('p3d_conv2d_nhwc_scaled_in', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int] + [_vp] * 6 + [_i32] * 5 + [ctypes.c_int64, _i32, _i32, _i32, _f32, _f32, _vp, ctypes.c_int64, _vp])
 _lib.register('p3d_up2_fir_bf16x3', ctypes.c_int, [_vp] * 8 + [_i32] * 5 + [ctypes.c_int64, _f32, _i32, _f32, _f32, _vp])
 _lib.register('p3d_up2_fir_f16', ctypes.c_int, [_vp] * 8 + [_i32] * 5 + [ctypes.c_int64, _f32, _i32, _f32, _f32, _vp])
 _lib.register('p3d_fir4_bias_act_nhwc', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int] + [_i32] * 9 + [_f32, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _vp])
@@ -255,7 +256,11 @@ def _pad_channels(x, wmod, transposed=False):
     return xp, wp
 
 
-def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None, act=0, gain=1.0, clamp=-1.0, down=1, split=False, out_scale=None, out_split=False):
+fuse_input_scale = os.environ.get('P3D_FUSE_INPUT_SCALE', '1') != '0'      # shared-weight layers: x * styles inside the convolution kernel (p3d_conv2d_nhwc_scaled_in); 0 = a pass of its own
+
+
+def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None, act=0, gain=1.0, clamp=-1.0, down=1, split=False, out_scale=None, out_split=False,
+           in_scale=None):
     """x NHWC [N,Ci,H,W] (channels_last strides), wmod [N or 1][Co][k*k][Ci] of the same dtype -> NHWC, same dtype.
     k*k = 9: 3x3 "same" correlation, or (transposed) the stride-2 transposed conv [N,Co,2H+1,2W+1], or (down=2) the valid
     stride-2 correlation [N,Co,(H-3)//2+1,(W-3)//2+1]; k*k = 1: 1x1.
@@ -282,7 +287,17 @@ def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None
     nbytes = int(_lib.lib().p3d_conv2d_nhwc_workspace(code_dtype, n, h, w, ci, co, stride, k, mode))
     work = torch.empty([nbytes // 4], dtype=torch.float32, device=x.device) if nbytes > 0 else None          # split-K partial tiles (low-resolution layers)
     with _lib.kernel_timer('conv_bf16x3' if split else ('conv_f16' if x.dtype == torch.float16 else 'conv_f32'), x):
-        if out_scale is not None:                          # [N, Co] fp32 on the accumulator (shared-weight form: the demodulation coefficients)
+        code = None
+        if in_scale is not None:                           # [N, Ci] fp32 on the activations as they enter the matrix cores (shared-weight form: the styles)
+            assert out_scale is not None and split and tuple(in_scale.shape) == (n, ci) and in_scale.dtype == torch.float32 and in_scale.is_contiguous()
+            code = _lib.lib().p3d_conv2d_nhwc_scaled_in(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), code_dtype, _lib.ptr(in_scale), _lib.ptr(out_scale), _lib.ptr(b32), _lib.ptr(nz),
+                                                        _lib.ptr(ns), _lib.ptr(_zeros_page(x.device)), n, h, w, ci, co, stride, k, mode, int(act), float(gain), float(clamp),
+                                                        _lib.ptr(work), nbytes, _lib.stream_of(x))
+            if code == _lib.P3D_ERR_UNSUPPORTED:           # more scale rows per tile than the kernel's table holds: scale x in a pass of its own
+                x, code = scale_input(x, in_scale), None
+        if code is not None:
+            pass
+        elif out_scale is not None:                        # [N, Co] fp32 on the accumulator (shared-weight form: the demodulation coefficients)
             assert out_scale.dtype == torch.float32 and out_scale.is_contiguous() and tuple(out_scale.shape) == (n, co) and x.dtype == torch.float32
             code = _lib.lib().p3d_conv2d_nhwc_scaled(_lib.ptr(x), _lib.ptr(wmod), _lib.ptr(y), code_dtype, _lib.ptr(out_scale), _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns),
                                                      _lib.ptr(_zeros_page(x.device)), n, h, w, ci, co, stride, k, mode, int(act), float(gain), float(clamp),
@@ -582,13 +597,17 @@ def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=No
     clampv = -1.0 if clamp is None else float(clamp)
     if split and use_shared_weights(x, weight, styles):
         d = pre[0] if pre is not None and pre[1] == ('shared', up, BF16X3) else demod_coefs(weight, styles)
-        xs, wsh = scale_input(x, styles), shared_split_weights(weight)
+        wsh = shared_split_weights(weight)
+        if fuse_input_scale and x.shape[1] % 32 == 0:      # x * styles happens inside the convolution (bit-identical to the separate pass)
+            xs, isc = x, styles.detach().float().contiguous()
+        else:
+            xs, isc = scale_input(x, styles), None
         if up == 1 and act_idx is not None:
-            return conv2d(xs, wsh, bias=bias, noise=noise_const, noise_strength=noise_strength, act=act_idx, gain=act_gain, clamp=clampv, split=True, out_scale=d)
+            return conv2d(xs, wsh, bias=bias, noise=noise_const, noise_strength=noise_strength, act=act_idx, gain=act_gain, clamp=clampv, split=True, out_scale=d, in_scale=isc)
         if up == 1:
-            y = conv2d(xs, wsh, noise=noise_const, noise_strength=noise_strength, split=True, out_scale=d)
+            y = conv2d(xs, wsh, noise=noise_const, noise_strength=noise_strength, split=True, out_scale=d, in_scale=isc)
             return bias_act.bias_act(y, (None if bias is None else bias.to(y.dtype)), act=act, gain=act_gain, clamp=clamp)
-        y = conv2d(xs, wsh, transposed=True, split=True, out_scale=d)
+        y = conv2d(xs, wsh, transposed=True, split=True, out_scale=d, in_scale=isc)
         if act_idx is not None and tuple(resample_filter.shape) == (4, 4) and y.shape[1] % 32 == 0:
             return fir4_bias_act(y, resample_filter, bias, noise_const, noise_strength, act, act_gain, clampv, out_split=out_split)
         y = upfirdn2d.upfirdn2d(y, resample_filter, padding=[1, 1, 1, 1], gain=4)

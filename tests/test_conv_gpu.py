@@ -352,7 +352,8 @@ def test_style_affines_in_one_launch(hip_lib):
 
 
 @pytest.mark.parametrize('n,ci,co,res,up,act', [(4, 512, 512, 4, 1, 'lrelu'), (4, 512, 512, 4, 2, 'lrelu'), (4, 512, 512, 16, 1, 'lrelu'), (3, 256, 128, 32, 2, 'lrelu'),
-                                                (2, 64, 96, 8, 1, 'linear'), (4, 128, 64, 32, 1, 'lrelu'), (5, 96, 160, 12, 2, 'linear')])
+                                                (2, 64, 96, 8, 1, 'linear'), (4, 128, 64, 32, 1, 'lrelu'), (5, 96, 160, 12, 2, 'linear'),
+                                                (8, 512, 256, 4, 1, 'lrelu'), (4, 512, 512, 32, 2, 'lrelu'), (6, 160, 128, 6, 1, 'lrelu')])   # (8 x 512 scales per tile: the table overflows -> own pass)
 def test_shared_weight_form_of_the_low_resolution_layers(hip_lib, n, ci, co, res, up, act):
     """x * styles -> convolution with the UNMODULATED weights (batch folded into the GEMM rows) -> * demodulation coefficients
     (modconv.use_shared_weights) against the per-image-weights route and against fp64 torch: the same function, <= 1e-5 of the range."""
@@ -371,6 +372,14 @@ def test_shared_weight_form_of_the_low_resolution_layers(hip_lib, n, ci, co, res
         modconv.shared_weight_max_pixels = 1024
         assert modconv.use_shared_weights(x, weight, styles)
         y1 = modconv.synthesis_layer(x, weight, styles, bias, up, f, noise_const=nz, noise_strength=ns, act=act, act_gain=gain, clamp=None)
+        # x * styles inside the convolution kernel (p3d_conv2d_nhwc_scaled_in, the default) against the pass of its own it replaces: the same rounded
+        # fp32 product enters the same split and the same MFMAs -> bit-identical
+        prev_f, modconv.fuse_input_scale = modconv.fuse_input_scale, False
+        try:
+            y1_two = modconv.synthesis_layer(x, weight, styles, bias, up, f, noise_const=nz, noise_strength=ns, act=act, act_gain=gain, clamp=None)
+        finally:
+            modconv.fuse_input_scale = prev_f
+        assert prev_f and torch.equal(y1, y1_two)
         modconv.shared_weight_max_pixels = 0
         y0 = modconv.synthesis_layer(x, weight, styles, bias, up, f, noise_const=nz, noise_strength=ns, act=act, act_gain=gain, clamp=None)
     finally:
