@@ -373,6 +373,11 @@ int p3d_torgb_wide_split(const void* x_split, const void* wmod_split, const floa
                          int32_t n_img, int32_t h, int32_t w, int32_t ci, int32_t co, float clamp, p3d_stream_t stream);
 /* d[n][o] = rsqrt(sum_i styles[n][i]^2 * w2[o][i] + 1e-8) with w2[o][i] = sum over the taps of weight[o][i][.]^2 (networks_stylegan2.py:57-63) */
 int p3d_demod_coefs(const float* styles, const float* w2, float* d, int32_t n_rows, int32_t ci, int32_t co, p3d_stream_t stream);
+/* Several layers at once (one launch): job j writes d_j [n_rows][co_j] from styles_j [n_rows][ci_j] and w2_j [co_j][ci_j]; all jobs share n_rows.  The
+ * job array is HOST memory, copied into the kernel arguments.  Results are bit-identical to p3d_demod_coefs per job.                          */
+#define P3D_DEMOD_MAX_JOBS 24
+typedef struct p3d_demod_job { const float* styles; const float* w2; float* d; int32_t ci, co; } p3d_demod_job;
+int p3d_demod_coefs_multi(const p3d_demod_job* jobs_host, int32_t n_jobs, int32_t n_rows, p3d_stream_t stream);
 /* Its gradient for the training passes: given gd = dL/dd [N][Co] and the forward's d, writes gs = dL/dstyles [N][Ci] and gw = dL/dweight [Co][Ci][taps]
  * (weight: the fp32 [Co][Ci][taps] tensor w2 was summed from); either output may be null.  The reference gets these from autograd through
  * (w * s).square().sum().rsqrt() on the [N][Co][Ci][k][k] product (networks_stylegan2.py:57-63).                                                    */

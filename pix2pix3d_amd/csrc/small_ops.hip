@@ -101,6 +101,41 @@ __global__ void __launch_bounds__(256) demod_coefs_kernel(const float* __restric
     }
 }
 
+// Several layers' coefficients in one launch (device inference: every shared-weight layer of a network depends on the latents alone, so the host issues
+// them together ahead of the convolutions: modconv.premodulate_many): block b serves job j with first_block[j] <= b < first_block[j + 1].
+struct DemodJobs { p3d_demod_job job[P3D_DEMOD_MAX_JOBS]; int first_block[P3D_DEMOD_MAX_JOBS + 1]; int njobs; int n_rows; };
+__global__ void __launch_bounds__(256) demod_coefs_multi_kernel(DemodJobs a)
+{
+    extern __shared__ float xs[];
+    int j = 0;
+    while (j + 1 < a.njobs && (int)blockIdx.x >= a.first_block[j + 1]) ++j;
+    const p3d_demod_job& q = a.job[j];
+    const int ci = q.ci, co = q.co, n_rows = a.n_rows;
+    for (int e = threadIdx.x; e < n_rows * ci; e += 256) { const float v = q.styles[e]; xs[e] = v * v; }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int o = ((int)blockIdx.x - a.first_block[j]) * 4 + wave;
+    if (o >= co) return;
+    float acc[FC_MAXN];
+#pragma unroll
+    for (int n = 0; n < FC_MAXN; ++n) acc[n] = 0.f;
+    for (int k = lane; k < ci; k += 64) {                           // (demod_coefs_kernel's arithmetic, operation for operation: the results are bit-identical)
+        const float wv = q.w2[(int64_t)o * ci + k];
+#pragma unroll
+        for (int n = 0; n < FC_MAXN; ++n)
+            if (n < n_rows) acc[n] = fmaf(wv, xs[n * ci + k], acc[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < FC_MAXN; ++n) {
+        if (n < n_rows) {
+            float v = acc[n];
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+            if (lane == 0) q.d[(int64_t)n * co + o] = rsqrtf(v + 1e-8f);
+        }
+    }
+}
+
 // Gradient of the demodulation coefficients (training passes).  With t[n][o] = gd[n][o] * d[n][o]^3:
 //   gs[n][i]      = -styles[n][i] * sum_o t[n][o] * w2[o][i]                     (demod_bwd_styles_kernel: a thread per input channel, four slices of o per block)
 //   gw[o][i][tap] = -weight[o][i][tap] * sum_n t[n][o] * styles[n][i]^2          (demod_bwd_weight_kernel: a thread per weight element)
@@ -303,6 +338,29 @@ extern "C" int p3d_demod_coefs(const float* styles, const float* w2, float* d, i
     hipLaunchKernelGGL(demod_coefs_kernel, dim3((co + 3) / 4), dim3(256), shm, (hipStream_t)stream, styles, w2, d, n_rows, ci, co);
     count_launch(FAM_AUX);
     return check_launch("demod_coefs");
+}
+
+extern "C" int p3d_demod_coefs_multi(const p3d_demod_job* jobs_host, int32_t n_jobs, int32_t n_rows, p3d_stream_t stream)
+{
+    using namespace p3d;
+    P3D_REQUIRE(jobs_host && n_jobs >= 1 && n_jobs <= P3D_DEMOD_MAX_JOBS, "demod_coefs_multi: 1 .. %d jobs", P3D_DEMOD_MAX_JOBS);
+    P3D_REQUIRE(n_rows >= 1 && n_rows <= FC_MAXN, "demod_coefs_multi: 1 .. %d rows", FC_MAXN);
+    DemodJobs a{};
+    a.njobs = n_jobs; a.n_rows = n_rows;
+    int blocks = 0, max_ci = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const p3d_demod_job& q = jobs_host[j];
+        P3D_REQUIRE(q.styles && q.w2 && q.d && q.ci >= 1 && q.co >= 1, "demod_coefs_multi: job %d has a null pointer or an empty size", j);
+        a.job[j] = q; a.first_block[j] = blocks;
+        blocks += (q.co + 3) / 4;
+        if (q.ci > max_ci) max_ci = q.ci;
+    }
+    a.first_block[n_jobs] = blocks;
+    const size_t shm = (size_t)n_rows * max_ci * sizeof(float);
+    P3D_REQUIRE(shm <= 64 * 1024, "demod_coefs_multi: n_rows * ci too large for the LDS stage");
+    hipLaunchKernelGGL(demod_coefs_multi_kernel, dim3(blocks), dim3(256), shm, (hipStream_t)stream, a);
+    count_launch(FAM_AUX);
+    return check_launch("demod_coefs_multi");
 }
 
 extern "C" int p3d_demod_coefs_backward(const float* gd, const float* d, const float* styles, const float* w2, const float* weight, float* gs, float* gw,

@@ -214,6 +214,31 @@ def demod_coefs(weight, styles):
     return d
 
 
+class _DemodJob(ctypes.Structure):
+    _fields_ = [('styles', ctypes.c_void_p), ('w2', ctypes.c_void_p), ('d', ctypes.c_void_p), ('ci', ctypes.c_int32), ('co', ctypes.c_int32)]
+
+
+DEMOD_MAX_JOBS = 24
+_lib.register('p3d_demod_coefs_multi', ctypes.c_int, [ctypes.c_void_p, _i32, _i32, _vp])
+
+
+def demod_coefs_many(pairs):
+    """demod_coefs for several (weight, styles) pairs with the same row count in ONE launch (bit-identical to one call each)."""
+    if len(pairs) == 1 or len(pairs) > DEMOD_MAX_JOBS or len({st.shape[0] for _, st in pairs}) != 1:
+        return [demod_coefs(w, st) for w, st in pairs]
+    arr, keep, outs = (_DemodJob * len(pairs))(), [], []
+    n = pairs[0][1].shape[0]
+    for k, (weight, styles) in enumerate(pairs):
+        w2 = _cached_weight(weight, 'w2_tapsum', lambda weight=weight: weight.detach().float().square().sum(dim=[2, 3]).contiguous())
+        s32 = styles.detach().float().contiguous()
+        d = torch.empty([n, weight.shape[0]], dtype=torch.float32, device=weight.device)
+        keep.append((w2, s32))
+        outs.append(d)
+        arr[k] = _DemodJob(_lib.ptr(s32), _lib.ptr(w2), _lib.ptr(d), s32.shape[1], weight.shape[0])
+    _lib.check(_lib.lib().p3d_demod_coefs_multi(ctypes.cast(arr, ctypes.c_void_p), len(pairs), n, _lib.stream_of(outs[0])), 'demod_coefs_multi')
+    return outs
+
+
 def scale_input(x, styles):
     """x * styles[:, :, None, None] on a dense device tensor, one launch (csrc/bcast_ops.hip), no autograd (inference route)."""
     from . import bcast
@@ -554,6 +579,34 @@ def _small_layer(x, weight, styles, up, wm=None):
         wm = modulate_weights(weight, styles, demodulate=True, dtype=x.dtype, oihw=False)   # [N, Co, 9, Ci]
     cols = torch.bmm(wm.reshape(n, co * 9, ci), x.contiguous().reshape(n, ci, h * w))      # [N, Co*9, H*W]
     return torch.nn.functional.fold(cols, output_size=(2 * h + 1, 2 * w + 1), kernel_size=3, stride=2)
+
+
+def premodulate_many(items):
+    """premodulate for a list of (weight, styles, up, in_pixels, dtype) — ``in_pixels`` None (a ToRGB layer) gives None — with the demodulation coefficients of
+    all the shared-weight layers among them computed by ONE launch.
+    A GENERATOR: each layer's product is launched when it is asked for, so that the caller can record the event a layer waits on right behind that layer's own
+    work (the shared-weight coefficients — the low-resolution layers, which run first — are all issued at the first request)."""
+    shared = [k for k, (w, st, up, px, dt) in enumerate(items) if px is not None and _premod_route(w, st, up, px, dt) == 'shared']
+    ds = dict(zip(shared, demod_coefs_many([(items[k][0], items[k][1]) for k in shared]))) if shared else {}
+    for k, (w, st, up, px, dt) in enumerate(items):
+        if px is None:
+            yield None
+        elif k in ds:
+            shared_split_weights(w)                        # (warm the per-weight cache off the critical path)
+            yield (ds[k], ('shared', up, BF16X3))
+        else:
+            yield premodulate(w, st, up, px, dt)
+
+
+def _premod_route(weight, styles, up, in_pixels, dtype):
+    """'gemm' / 'shared' / 'mfma': which of premodulate's three products a layer gets."""
+    if in_pixels <= (gemm_max_pixels if up == 1 else gemm_max_pixels_up):
+        return 'gemm'
+    if split_bf16 and dtype == torch.float32 and in_pixels >= split_bf16_min_pixels and weight.shape[1] % 32 == 0:
+        if (shared_weight_max_pixels > 0 and 1 < styles.shape[0] <= 16 and in_pixels <= shared_weight_max_pixels and weight.shape[1] % 4 == 0
+                and tuple(weight.shape[2:]) == (3, 3)):
+            return 'shared'
+    return 'mfma'
 
 
 def premodulate(weight, styles, up, in_pixels, dtype):

@@ -567,8 +567,8 @@ def prefetch_styles(blocks, block_ws, block_kwargs):
                    and all(modconv.fc_supported(w, l.affine.weight, l.affine.bias, l.affine.activation) for l, w, *_ in todo))
         all_styles = (modconv.fc_multi([(w, l.affine, sc) for l, w, sc, _, _ in todo]) if batched
                       else [l.affine(w) if sc == 1 else l.affine(w, out_scale=sc) for l, w, sc, _, _ in todo])
-        for (layer, _, _, in_pixels, dtype), styles in zip(todo, all_styles):
-            pre = None if in_pixels is None else modconv.premodulate(layer.weight, styles, layer.up, in_pixels, dtype)
+        pres = modconv.premodulate_many([(layer.weight, styles, getattr(layer, 'up', 1), in_pixels, dtype) for (layer, _, _, in_pixels, dtype), styles in zip(todo, all_styles)])
+        for (layer, _, _, in_pixels, dtype), styles, pre in zip(todo, all_styles, pres):
             ev = torch.cuda.Event()
             ev.record(side)
             modconv._plan[id(layer)] = (styles, pre, ev)

@@ -218,3 +218,19 @@ def test_plain_layer_weight_cache_survives_recycled_tensors(hip_lib):
         assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < 1e-5, i
         del layer
         gc.collect()
+
+
+@pytest.mark.gpu
+def test_demod_coefficients_of_several_layers_in_one_launch(hip_lib):
+    """p3d_demod_coefs_multi (modconv.demod_coefs_many: every shared-weight layer of a network ahead of the convolutions) == one p3d_demod_coefs each, bit for bit,
+    and == the reference's rsqrt(sum (w s)^2 + 1e-8) (networks_stylegan2.py:57-63)."""
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    torch.manual_seed(3)
+    pairs = [(torch.randn(co, ci, 3, 3, device='cuda'), torch.randn(4, ci, device='cuda') + 1) for co, ci in ((512, 512), (512, 512), (256, 512), (96, 64), (130, 36), (512, 512), (64, 128))]
+    many = modconv.demod_coefs_many(pairs)
+    for (w, s), d in zip(pairs, many):
+        one = modconv.demod_coefs(w, s)
+        assert d.shape == one.shape == (4, w.shape[0]) and torch.equal(d, one)
+        ref = ((w.double()[None] * s.double()[:, None, :, None, None]).square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt()
+        assert float(((d.double() - ref).abs() / ref).max()) < 1e-5
+    assert len(modconv.demod_coefs_many(pairs[:1])) == 1
