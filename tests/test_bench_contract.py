@@ -1,4 +1,4 @@
-"""The benchmark line's contract, checked on the line this round's tree printed on an MI355X (profiles/round4_bench_line_default.json) and on
+"""The benchmark line's contract, checked on the line this round's tree printed on an MI355X (profiles/round5_bench_line_default.json) and on
 bench.py's argument surface: the keys the driver parses, the roofline object backed by committed counter passes whose hash matches the
 kernel sources of this tree, the CPU baseline, the exact-fp32 leg and the six-phase training step."""
 import hashlib
@@ -15,7 +15,7 @@ def _line(name):
 
 
 def test_default_line_has_the_contract_keys():
-    d = _line('round4_bench_line_default.json')
+    d = _line('round5_bench_line_default.json')
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
               'roofline', 'cpu_baseline', 'exact_fp32', 'train_step'):
         assert k in d, k
@@ -40,6 +40,21 @@ def test_default_line_has_the_contract_keys():
     assert g['ms_per_iteration'] < t['ms_per_iteration'] and abs(g['phase_ms']['Dreg'] - t['phase_ms']['Dreg']) < 0.1 * t['phase_ms']['Dreg']     # the discriminators' arithmetic is untouched
     r = t['roofline']
     assert r is None or (r['dominant']['bound'] in ('mfma', 'valu_issue', 'lds', 'hbm') and 0 < r['dominant']['frac'] <= 1)
+    # round 5: the other BASELINE configurations, the real-data MFMA ceiling, the matrix-pipe floor of every training phase
+    assert 'rccl' in d and d['rccl'] is None                                            # one GPU: no collective library in the line
+    cfgs = d['configs']
+    assert len(cfgs) == 3 and any('edge2car' in k for k in cfgs) and any('seg2face' in k for k in cfgs) and any('48+48' in k for k in cfgs)
+    for k, v in cfgs.items():
+        assert v['value'] > 0 and v['launch'] == 'hipgraph' and v['ray_marcher']['ms_per_launch'] > 0 and set(v['stage_ms']) == {'backbone', 'render', 'sr'}, k
+        assert abs(v['ray_marcher']['ray_samples_per_s'] - v['ray_marcher']['ray_samples_per_launch'] / (v['ray_marcher']['ms_per_launch'] * 1e-3)) < 1e-3 * v['ray_marcher']['ray_samples_per_s']
+    c = d['mfma_real_data_ceiling']
+    assert 0.6 < c['frac_of_2p5pf'] < 0.75 and c['zero_operands_tflops'] > 2300 and 1.5 < c['clock_ghz'] < 1.9
+    assert abs(c['frac_of_it']['conv_f16'] - d['mfma_conv']['conv_f16']['tflops'] / c['tflops']) < 2e-3 and c['frac_of_it']['conv_f16'] < 1
+    fl = t['arithmetic_floor']['phases']
+    assert set(fl) == {'Gmain', 'Greg', 'Dmain', 'Dreg', 'D_semanticmain', 'D_semanticreg'}
+    for k, v in fl.items():
+        assert 0 < v['floor_ms_at_quoted_peaks'] < v['measured_ms'] and v['measured_over_floor'] > 1, k                 # a floor
+    assert fl['Gmain']['tflop']['f32_convs'] > 3 * fl['Dmain']['tflop']['f32_convs'] and fl['Gmain']['tflop']['f32_decoder_mlps'] > 0
 
 
 def test_committed_counter_passes_belong_to_this_trees_kernel():
@@ -56,7 +71,7 @@ def test_committed_counter_passes_belong_to_this_trees_kernel():
 def test_bench_argument_surface():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--help'], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0
-    for flag in ('--gpus', '--steps', '--warmup', '--train-step', '--no-exact-fp32', '--no-cpu-baseline', '--cpu-reps'):
+    for flag in ('--gpus', '--steps', '--warmup', '--train-step', '--no-exact-fp32', '--no-cpu-baseline', '--cpu-reps', '--no-configs'):
         assert flag in r.stdout, flag
 
 
