@@ -6,6 +6,8 @@ checkpoints map 1:1) and forward semantics; the arithmetic runs on this package'
 """
 import os
 
+import weakref
+
 import numpy as np
 import torch
 
@@ -503,10 +505,10 @@ class SynthesisBlock(torch.nn.Module):
                 # device inference: the batch of constants is the same tensor every pass — built once per (batch, dtype, layout, version of the parameter);
                 # nothing writes into a block's input in place (conv1 returns a new tensor), so the copy can be handed out again
                 key = (batch, dtype, fmt, self.const._version, self.const.data_ptr())
-                hit = getattr(self, '_const_batch', None)
+                hit = _const_batches.get(self)                   # (kept outside the module: nothing of it is pickled, deep-copied or moved with the module)
                 if hit is None or hit[0] != key:
                     hit = (key, self.const.detach().to(dtype=dtype).unsqueeze(0).repeat([batch, 1, 1, 1]).contiguous(memory_format=fmt))
-                    object.__setattr__(self, '_const_batch', hit)
+                    _const_batches[self] = hit
                 return hit[1]
             return self.const.to(dtype=dtype).unsqueeze(0).repeat([batch, 1, 1, 1]).contiguous(memory_format=fmt)
         in_res = self.resolution // self._in_div
@@ -532,6 +534,9 @@ class SynthesisBlock(torch.nn.Module):
 
     def extra_repr(self):
         return f'resolution={self.resolution:d}, architecture={self.architecture:s}'
+
+
+_const_batches = weakref.WeakKeyDictionary()      # SynthesisBlock (b4) -> (key, its learned constant repeated over the batch): device inference only
 
 
 def prefetch_styles(blocks, block_ws, block_kwargs):
