@@ -29,7 +29,7 @@ TRAFFIC_GROUPS = [['FETCH_SIZE'], ['WRITE_SIZE']]
 HBM_PEAK_GBS = 8000.0
 WORKLOADS = {
     'train6': [sys.executable, os.path.join(ROOT, 'bench.py'), '--train-step', '--steps', '1', '--warmup', '1'],
-    'infer': [sys.executable, os.path.join(ROOT, 'bench.py'), '--no-graph', '--no-cpu-baseline', '--no-train-step', '--no-exact-fp32', '--steps', '4', '--warmup', '2'],
+    'infer': [sys.executable, os.path.join(ROOT, 'bench.py'), '--no-graph', '--no-cpu-baseline', '--no-train-step', '--no-exact-fp32', '--no-configs', '--steps', '4', '--warmup', '2'],
     'train': [sys.executable, os.path.join(ROOT, 'tests', 'gpu_train_census.py'), '4', '128', '--no-census'],
 }
 PASS_TIMEOUT_S = int(os.environ.get('PMC_PASS_TIMEOUT', 150))
