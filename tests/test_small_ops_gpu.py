@@ -234,3 +234,53 @@ def test_demod_coefficients_of_several_layers_in_one_launch(hip_lib):
         ref = ((w.double()[None] * s.double()[:, None, :, None, None]).square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt()
         assert float(((d.double() - ref).abs() / ref).max()) < 1e-5
     assert len(modconv.demod_coefs_many(pairs[:1])) == 1
+
+
+@pytest.mark.gpu
+def test_rays_straight_from_the_camera_labels(hip_lib):
+    """RaySampler.forward on the two views the generators pass (c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3): p3d_ray_sample_labels reads the label rows in
+    place) == the same call on contiguous copies (p3d_ray_sample), bit for bit, == the oracle's ray_sampler (ray_sampler.py:24-62); a view that is NOT such a pair
+    takes the copying route."""
+    from oracle import render_oracle as R
+    from pix2pix3d_amd import _lib, configs
+    from pix2pix3d_amd.training.volumetric_rendering.ray_sampler import RaySampler
+    rs = RaySampler()
+    c = torch.tensor(np.stack([configs.orbit_camera(7 * k + 3, radius=2.7, pivot=[0, 0, -0.06]) for k in range(5)]), device='cuda')
+    for lab in (c, torch.cat([c, torch.zeros(5, 7, device='cuda')], 1)):           # 25-float rows, and rows padded to 32 floats
+        c2w, k = lab[:, :16].view(-1, 4, 4), lab[:, 16:25].view(-1, 3, 3)
+        assert not c2w.is_contiguous()
+        n0 = _lib.launch_count('aux')
+        o1, d1 = rs(c2w, k, 48)
+        assert _lib.launch_count('aux') == n0 + 1
+        o0, d0 = rs(c2w.contiguous(), k.contiguous(), 48)
+        assert torch.equal(o1, o0) and torch.equal(d1, d0)
+        oo, do = R.ray_sampler(c2w.cpu().numpy(), k.cpu().numpy(), 48)
+        assert np.abs(o1.cpu().numpy() - oo).max() < 1e-6 and np.abs(d1.cpu().numpy() - do).max() < 2e-6
+    k_other = torch.eye(3, device='cuda').repeat(5, 1, 1) * 4.2647               # intrinsics from another tensor: not a label pair
+    o2, d2 = rs(c[:, :16].view(-1, 4, 4), k_other, 16)
+    o3, d3 = rs(c[:, :16].view(-1, 4, 4).contiguous(), k_other, 16)
+    assert torch.equal(o2, o3) and torch.equal(d2, d3)
+
+
+@pytest.mark.gpu
+def test_last_sr_block_stores_its_activations_when_somebody_looks(hip_lib):
+    """The super-resolution heads let their last block skip the store of x (nobody reads it) — unless a forward hook on that block could: then x is stored and the
+    image is the same."""
+    from pix2pix3d_amd.training.superresolution import SuperresolutionHybrid8XDC
+    torch.manual_seed(0)
+    sr = SuperresolutionHybrid8XDC(channels=32, img_resolution=512, sr_num_fp16_res=4, sr_antialias=True, channel_base=32768, channel_max=512,
+                                   fused_modconv_default='inference_only').cuda().eval().requires_grad_(False)
+    x = torch.randn(2, 32, 128, 128, device='cuda')
+    ws = torch.randn(2, 14, 512, device='cuda')
+    with torch.no_grad():
+        y0 = sr(x[:, :3].contiguous(), x, ws, noise_mode='none')
+    seen = []
+    h = sr.block1.register_forward_hook(lambda m, a, out: seen.append(out[0]))
+    try:
+        with torch.no_grad():
+            y1 = sr(x[:, :3].contiguous(), x, ws, noise_mode='none')
+    finally:
+        h.remove()
+    assert len(seen) == 1 and seen[0] is not None and tuple(seen[0].shape) == (2, 128, 512, 512) and bool(torch.isfinite(seen[0].float()).all())
+    assert y0.shape == y1.shape == (2, 3, 512, 512)
+    assert float((y0 - y1).abs().max()) <= 1e-5 * float(y1.abs().max())           # two epilogues of the same contraction (another fp32 summation order)
