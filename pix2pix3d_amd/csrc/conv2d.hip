@@ -75,6 +75,8 @@ struct ConvArgs {
     int osy, osx;          // output pixel = (i * osy + ooy, j * osx + oox)
     int isy, isx;          // input pixel of tap (dy, dx) = (i * isy + dy, j * isx + dx)   (2 for the stride-2 'down' convolution)
     int ncls;              // sub-problems solved by this launch (1: plain conv; 4: parity classes of the stride-2 transposed conv)
+    int cls_major;         // != 0 (generic kernel, ncls > 1): blockIdx.z = class * N + image instead of image * ncls + class — the classes are ordered by tap count
+                           // (4, 2, 2, 1), so the blocks with the longest K loops are dispatched first and the launch's tail is made of the shortest ones
     struct Cls { int SH, SW, ooy, oox, ntaps; ConvTap taps[9]; } cls[4];     // plain conv uses cls[0] with up to 9 taps; transposed classes have <= 4
     int act;               // 0: none (linear), 1: lrelu(0.2)
     float gain, clamp;     // clamp < 0: off
@@ -133,8 +135,8 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
     constexpr int NI = CO64 ? 1 : 2;                                           // 32-row tiles per wave
     const int rbase = CO64 ? wave * 32 : (wave >> 1) * 64, wn = CO64 ? 0 : wave & 1;   // wave's first tile row / 64-column half
     const int split = blockIdx.z % a.ksplit, zz = blockIdx.z / a.ksplit;
-    const int n = a.fold ? 0 : zz / a.ncls;
-    const ConvArgs::Cls& kc = a.cls[a.fold ? 0 : zz - n * a.ncls];
+    const int n = a.fold ? 0 : (a.cls_major ? zz % a.N : zz / a.ncls);
+    const ConvArgs::Cls& kc = a.cls[a.fold ? 0 : (a.cls_major ? zz / a.N : zz - n * a.ncls)];
     // XCD-aware tile order: workgroup L of a launch lands on XCD L % 8, each XCD with its own L2.  Consecutive slots
     // of one XCD get the output-channel blocks of the SAME pixel tile (they share the A operand), and pixel tiles
     // stride over XCDs, so an A neighbourhood is fetched into one L2 only.  Falls back to the plain order when the
@@ -432,8 +434,8 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(ConvArgs a, int Mp
         const int64_t rem = e - zz * per_z;
         int m = (int)(rem / co4);
         const int co = (int)(rem - (int64_t)m * co4) * 4;
-        int n = a.fold ? 0 : zz / a.ncls;
-        const ConvArgs::Cls& kc = a.cls[a.fold ? 0 : zz - n * a.ncls];
+        int n = a.fold ? 0 : (a.cls_major ? zz % a.N : zz / a.ncls);
+        const ConvArgs::Cls& kc = a.cls[a.fold ? 0 : (a.cls_major ? zz / a.N : zz - n * a.ncls)];
         const int MI = kc.SH * kc.SW;
         if (m >= (a.fold ? MI * a.N : MI)) continue;
         const float* src = a.partial + ((int64_t)zz * Mpad + m) * CoP + co;
@@ -1570,6 +1572,8 @@ static int launch_conv(ConvArgs& a, int dtype, hipStream_t s, void* workspace, i
     dim3 grid(gx, gy, z * a.ksplit);
     static const bool no_co64 = getenv("P3D_CONV_NO_CO64") != nullptr;          // (A/B switch of the measurement scripts)
     const bool co64 = !no_co64 && a.Co <= 64;
+    static const bool no_cls_major = [] { const char* e = getenv("P3D_CONV_CLASS_MAJOR"); return e && atoi(e) == 0; }();      // (A/B switch)
+    a.cls_major = (a.ncls > 1 && !a.fold && !no_cls_major) ? 1 : 0;
     if (a.iscale) {                                                             // the table of conv2d_nhwc_kernel<.., ISC>: the scale rows of every image a 128-row tile touches
         if (dtype != P3D_F32_BF16X3 || x_split) return fail(P3D_ERR_UNSUPPORTED, "conv2d_nhwc: the input scale is implemented for bf16x3 on plain fp32 activations");
         int worst = 1;
