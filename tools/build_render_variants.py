@@ -2,7 +2,7 @@
 hash pins the committed counter passes): csrc is copied to /tmp, render_device.h is patched there, and each variant is linked against the product's other objects into
 pix2pix3d_amd/libp3d_hip_rv<bits>.so (git-ignored; travels to the GPU box; select with P3D_LIB_PATH).
     python tools/build_render_variants.py 1 2 3 4 8 16
-bits: 1 no gather (features from the lane id), 2 no transcendentals in the decoder (softplus / sigmoid -> a multiply), 4 no MFMAs (operands kept alive),
+bits: 32 kRaysB = 8, 64 softplus without the threshold select, 128 sigmoid without the exponent's pre-multiply, 1 no gather (features from the lane id), 2 no transcendentals in the decoder (softplus / sigmoid -> a multiply), 4 no MFMAs (operands kept alive),
       8 no sched_barrier between the two nets of a sample, 16 exact-fp32 layer 2 on two accumulators."""
 import os
 import shutil
@@ -44,6 +44,10 @@ s = re.sub(r'__builtin_amdgcn_mfma_f32_32x32x2f32\(([^;]*?), 0, 0, 0\)', lambda 
 s = re.sub(r'__builtin_amdgcn_mfma_f32_32x32x16_bf16\(([^;]*?), 0, 0, 0\)', lambda m: 'P3D_MFMA(__builtin_amdgcn_mfma_f32_32x32x16_bf16, ' + m.group(1) + ')', s)
 # 8: the barrier that closes a net's share of a sample
 rep('                prev[n][r] = c;\n            }\n            __builtin_amdgcn_sched_barrier(0);\n', '                prev[n][r] = c;\n            }\n            if (!(P3D_RENDER_DEBUG & 8)) __builtin_amdgcn_sched_barrier(0);\n')
+# 32: eight rays at a time through the importance sampler; 64: softplus without its threshold select; 128: sigmoid without the pre-multiply of its exponent
+rep('constexpr int kRaysB = 4; ', 'constexpr int kRaysB = (P3D_RENDER_DEBUG & 32) ? 8 : 4; ')
+rep('    return xs > 28.853900817779268f ? xs : __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(xs));', '    if (P3D_RENDER_DEBUG & 64) return __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(xs));\n    if (P3D_RENDER_DEBUG & 256) return fmaxf(xs, __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(fminf(xs, 127.f))));\n    if (P3D_RENDER_DEBUG & 512) return __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(fminf(xs, 127.f)));\n    return xs > 28.853900817779268f ? xs : __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(xs));')
+rep('    return fmaf(__builtin_amdgcn_rcpf(1.f + fast_exp(-x)), 1.002f, -0.001f);', '    if (P3D_RENDER_DEBUG & 128) return fmaf(__builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x)), 1.002f, -0.001f);\n    return fmaf(__builtin_amdgcn_rcpf(1.f + fast_exp(-x)), 1.002f, -0.001f);')
 # 16: exact layer 2 on two accumulators (even / odd k-steps), summed at the end — does the single dependent chain of 32 MFMAs stall?
 rep("""            const float b = (s < 16) ? h0[s] : h1[s - 16];
             out = P3D_MFMA(__builtin_amdgcn_mfma_f32_32x32x2f32, a[e], b, out);""",

@@ -1,0 +1,11 @@
+#!/bin/bash
+# round-5 session l: micro-variants of the ray-marcher (tools/build_render_variants.py 0 64 256 264 512 520), bf16x3 decoder, three rounds interleaved
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out; T=round5_l
+: > gpurun_out/${T}_render_variants.log
+for rep in 1 2 3; do
+  for bits in 0 64 256 264 512 520; do
+    echo "round $rep variant $bits: $(P3D_LIB_PATH=$GRAFT_REPO_ROOT/pix2pix3d_amd/libp3d_hip_rv$bits.so ITERS=20 timeout 120 python tests/gpu_profile_render.py 2>/dev/null | tail -1 | cut -c1-60)" >> gpurun_out/${T}_render_variants.log
+  done
+done
+cat gpurun_out/${T}_render_variants.log
