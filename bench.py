@@ -587,25 +587,28 @@ def main():
         handles += hook(G.backbone.synthesis, 'backbone') + hook(G.renderer, 'render')
         handles += hook(G.superresolution, 'sr') + hook(G.superresolution_semantic, 'sr')
         n_prof = min(args.steps, 10)
-        for k in ('render_forward', 'conv_f16', 'conv_f32', 'conv_bf16x3', 'conv_flops'):
+        conv_keys = ('conv_f16', 'conv_f32', 'conv_bf16x3') + (('conv_bf16x6',) if _mc.f32_x6 else ())
+        mults = {'conv_bf16x3': 3.0, 'conv_bf16x6': 6.0}             # bf16 MFMAs executed per fp32 product
+        for k in ('render_forward', 'conv_flops') + conv_keys:
             _lib.kernel_events[k] = []
         for _ in range(n_prof):
             step()
         torch.cuda.synchronize()
         kern = _lib.kernel_events.pop('render_forward')
         render_kernel_ms = sum(a.elapsed_time(b) for a, b in kern) / max(len(kern), 1)
-        conv_ms = {k: sum(a.elapsed_time(b) for a, b in _lib.kernel_events.pop(k)) / n_prof for k in ('conv_f16', 'conv_f32', 'conv_bf16x3')}
+        conv_ms = {k: sum(a.elapsed_time(b) for a, b in _lib.kernel_events.pop(k)) / n_prof for k in conv_keys}
         flops = _lib.kernel_events.pop('conv_flops')
         conv_fl = {'conv_f16': sum(f for d, f in flops if 'float16' in d) / n_prof, 'conv_f32': sum(f for d, f in flops if 'float32' in d) / n_prof,
-                   'conv_bf16x3': sum(f for d, f in flops if d == 'bf16x3') / n_prof}
+                   'conv_bf16x3': sum(f for d, f in flops if d == 'bf16x3') / n_prof, 'conv_bf16x6': sum(f for d, f in flops if d == 'bf16x6') / n_prof}
         for h in handles:
             h.remove()
         stage_ms = {k: (sum(a.elapsed_time(b) for a, b in v) / n_prof if v else 0.0) for k, v in stage_events.items()}
         # conv_f32: exact fp32 MFMA kernels vs the 157.3 TF fp32 matrix peak.  conv_bf16x3: the fp32 layers computed as three bf16 MFMAs per
         # product: 'tflops' counts each fp32 multiply-add once (fp32-equivalent), 'frac_of_peak' the 3x bf16 MFMA work it executes vs 2.5 PF
+        # (conv_bf16x6, only with modconv.f32_x6: six per product)
         mfma_conv = {k: {'ms_per_step': round(conv_ms[k], 3), 'tflops': round(conv_fl[k] / (conv_ms[k] * 1e-3) / 1e12, 1) if conv_ms[k] > 0 else None,
-                         'frac_of_peak': round(conv_fl[k] * (3.0 if k == 'conv_bf16x3' else 1.0) / (conv_ms[k] * 1e-3) / 1e12 / (157.3 if k == 'conv_f32' else 2500.0), 3) if conv_ms[k] > 0 else None}
-                     for k in ('conv_f16', 'conv_f32', 'conv_bf16x3')}
+                         'frac_of_peak': round(conv_fl[k] * mults.get(k, 1.0) / (conv_ms[k] * 1e-3) / 1e12 / (157.3 if k == 'conv_f32' else 2500.0), 3) if conv_ms[k] > 0 else None}
+                     for k in conv_keys}
         return dict(elapsed=elapsed, launch=launch, render_kernel_ms=render_kernel_ms, n_render=len(kern), stage_ms=stage_ms, mfma_conv=mfma_conv)
 
     def roofline(m, mlp_bf3):
@@ -652,6 +655,21 @@ def main():
                      'roofline': roofline(exact_m, False),
                      'what': 'P3D_BF16X3=0 P3D_MLP_BF16X3=0: every fp32 convolution and the decoder MLPs on the f32-input MFMA (exact fp32 products, the arithmetic class the reference '
                              'insists on, training_loop.py:278-280); super-resolution heads unchanged'}
+            # the same fp32-accurate leg with the backbone's products formed on the bf16 matrix pipe (P3D_F32_BF16X6: three-piece splits in
+            # registers, six MFMAs per product; plain fp32 tensors and weights — DESIGN 2.4c); the decoder stays on the f32-input MFMA
+            prev6, _mc.f32_x6 = _mc.f32_x6, True
+            try:
+                torch.cuda.empty_cache()
+                x6_m = measure(3.0)
+                exact['backbone_as_bf16x6'] = {'value': round(args.batch * world * args.steps / x6_m['elapsed'], 3), 'unit': 'img/s',
+                                               'ms_per_step': round(x6_m['elapsed'] / args.steps * 1e3, 3), 'launch': x6_m['launch'],
+                                               'stage_ms': {k: round(v, 3) for k, v in x6_m['stage_ms'].items()}, 'mfma_conv': x6_m['mfma_conv'],
+                                               'what': 'P3D_F32_BF16X6=1 on top: the fp32 convolutions as six bf16 MFMAs per product (hi/mid/lo pieces, error class of the exact kernel: '
+                                                       'tests/test_conv_gpu.py::test_bf16x6_formulation_of_the_fp32_convolution)'}
+            except Exception as e:                                   # noqa: BLE001
+                exact['backbone_as_bf16x6'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+            finally:
+                _mc.f32_x6 = prev6
         except Exception as e:                                       # noqa: BLE001 - the headline line must still be printed
             exact = {'error': f'{type(e).__name__}: {e}'[:300]}
         finally:
@@ -709,11 +727,22 @@ def main():
                 train['generator_bf16x3'] = {'error': f'{type(e).__name__}: {e}'[:300]}
             finally:
                 _tp.train_products_bf16x3 = prev_tp
+            prev6, _mc.f32_x6 = _mc.f32_x6, True                     # fp32-ACCURATE products on the bf16 pipe: every fp32 forward / data-gradient convolution, G and D
+            try:
+                t3, _ = run_train(args, device, world, dist, 3, 1)
+                train['fp32_as_bf16x6'] = {'what': 'P3D_F32_BF16X6=1: every fp32 forward and data-gradient convolution (generator, discriminators, frozen passes) as six bf16 MFMAs per '
+                                                   'product of three-piece splits — the error class of the exact kernels; weight gradients stay on the f32-input MFMA',
+                                           'ms_per_iteration': t3['ms_per_iteration'], 'img_per_s': t3['img_per_s'], 'phase_ms': t3['phase_ms'],
+                                           'lazy_schedule_ms': t3['lazy_schedule']['ms_per_iteration']}
+            except Exception as e:                                   # noqa: BLE001
+                train['fp32_as_bf16x6'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+            finally:
+                _mc.f32_x6 = prev6
 
     if rank == 0:
         ceiling = mfma_real_data_ceiling()
         if ceiling:                                                  # the same classes against what the pipe can do on real data at the clock it then holds
-            ceiling['frac_of_it'] = {k: (round(v['tflops'] * (3.0 if k == 'conv_bf16x3' else 1.0) / ceiling['tflops'], 3) if v.get('tflops') else None)
+            ceiling['frac_of_it'] = {k: (round(v['tflops'] * {'conv_bf16x3': 3.0, 'conv_bf16x6': 6.0}.get(k, 1.0) / ceiling['tflops'], 3) if v.get('tflops') else None)
                                      for k, v in main_m['mfma_conv'].items() if k != 'conv_f32'}
         bb = ('f32 tensors + f32 accumulation; the backbone convolutions (3x3 and the 1x1 ToRGB) form each product as 3 bf16 MFMAs of (hi, lo) splits ("bf16x3", <= 5e-6 of the '
               'output range vs fp64 per layer; P3D_BF16X3=0 = exact f32 MFMA, timed as `exact_fp32`)') if _mc.split_bf16 else 'f32 (exact f32 MFMA)'

@@ -37,7 +37,12 @@ enum p3d_status {
 enum p3d_dtype { P3D_F32 = 0, P3D_F16 = 1, P3D_F64 = 2,
                  P3D_F32_BF16X3 = 3     /* conv entry points only: fp32 tensors, fp32 accumulation, every product formed as three bf16
                                            products of (hi, lo) splits — ~2^-16 relative per product at up to 5x the fp32 matrix rate;
-                                           weights come from p3d_modulate_weights with the same code ([32 x hi | 32 x lo] K rows)      */ };
+                                           weights come from p3d_modulate_weights with the same code ([32 x hi | 32 x lo] K rows)      */,
+                 P3D_F32_BF16X6 = 4     /* conv entry points only (p3d_conv2d_nhwc*, p3d_conv2d_forward / _bwd_data): fp32 tensors AND fp32 weights in the
+                                           P3D_F32 layouts, fp32 accumulation; every operand is split IN REGISTERS into three bf16 pieces (hi + mid + lo = the
+                                           fp32 value exactly: 3 x 8 significand bits) and every product formed as the six bf16 products of magnitude
+                                           >= 2^-16 (hh, hm, mh, hl, lh, mm; the three dropped ones are <= 2^-23 relative together: the size of one fp32
+                                           rounding) — fp32-accurate products at 6/16 of the f32-input MFMA's time, on the pipe that overlaps vector work */ };
 
 /* ---- library services ------------------------------------------------------------------- */
 const char* p3d_last_error(void);        /* message of the last failure on this host thread      */

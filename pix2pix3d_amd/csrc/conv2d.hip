@@ -45,19 +45,49 @@ constexpr int BM = 128, BN = 128;          // block tile; the K step is one 128-
 #define P3D_BF16_TERMS 3
 #endif
 constexpr int kBf16Terms = P3D_BF16_TERMS;     // 3: xh*wh + xh*wl + xl*wh (term order: hh, hl, lh); 4 adds xl*wl (measured: no accuracy gain)
+typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(const f32x2_t v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2_t)); }
+__device__ __forceinline__ f32x2_t bf16_pair_as_f32(const uint32_t p) { return f32x2_t{__builtin_bit_cast(float, p << 16), __builtin_bit_cast(float, p & 0xffff0000u)}; }
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split_bf16x8(const f32x4& a0, const f32x4& a1, bf8& hi, bf8& lo)
 {
+    u32x4_t h, l;                                                     // on pairs (see split3_bf16x8 below): 2.5 - 3 vector instructions per value instead of 4
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float x = a0[e], y = a1[e];
-        const __bf16 hx = (__bf16)x, hy = (__bf16)y;                  // round to nearest even
-        hi[e] = hx; hi[4 + e] = hy;
-        lo[e] = (__bf16)(x - (float)hx); lo[4 + e] = (__bf16)(y - (float)hy);
+    for (int p = 0; p < 4; ++p) {
+        const f32x2_t x = p < 2 ? f32x2_t{a0[2 * p], a0[2 * p + 1]} : f32x2_t{a1[2 * p - 4], a1[2 * p - 3]};
+        h[p] = cvt_pk_bf16(x);                                        // round to nearest even
+        l[p] = cvt_pk_bf16(x - bf16_pair_as_f32(h[p]));
     }
+    hi = __builtin_bit_cast(bf8, h); lo = __builtin_bit_cast(bf8, l);
     // every converted register complete before the first MFMA reads any of them: see the hazard note at split8 in render_device.h
     // (v_cvt_pk_bf16_f32 -> MFMA operand at the compiler's two wait states returned stale 16-lane groups in the ray-marcher)
     asm volatile("s_nop 4" : "+v"(hi), "+v"(lo));
 }
+
+// "bf16x6" (P3D_F32_BF16X6): three bf16 pieces per fp32 value — hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid); both subtractions are exact in fp32 and
+// after them at most 8 significant bits are left, so hi + mid + lo == x — and the six products of magnitude >= 2^-16: fp32-accurate, no pre-split layout anywhere.
+// Written on PAIRS: one v_cvt_pk_bf16_f32 makes two pieces and IS the operand register; the pieces go back to fp32 with one shift / one mask.  (The
+// element-wise form compiled to 7.5 vector instructions per value — the compiler converted every value twice, once alone for the subtraction and once
+// in a pair for the operand — and the kernel was bound by them: 300 vector instructions per 24 MFMAs.  This form: 5.5, or 4.5 where the subtractions pair
+// up as v_pk_add_f32.)  Same roundings, same bits.
+__device__ __forceinline__ void split3_bf16x8(const f32x4& a0, const f32x4& a1, bf8& hi, bf8& mid, bf8& lo)
+{
+    u32x4_t h, m, l;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const f32x2_t x = p < 2 ? f32x2_t{a0[2 * p], a0[2 * p + 1]} : f32x2_t{a1[2 * p - 4], a1[2 * p - 3]};
+        h[p] = cvt_pk_bf16(x);
+        const f32x2_t r1 = x - bf16_pair_as_f32(h[p]);
+        m[p] = cvt_pk_bf16(r1);
+        l[p] = cvt_pk_bf16(r1 - bf16_pair_as_f32(m[p]));
+    }
+    hi = __builtin_bit_cast(bf8, h); mid = __builtin_bit_cast(bf8, m); lo = __builtin_bit_cast(bf8, l);
+    asm volatile("s_nop 4" : "+v"(hi), "+v"(mid), "+v"(lo));         // conversion -> MFMA operand hazard: see split_bf16x8
+}
+// term t of the six: (A piece, B piece) = (h,h) (h,m) (m,h) (h,l) (l,h) (m,m)
+#define P3D_X6_A(t, h, m, l) ((t) == 2 || (t) == 5 ? (m) : ((t) == 4 ? (l) : (h)))
+#define P3D_X6_B(t, h, m, l) ((t) == 1 || (t) == 5 ? (m) : ((t) == 3 ? (l) : (h)))
 
 struct ConvTap { int dy, dx, widx; };
 
@@ -121,9 +151,10 @@ template <> struct ConvTraits<float>  { static constexpr int BK = 32; };
 // ISC: ConvArgs::iscale.  The scales a tile can need — its image's row, or with the batch folded into the GEMM rows the rows of the (few) images its 128 GEMM rows
 // belong to — sit in an 8 KB LDS table (host: images per tile x Ci <= kIscaleFloats), read 32 bytes per fragment piece next to the activation itself.
 constexpr int kIscaleFloats = 2048;
-template <class T, bool BF3 = false, bool XS = false, bool CO64 = false, bool ISC = false>
+template <class T, bool BF3 = false, bool XS = false, bool CO64 = false, bool ISC = false, bool X6 = false>
 __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
 {
+    static_assert(!X6 || (sizeof(T) == 4 && !BF3 && !XS && !ISC), "bf16x6 is an arithmetic of the plain fp32 kernel");
     static_assert(!ISC || (BF3 && !XS && !CO64), "the input scale rides on the in-register split of plain fp32 activations");
     static_assert(!BF3 || sizeof(T) == 4, "bf16x3 is a formulation of the fp32 convolution");
     static_assert(!XS || BF3, "pre-split activations are the bf16x3 kernels' input format");
@@ -131,7 +162,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
     constexpr int EPC = 16 / sizeof(T);                                        // elements per 16-byte chunk
     __shared__ __attribute__((aligned(16))) f32x4 lds[2][2][BM * 8];          // [buffer][A|B][row*8 + chunk], 16-byte slots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    static_assert(!CO64 || !BF3, "the 64-column form is instantiated for the exact kernels only");
+    static_assert(!CO64 || !BF3, "the 64-column form is instantiated for the fp32-layout kernels only");
     constexpr int NI = CO64 ? 1 : 2;                                           // 32-row tiles per wave
     const int rbase = CO64 ? wave * 32 : (wave >> 1) * 64, wn = CO64 ? 0 : wave & 1;   // wave's first tile row / 64-column half
     const int split = blockIdx.z % a.ksplit, zz = blockIdx.z / a.ksplit;
@@ -273,6 +304,24 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
 #pragma unroll
                             for (int j = 0; j < 2; ++j)
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(term >= 2 ? al[i] : ah[i], (term & 1) ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
+                }
+            } else if constexpr (X6) {                                          // fp32 tiles on both sides, split in registers: 2 x 16 channels, six bf16 MFMAs per product tile
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    bf8 ah[NI], am[NI], al[NI], bh[2], bm[2], bl[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        if (i < NI) { const int ra = rbase + i * 32 + frow; split3_bf16x8(lds[buf][0][swz(ra, 4 * m + 2 * fk)], lds[buf][0][swz(ra, 4 * m + 2 * fk + 1)], ah[i], am[i], al[i]); }
+                        const int rb = wn * 64 + i * 32 + frow;
+                        split3_bf16x8(lds[buf][1][swz(rb, 4 * m + 2 * fk)], lds[buf][1][swz(rb, 4 * m + 2 * fk + 1)], bh[i], bm[i], bl[i]);
+                    }
+#pragma unroll
+                    for (int term = 0; term < 6; ++term)
+#pragma unroll
+                        for (int i = 0; i < NI; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P3D_X6_A(term, ah[i], am[i], al[i]), P3D_X6_B(term, bh[j], bm[j], bl[j]), acc[i][j], 0, 0, 0);
                 }
             } else
 #pragma unroll
@@ -472,7 +521,7 @@ constexpr int PH = 8, PW = 16;                      // pixel patch of a block (P
 constexpr int SLAB_W = PW + 2, SLAB_ROWS = (PH + 2) * (PW + 2);          // 18, 180 slab pixels
 constexpr int SLAB_SLOTS = ((SLAB_ROWS + 7) / 8) * 8 * 8;                // padded to whole 8-row DMA groups, 16-byte slots
 
-template <class T, bool BF3 = false, bool XS = false>
+template <class T, bool BF3 = false, bool XS = false, bool X6 = false>
 __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(ConvArgs a)
 {
     static_assert(!BF3 || sizeof(T) == 4, "bf16x3 is a formulation of the fp32 convolution");
@@ -578,6 +627,27 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(ConvArgs a)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(term >= 2 ? al[i] : ah[i], (term & 1) ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else if constexpr (X6) {
+            static_assert(!X6 || (sizeof(T) == 4 && !BF3 && !XS), "bf16x6 is an arithmetic of the plain fp32 kernel");
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                bf8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int sr = arow[i] + toff, key = (sr >> 1) & 7, rb = wn * 64 + i * 32 + frow;
+                    split3_bf16x8(slab[sb][sr * 8 + ((4 * m + 2 * fk) ^ key)], slab[sb][sr * 8 + ((4 * m + 2 * fk + 1) ^ key)], ah[i], am[i], al[i]);
+                    split3_bf16x8(wt[wb][swz(rb, 4 * m + 2 * fk)], wt[wb][swz(rb, 4 * m + 2 * fk + 1)], bh[i], bm[i], bl[i]);
+                }
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        if (co64 && i == 1) continue;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P3D_X6_A(term, ah[i], am[i], al[i]), P3D_X6_B(term, bh[j], bm[j], bl[j]), acc[i][j], 0, 0, 0);
                     }
             }
         } else
@@ -1590,6 +1660,8 @@ static int launch_conv(ConvArgs& a, int dtype, hipStream_t s, void* workspace, i
     }
     if (dtype == P3D_F16 && co64)     hipLaunchKernelGGL((conv2d_nhwc_kernel<__half, false, false, true>), grid, dim3(256), 0, s, a);
     else if (dtype == P3D_F32 && co64) hipLaunchKernelGGL((conv2d_nhwc_kernel<float, false, false, true>), grid, dim3(256), 0, s, a);
+    else if (dtype == P3D_F32_BF16X6 && co64) hipLaunchKernelGGL((conv2d_nhwc_kernel<float, false, false, true, false, true>), grid, dim3(256), 0, s, a);
+    else if (dtype == P3D_F32_BF16X6) hipLaunchKernelGGL((conv2d_nhwc_kernel<float, false, false, false, false, true>), grid, dim3(256), 0, s, a);
     else if (dtype == P3D_F16)        hipLaunchKernelGGL(conv2d_nhwc_kernel<__half>, grid, dim3(256), 0, s, a);
     else if (dtype == P3D_F32_BF16X3 && x_split) hipLaunchKernelGGL((conv2d_nhwc_kernel<float, true, true>), grid, dim3(256), 0, s, a);
     else if (dtype == P3D_F32_BF16X3 && a.iscale) hipLaunchKernelGGL((conv2d_nhwc_kernel<float, true, false, false, true>), grid, dim3(256), 0, s, a);
@@ -1738,7 +1810,7 @@ int p3d::conv2d_nhwc_run_io(const void* x, const void* w, void* y, int dtype, co
     P3D_REQUIRE(resample >= 0 && resample <= 2, "conv2d_nhwc: resample must be 0 (same), 1 (transposed x2) or 2 (valid, stride 2)");
     P3D_REQUIRE(x && w && y && zeros128, "conv2d_nhwc: null pointer");
     P3D_REQUIRE(n_img >= 1 && h >= 1 && wdt >= 1 && co >= 1, "conv2d_nhwc: bad sizes");
-    P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32 || dtype == P3D_F32_BF16X3, "conv2d_nhwc: dtype must be fp16, fp32 or fp32-as-bf16x3");
+    P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32 || dtype == P3D_F32_BF16X3 || dtype == P3D_F32_BF16X6, "conv2d_nhwc: dtype must be fp16, fp32, fp32-as-bf16x3 or fp32-as-bf16x6");
     P3D_REQUIRE(kernel_size == 3 || (kernel_size == 1 && !transposed_stride2), "conv2d_nhwc: kernel 3x3, or 1x1 without upsampling");
     P3D_REQUIRE(!out_scale || dtype != P3D_F16, "conv2d_nhwc: the per-image output scale is implemented for fp32 tensors");
     static const bool no_h2t = getenv("P3D_CONV_NO_H2") != nullptr;
@@ -1800,6 +1872,7 @@ int p3d::conv2d_nhwc_run_io(const void* x, const void* w, void* y, int dtype, co
             if (dtype == P3D_F16)             hipLaunchKernelGGL(conv3x3_halo_kernel<__half>, grid, dim3(256), 0, s, a);
             else if (dtype == P3D_F32_BF16X3 && x_split) hipLaunchKernelGGL((conv3x3_halo_kernel<float, true, true>), grid, dim3(256), 0, s, a);
             else if (dtype == P3D_F32_BF16X3) hipLaunchKernelGGL((conv3x3_halo_kernel<float, true>), grid, dim3(256), 0, s, a);
+            else if (dtype == P3D_F32_BF16X6) hipLaunchKernelGGL((conv3x3_halo_kernel<float, false, false, true>), grid, dim3(256), 0, s, a);
             else                              hipLaunchKernelGGL(conv3x3_halo_kernel<float>, grid, dim3(256), 0, s, a);
             count_launch(FAM_CONV);
             return check_launch("conv3x3_halo");

@@ -802,13 +802,13 @@ static int conv_forward_impl(const void* x, const void* weight, void* y, void* w
     const bool dry = query != nullptr;
     if (dry) { *query = 0; x = weight = zeros128 = (const void*)(uintptr_t)16; y = w_scratch = (void*)(uintptr_t)16; }
     P3D_REQUIRE(x && weight && y, "conv2d_forward: null pointer");
-    P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32 || dtype == P3D_F32_BF16X3, "conv2d_forward: dtype must be fp16, fp32 or fp32-as-bf16x3");
+    P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32 || dtype == P3D_F32_BF16X3 || dtype == P3D_F32_BF16X6, "conv2d_forward: dtype must be fp16, fp32, fp32-as-bf16x3 or fp32-as-bf16x6");
     P3D_REQUIRE(n_img >= 1 && h >= 1 && wdt >= 1 && ci >= 1 && co >= 1, "conv2d_forward: bad sizes");
     P3D_REQUIRE((kernel_size == 3 && (stride == 1 || stride == 2)) || (kernel_size == 1 && stride == 1), "conv2d_forward: 3x3 at stride 1 / 2 or 1x1 at stride 1");
     hipStream_t s = (hipStream_t)stream;
     const int taps = kernel_size * kernel_size;
     if (kernel_size == 1 && (!mfma_channels_ok(dtype, ci) || co < 32)) {
-        if (dtype == P3D_F32_BF16X3) dtype = P3D_F32;                       // the skinny kernels are plain fp32 VALU
+        if (dtype == P3D_F32_BF16X3 || dtype == P3D_F32_BF16X6) dtype = P3D_F32;      // the skinny kernels are plain fp32 VALU
         // skinny 1x1 (either direction: a transposed 1x1 is the same product with the weight read transposed), channels-last
         if (dry) return P3D_OK;
         const int64_t npix = (int64_t)n_img * h * wdt;

@@ -518,13 +518,18 @@ constexpr int UB_LDS = (2 * (UB_SLAB_SLOTS + UB_WT_SLOTS) * 16 > UB_CT_FLOATS * 
 
 __device__ __forceinline__ void ub_split(const uf4& a0, const uf4& a1, ubf8& hi, ubf8& lo)
 {
+    typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));        // on pairs, as split_bf16x8 in conv2d.hip: one conversion instruction per two pieces
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t h, l;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float x = a0[e], y = a1[e];
-        const __bf16 hx = (__bf16)x, hy = (__bf16)y;
-        hi[e] = hx; hi[4 + e] = hy;
-        lo[e] = (__bf16)(x - (float)hx); lo[4 + e] = (__bf16)(y - (float)hy);
+    for (int p = 0; p < 4; ++p) {
+        const f32x2_t x = p < 2 ? f32x2_t{a0[2 * p], a0[2 * p + 1]} : f32x2_t{a1[2 * p - 4], a1[2 * p - 3]};
+        h[p] = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf2_t));
+        const f32x2_t hf = {__builtin_bit_cast(float, h[p] << 16), __builtin_bit_cast(float, h[p] & 0xffff0000u)};
+        l[p] = __builtin_bit_cast(uint32_t, __builtin_convertvector(x - hf, bf2_t));
     }
+    hi = __builtin_bit_cast(ubf8, h); lo = __builtin_bit_cast(ubf8, l);
     asm volatile("s_nop 4" : "+v"(hi), "+v"(lo));              // conversion -> MFMA operand hazard: see split8 in render_device.h
 }
 

@@ -194,6 +194,10 @@ def _native_conv(x, w, cfg, k, stride):
     y = torch.empty([n, co, oh, ow], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     scratch = None if skinny else torch.empty([co * ci * k * k], dtype=x.dtype, device=x.device)
     code_dtype = 3 if (cfg.split and x.dtype == torch.float32 and not skinny and k == 3 and ci % 32 == 0) else _lib.DTYPE_CODE[x.dtype]     # 3 = P3D_F32_BF16X3
+    if code_dtype == 0 and not skinny and ci % 32 == 0:
+        from . import modconv
+        if modconv.f32_x6:
+            code_dtype = 4                                     # P3D_F32_BF16X6: fp32-accurate products on the bf16 matrix pipe (opt-in, modconv.f32_x6)
     nbytes = 0 if skinny else int(_lib.lib().p3d_conv2d_forward_workspace(code_dtype, n, h, wd, ci, co, k, stride, int(tr)))
     work = torch.empty([nbytes // 4], dtype=torch.float32, device=x.device) if nbytes > 0 else None      # split-K partial tiles (low-resolution layers)
     code = _lib.lib().p3d_conv2d_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), _lib.ptr(scratch), _lib.ptr(_zeros_page(x.device)), code_dtype,
@@ -203,7 +207,7 @@ def _native_conv(x, w, cfg, k, stride):
     native_calls['forward'] += 1
     log = _lib.kernel_events.get('conv_flops')               # bench.py's arithmetic floor: (arithmetic class, multiply-add FLOPs) of every native convolution
     if log is not None:
-        log.append(('bf16x3' if code_dtype == 3 else str(x.dtype), 2.0 * n * ci * co * k * k * (h * wd if (tr and stride == 2) else oh * ow)))
+        log.append(('bf16x3' if code_dtype == 3 else ('bf16x6' if code_dtype == 4 else str(x.dtype)), 2.0 * n * ci * co * k * k * (h * wd if (tr and stride == 2) else oh * ow)))
     return y
 
 

@@ -124,6 +124,9 @@ def torgb_supported(x, weight, styles, fused_modconv):
 
 BF16X3 = 'bf16x3'            # dtype tag: fp32 tensors whose products run as three bf16 MFMAs of (hi, lo) splits (csrc/conv2d.hip)
 DTYPE_F32_BF16X3 = 3         # p3d_dtype code of that formulation (include/p3d_hip.h)
+DTYPE_F32_BF16X6 = 4         # P3D_F32_BF16X6: plain fp32 tensors and weights, every product as SIX bf16 MFMAs of three-piece splits made in registers (fp32-accurate)
+f32_x6 = os.environ.get('P3D_F32_BF16X6', '0') == '1'      # opt-in: the fp32 convolutions that would run on the f32-input MFMA (exact products) run as bf16x6 instead —
+                             # inference layers here, training-mode forward / data gradient in conv2d_gradfix; ignored wherever bf16x3 is selected
 fuse_up2_f32_min_res = int(os.environ.get('P3D_FUSE_UP2_F32_MIN_RES', 1 << 30))      # fp32 (bf16x3) x2 layers from this input resolution up take the one-kernel form.
                              # OFF by default: measured SLOWER than transposed conv + FIR (256->128 @128^2: 331 vs 302 us, 512->256 @64^2: 313 vs 234 us, batch 4) — its fp32
                              # tile needs 131 KB of LDS, i.e. one 4-wave block per CU with nothing to hide the staging behind; kept, with its parity test, as the starting point
@@ -308,10 +311,13 @@ def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None
     ns = None if noise is None else noise_strength.detach().float().reshape(1).contiguous()
     mode = 1 if transposed else (2 if down == 2 else 0)
     code_dtype = DTYPE_F32_BF16X3 if split else _lib.DTYPE_CODE[x.dtype]          # split: wmod came from modulate_weights(dtype=BF16X3)
+    x6 = f32_x6 and not split and x.dtype == torch.float32 and ci % 32 == 0
+    if x6:
+        code_dtype = DTYPE_F32_BF16X6
     assert not split or x.dtype == torch.float32
     nbytes = int(_lib.lib().p3d_conv2d_nhwc_workspace(code_dtype, n, h, w, ci, co, stride, k, mode))
     work = torch.empty([nbytes // 4], dtype=torch.float32, device=x.device) if nbytes > 0 else None          # split-K partial tiles (low-resolution layers)
-    with _lib.kernel_timer('conv_bf16x3' if split else ('conv_f16' if x.dtype == torch.float16 else 'conv_f32'), x):
+    with _lib.kernel_timer('conv_bf16x3' if split else ('conv_f16' if x.dtype == torch.float16 else ('conv_bf16x6' if x6 else 'conv_f32')), x):
         code = None
         if in_scale is not None:                           # [N, Ci] fp32 on the activations as they enter the matrix cores (shared-weight form: the styles)
             assert out_scale is not None and split and tuple(in_scale.shape) == (n, ci) and in_scale.dtype == torch.float32 and in_scale.is_contiguous()
@@ -334,7 +340,7 @@ def conv2d(x, wmod, transposed=False, bias=None, noise=None, noise_strength=None
     _lib.check(code, 'conv2d_nhwc')
     log = _lib.kernel_events.get('conv_flops')
     if log is not None:                                  # bench.py: FLOPs of the launches it is timing (2*Ci*Co*k*k per output / input pixel)
-        log.append(('bf16x3' if split else str(x.dtype), 2.0 * n * ci * co * k * k * (oh * ow if down == 2 else h * w)))
+        log.append(('bf16x3' if split else ('bf16x6' if x6 else str(x.dtype)), 2.0 * n * ci * co * k * k * (oh * ow if down == 2 else h * w)))
     return y
 
 

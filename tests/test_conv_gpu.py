@@ -495,3 +495,55 @@ def test_x2_layer_in_one_kernel_fp32_as_bf16x3(hip_lib, ci, co, h, w, n, noise, 
     print(ci, co, h, w, 'fused', e1, 'two-kernel', e0)
     tol = 1e-5 if clamp is None else 1e-4                                        # (a clamp at 0.5 shrinks the range the error is measured against)
     assert e1 < tol and e0 < tol
+
+
+@pytest.fixture
+def f32_x6():
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    old = modconv.f32_x6
+    modconv.f32_x6 = True
+    yield modconv
+    modconv.f32_x6 = old
+
+
+@pytest.mark.parametrize('ci,co,h,w,n,k,mode', [
+    (256, 256, 64, 64, 2, 3, 'same'),          # halo-slab kernel
+    (64, 96, 70, 52, 2, 3, 'same'),            # ragged tiles, channel count that is no multiple of the tile
+    (32, 64, 40, 40, 3, 3, 'same'),            # the 64-channel tile form
+    (512, 512, 16, 16, 4, 3, 'same'),          # the split-K schedule
+    (256, 128, 64, 64, 2, 3, 'transposed'),    # four parity classes, class-major order
+    (32, 256, 33, 40, 3, 3, 'transposed'),
+    (128, 130, 24, 24, 2, 1, 'same'),          # 1x1 on the matrix pipe
+    (128, 128, 33, 33, 2, 3, 'down'),          # valid, stride 2
+])
+def test_bf16x6_formulation_of_the_fp32_convolution(hip_lib, f32_x6, ci, co, h, w, n, k, mode):
+    """P3D_F32_BF16X6: plain fp32 activations and weights, every product as six bf16 MFMAs of three-piece splits made in registers.  Bar: the error
+    class of the exact fp32 MFMA kernel (3e-6 of the output's maximum against an fp64 convolution of the same fp32 operands) and within 2x of
+    what that kernel measures on the same inputs — fp32-accurate, unlike bf16x3 (1e-5)."""
+    modconv = f32_x6
+    torch.manual_seed(ci + co + h + k)
+    x = _nhwc(torch.randn(n, ci, h, w, device='cuda'))
+    weight = torch.randn(co, ci, k, k, device='cuda')
+    styles = torch.randn(n, ci, device='cuda') + 1
+    w32 = modconv.modulate_weights(weight, styles, demodulate=(k == 3), dtype=torch.float32)
+    wq = w32.double().reshape(n, co, k, k, ci).permute(0, 1, 4, 2, 3).cpu()
+    xd = x.double().cpu()
+    kw = dict(transposed=True) if mode == 'transposed' else (dict(down=2) if mode == 'down' else dict(bias=torch.randn(co, device='cuda'), act=1, gain=2 ** 0.5))
+
+    y6 = modconv.conv2d(x, w32, **kw)
+    modconv.f32_x6 = False
+    y1 = modconv.conv2d(x, w32, **kw)
+    modconv.f32_x6 = True
+    if mode == 'transposed':
+        ref = torch.stack([F.conv_transpose2d(xd[i:i + 1], wq[i].transpose(0, 1), stride=2)[0] for i in range(n)])
+    elif mode == 'down':
+        ref = torch.stack([F.conv2d(xd[i:i + 1], wq[i], stride=2)[0] for i in range(n)])
+    else:
+        ref = torch.stack([F.conv2d(xd[i:i + 1], wq[i], padding=k // 2)[0] for i in range(n)])
+        ref = F.leaky_relu(ref + kw['bias'].double().cpu().view(1, -1, 1, 1), 0.2) * 2 ** 0.5
+    assert y6.shape == ref.shape
+    e6 = rel_err(y6.double().cpu().numpy(), ref.numpy())
+    e1 = rel_err(y1.double().cpu().numpy(), ref.numpy())
+    print((ci, co, h, w, n, k, mode), 'bf16x6', e6, 'exact', e1)
+    assert e6 < 3e-6 and e6 < 2 * e1 + 1e-7, (e6, e1)
+    assert not torch.equal(y6, y1)                       # (the other arithmetic did run)

@@ -160,3 +160,36 @@ def test_weight_gradient_at_training_sizes(hip_lib, gradfix):
     xp = F.pad(x.float(), (1, 1, 1, 1))
     ref = torch.stack([torch.stack([torch.einsum('nohw,nihw->oi', gy.float(), xp[:, :, ky:ky + h, kx:kx + h]) for kx in range(3)], -1) for ky in range(3)], -2)
     assert rel_err(gw.float().cpu(), ref.cpu()) < 4e-3
+
+
+@pytest.mark.parametrize('geom', [g for g in GEOM if g[0] in ('same3x3', 'same3x3_big', 'same1x1', 'down3x3_even', 'up3x3', 'up3x3_big_op1', 'sameT3x3', 'fold8x8', 'odd_channels', 'row64')],
+                         ids=lambda g: g[0])
+def test_forward_and_data_gradient_as_bf16x6(hip_lib, gradfix, geom):
+    """modconv.f32_x6 (P3D_F32_BF16X6=1): the fp32 forward and data-gradient convolutions as six bf16 MFMAs per product of three-piece splits — the error
+    class of the exact fp32 kernels (bar 4e-6 of the range against fp64, and within 2x of what the exact kernels measure on the same tensors); the weight
+    gradient is the exact kernel either way."""
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    x64, w64, g = _make(geom, torch.float32)
+    xr, wr = x64.clone().requires_grad_(True), w64.clone().requires_grad_(True)
+    yr = _ref_op(xr, wr, geom)
+    gy64 = torch.randn(yr.shape, generator=g).float().double()
+    gxr, gwr = torch.autograd.grad(yr, [xr, wr], gy64)
+    errs = {}
+    prev = modconv.f32_x6
+    try:
+        for x6 in (True, False):
+            modconv.f32_x6 = x6
+            xd = x64.to('cuda', torch.float32).requires_grad_(True)
+            wd = w64.to('cuda', torch.float32).requires_grad_(True)
+            c0 = dict(gradfix.native_calls)
+            yd = _dev_op(xd, wd, geom)
+            gxd, gwd = torch.autograd.grad(yd, [xd, wd], gy64.to('cuda', torch.float32))
+            torch.cuda.synchronize()
+            assert gradfix.native_calls['forward'] == c0['forward'] + 2 and gradfix.native_calls['aten'] == c0['aten']
+            errs[x6] = dict(y=rel_err(yd.detach().double().cpu(), yr.detach()), gx=rel_err(gxd.double().cpu(), gxr), gw=rel_err(gwd.double().cpu(), gwr))
+    finally:
+        modconv.f32_x6 = prev
+    print(geom[0], 'bf16x6', errs[True], 'exact', errs[False])
+    for k in ('y', 'gx'):
+        assert errs[True][k] < 4e-6 and errs[True][k] < 2 * errs[False][k] + 1e-7, (k, errs)
+    assert abs(errs[True]['gw'] - errs[False]['gw']) < 1e-7

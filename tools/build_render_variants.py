@@ -3,7 +3,7 @@ hash pins the committed counter passes): csrc is copied to /tmp, render_device.h
 pix2pix3d_amd/libp3d_hip_rv<bits>.so (git-ignored; travels to the GPU box; select with P3D_LIB_PATH).
     python tools/build_render_variants.py 1 2 3 4 8 16
 bits: 32 kRaysB = 8, 64 softplus without the threshold select, 128 sigmoid without the exponent's pre-multiply, 1 no gather (features from the lane id), 2 no transcendentals in the decoder (softplus / sigmoid -> a multiply), 4 no MFMAs (operands kept alive),
-      8 no sched_barrier between the two nets of a sample, 16 exact-fp32 layer 2 on two accumulators."""
+      8 no sched_barrier between the two nets of a sample, 16 exact-fp32 layer 2 on two accumulators, 1024 split8 written on pairs (correct results)."""
 import os
 import shutil
 import subprocess
@@ -70,6 +70,36 @@ rep("""            else out = P3D_MFMA(__builtin_amdgcn_mfma_f32_32x32x2f32, a[e
     if (P3D_RENDER_DEBUG & 16) out = out + out2;
 }
 """)
+# 1024: split8 on pairs (one v_cvt_pk_bf16_f32 per two pieces, the piece back to fp32 by shift / mask) — same bits out; does the decoder's vector share shrink?
+rep("""#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = v[e];
+        const __bf16 hx = (__bf16)x;
+        hi[e] = hx;
+        lo[e] = (__bf16)(x - (float)hx);
+    }
+    asm volatile("s_nop 4" : "+v"(hi), "+v"(lo));""", """    if (P3D_RENDER_DEBUG & 1024) {
+        typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        u32x4_t hh, ll;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const f32x2_t x = {v[2 * p], v[2 * p + 1]};
+            hh[p] = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf2_t));
+            const f32x2_t hf = {__builtin_bit_cast(float, hh[p] << 16), __builtin_bit_cast(float, hh[p] & 0xffff0000u)};
+            ll[p] = __builtin_bit_cast(uint32_t, __builtin_convertvector(x - hf, bf2_t));
+        }
+        hi = __builtin_bit_cast(bf8, hh); lo = __builtin_bit_cast(bf8, ll);
+    } else
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = v[e];
+        const __bf16 hx = (__bf16)x;
+        hi[e] = hx;
+        lo[e] = (__bf16)(x - (float)hx);
+    }
+    asm volatile("s_nop 4" : "+v"(hi), "+v"(lo));""")
 open(hdr, 'w').write(s)
 
 objs = [os.path.join(B.OBJ_DIR, f) for f in os.listdir(B.OBJ_DIR) if f.endswith('.o') and f not in ('render.o', 'hazard_probe.o', 'mfma_rate_probe.o')]
