@@ -266,7 +266,8 @@ def train_summary(timers, sizes, world, batch, wall_ms):
                     'the generated pair, fwd + bwd; then the cross-view block: no-grad render from gen_c -> arg-max label map -> differentiated render -> no-grad reconstruction -> smooth-L1 backward: FOUR '
                     'generator passes) + Greg (density regularisation on the fused point kernels) + Dmain (one no-grad generator pass, generated + real) + Dreg (R1 double backward) + D_semanticmain + '
                     f'D_semanticreg (the same two on image + 6 label channels), each with its flat gradient all-reduce and Adam step, then G_ema; batch {batch}/GPU, 128^2 rays x 48+48; every convolution '
-                    'forward / data gradient / weight gradient on libp3d_hip.so.  Not in it: LPIPS (lambda_lpips 0: a pretrained VGG that does not exist offline) and the augmentation pipe (--aug=noaug)',
+                    'forward / data gradient / weight gradient on libp3d_hip.so; fp32 products: ' + ('forward / data gradient as six bf16 MFMAs of three-piece register splits (bf16x6: the exact '
+                    'kernels\' error against fp64, P3D_F32_BF16X6=0 = the f32-input MFMA), weight gradients on the f32-input MFMA' if _x6_on() else 'all on the f32-input MFMA') + '.  Not in it: LPIPS (lambda_lpips 0: a pretrained VGG that does not exist offline) and the augmentation pipe (--aug=noaug)',
             'ms_per_iteration': round(wall_ms, 2), 'img_per_s': round(batch * world / (wall_ms * 1e-3), 2),
             'phase_ms': {k: round(v, 2) for k, v in ph.items()},
             'lazy_schedule': {'G_reg_interval': G_REG_INTERVAL, 'D_reg_interval': D_REG_INTERVAL, 'ms_per_iteration': round(lazy, 2), 'img_per_s': round(batch * world / (lazy * 1e-3), 2),
@@ -299,9 +300,15 @@ def train_roofline():
             'dominant': out[0] if out else None, 'next': out[1:]}
 
 
+def _x6_on():
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    return bool(modconv.f32_x6)
+
+
 def train_arithmetic_floor(st, args, phase_ms):
     """One more (untimed) iteration with every native convolution logging its multiply-add FLOPs and arithmetic class, cut per phase: what the phase would
-    take if its matrix work ran at the quoted peaks — exact-fp32 MFMA 157.3 TFLOP/s, fp16 / bf16 MFMA 2.5 PFLOP/s (each bf16x3 product = three bf16 MFMAs) — and at
+    take if its matrix work ran at the quoted peaks — exact-fp32 MFMA 157.3 TFLOP/s, fp16 / bf16 MFMA 2.5 PFLOP/s (each bf16x3 product = three bf16 MFMAs, each bf16x6
+    product — the default of the fp32 forward / data-gradient convolutions — six) — and at
     what the matrix pipe sustains on real operands (mfma_real_data_ceiling).  The decoder MLPs of the fused renderer (exact fp32 MFMA in training: forward, and
     in the backward the recomputation + data gradient + weight gradient) are added from the sample counts; element-wise work, the gathers and the optimizer are
     not arithmetic the matrix pipes do and are left out: a FLOOR, to read the measured phase times against."""
@@ -326,25 +333,25 @@ def train_arithmetic_floor(st, args, phase_ms):
     samples = args.batch * args.train_nrr * args.train_nrr * 96          # config 3: 48 + 48 samples per ray
     out = {}
     for name, ((i0, b0, l0), (i1, b1, l1)) in cuts.items():
-        fl = {'float32': 0.0, 'float16': 0.0, 'bf16x3': 0.0}
+        fl = {'float32': 0.0, 'float16': 0.0, 'bf16x3': 0.0, 'bf16x6': 0.0}
         for d, f in log[i0:i1]:
-            key = 'bf16x3' if d == 'bf16x3' else ('float16' if 'float16' in d else 'float32')
+            key = d if d in ('bf16x3', 'bf16x6') else ('float16' if 'float16' in d else 'float32')
             fl[key] += f
         n_bwd = b1.get('fused', 0) - b0.get('fused', 0)
         n_fwd = l1 - l0                                                  # (the density regularisation's point queries are 2 x 1000 points per image: not counted)
         mlp = samples * MLP_FLOP_PER_SAMPLE * (COARSE_FACTOR * n_fwd + 3.0 * n_bwd)
         f32 = fl['float32'] + mlp
-        half = fl['float16'] + 3.0 * fl['bf16x3']
+        half = fl['float16'] + 3.0 * fl['bf16x3'] + 6.0 * fl['bf16x6']
         floor_ms = (f32 / (F32_MFMA_PEAK_TF * 1e12) + half / 2.5e15) * 1e3
         rec = {'tflop': {'f32_convs': round(fl['float32'] / 1e12, 3), 'f32_decoder_mlps': round(mlp / 1e12, 3), 'f16_convs': round(fl['float16'] / 1e12, 3),
-                         'bf16x3_convs_fp32_equivalent': round(fl['bf16x3'] / 1e12, 3)},
+                         'bf16x3_convs_fp32_equivalent': round(fl['bf16x3'] / 1e12, 3), 'bf16x6_convs_fp32_equivalent': round(fl['bf16x6'] / 1e12, 3)},
                'floor_ms_at_quoted_peaks': round(floor_ms, 2), 'measured_ms': phase_ms.get(name),
                'measured_over_floor': round(phase_ms[name] / floor_ms, 2) if phase_ms.get(name) and floor_ms > 0 else None}
         if ceil_tf:
             rec['floor_ms_half_precision_at_real_data_ceiling'] = round((f32 / (F32_MFMA_PEAK_TF * 1e12) + half / (ceil_tf * 1e12)) * 1e3, 2)
         out[name] = rec
     return {'what': 'matrix-pipe floor per phase: FLOPs of every native convolution (forward, data gradient, weight gradient) and of the renderer\'s decoder MLPs by arithmetic '
-                    'class / the pipe\'s rate for that class; exact fp32 MFMA 157.3 TFLOP/s, fp16 / bf16 MFMA 2.5 PFLOP/s quoted (' + (f'{ceil_tf:.0f} TFLOP/s on real operands' if ceil_tf else 'no probe record') + ')',
+                    'class / the pipe\'s rate for that class; exact fp32 MFMA 157.3 TFLOP/s (weight gradients, decoder MLPs), fp16 / bf16 MFMA 2.5 PFLOP/s quoted, with a bf16x6 product counted as six and a bf16x3 product as three (' + (f'{ceil_tf:.0f} TFLOP/s on real operands' if ceil_tf else 'no probe record') + ')',
             'phases': out}
 
 
@@ -485,7 +492,7 @@ def main():
             line = {'metric': 'training img/s (seg2cat 512^2, batch 4/GPU, 128^2 rays x 48+48 samples; Gmain + Greg + Dmain + Dreg + D_semanticmain + D_semanticreg, all-reduce + Adam per phase)',
                     'value': summary['img_per_s'], 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                     'ms_per_step': summary['ms_per_iteration'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-                    'dtype': 'f32 (backbone, ray-marcher) + f16/f32-acc (super-resolution, discriminator top blocks), as train.py configures', 'data': 'synthetic',
+                    'dtype': 'f32 (backbone, ray-marcher' + ('; convolution products formed as bf16x6, fp32-accurate' if _x6_on() else '') + ') + f16/f32-acc (super-resolution, discriminator top blocks), as train.py configures', 'data': 'synthetic',
                     'config': {'workload': summary['what'], 'launch': 'eager', 'parallelism': f'dp{world} (batch sharded, flat fp32 gradient all-reduce per phase)'},
                     'train_step': summary, 'rccl': rccl}
             print(json.dumps(line), flush=True)
@@ -645,35 +652,35 @@ def main():
     main_m = measure(8.0)
     exact = None
     if not args.no_exact_fp32:                                       # the same loop with every bf16x3 switch off: exact fp32 MFMA in the backbone and the decoder
-        prev = (_mc.split_bf16, rmod.mlp_bf16x3)
-        _mc.split_bf16, rmod.mlp_bf16x3 = False, False
+        prev = (_mc.split_bf16, rmod.mlp_bf16x3, _mc.f32_x6)
+        _mc.split_bf16, rmod.mlp_bf16x3, _mc.f32_x6 = False, False, False
         try:
             torch.cuda.empty_cache()
             exact_m = measure(3.0)
             exact = {'value': round(args.batch * world * args.steps / exact_m['elapsed'], 3), 'unit': 'img/s', 'ms_per_step': round(exact_m['elapsed'] / args.steps * 1e3, 3),
                      'launch': exact_m['launch'], 'stage_ms': {k: round(v, 3) for k, v in exact_m['stage_ms'].items()}, 'mfma_conv': exact_m['mfma_conv'],
                      'roofline': roofline(exact_m, False),
-                     'what': 'P3D_BF16X3=0 P3D_MLP_BF16X3=0: every fp32 convolution and the decoder MLPs on the f32-input MFMA (exact fp32 products, the arithmetic class the reference '
+                     'what': 'P3D_BF16X3=0 P3D_MLP_BF16X3=0 P3D_F32_BF16X6=0: every fp32 convolution and the decoder MLPs on the f32-input MFMA (exact fp32 products, the arithmetic class the reference '
                              'insists on, training_loop.py:278-280); super-resolution heads unchanged'}
             # the same fp32-accurate leg with the backbone's products formed on the bf16 matrix pipe (P3D_F32_BF16X6: three-piece splits in
             # registers, six MFMAs per product; plain fp32 tensors and weights — DESIGN 2.4c); the decoder stays on the f32-input MFMA
-            prev6, _mc.f32_x6 = _mc.f32_x6, True
+            _mc.f32_x6 = True
             try:
                 torch.cuda.empty_cache()
                 x6_m = measure(3.0)
                 exact['backbone_as_bf16x6'] = {'value': round(args.batch * world * args.steps / x6_m['elapsed'], 3), 'unit': 'img/s',
                                                'ms_per_step': round(x6_m['elapsed'] / args.steps * 1e3, 3), 'launch': x6_m['launch'],
                                                'stage_ms': {k: round(v, 3) for k, v in x6_m['stage_ms'].items()}, 'mfma_conv': x6_m['mfma_conv'],
-                                               'what': 'P3D_F32_BF16X6=1 on top: the fp32 convolutions as six bf16 MFMAs per product (hi/mid/lo pieces, error class of the exact kernel: '
+                                               'what': 'P3D_BF16X3=0 P3D_MLP_BF16X3=0 alone (P3D_F32_BF16X6 at its default, 1): the fp32 convolutions as six bf16 MFMAs per product (hi/mid/lo pieces, error class of the exact kernel: '
                                                        'tests/test_conv_gpu.py::test_bf16x6_formulation_of_the_fp32_convolution)'}
             except Exception as e:                                   # noqa: BLE001
                 exact['backbone_as_bf16x6'] = {'error': f'{type(e).__name__}: {e}'[:300]}
             finally:
-                _mc.f32_x6 = prev6
+                _mc.f32_x6 = False
         except Exception as e:                                       # noqa: BLE001 - the headline line must still be printed
             exact = {'error': f'{type(e).__name__}: {e}'[:300]}
         finally:
-            _mc.split_bf16, rmod.mlp_bf16x3 = prev
+            _mc.split_bf16, rmod.mlp_bf16x3, _mc.f32_x6 = prev
 
     # BASELINE.json's other single-GPU shapes, each timed the same way (own warm-up, own hipGraph, short settling): configs[1] at its own 48+48
     # samples, configs[3]'s per-GPU share (edge2car, batch 16 over 2 GPUs: train.py:451-461) and configs[4]'s (seg2face, batch 8 over 4 GPUs:
@@ -727,15 +734,15 @@ def main():
                 train['generator_bf16x3'] = {'error': f'{type(e).__name__}: {e}'[:300]}
             finally:
                 _tp.train_products_bf16x3 = prev_tp
-            prev6, _mc.f32_x6 = _mc.f32_x6, True                     # fp32-ACCURATE products on the bf16 pipe: every fp32 forward / data-gradient convolution, G and D
+            prev6, _mc.f32_x6 = _mc.f32_x6, False                    # the iteration with every fp32 product on the f32-input MFMA (the default forms them as bf16x6: same error class)
             try:
                 t3, _ = run_train(args, device, world, dist, 3, 1)
-                train['fp32_as_bf16x6'] = {'what': 'P3D_F32_BF16X6=1: every fp32 forward and data-gradient convolution (generator, discriminators, frozen passes) as six bf16 MFMAs per '
-                                                   'product of three-piece splits — the error class of the exact kernels; weight gradients stay on the f32-input MFMA',
+                train['f32_input_mfma'] = {'what': 'P3D_F32_BF16X6=0: every fp32 forward and data-gradient convolution (generator, discriminators, frozen passes) on v_mfma_f32_32x32x2_f32 instead of '
+                                                   'six bf16 MFMAs per product of three-piece splits (the default; weight gradients are on the f32-input MFMA either way)',
                                            'ms_per_iteration': t3['ms_per_iteration'], 'img_per_s': t3['img_per_s'], 'phase_ms': t3['phase_ms'],
                                            'lazy_schedule_ms': t3['lazy_schedule']['ms_per_iteration']}
             except Exception as e:                                   # noqa: BLE001
-                train['fp32_as_bf16x6'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+                train['f32_input_mfma'] = {'error': f'{type(e).__name__}: {e}'[:300]}
             finally:
                 _mc.f32_x6 = prev6
 

@@ -30,7 +30,6 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
 constexpr int BM = 128, BN = 128;          // block tile; the K step is one 128-byte row: 64 halfs or 32 floats
 
@@ -45,49 +44,7 @@ constexpr int BM = 128, BN = 128;          // block tile; the K step is one 128-
 #define P3D_BF16_TERMS 3
 #endif
 constexpr int kBf16Terms = P3D_BF16_TERMS;     // 3: xh*wh + xh*wl + xl*wh (term order: hh, hl, lh); 4 adds xl*wl (measured: no accuracy gain)
-typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t cvt_pk_bf16(const f32x2_t v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2_t)); }
-__device__ __forceinline__ f32x2_t bf16_pair_as_f32(const uint32_t p) { return f32x2_t{__builtin_bit_cast(float, p << 16), __builtin_bit_cast(float, p & 0xffff0000u)}; }
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split_bf16x8(const f32x4& a0, const f32x4& a1, bf8& hi, bf8& lo)
-{
-    u32x4_t h, l;                                                     // on pairs (see split3_bf16x8 below): 2.5 - 3 vector instructions per value instead of 4
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const f32x2_t x = p < 2 ? f32x2_t{a0[2 * p], a0[2 * p + 1]} : f32x2_t{a1[2 * p - 4], a1[2 * p - 3]};
-        h[p] = cvt_pk_bf16(x);                                        // round to nearest even
-        l[p] = cvt_pk_bf16(x - bf16_pair_as_f32(h[p]));
-    }
-    hi = __builtin_bit_cast(bf8, h); lo = __builtin_bit_cast(bf8, l);
-    // every converted register complete before the first MFMA reads any of them: see the hazard note at split8 in render_device.h
-    // (v_cvt_pk_bf16_f32 -> MFMA operand at the compiler's two wait states returned stale 16-lane groups in the ray-marcher)
-    asm volatile("s_nop 4" : "+v"(hi), "+v"(lo));
-}
-
-// "bf16x6" (P3D_F32_BF16X6): three bf16 pieces per fp32 value — hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid); both subtractions are exact in fp32 and
-// after them at most 8 significant bits are left, so hi + mid + lo == x — and the six products of magnitude >= 2^-16: fp32-accurate, no pre-split layout anywhere.
-// Written on PAIRS: one v_cvt_pk_bf16_f32 makes two pieces and IS the operand register; the pieces go back to fp32 with one shift / one mask.  (The
-// element-wise form compiled to 7.5 vector instructions per value — the compiler converted every value twice, once alone for the subtraction and once
-// in a pair for the operand — and the kernel was bound by them: 300 vector instructions per 24 MFMAs.  This form: 5.5, or 4.5 where the subtractions pair
-// up as v_pk_add_f32.)  Same roundings, same bits.
-__device__ __forceinline__ void split3_bf16x8(const f32x4& a0, const f32x4& a1, bf8& hi, bf8& mid, bf8& lo)
-{
-    u32x4_t h, m, l;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const f32x2_t x = p < 2 ? f32x2_t{a0[2 * p], a0[2 * p + 1]} : f32x2_t{a1[2 * p - 4], a1[2 * p - 3]};
-        h[p] = cvt_pk_bf16(x);
-        const f32x2_t r1 = x - bf16_pair_as_f32(h[p]);
-        m[p] = cvt_pk_bf16(r1);
-        l[p] = cvt_pk_bf16(r1 - bf16_pair_as_f32(m[p]));
-    }
-    hi = __builtin_bit_cast(bf8, h); mid = __builtin_bit_cast(bf8, m); lo = __builtin_bit_cast(bf8, l);
-    asm volatile("s_nop 4" : "+v"(hi), "+v"(mid), "+v"(lo));         // conversion -> MFMA operand hazard: see split_bf16x8
-}
-// term t of the six: (A piece, B piece) = (h,h) (h,m) (m,h) (h,l) (l,h) (m,m)
-#define P3D_X6_A(t, h, m, l) ((t) == 2 || (t) == 5 ? (m) : ((t) == 4 ? (l) : (h)))
-#define P3D_X6_B(t, h, m, l) ((t) == 1 || (t) == 5 ? (m) : ((t) == 3 ? (l) : (h)))
+#include "bf16_split.h"
 
 struct ConvTap { int dy, dx, widx; };
 

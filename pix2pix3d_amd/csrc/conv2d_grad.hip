@@ -19,6 +19,7 @@ namespace p3d {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "bf16_split.h"
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- weight re-layout: torch [A][B][taps] -> tap-major [O][taps][I] in the same dtype ------------------------------------------------
@@ -102,11 +103,17 @@ __device__ __forceinline__ void pix_advance(PixPos& p, int d, int HS, int WS)
 // SMALL (with FAST, psplit == 4): both sides hold at most 64 channels.  The 128-channel loader would leave half of its threads without a load and a wave with a
 // quarter of a chunk's MFMAs against a whole chunk's staging and barrier (61 TFLOP/s on the fp32 64 x 64 layers at 512^2); here every thread loads, the chunk
 // is twice as long (KP = two chunks of the split plan) and the LDS image is 64 channels wide.
-template <class T, int KP, bool FAST, bool SMALL = false>
+// X6 (fp32, psplit == 1): the products as bf16x6 (bf16_split.h; P3D_F32_BF16X6) — a chunk's 16 pixels are ONE k-step of v_mfma_f32_32x32x16_bf16: lane (frow, fk) gathers
+// pixels 8 fk .. 8 fk + 7 of its channel from the pixel-major LDS image (the same 32 ds_read_b32 per chunk as the exact loop's), splits them in registers and issues 24
+// MFMAs (768 cycles) where the f32-input MFMA needs 32 (2048).
+// (LDS row pitch of the fp32 image: 128 / 64 floats.  Rows padded so that lanes l and l + 32 of a fragment read land 32 banks apart — 160 / 96, and 132 for the bf16x6
+// loop's rows 8 apart — measured no faster, the 64-channel form 20 % slower: profiles/round5_q_wgrad_variants.txt.)
+template <class T, int KP, bool FAST, bool SMALL = false, bool X6 = false>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
 {
     typedef WgradTraits<T> TR;
     static_assert(FAST || !SMALL, "the 64-channel form exists for aligned geometries only");
+    static_assert(!X6 || (sizeof(T) == 4 && !SMALL && KP == 16), "bf16x6 is an arithmetic of the plain fp32 loop (whole 128 x 128 tiles)");
     constexpr int EPC = TR::EPC, PITCH = !SMALL ? TR::PITCH : (sizeof(T) == 2 ? KP + 8 : 64);
     constexpr int KPB = SMALL ? KP / 2 : KP;                                   // pixels of one chunk of the split plan
     constexpr int OPER = sizeof(T) == 2 ? (SMALL ? 64 : 128) * PITCH : KP * PITCH;   // elements of one operand image
@@ -288,6 +295,26 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a)
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
+        } else if constexpr (X6) {
+            bf8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x4 a0, a1, b0, b1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a0[e] = ls[(8 * fk + e) * PITCH + wm * 64 + i * 32 + frow]; a1[e] = ls[(8 * fk + 4 + e) * PITCH + wm * 64 + i * 32 + frow];
+                    b0[e] = lb[(8 * fk + e) * PITCH + wn * 64 + i * 32 + frow]; b1[e] = lb[(8 * fk + 4 + e) * PITCH + wn * 64 + i * 32 + frow];
+                }
+                split3_bf16x8(a0, a1, ah[i], am[i], al[i]);
+                split3_bf16x8(b0, b1, bh[i], bm[i], bl[i]);
+            }
+#pragma unroll
+            for (int term = 0; term < 6; ++term)                                // term outermost: consecutive MFMAs never share an accumulator
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P3D_X6_A(term, ah[i], am[i], al[i]), P3D_X6_B(term, bh[j], bm[j], bl[j]), acc[i][j], 0, 0, 0);
         } else {
 #pragma unroll
             for (int kk = 0; kk < KP / 2; ++kk) {
@@ -892,7 +919,9 @@ static int bwd_weight_impl(const void* small_img, const void* big_img, void* gw,
                            int32_t kernel_size, int32_t stride, int32_t pad, bool out_f32, float scale, p3d_stream_t stream)
 {
     P3D_REQUIRE(small_img && big_img && gw && workspace, "conv2d_bwd_weight: null pointer");
-    P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32, "conv2d_bwd_weight: dtype must be fp16 or fp32");
+    P3D_REQUIRE(dtype == P3D_F16 || dtype == P3D_F32 || dtype == P3D_F32_BF16X6, "conv2d_bwd_weight: dtype must be fp16, fp32 or fp32-as-bf16x6");
+    const bool x6 = dtype == P3D_F32_BF16X6;                                     // fp32 tensors; the arithmetic of the whole-tile kernel only (anything else: the exact kernels)
+    if (x6) dtype = P3D_F32;
     P3D_REQUIRE(n_img >= 1 && small_h >= 1 && small_w >= 1 && big_h >= 1 && big_w >= 1 && c_small >= 1 && c_big >= 1, "conv2d_bwd_weight: bad sizes");
     P3D_REQUIRE((kernel_size == 1 || kernel_size == 3) && (stride == 1 || stride == 2) && pad >= 0 && pad <= 1, "conv2d_bwd_weight: k in {1,3}, stride in {1,2}, pad in {0,1}");
     P3D_REQUIRE(workspace_bytes >= p3d_conv2d_bwd_weight_workspace(dtype, n_img, small_h, small_w, c_small, c_big, kernel_size), "conv2d_bwd_weight: workspace too small");
@@ -967,6 +996,7 @@ static int bwd_weight_impl(const void* small_img, const void* big_img, void* gw,
         else           hipLaunchKernelGGL((conv_wgrad_kernel<__half, 64, false>), dim3(blocks), dim3(256), 0, s, a);
     } else {
         if (small64)   hipLaunchKernelGGL((conv_wgrad_kernel<float, 32, true, true>), dim3(blocks), dim3(256), 0, s, a);
+        else if (fast && x6 && a.psplit == 1) hipLaunchKernelGGL((conv_wgrad_kernel<float, 16, true, false, true>), dim3(blocks), dim3(256), 0, s, a);
         else if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<float, 16, true>), dim3(blocks), dim3(256), 0, s, a);
         else           hipLaunchKernelGGL((conv_wgrad_kernel<float, 16, false>), dim3(blocks), dim3(256), 0, s, a);
     }

@@ -238,6 +238,14 @@ def _native_weight_grad(grad_output, x, cfg, k, stride, scale=None):
     assert (cs, cb) == tuple(cfg.wshape[:2]) and big.shape[0] == n
     gw = torch.empty(cfg.wshape, dtype=x.dtype if scale is None else torch.float32, device=x.device)
     code_dtype = _lib.DTYPE_CODE[x.dtype]
+    x6 = False
+    if x.dtype == torch.float32:
+        from . import modconv
+        # P3D_F32_BF16X6 in the weight gradient: the whole-tile kernel's arithmetic only (both sides > 64 channels, whole aligned channel groups) — the library
+        # takes the exact kernels for every other geometry, whatever the code says; mirrored here for the FLOP log's arithmetic class
+        x6 = modconv.f32_x6 and modconv.wgrad_x6 and cs > 64 and cb > 64 and cs % 4 == 0 and cb % 4 == 0
+        if x6:
+            code_dtype = 4
     nbytes = int(_lib.lib().p3d_conv2d_bwd_weight_workspace(code_dtype, n, hs, ws_, cs, cb, k))
     work = torch.empty([nbytes // 4], dtype=torch.float32, device=x.device)
     if scale is None:
@@ -250,7 +258,7 @@ def _native_weight_grad(grad_output, x, cfg, k, stride, scale=None):
     native_calls['weight_grad'] += 1
     log = _lib.kernel_events.get('conv_flops')
     if log is not None:
-        log.append((str(x.dtype), 2.0 * n * cs * cb * k * k * hs * ws_))
+        log.append(('bf16x6' if x6 else str(x.dtype), 2.0 * n * cs * cb * k * k * hs * ws_))
     return gw
 
 

@@ -125,8 +125,10 @@ def torgb_supported(x, weight, styles, fused_modconv):
 BF16X3 = 'bf16x3'            # dtype tag: fp32 tensors whose products run as three bf16 MFMAs of (hi, lo) splits (csrc/conv2d.hip)
 DTYPE_F32_BF16X3 = 3         # p3d_dtype code of that formulation (include/p3d_hip.h)
 DTYPE_F32_BF16X6 = 4         # P3D_F32_BF16X6: plain fp32 tensors and weights, every product as SIX bf16 MFMAs of three-piece splits made in registers (fp32-accurate)
-f32_x6 = os.environ.get('P3D_F32_BF16X6', '0') == '1'      # opt-in: the fp32 convolutions that would run on the f32-input MFMA (exact products) run as bf16x6 instead —
-                             # inference layers here, training-mode forward / data gradient in conv2d_gradfix; ignored wherever bf16x3 is selected
+f32_x6 = os.environ.get('P3D_F32_BF16X6', '1') == '1'      # the fp32 convolutions that would run on the f32-input MFMA run as bf16x6 instead — inference layers here (when bf16x3 is off),
+                             # training-mode forward / data gradient in conv2d_gradfix; ignored wherever bf16x3 is selected.  On by default since the whole GPU suite passed
+                             # under it with unchanged bounds and its error against fp64 is the exact kernels' (DESIGN 2.4c); '0' = every product on v_mfma_f32_32x32x2_f32
+wgrad_x6 = os.environ.get('P3D_WGRAD_BF16X6', '1') == '1'     # with f32_x6: the fp32 WEIGHT gradients of whole 128 x 128 tiles (both sides > 64 channels) the same way
 fuse_up2_f32_min_res = int(os.environ.get('P3D_FUSE_UP2_F32_MIN_RES', 1 << 30))      # fp32 (bf16x3) x2 layers from this input resolution up take the one-kernel form.
                              # OFF by default: measured SLOWER than transposed conv + FIR (256->128 @128^2: 331 vs 302 us, 512->256 @64^2: 313 vs 234 us, batch 4) — its fp32
                              # tile needs 131 KB of LDS, i.e. one 4-wave block per CU with nothing to hide the staging behind; kept, with its parity test, as the starting point

@@ -23,7 +23,7 @@ for dt, n, hs, cs, cb, k, stride, pad in GEO:
     small = torch.randn(n, hs, hs, cs, device=dev, generator=g).to(dt)
     big = torch.randn(n, hb, hb, cb, device=dev, generator=g).to(dt)
     gw = torch.empty(cs, cb, k, k, dtype=dt, device=dev)
-    code = _lib.DTYPE_CODE[dt]
+    code = 4 if (dt == torch.float32 and os.environ.get('WGRAD_X6') == '1') else _lib.DTYPE_CODE[dt]      # 4 = P3D_F32_BF16X6
     nbytes = int(L.p3d_conv2d_bwd_weight_workspace(code, n, hs, hs, cs, cb, k))
     work = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     call = lambda: _lib.check(L.p3d_conv2d_bwd_weight(_lib.ptr(small), _lib.ptr(big), _lib.ptr(gw), _lib.ptr(work), nbytes, code, n, hs, hs, cs, hb, hb, cb, k, stride, pad,

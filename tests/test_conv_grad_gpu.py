@@ -162,12 +162,19 @@ def test_weight_gradient_at_training_sizes(hip_lib, gradfix):
     assert rel_err(gw.float().cpu(), ref.cpu()) < 4e-3
 
 
-@pytest.mark.parametrize('geom', [g for g in GEOM if g[0] in ('same3x3', 'same3x3_big', 'same1x1', 'down3x3_even', 'up3x3', 'up3x3_big_op1', 'sameT3x3', 'fold8x8', 'odd_channels', 'row64')],
-                         ids=lambda g: g[0])
+X6_GEOM = [g for g in GEOM if g[0] in ('same3x3', 'same3x3_big', 'same1x1', 'down3x3_even', 'up3x3', 'up3x3_big_op1', 'sameT3x3', 'fold8x8', 'odd_channels', 'row64', 'half_tile_b')] + [
+    ('wide_down', False, 3, 2, 128, 256, 65, 65, 2, 0),              # weight gradient as bf16x6: whole 128 x 128 tiles at stride 2 ...
+    ('wide_up', True, 3, 2, 256, 128, 32, 32, 2, 0),                 # ... with the roles swapped (transposed op) ...
+    ('wide_1x1', False, 1, 1, 128, 160, 40, 36, 3, 0),               # ... one tap, a ragged tile on the big side
+    ('wide_ragged', False, 3, 1, 132, 200, 21, 23, 3, 0),            # ... channel counts that are multiples of 4 only, a pixel count that is no multiple of the chunk
+]
+
+
+@pytest.mark.parametrize('geom', X6_GEOM, ids=lambda g: g[0])
 def test_forward_and_data_gradient_as_bf16x6(hip_lib, gradfix, geom):
-    """modconv.f32_x6 (P3D_F32_BF16X6=1): the fp32 forward and data-gradient convolutions as six bf16 MFMAs per product of three-piece splits — the error
-    class of the exact fp32 kernels (bar 4e-6 of the range against fp64, and within 2x of what the exact kernels measure on the same tensors); the weight
-    gradient is the exact kernel either way."""
+    """modconv.f32_x6 (P3D_F32_BF16X6, the default): the fp32 forward and data-gradient convolutions — and the weight gradients of whole 128 x 128 tiles (both sides
+    > 64 channels; modconv.wgrad_x6) — as six bf16 MFMAs per product of three-piece splits: the error class of the exact fp32 kernels (bar 4e-6 of the range
+    against fp64, and within 2x of what the exact kernels measure on the same tensors)."""
     from pix2pix3d_amd.torch_utils.ops import modconv
     x64, w64, g = _make(geom, torch.float32)
     xr, wr = x64.clone().requires_grad_(True), w64.clone().requires_grad_(True)
@@ -186,10 +193,13 @@ def test_forward_and_data_gradient_as_bf16x6(hip_lib, gradfix, geom):
             gxd, gwd = torch.autograd.grad(yd, [xd, wd], gy64.to('cuda', torch.float32))
             torch.cuda.synchronize()
             assert gradfix.native_calls['forward'] == c0['forward'] + 2 and gradfix.native_calls['aten'] == c0['aten']
+            assert gradfix.native_calls['weight_grad'] == c0['weight_grad'] + 1
             errs[x6] = dict(y=rel_err(yd.detach().double().cpu(), yr.detach()), gx=rel_err(gxd.double().cpu(), gxr), gw=rel_err(gwd.double().cpu(), gwr))
     finally:
         modconv.f32_x6 = prev
     print(geom[0], 'bf16x6', errs[True], 'exact', errs[False])
-    for k in ('y', 'gx'):
+    for k in ('y', 'gx', 'gw'):
         assert errs[True][k] < 4e-6 and errs[True][k] < 2 * errs[False][k] + 1e-7, (k, errs)
-    assert abs(errs[True]['gw'] - errs[False]['gw']) < 1e-7
+    name, tr, k, stride, ci, co = geom[:6]
+    if min(ci, co) > 64 and ci % 4 == 0 and co % 4 == 0:
+        assert errs[True]['gw'] != errs[False]['gw']                # (the other arithmetic did run)

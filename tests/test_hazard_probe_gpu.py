@@ -31,9 +31,9 @@ def test_cvt_to_mfma_distance_of_the_workaround_is_clean(hip_lib):
 
 
 def test_the_kernels_still_carry_the_guard():
-    """Source-level pin: both bf16x3 split helpers end in the `s_nop 4` that ties every converted register to one point."""
+    """Source-level pin: every in-register split helper (bf16x3's two pieces, bf16x6's three) ends in the `s_nop 4` that ties every converted register to one point."""
     csrc = os.path.join(ROOT, 'pix2pix3d_amd', 'csrc')
-    for fn, helper in (('render_device.h', 'split8'), ('conv2d.hip', 'split_bf16x8')):
+    for fn, helper in (('render_device.h', 'split8'), ('bf16_split.h', 'split_bf16x8'), ('bf16_split.h', 'split3_bf16x8'), ('up2_fir.hip', 'ub_split')):
         src = open(os.path.join(csrc, fn)).read()
         body = src[src.index(helper + '('):]
         body = body[:body.index('\n}\n')]
