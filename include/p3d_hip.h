@@ -38,7 +38,7 @@ enum p3d_dtype { P3D_F32 = 0, P3D_F16 = 1, P3D_F64 = 2,
                  P3D_F32_BF16X3 = 3     /* conv entry points only: fp32 tensors, fp32 accumulation, every product formed as three bf16
                                            products of (hi, lo) splits — ~2^-16 relative per product at up to 5x the fp32 matrix rate;
                                            weights come from p3d_modulate_weights with the same code ([32 x hi | 32 x lo] K rows)      */,
-                 P3D_F32_BF16X6 = 4     /* conv entry points only (p3d_conv2d_nhwc*, p3d_conv2d_forward / _bwd_data): fp32 tensors AND fp32 weights in the
+                 P3D_F32_BF16X6 = 4     /* conv entry points only (p3d_conv2d_nhwc*, p3d_conv2d_forward / _bwd_data / _bwd_weight*): fp32 tensors AND fp32 weights in the
                                            P3D_F32 layouts, fp32 accumulation; every operand is split IN REGISTERS into three bf16 pieces (hi + mid + lo = the
                                            fp32 value exactly: 3 x 8 significand bits) and every product formed as the six bf16 products of magnitude
                                            >= 2^-16 (hh, hm, mh, hl, lh, mm; the three dropped ones are <= 2^-23 relative together: the size of one fp32
@@ -283,7 +283,8 @@ int p3d_conv2d_nhwc(const void* x, const void* w, void* y, int dtype, const floa
  *   p3d_conv2d_bwd_data    :139-143   "grad_input = the transposed op" with output_padding from the shapes (:95-104)
  *   p3d_conv2d_bwd_weight  :155-194   Conv2dGradWeight (aten::convolution_backward with mask [F,T,F]; a matmul for 1x1)
  * All tensors channels-last ([N][H][W][C]), fp16 or fp32 with fp32 accumulation (dtype P3D_F32_BF16X3 for forward / bwd_data: fp32 tensors,
- * products as three bf16 MFMAs), groups = 1, dilation = 1, weights SHARED across the
+ * products as three bf16 MFMAs; P3D_F32_BF16X6 for all three: fp32 tensors, fp32-accurate products as six bf16 MFMAs — the weight gradient
+ * takes it for whole 128 x 128 tiles and the exact kernels otherwise), groups = 1, dilation = 1, weights SHARED across the
  * batch and passed in torch's own layout and in the activation dtype.  The family (what conv2d_resample.py:96-136 ever asks for):
  *   transposed = 0: conv2d,            weight [Co][Ci][k][k]:  k in {1, 3} at stride 1 / padding k/2,  k = 3 at stride 2 / padding 0
  *   transposed = 1: conv_transpose2d,  weight [Ci][Co][k][k]:  the same two geometries; at stride 2 the output is [2H+1 | 2H+2]

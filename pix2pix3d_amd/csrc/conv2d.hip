@@ -79,6 +79,7 @@ struct ConvArgs {
     float* rgb_out;        // [N][rgb_co][H][W] fp32, accumulated into
     int rgb_co;            // <= 8
     float rgb_clamp;       // on (sum + bias) before the accumulation; < 0: off
+    int cb_loop;           // conv3x3_h2_f16_kernel<false> with the fused ToRGB: channel blocks of 128 one work-group walks (grid.y = Co / 128 / cb_loop); 0 / 1 = one
     const float* oscale;   // [N][Co] or null (generic kernel, fp32 tensors): the accumulator is multiplied by oscale[image][channel] before the
                            // rest of the epilogue — the demodulation coefficient of the SHARED-weight form of the modulated convolution
     const float* iscale;   // [N][Ci] or null (generic kernel, bf16x3 on plain fp32 activations: conv2d_nhwc_kernel<float, true, false, false, true>): every activation is
@@ -695,7 +696,8 @@ constexpr int H2_SLAB_PIECES = (H2_SLAB_ROWS * 64 + 1023) / 1024;   // 23 DMA pi
 constexpr int H2_SLAB_BUF = H2_SLAB_PIECES * 1024;              // 23552
 constexpr int H2_WT_BYTES = BN * 64;                            // 8192
 constexpr int H2_WT_BASE = 2 * H2_SLAB_BUF;                     // 47104
-constexpr int H2_LDS = H2_WT_BASE + 3 * H2_WT_BYTES;            // 71680 (>= the 69632-byte epilogue stage)
+constexpr int H2_RGB_BASE = H2_WT_BASE + 3 * H2_WT_BYTES;       // 71680 (>= the 69632-byte epilogue stage): partial ToRGB sums [8][256 pixels] fp32 between the passes of a
+constexpr int H2_LDS = H2_RGB_BASE + 8 * 256 * 4;               // work-group that walks several channel blocks (ConvArgs::cb_loop) — 79872; two work-groups a CU: 156 of 160 KB
 
 // TR (p3d_conv3x3_torgb_f16 with y == null: the last block of a super-resolution head, whose activations only its ToRGB reads): the MFMA operands
 // are SWAPPED — weights as A, pixels as B — so an accumulator tile is y^T: a lane holds 16 channels of ONE pixel ((r & 3) + 8 (r >> 2) + 4 fk of its
@@ -703,9 +705,12 @@ constexpr int H2_LDS = H2_WT_BASE + 3 * H2_WT_BYTES;            // 71680 (>= the
 // channels (the k <-> channel permutation is put into the ToRGB weights' A fragments), and its result tile has the pixel in the lane again: the
 // epilogue needs no LDS image, no rendezvous and no store of y — 128 two-byte LDS stores, 16 LDS reads, 16 global stores and three block-wide
 // barriers per thread become 16 MFMAs and a handful of read-modify-writes of the skip image.
-template <bool TR>
+// CBL (p3d_conv3x3_torgb_f16 at Co = 256): the work-group walks ConvArgs::cb_loop channel blocks of its patch, see `ncbi` below.  A build of its own so that the one-block
+// kernels keep their register allocation (with the loop around the pipeline the compiler hoists the epilogue's address arithmetic above it: 241 -> 256 registers + spills).
+template <bool TR, bool CBL = false>
 __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
 {
+    static_assert(!(TR && CBL), "the channel-block loop is a form of the LDS-image epilogue");
     // ONE __shared__ object on purpose: with two, hipcc drains vmcnt to 0 before the first ds_read of every step and the counted
     // waits below are moot (cdna_hip_programming.md, 'three .s-level traps' (a))
     __shared__ __attribute__((aligned(16))) char lds_b[H2_LDS];
@@ -718,7 +723,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
         if ((nmt & 7) == 0) { const int q = L >> 3, r = L & 7; cb = q % ncb; mt = (q / ncb) * 8 + r; }
     }
     const int ty0 = mt / tiles_x, tx0 = mt - ty0 * tiles_x;
-    const int oy0 = ty0 * QH, ox0 = tx0 * QW, co0 = cb * BN;
+    const int oy0 = ty0 * QH, ox0 = tx0 * QW;
+    // fused ToRGB of a layer with more than 128 channels: this work-group takes `ncbi` channel blocks one after the other (the whole pipeline per block) and carries
+    // the ToRGB contraction's partial sums from pass to pass in LDS — bias, clamp and the read-modify-write of the skip image happen once, after the last
+    const int ncbi = CBL ? a.cb_loop : 1;
+    int co0 = cb * ncbi * BN;
     const char* const xin_b = (const char*)((const __half*)a.x + (int64_t)n * a.H * a.W * a.Ci);
     const char* const wgt_b = (const char*)((const __half*)a.w + (int64_t)n * a.w_img_stride);
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -726,11 +735,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
     const int pos = lane & 3, prow = lane >> 2;                                // DMA lane: 16-byte position / row within its 16-row piece
     const int kpairs = a.Ci / 64;                                              // the loop body covers TWO 32-channel chunks (18 taps)
 
-    unsigned woff[2];                                                          // weight pieces 2 * wave, 2 * wave + 1 (16 rows each)
+    unsigned woff[2];                                                          // weight pieces 2 * wave, 2 * wave + 1 (16 rows each) of the channel block at hand
 #pragma unroll
     for (int p2 = 0; p2 < 2; ++p2) {
         const int row = (wave * 2 + p2) * 16 + prow;
-        woff[p2] = (unsigned)(((co0 + row) * 9 * a.Ci + (pos ^ ((row >> 2) & 3)) * 8) * 2);
+        woff[p2] = (unsigned)((row * 9 * a.Ci + (pos ^ ((row >> 2) & 3)) * 8) * 2);
     }
     unsigned soff[6]; bool sok[6];                                             // slab pieces wave, wave + 4, ...  (6, or 5 for wave 3)
 #pragma unroll
@@ -751,20 +760,15 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
             }
         }
     };
+    const char* wgt_cb = wgt_b + (int64_t)co0 * 9 * a.Ci * 2;                   // (uniform) the channel block's first weight row
     auto stage_w = [&](int cc, int t, int slot) {
-        const char* base = wgt_b + (t * a.Ci + cc * 32) * 2;
+        const char* base = wgt_cb + (t * a.Ci + cc * 32) * 2;
 #pragma unroll
         for (int p2 = 0; p2 < 2; ++p2)
             __builtin_amdgcn_global_load_lds((glb_ptr)(base + woff[p2]), (lds_ptr)(lds_b + H2_WT_BASE + slot * H2_WT_BYTES + (wave * 2 + p2) * 1024), 16, 0, 0);
     };
 
     f32x16 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     // fragment addresses (LDS byte offsets).  A: pixel (wave*4 + 2i + frow/16, frow%16) of the patch at tap (ty, tx) is slab row
     // (that pixel row + ty) * PITCH + column + tx; its 16-byte piece c sits at position c ^ key with the key taken from the slab
     // COLUMN.  Only tx changes the key: 3 x 2 lane constants; i, ty, the slab buffer and the ring slot are instruction immediates.
@@ -798,6 +802,14 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
     // TWO steps earlier, while the group issued one step earlier (tile ks+2, plus a slab after tap 0) stays in flight under a counted
     // vmcnt.  Two full steps of flight out of three slots (PMC on a one-step version: 46 % of the wave cycles waiting at vmcnt(0) +
     // barrier).  Nine taps and three slots: the slot index is t % 3, a compile-time constant of the unrolled body.
+#pragma nounroll
+    for (int cbi = 0; cbi < ncbi; ++cbi, co0 += BN, wgt_cb += (int64_t)BN * 9 * a.Ci * 2) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     stage_slab(0, 0);
     stage_w(0, 0, 0);
     stage_w(0, 1, 1);
@@ -908,6 +920,13 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
         return;
     }
     __syncthreads();                                                            // every wave is done with the slabs and tiles
+    // (CBL: opaque copies of everything the epilogue derives its addresses from, so that they are computed HERE — with the loop around the pipeline the compiler otherwise
+    // hoists ~70 loop-invariant epilogue values above it and spills them: 147 MB of scratch traffic per launch)
+    int oy0e = oy0, ox0e = ox0, tid_e = tid;
+    if constexpr (CBL) asm volatile("" : "+s"(oy0e), "+s"(ox0e), "+v"(tid_e));
+    const int lane_e = CBL ? (tid_e & 63) : lane, wave_e = CBL ? __builtin_amdgcn_readfirstlane(tid_e >> 6) : wave;
+    {   // ---- epilogue scope: tid / lane / wave / frow / fk below are the copies
+    const int tid = tid_e, lane = lane_e, wave = wave_e, frow = lane_e & 31, fk = lane_e >> 5;
 
     // Epilogue through LDS (the slabs are free now): each lane holds ONE channel of 64 pixels, which as direct stores is 64 two-byte
     // writes per lane.  Instead the finished tile is laid out [256 pixels][128 channels] (pitch 136 halfs: the fk = 1 half-wave lands
@@ -917,7 +936,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
     float* const nz = (float*)(ot + 256 * OP);                                   // the tile's noise: bytes 69632 .. 70656 < H2_LDS
     const float ns = a.noise ? a.noise_strength[0] : 0.f;
     if (a.noise) {
-        const int oy = oy0 + (tid >> 4), ox = ox0 + (tid & 15);
+        const int oy = oy0e + (tid >> 4), ox = ox0e + (tid & 15);
         nz[tid] = (oy < a.H && ox < a.W) ? a.noise[(int64_t)oy * a.W + ox] * ns : 0.f;
         __syncthreads();
     }
@@ -945,7 +964,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int idx = it * 256 + tid, p = idx >> 4, ch = idx & 15;
-            const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15), co = co0 + ch * 8;
+            const int oy = oy0e + (p >> 4), ox = ox0e + (p & 15), co = co0 + ch * 8;
             if (oy < a.H && ox < a.W && co < a.Co)
                 *(f32x4*)(yout + ((int64_t)oy * a.W + ox) * a.Co + co) = *(const f32x4*)(ot + p * OP + ch * 8);
         }
@@ -960,7 +979,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
 #pragma unroll
             for (int e = 0; e < 8; ++e) bw[sidx][e] = (_Float16)0.f;
             if (col < a.rgb_co) {
-                const float* wp = a.rgb_w + ((int64_t)n * a.rgb_co + col) * 128 + sidx * 16 + kg * 8;
+                const float* wp = a.rgb_w + ((int64_t)n * a.rgb_co + col) * a.Co + co0 + sidx * 16 + kg * 8;
                 const f32x4 w0 = *(const f32x4*)wp, w1 = *(const f32x4*)(wp + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { bw[sidx][e] = (_Float16)w0[e]; bw[sidx][4 + e] = (_Float16)w1[e]; }
@@ -977,27 +996,38 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
                 rr[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bw[sidx], rr[i], 0, 0, 0);
             }
         }
-        __syncthreads();                                                        // every wave has read its rows of the tile: it becomes the hand-over buffer
-        float* const ro = (float*)lds_b;                                        // [rgb_co][256 pixels]
+        // hand-over buffer [rgb_co][256 pixels]: its own region behind the slabs and the ring, so that the sums of this channel block survive the next pass's staging
+        float* const ro = (float*)(lds_b + H2_RGB_BASE);
+        const bool last = cbi + 1 == ncbi;
         if (col < a.rgb_co) {
-            const float b = a.rgb_bias ? a.rgb_bias[col] : 0.f;
+            const float b = (last && a.rgb_bias) ? a.rgb_bias[col] : 0.f;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
+                    float* slot = ro + col * 256 + wave * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;      // (written and read back by the same lane)
                     float v = rr[i][e] + b;
-                    if (a.rgb_clamp >= 0.f) v = fminf(fmaxf(v, -a.rgb_clamp), a.rgb_clamp);
-                    ro[col * 256 + wave * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg] = v;
+                    if (cbi > 0) v += *slot;
+                    if (last && a.rgb_clamp >= 0.f) v = fminf(fmaxf(v, -a.rgb_clamp), a.rgb_clamp);
+                    *slot = v;
                 }
         }
-        __syncthreads();
-        const int p = tid, oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
-        if (oy < a.H && ox < a.W)
-            for (int o = 0; o < a.rgb_co; ++o) {
-                float* dst = a.rgb_out + (((int64_t)n * a.rgb_co + o) * a.H + oy) * a.W + ox;
-                *dst += ro[o * 256 + p];
-            }
+        if (last) {
+            __syncthreads();
+            const int p = tid, oy = oy0e + (p >> 4), ox = ox0e + (p & 15);
+            if (oy < a.H && ox < a.W)
+                for (int o = 0; o < a.rgb_co; ++o) {
+                    float* dst = a.rgb_out + (((int64_t)n * a.rgb_co + o) * a.H + oy) * a.W + ox;
+                    *dst += ro[o * 256 + p];
+                }
+        }
     }
+    }   // ---- epilogue scope
+    if (cbi + 1 < ncbi) {                                                       // the next pass stages over the tile image: every wave done with it, every store of y retired
+        wait_vmcnt<0>();                                                        // (the counted waits of the pipeline count loads only)
+        __syncthreads();
+    }
+    }   // channel blocks of this work-group
 }
 
 // ---- the same pipeline for the bf16x3 form of the fp32 layers, on activations that arrive split (XS) -----------------------------------
@@ -1660,8 +1690,8 @@ extern "C" int p3d_conv3x3_torgb_f16(const void* x, const void* w, void* y, cons
     P3D_REQUIRE(x && w && zeros128 && rgb_w && rgb_out, "conv3x3_torgb_f16: null pointer");      // y may be null: the layer's activations have no other consumer
     P3D_REQUIRE(rgb_co >= 1 && rgb_co <= 8, "conv3x3_torgb_f16: 1 .. 8 image channels");
     P3D_REQUIRE(act == 0 || act == 1, "conv3x3_torgb_f16: act must be 0 (linear) or 1 (lrelu)");
-    if (co != BN || ci % 64 != 0 || h < 32 || wdt < 32 || ((uintptr_t)y & 15u) || ((uintptr_t)rgb_w & 15u) || (bias && ((uintptr_t)bias & 15u)))
-        return fail(P3D_ERR_UNSUPPORTED, "conv3x3_torgb_f16: needs Co = 128, Ci %% 64 = 0, an image of 32 x 32 or more (got %d, %d, %d x %d)", co, ci, h, wdt);
+    if ((co != BN && co != 2 * BN) || ci % 64 != 0 || h < 32 || wdt < 32 || ((uintptr_t)y & 15u) || ((uintptr_t)rgb_w & 15u) || (bias && ((uintptr_t)bias & 15u)))
+        return fail(P3D_ERR_UNSUPPORTED, "conv3x3_torgb_f16: needs Co = 128 or 256, Ci %% 64 = 0, an image of 32 x 32 or more (got %d, %d, %d x %d)", co, ci, h, wdt);
     P3D_REQUIRE((((uintptr_t)x) & 15u) == 0 && (((uintptr_t)w) & 15u) == 0 && (((uintptr_t)zeros128) & 15u) == 0, "conv3x3_torgb_f16: x, w and zeros128 must be 16-byte aligned");
     ConvArgs a{};
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.zeros = zeros128;
@@ -1672,8 +1702,10 @@ extern "C" int p3d_conv3x3_torgb_f16(const void* x, const void* w, void* y, cons
     a.rgb_w = rgb_w; a.rgb_bias = rgb_bias; a.rgb_out = rgb_out; a.rgb_co = rgb_co; a.rgb_clamp = rgb_clamp;
     dim3 grid(((h + QH - 1) / QH) * ((wdt + QW - 1) / QW), 1, n_img);
     static const bool no_tr = [] { const char* d = getenv("P3D_TORGB_NO_TR"); return d && atoi(d) != 0; }();      // A/B switch: the LDS-image epilogue without the store
-    if (!y && !no_tr) hipLaunchKernelGGL(conv3x3_h2_f16_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else              hipLaunchKernelGGL(conv3x3_h2_f16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    a.cb_loop = co / BN;                                                        // Co = 256: each work-group walks both channel blocks of its patch (the contraction runs over all of them)
+    if (a.cb_loop > 1)     hipLaunchKernelGGL((conv3x3_h2_f16_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (!y && !no_tr) hipLaunchKernelGGL(conv3x3_h2_f16_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else                   hipLaunchKernelGGL(conv3x3_h2_f16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
     count_launch(FAM_CONV);
     return check_launch("conv3x3_torgb_f16");
 }

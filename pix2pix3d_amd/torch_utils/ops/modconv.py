@@ -764,6 +764,7 @@ def fir4_bias_act(y, f, bias, noise, noise_strength, act, act_gain, clamp, out_s
 
 
 fused_torgb_calls = 0        # launches of the fused conv1 + ToRGB kernel (tests)
+fuse_torgb_256 = os.environ.get('P3D_FUSE_TORGB_256', '1') != '0'      # ... and at Co = 256 (the first block of a super-resolution head: its ToRGB re-read 134 MB of activations per launch)
 fuse_torgb = os.environ.get('P3D_FUSE_TORGB', '1') != '0'      # SynthesisBlock.conv1 + ToRGB + skip-image sum in one launch where the kernel allows (Co = 128, fp16)
 
 
@@ -774,13 +775,14 @@ def torgb_fusable(x, conv_weight, rgb_weight, img, up, noise_const, act):
     n, ci, h, w = x.shape
     if n * ((h + 15) // 16) * ((w + 15) // 16) < 192:         # too few 16 x 16 patches to fill the chip: the dispatcher would take the split-K kernel
         return False
-    return (conv_weight.shape[0] == 128 and tuple(conv_weight.shape[2:]) == (3, 3) and ci % 64 == 0 and h >= 32 and w >= 32 and rgb_weight.shape[0] <= 8
-            and tuple(rgb_weight.shape[1:]) == (128, 1, 1) and img.dtype == torch.float32 and img.is_contiguous() and tuple(img.shape) == (n, rgb_weight.shape[0], h, w)
+    co = conv_weight.shape[0]                                  # 128: one channel block per work-group; 256 (fuse_torgb_256): each work-group walks both blocks of its patch
+    return (co in ((128, 256) if fuse_torgb_256 else (128,)) and tuple(conv_weight.shape[2:]) == (3, 3) and ci % 64 == 0 and h >= 32 and w >= 32 and rgb_weight.shape[0] <= 8
+            and tuple(rgb_weight.shape[1:]) == (co, 1, 1) and img.dtype == torch.float32 and img.is_contiguous() and tuple(img.shape) == (n, rgb_weight.shape[0], h, w)
             and not img.requires_grad and _no_grad_needed(x, conv_weight, rgb_weight))
 
 
 def conv3x3_torgb(x, wmod, bias, act, gain, clamp, rgb_wmod, rgb_bias, rgb_clamp, img, store_y=True):
-    """3x3 'same' modulated conv (fp16 NHWC, Co = 128) + epilogue, and img += clamp(ToRGB(y) + rgb_bias) from the same launch.
+    """3x3 'same' modulated conv (fp16 NHWC, Co = 128 or 256) + epilogue, and img += clamp(ToRGB(y) + rgb_bias) from the same launch.
     ``store_y=False``: the layer's activations have no reader but this ToRGB (the last block of a super-resolution head) — they are not written
     (268 MB per launch at 512^2, batch 4) and None is returned."""
     n, ci, h, w = x.shape

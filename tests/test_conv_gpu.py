@@ -402,15 +402,16 @@ def test_shared_weight_form_of_the_low_resolution_layers(hip_lib, n, ci, co, res
     assert y1.shape == y0.shape and e1 < 1e-5 and e0 < 1e-5
 
 
-@pytest.mark.parametrize('img_channels,in_ch,res', [(3, 256, 256), (6, 128, 176), (1, 64, 160)])
-def test_last_conv_and_torgb_in_one_launch(hip_lib, img_channels, in_ch, res):
+@pytest.mark.parametrize('img_channels,in_ch,res,out_ch', [(3, 256, 256, 128), (6, 128, 176, 128), (1, 64, 160, 128),
+                                                           (3, 128, 256, 256), (6, 256, 176, 256)])      # 256: both channel blocks of a patch in one work-group (SR block0)
+def test_last_conv_and_torgb_in_one_launch(hip_lib, img_channels, in_ch, res, out_ch):
     """SynthesisBlock.conv1 + ToRGB + skip-image sum from one launch (p3d_conv3x3_torgb_f16) against the three-launch form: the same x
     (bit-identical: the convolution is untouched) and the same skip image up to the ToRGB weights' precision."""
     from pix2pix3d_amd import _lib
     from pix2pix3d_amd.training.networks_stylegan2 import SynthesisBlock
     from pix2pix3d_amd.torch_utils.ops import modconv
     torch.manual_seed(img_channels)
-    blk = SynthesisBlock(in_ch, 128, w_dim=64, resolution=res, img_channels=img_channels, is_last=True, use_fp16=True, conv_clamp=256,
+    blk = SynthesisBlock(in_ch, out_ch, w_dim=64, resolution=res, img_channels=img_channels, is_last=out_ch == 128, use_fp16=True, conv_clamp=256,
                          fp16_channels_last=True).cuda().eval().requires_grad_(False)
     blk.torgb.bias.normal_(); blk.conv1.bias.normal_()
     n = 2
