@@ -54,7 +54,14 @@ def test_default_line_has_the_contract_keys():
     assert set(fl) == {'Gmain', 'Greg', 'Dmain', 'Dreg', 'D_semanticmain', 'D_semanticreg'}
     for k, v in fl.items():
         assert 0 < v['floor_ms_at_quoted_peaks'] < v['measured_ms'] and v['measured_over_floor'] > 1, k                 # a floor
-    assert fl['Gmain']['tflop']['f32_convs'] > 3 * fl['Dmain']['tflop']['f32_convs'] and fl['Gmain']['tflop']['f32_decoder_mlps'] > 0
+    f32 = lambda ph: fl[ph]['tflop']['f32_convs'] + fl[ph]['tflop'].get('bf16x6_convs_fp32_equivalent', 0.0)      # fp32 tensors, whichever pipe forms the products
+    assert f32('Gmain') > 3 * f32('Dmain') and fl['Gmain']['tflop']['f32_decoder_mlps'] > 0
+    # round 5, bf16x6 (fp32-accurate products on the bf16 pipe, the default): the exact leg carries the same loop with the backbone's products formed that way,
+    # the training iteration the variant with every product back on the f32-input MFMA
+    x6 = e['backbone_as_bf16x6']
+    assert x6['value'] > e['value'] and x6['mfma_conv']['conv_bf16x6']['tflops'] > e['mfma_conv']['conv_f32']['tflops']
+    assert fl['Gmain']['tflop']['bf16x6_convs_fp32_equivalent'] > fl['Gmain']['tflop']['f32_convs']
+    assert t['f32_input_mfma']['ms_per_iteration'] > t['ms_per_iteration']
 
 
 def test_committed_counter_passes_belong_to_this_trees_kernel():
