@@ -686,7 +686,7 @@ def main():
     # samples, configs[3]'s per-GPU share (edge2car, batch 16 over 2 GPUs: train.py:451-461) and configs[4]'s (seg2face, batch 8 over 4 GPUs:
     # train.py:425-437).  configs[0] is the reference's CPU case (cpu_baseline), configs[2] the training iteration (train_step).
     other = None
-    if not args.no_configs and args.dataset == 'seg2cat' and args.batch == 4 and args.depth == 128 and not args.force_fp32:
+    if not args.no_configs and world == 1 and args.dataset == 'seg2cat' and args.batch == 4 and args.depth == 128 and not args.force_fp32:      # (N > 1: the scaling run times configs[1]'s headline shape only)
         import copy as _copy
         other = {}
         G = G.cpu()
