@@ -326,11 +326,12 @@ int p3d_conv2d_nhwc_ws(const void* x, const void* w, void* y, int dtype, const f
                        const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
                        int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, void* workspace, int64_t workspace_bytes,
                        p3d_stream_t stream);
-/* The last 3x3 layer of a synthesis block and its ToRGB in one launch (fp16, Co = 128: SynthesisBlock.conv1 + .torgb + the skip-image
+/* The last 3x3 layer of a synthesis block and its ToRGB in one launch (fp16, Co = 128 or 256: SynthesisBlock.conv1 + .torgb + the skip-image
  * sum, training/networks_stylegan2.py:449-459): y = act(conv3x3(x, w) + bias) * gain, clamped, as p3d_conv2d_nhwc would write it, and
  *   rgb_out[n][o][pixel] += clamp(sum_c y[n][pixel][c] * rgb_w[n][o][c] + rgb_bias[o], rgb_clamp)        (rgb_out fp32 NCHW, o < rgb_co <= 8)
- * from the finished tile while it is still in LDS.  rgb_w = ToRGB weight * styles, fp32 [N][rgb_co][128].  No noise input (layers with
- * noise keep the two-launch form).  Co != 128, Ci % 64 != 0 or images under 32 x 32: P3D_ERR_UNSUPPORTED.
+ * from the finished tile while it is still in LDS.  rgb_w = ToRGB weight * styles, fp32 [N][rgb_co][Co].  No noise input (layers with
+ * noise keep the two-launch form).  Co = 256: a work-group walks both 128-channel blocks of its pixel patch and sums the two
+ * contractions before bias / clamp.  Any other Co, Ci % 64 != 0 or images under 32 x 32: P3D_ERR_UNSUPPORTED.
  * y may be NULL: the activations are then not stored at all — the LAST block of a super-resolution head returns x to a caller that drops
  * it (training/superresolution.py:297-354 return rgb only), so its 268 MB of fp16 activations per launch have the ToRGB as only reader.  */
 int p3d_conv3x3_torgb_f16(const void* x, const void* w, void* y, const float* bias, const void* zeros128, const float* rgb_w, const float* rgb_bias,
