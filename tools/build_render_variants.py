@@ -100,6 +100,14 @@ rep("""#pragma unroll
         lo[e] = (__bf16)(x - (float)hx);
     }
     asm volatile("s_nop 4" : "+v"(hi), "+v"(lo));""")
+# 2048 / 4096: the compiler's MFMA-interleaving strategies (iglp_opt 0 / 1) for the scheduling region of each net of a sample (fine pass)
+rep("""            const int n = (idx == 0) ? SN : idx - 1;
+            f32x16 h0, h1, o;
+            if constexpr (BF3)  mlp_layer1_bf3(lds, n, lane, h, fh, fl, h0, h1);""", """            const int n = (idx == 0) ? SN : idx - 1;
+            f32x16 h0, h1, o;
+            if (P3D_RENDER_DEBUG & 2048) __builtin_amdgcn_iglp_opt(0);
+            if (P3D_RENDER_DEBUG & 4096) __builtin_amdgcn_iglp_opt(1);
+            if constexpr (BF3)  mlp_layer1_bf3(lds, n, lane, h, fh, fl, h0, h1);""")
 open(hdr, 'w').write(s)
 
 objs = [os.path.join(B.OBJ_DIR, f) for f in os.listdir(B.OBJ_DIR) if f.endswith('.o') and f not in ('render.o', 'hazard_probe.o', 'mfma_rate_probe.o')]
