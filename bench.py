@@ -171,6 +171,7 @@ def pmc_record(args, nrr, exact=False):
     return None
 
 
+FUSED_ADAM = os.environ.get('P3D_BENCH_FUSED_ADAM', '1') != '0'
 G_REG_INTERVAL, D_REG_INTERVAL = 4, 16        # train.py:239, 466 (--density_reg_every) and training_loop.py:249: the lazy-regularisation schedule
 PHASE_ORDER = ('Gmain', 'Greg', 'Dmain', 'Dreg', 'D_semanticmain', 'D_semanticreg')
 
@@ -197,7 +198,10 @@ def train_setup(args, device, world):
     phases = []                                                        # training_loop.py:360-373
     for name, lr, interval in (('G', 0.0025, G_REG_INTERVAL), ('D', 0.002, D_REG_INTERVAL), ('D_semantic', 0.002, D_REG_INTERVAL)):
         mb = interval / (interval + 1)
-        opt = torch.optim.Adam(nets[name].parameters(), lr=lr * mb, betas=[0 ** mb, 0.99 ** mb], eps=1e-8)
+        # training_loop.py:362-368 builds torch.optim.Adam from opt_kwargs (betas, eps, lr); ``fused=True`` is that optimizer's one-pass device implementation (one
+        # multi-tensor launch over p, g, m, v per step instead of the ~8 element-wise passes of the default "foreach" form — the 336 MB generator pays each pass
+        # at HBM rate); same update rule, fp32 state.  P3D_BENCH_FUSED_ADAM=0: the default form.
+        opt = torch.optim.Adam(nets[name].parameters(), lr=lr * mb, betas=[0 ** mb, 0.99 ** mb], eps=1e-8, fused=FUSED_ADAM and device.type == 'cuda')
         phases += [dict(name=name + 'main', module=nets[name], opt=opt, interval=1), dict(name=name + 'reg', module=nets[name], opt=opt, interval=interval)]
     n = args.batch
     g = torch.Generator().manual_seed(99 + int(os.environ.get('RANK', 0)))
@@ -274,6 +278,7 @@ def train_summary(timers, sizes, world, batch, wall_ms):
                               'note': 'amortised as the loop runs it: Gmain + Greg / 4 + Dmain + Dreg / 16 + D_semanticmain + D_semanticreg / 16 + ema'},
             'four_phase_ms': {'value': round(four, 2), 'note': "round 3's workload for comparison: Gmain + Greg + Dmain + Dreg + ema of THIS run (Gmain here carries the D_semantic term and the cross-view block, "
                                                                'which round 3 did not have)'},
+            'optimizer': 'torch.optim.Adam(fused=True): one multi-tensor launch per step' if FUSED_ADAM else 'torch.optim.Adam (default foreach form)',
             'allreduce': {'bytes_per_phase': sizes, 'note': ('world 1: concatenate + nan_to_num + scatter only' if world == 1 else 'RCCL ring over xGMI') + '; inside the phase times'}}
 
 

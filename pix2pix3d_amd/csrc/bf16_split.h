@@ -28,6 +28,10 @@ __device__ __forceinline__ void split_bf16x8(const f32x4& a0, const f32x4& a1, b
 // element-wise form compiled to 7.5 vector instructions per value — the compiler converted every value twice, once alone for the subtraction and once
 // in a pair for the operand — and the kernel was bound by them: 300 vector instructions per 24 MFMAs.  This form: 5.5, or 4.5 where the subtractions pair
 // up as v_pk_add_f32.)  Same roundings, same bits.
+// Non-finite and out-of-range operands: for x = +-inf, and for finite |x| > 3.396e38 (bf16(x) rounds to inf), the residual x - hi is inf - inf or -+inf, so every output
+// the operand reaches is NaN — where the f32-input MFMA (P3D_F32_BF16X6=0) and the reference give +-inf when the sum is well defined.  Non-finite in, non-finite out
+// either way; the KIND differs (the reference loop's nan_to_num maps nan -> 0, +-inf -> +-1e5).  A guard would cost one compare + one select per value in kernels that are
+// bound by this very vector work, so it is stated instead (pinned by tests/test_conv_gpu.py::test_bf16x6_non_finite_operands).
 __device__ __forceinline__ void split3_bf16x8(const f32x4& a0, const f32x4& a1, bf8& hi, bf8& mid, bf8& lo)
 {
     u32x4_t h, m, l;

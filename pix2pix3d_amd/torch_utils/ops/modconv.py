@@ -28,13 +28,47 @@ def side_stream(device):
     return st
 
 
+_plan_seq = [0]              # position of the newest event on the prefetch stream (monotonic for the life of the process)
+after_prefetch = []          # callables a network's prefetch_styles runs once its own plan is issued (the plans of networks LATER in the step: triplane._render)
+_ahead = {}                  # id(network) -> (the ws it was planned for, the plan's keys): plans issued ahead, picked up by that network's forward
+_plan_first = [0]            # position of the first event of the newest plan issued for the CURRENT network (prefetch_styles, not ahead)
+_plan_latest = [None, -1]    # (event, position): the newest event on the prefetch stream
+_plan_waited = {}            # consuming stream (its handle) -> position on the prefetch stream (the sequence number of an event) it already waits behind
+
+
 def take_plan(layer):
-    """Pop this layer's prefetched (styles, premodulated weights) and make the current stream wait for them."""
+    """Pop this layer's prefetched (styles, premodulated weights) and make the current stream wait for them.
+    Entries carry the POSITION of their event on the prefetch stream (prefetch_styles numbers them; layers that launched nothing new share the event of the
+    last one that did): a layer whose position the stream already waits behind adds no second wait.  In the captured step every such wait is an edge
+    between two branches of the graph — idle device in front of the layer's first kernel whether or not the event fired long ago (27 of them per step,
+    5.8 us each under the profiler: profiles/round5_u_step_trace.txt; same-box A/B of the elision: +0.4 ... +1.1 %, profiles/round6_a_*).
+    The FIRST wait of a stream on a plan is for the layer's own event (the network's first layer must not stand behind every modulation of the step); a
+    LATER one is for everything issued so far (``_plan_latest``: by then — the first per-image-weight layer, hundreds of microseconds into the network — the
+    prefetch stream has long run dry), so a network costs two edges, and the heads whose plans were issued ahead none."""
     hit = _plan.pop(id(layer), None)
     if hit is None:
         return None
-    torch.cuda.current_stream().wait_event(hit[2])
+    seq = hit[3] if len(hit) > 3 else None
+    cur = torch.cuda.current_stream()
+    waited = _plan_waited.get(cur.cuda_stream, -1)
+    if seq is None or not plan_wait_elision or seq > waited:
+        ev = hit[2]
+        if seq is not None and plan_wait_elision and plan_wait_latest and waited >= _plan_first[0] and _plan_latest[0] is not None:
+            ev, seq = _plan_latest
+        cur.wait_event(ev)
+        if seq is not None:
+            _plan_waited[cur.cuda_stream] = seq
     return hit[0], hit[1]
+
+
+def plan_joined(stream):
+    """True when ``stream`` already waits behind everything on the prefetch stream (finish_prefetch then adds no further edge)."""
+    return plan_wait_elision and _plan_latest[0] is not None and _plan_waited.get(stream.cuda_stream, -1) >= _plan_latest[1]
+
+
+plan_wait_elision = os.environ.get('P3D_PLAN_WAIT_ELISION', '1') != '0'      # take_plan skips waits its stream already stands behind; 0 = one wait per layer (A/B)
+plan_wait_latest = os.environ.get('P3D_PLAN_WAIT_LATEST', '1') != '0'        # ... and a stream's SECOND wait on a plan is for everything issued so far (0 = the layer's own event)
+sr_prefetch_ahead = os.environ.get('P3D_SR_PREFETCH_AHEAD', '1') != '0'      # the super-resolution heads' plans issued from inside the backbone's forward (superresolution.prefetch_ahead)
 
 
 _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
@@ -418,6 +452,17 @@ def invalidate_caches():
     bypass it (``param.data.copy_()``, ``dist.broadcast(param.data)``) do not bump it — code that overwrites parameters that way (dp.broadcast_module,
     misc.copy_params_and_buffers, the checkpoint loader) calls this afterwards."""
     _plain_weights.clear()
+    for hook in _invalidate_hooks:
+        hook()
+
+
+_invalidate_hooks = []                                   # other modules' caches of parameter-derived tensors (networks_stylegan2: b4's batch of constants)
+
+
+def on_invalidate(hook):
+    """Register a zero-argument callable that drops another module's parameter-derived cache whenever ``invalidate_caches()`` runs."""
+    _invalidate_hooks.append(hook)
+    return hook
 
 
 def plain_layer_supported(x, weight, up, down, activation):
@@ -596,14 +641,30 @@ def premodulate_many(items):
     work (the shared-weight coefficients — the low-resolution layers, which run first — are all issued at the first request)."""
     shared = [k for k, (w, st, up, px, dt) in enumerate(items) if px is not None and _premod_route(w, st, up, px, dt) == 'shared']
     ds = dict(zip(shared, demod_coefs_many([(items[k][0], items[k][1]) for k in shared]))) if shared else {}
+    for k in shared:
+        shared_split_weights(items[k][0])                  # (warm the per-weight cache off the critical path; all of them HERE, so that a later shared layer launches nothing)
     for k, (w, st, up, px, dt) in enumerate(items):
         if px is None:
             yield None
         elif k in ds:
-            shared_split_weights(w)                        # (warm the per-weight cache off the critical path)
             yield (ds[k], ('shared', up, BF16X3))
         else:
             yield premodulate(w, st, up, px, dt)
+
+
+def premodulate_launches(items):
+    """For the list premodulate_many takes: does asking for item k launch anything?  (A ToRGB layer: nothing.  A shared-weight layer: everything of all of them
+    at the FIRST one.  Anything else: its own modulation.)  prefetch_styles gives the layers that launch nothing the event of the last one that did."""
+    out, first_shared = [], True
+    for w, st, up, px, dt in items:
+        if px is None:
+            out.append(False)
+        elif _premod_route(w, st, up, px, dt) == 'shared':
+            out.append(first_shared)
+            first_shared = False
+        else:
+            out.append(True)
+    return out
 
 
 def _premod_route(weight, styles, up, in_pixels, dtype):

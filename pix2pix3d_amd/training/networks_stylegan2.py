@@ -504,12 +504,20 @@ class SynthesisBlock(torch.nn.Module):
             if self.const.is_cuda and not torch.is_grad_enabled():
                 # device inference: the batch of constants is the same tensor every pass — built once per (batch, dtype, layout, version of the parameter);
                 # nothing writes into a block's input in place (conv1 returns a new tensor), so the copy can be handed out again
-                key = (batch, dtype, fmt, self.const._version, self.const.data_ptr())
-                hit = _const_batches.get(self)                   # (kept outside the module: nothing of it is pickled, deep-copied or moved with the module)
-                if hit is None or hit[0] != key:
-                    hit = (key, self.const.detach().to(dtype=dtype).unsqueeze(0).repeat([batch, 1, 1, 1]).contiguous(memory_format=fmt))
-                    _const_batches[self] = hit
-                return hit[1]
+                # every (batch, dtype, layout) keeps its own tensor: a captured hipGraph reads the one it was captured with, so a later call
+                # with another batch must not free it.  modconv.invalidate_caches() drops them all (writes through .data bump no version).
+                slot, stamp = (batch, dtype, fmt), (self.const._version, self.const.data_ptr())
+                held = _const_batches.get(self)                  # (kept outside the module: nothing of it is pickled, deep-copied or moved with the module)
+                if held is None or held[0] != stamp:
+                    held = (stamp, {})
+                    _const_batches[self] = held
+                hit = held[1].get(slot)
+                if hit is None:
+                    if len(held[1]) >= 8:
+                        held[1].clear()
+                    hit = self.const.detach().to(dtype=dtype).unsqueeze(0).repeat([batch, 1, 1, 1]).contiguous(memory_format=fmt)
+                    held[1][slot] = hit
+                return hit
             return self.const.to(dtype=dtype).unsqueeze(0).repeat([batch, 1, 1, 1]).contiguous(memory_format=fmt)
         in_res = self.resolution // self._in_div
         misc.assert_shape(x, [None, self.in_channels, in_res, in_res])
@@ -536,24 +544,31 @@ class SynthesisBlock(torch.nn.Module):
         return f'resolution={self.resolution:d}, architecture={self.architecture:s}'
 
 
-_const_batches = weakref.WeakKeyDictionary()      # SynthesisBlock (b4) -> (key, its learned constant repeated over the batch): device inference only
+_const_batches = weakref.WeakKeyDictionary()      # SynthesisBlock (b4) -> (stamp of the parameter, {(batch, dtype, layout): its learned constant repeated over the batch}): device inference only
+modconv.on_invalidate(_const_batches.clear)
 
 
-def prefetch_styles(blocks, block_ws, block_kwargs):
+def prefetch_styles(blocks, block_ws, block_kwargs, ahead=False):
     """Device inference: every layer's style affine and weight modulation depend on ``ws`` alone, so they are issued up front on a
     second stream and run under the convolutions of the layers before them (they are memory-bound, the convolutions are not);
-    each layer waits on its own event (modconv.take_plan).  Anything the plan gets wrong (a layer that ends up on another route) is
-    simply recomputed.  Returns True when a plan was made: the caller joins the side stream and clears the plan afterwards."""
+    a layer waits for its entry's event (modconv.take_plan).  Anything the plan gets wrong (a layer that ends up on another route) is
+    simply recomputed.  Returns the plan's keys when a plan was made — the caller joins the side stream and drops them afterwards (finish_prefetch) — else None.
+    ``ahead``: issued for a network that runs LATER in the step (the super-resolution heads, from inside the backbone's forward right after its own plan,
+    ``modconv.after_prefetch``): the side stream is already ordered behind whatever made ``ws`` and nothing of the earlier plan has been released yet, so
+    it neither waits for the calling stream again nor touches other networks' entries."""
     ws0 = block_ws[0]
     fused = block_kwargs.get('fused_modconv')
+    own = [id(l) for b in blocks for l in (getattr(b, 'conv0', None), b.conv1, getattr(b, 'torgb', None)) if l is not None]
+    for k in own:
+        modconv._plan.pop(k, None)    # entries an interrupted forward left behind must never reach a layer of this one
     if not (modconv.prefetch_styles and modconv.enabled and native_channels_last and ws0.is_cuda and not torch.is_grad_enabled()
             and (fused is None or fused is True)):
-        modconv._plan.clear()         # entries an interrupted forward left behind must never reach a layer of this one
-        return False
+        return None
     force_fp32 = bool(block_kwargs.get('force_fp32', False))
     main, side = torch.cuda.current_stream(), modconv.side_stream(ws0.device)
-    side.wait_stream(main)
-    modconv._plan.clear()
+    if not ahead:
+        side.wait_stream(main)
+    keys = []
     with torch.cuda.stream(side):
         todo = []                                          # (layer, latent row, out_scale, input pixels or None for ToRGB, dtype)
         for block, cur in zip(blocks, block_ws):
@@ -572,17 +587,39 @@ def prefetch_styles(blocks, block_ws, block_kwargs):
                    and all(modconv.fc_supported(w, l.affine.weight, l.affine.bias, l.affine.activation) for l, w, *_ in todo))
         all_styles = (modconv.fc_multi([(w, l.affine, sc) for l, w, sc, _, _ in todo]) if batched
                       else [l.affine(w) if sc == 1 else l.affine(w, out_scale=sc) for l, w, sc, _, _ in todo])
-        pres = modconv.premodulate_many([(layer.weight, styles, getattr(layer, 'up', 1), in_pixels, dtype) for (layer, _, _, in_pixels, dtype), styles in zip(todo, all_styles)])
-        for (layer, _, _, in_pixels, dtype), styles, pre in zip(todo, all_styles, pres):
-            ev = torch.cuda.Event()
-            ev.record(side)
-            modconv._plan[id(layer)] = (styles, pre, ev)
-    return True
+        items = [(layer.weight, styles, getattr(layer, 'up', 1), in_pixels, dtype) for (layer, _, _, in_pixels, dtype), styles in zip(todo, all_styles)]
+        pres = modconv.premodulate_many(items)
+        # one event per layer that LAUNCHED something; a layer that did not (ToRGB: styles only; a shared-weight layer after the first) shares the event of the
+        # last one that did, and take_plan skips a position its stream already waits behind — every wait is an edge between two branches of the captured graph.
+        # Positions number the side stream's events for the life of the process (one side stream per device: a later position implies every earlier one).
+        ev = None
+        for (layer, _, _, in_pixels, dtype), styles, pre, fresh in zip(todo, all_styles, pres, modconv.premodulate_launches(items)):
+            if fresh or ev is None:
+                first = ev is None
+                ev = torch.cuda.Event()
+                ev.record(side)
+                modconv._plan_seq[0] += 1
+                modconv._plan_latest[:] = [ev, modconv._plan_seq[0]]
+                if first and not ahead:
+                    modconv._plan_first[0] = modconv._plan_seq[0]
+            modconv._plan[id(layer)] = (styles, pre, ev, modconv._plan_seq[0])
+            keys.append(id(layer))
+    if not ahead:
+        hooks, modconv.after_prefetch[:] = list(modconv.after_prefetch), []
+        for hook in hooks:             # (networks later in the step: their plans follow this one on the side stream, before any of its tensors is released)
+            hook()
+    return keys
 
 
-def finish_prefetch(device):
-    torch.cuda.current_stream().wait_stream(modconv.side_stream(device))
-    modconv._plan.clear()
+def finish_prefetch(device, keys=None):
+    main = torch.cuda.current_stream()
+    if not modconv.plan_joined(main):                      # (a stream that already waits behind the prefetch stream's newest event IS joined: no further edge)
+        main.wait_stream(modconv.side_stream(device))
+    if keys is None:
+        modconv._plan.clear()
+    else:
+        for k in keys:
+            modconv._plan.pop(k, None)
 
 
 @persistence.persistent_class
@@ -627,8 +664,8 @@ class SynthesisNetwork(torch.nn.Module):
                 hooked = bool(_m._global_forward_hooks or _m._global_forward_pre_hooks or block._forward_hooks or (nxt is not None and nxt._forward_pre_hooks))
                 x, img = block(x, img, cur, _split_ok=not hooked, **block_kwargs)
         finally:
-            if planned:
-                finish_prefetch(ws.device)
+            if planned is not None:
+                finish_prefetch(ws.device, planned)
         return img
 
     def _prefetch(self, block_ws, block_kwargs):

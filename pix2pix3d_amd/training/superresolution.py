@@ -35,22 +35,42 @@ class _SuperresolutionBase(torch.nn.Module):
             rgb = torch.nn.functional.interpolate(rgb, size=size, mode='bilinear', align_corners=False, antialias=self.sr_antialias)
         return rgb, x
 
+    def prefetch_ahead(self, ws, **block_kwargs):
+        """Device inference: this head's style affines and weight modulations, issued NOW on the prefetch stream for a forward that comes later in the step
+        (they depend on ``ws`` alone; triplane._render has the backbone's forward call this right after its own plan).  ``forward(…, ws)`` with the same
+        tensor picks the plan up; any other call drops it."""
+        from ..torch_utils.ops import modconv
+        if not (ws.is_cuda and not torch.is_grad_enabled()):
+            return
+        row = ws[:, -1:, :].expand(-1, 3, -1)
+        keys = prefetch_styles([self.block0, self.block1], [row, row], block_kwargs, ahead=True)
+        if keys is not None:
+            modconv._ahead[id(self)] = (ws, keys)
+
     def forward(self, rgb, x, ws, **block_kwargs):
+        from ..torch_utils.ops import modconv
+        ahead = modconv._ahead.pop(id(self), None)
+        if ahead is not None and ahead[0] is not ws:             # planned for another latent tensor: not ours
+            for k in ahead[1]:
+                modconv._plan.pop(k, None)
+            ahead = None
         if ws.is_cuda and not torch.is_grad_enabled():
             ws = ws[:, -1:, :].expand(-1, 3, -1)                  # device inference: the three layers read the SAME row in place (a stride-0 view; repeat() is three launches per head)
         else:
             ws = ws[:, -1:, :].repeat(1, 3, 1)
         rgb, x = self._prep(rgb, x)
-        planned = prefetch_styles([self.block0, self.block1], [ws, ws], block_kwargs)
+        planned = ahead[1] if ahead is not None else prefetch_styles([self.block0, self.block1], [ws, ws], block_kwargs)
         try:
             x, rgb = self.block0(x, rgb, ws, **block_kwargs)
             # block1's x is returned to nobody (:297-354 of the reference return rgb only): unless somebody hooked the block to look at it, its last
             # layer need not store it (networks_stylegan2.SynthesisBlock.forward: _x_dead)
-            hooked = bool(torch.nn.modules.module._global_forward_hooks or self.block1._forward_hooks)
+            # (a hook on the block OR on any layer inside it — a feature extractor on block1.conv1 must still be handed the activations)
+            gm = torch.nn.modules.module
+            hooked = bool(gm._global_forward_hooks or getattr(gm, '_global_forward_hooks_always_called', None)) or any(m._forward_hooks for m in self.block1.modules())
             x, rgb = self.block1(x, rgb, ws, _x_dead=skip_dead_x and not hooked, **block_kwargs)
         finally:
-            if planned:
-                finish_prefetch(ws.device)
+            if planned is not None:
+                finish_prefetch(ws.device, planned)
         return rgb
 
 

@@ -9,6 +9,7 @@ import torch
 
 from .. import dnnlib
 from ..torch_utils import persistence
+from ..torch_utils.ops import modconv
 from .networks_stylegan2 import FullyConnectedLayer, Generator as StyleGAN2Backbone
 from .volumetric_rendering.renderer import ImportanceRenderer
 from .volumetric_rendering.ray_sampler import RaySampler
@@ -113,7 +114,9 @@ class _TriPlaneCore(torch.nn.Module):
             self._last_planes = planes
         return planes.view(len(planes), 3, 32, planes.shape[-2], planes.shape[-1])
 
-    def _render(self, ws, c, neural_rendering_resolution, update_emas, cache_backbone, use_cached_backbone, synthesis_kwargs):
+    def _render(self, ws, c, neural_rendering_resolution, update_emas, cache_backbone, use_cached_backbone, synthesis_kwargs, heads=()):
+        """Planes -> fused ray-marcher.  ``heads``: the super-resolution modules the caller runs on the result with THIS ``ws`` — on the device their style affines
+        and weight modulations are issued by the backbone's forward right behind its own (``prefetch_ahead``), under the backbone's launch-bound first layers."""
         cam2world = c[:, :16].view(-1, 4, 4)
         intrinsics = c[:, 16:25].view(-1, 3, 3)
         if neural_rendering_resolution is None:
@@ -122,7 +125,13 @@ class _TriPlaneCore(torch.nn.Module):
             self.neural_rendering_resolution = neural_rendering_resolution
         ray_o, ray_d = self.ray_sampler(cam2world, intrinsics, neural_rendering_resolution)
         n = ray_o.shape[0]
-        planes = self._planes(ws, update_emas, synthesis_kwargs, cache_backbone, use_cached_backbone)
+        if heads and modconv.sr_prefetch_ahead and ws.is_cuda and not torch.is_grad_enabled():
+            sr_kw = self._sr_kwargs(synthesis_kwargs)
+            modconv.after_prefetch.append(lambda: [h.prefetch_ahead(ws, **sr_kw) for h in heads if hasattr(h, 'prefetch_ahead')])
+        try:
+            planes = self._planes(ws, update_emas, synthesis_kwargs, cache_backbone, use_cached_backbone)
+        finally:
+            modconv.after_prefetch.clear()                         # (a backbone that made no plan never ran it)
         feat, depth, _ = self.renderer(planes, self.decoder, ray_o, ray_d, self.rendering_kwargs)
         r = self.neural_rendering_resolution
         if feat.is_cuda and not torch.is_grad_enabled():

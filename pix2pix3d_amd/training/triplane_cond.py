@@ -436,7 +436,7 @@ class TriPlaneGenerator(_TriPlaneBase):
 
     @frozen_pass
     def synthesis(self, ws, c, neural_rendering_resolution=None, update_emas=False, cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
-        feature_image, depth_image = self._render(ws, c, neural_rendering_resolution, update_emas, cache_backbone, use_cached_backbone, synthesis_kwargs)
+        feature_image, depth_image = self._render(ws, c, neural_rendering_resolution, update_emas, cache_backbone, use_cached_backbone, synthesis_kwargs, heads=(self.superresolution,))
         rgb_image = feature_image[:, :3]
         sr_image = self.superresolution(rgb_image, feature_image, ws, **self._sr_kwargs(synthesis_kwargs))
         return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image}
@@ -461,7 +461,8 @@ class TriPlaneSemanticEntangleGenerator(_TriPlaneBase):
 
     @frozen_pass
     def synthesis(self, ws, c, neural_rendering_resolution=None, update_emas=False, cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
-        feature_image, depth_image = self._render(ws, c, neural_rendering_resolution, update_emas, cache_backbone, use_cached_backbone, synthesis_kwargs)
+        feature_image, depth_image = self._render(ws, c, neural_rendering_resolution, update_emas, cache_backbone, use_cached_backbone, synthesis_kwargs,
+                                                  heads=(self.superresolution, self.superresolution_semantic))
         half = feature_image.shape[1] // 2
         rgb_feat, sem_feat = feature_image[:, :half], feature_image[:, half:]
         sr_kw = self._sr_kwargs(synthesis_kwargs)

@@ -548,3 +548,31 @@ def test_bf16x6_formulation_of_the_fp32_convolution(hip_lib, f32_x6, ci, co, h, 
     print((ci, co, h, w, n, k, mode), 'bf16x6', e6, 'exact', e1)
     assert e6 < 3e-6 and e6 < 2 * e1 + 1e-7, (e6, e1)
     assert not torch.equal(y6, y1)                       # (the other arithmetic did run)
+
+
+def test_bf16x6_non_finite_operands(hip_lib, f32_x6):
+    """What csrc/bf16_split.h states about operands outside bf16's range: an +-inf (or a finite value >= 3.39e38, which rounds to inf as bf16) makes every output it reaches
+    non-finite under both arithmetics — NaN under bf16x6 (inf - inf in the residual), +-inf / NaN under the f32-input MFMA — and touches nothing else: the other images of the
+    batch and the pixels outside the 3 x 3 footprint stay in the exact kernel's error class."""
+    modconv = f32_x6
+    torch.manual_seed(5)
+    n, ci, co, h, w = 3, 64, 64, 24, 24
+    x = torch.randn(n, ci, h, w, device='cuda')
+    x[0, 7, 10, 11] = float('inf')
+    x[1, 3, 5, 5] = 3.4e38                                      # finite in fp32 (max 3.4028e38), inf as bf16 (anything above 3.3961e38 rounds up)
+    x = _nhwc(x)
+    weight = torch.randn(co, ci, 3, 3, device='cuda')
+    w32 = modconv.modulate_weights(weight, torch.ones(n, ci, device='cuda'), demodulate=True, dtype=torch.float32)
+    y6 = modconv.conv2d(x, w32)
+    modconv.f32_x6 = False
+    y1 = modconv.conv2d(x, w32)
+    modconv.f32_x6 = True
+    foot = torch.zeros(n, 1, h, w, dtype=torch.bool, device='cuda')
+    foot[0, 0, 9:12, 10:13] = True
+    foot[1, 0, 4:7, 4:7] = True
+    foot = foot.expand(n, co, h, w)
+    assert not bool(torch.isfinite(y6[foot]).any()) and bool(torch.isnan(y6[foot]).all())
+    assert not bool(torch.isfinite(y1[0:1][foot[0:1]]).any())                  # the exact kernel: +-inf (or NaN where +inf and -inf meet)
+    clean6, clean1 = y6[~foot], y1[~foot]
+    assert bool(torch.isfinite(clean6).all()) and bool(torch.isfinite(clean1).all())
+    assert float((clean6 - clean1).abs().max()) <= 3e-6 * float(clean1.abs().max())

@@ -57,3 +57,26 @@ def test_sample_mixed_on_gpu(hip_lib, name):
     finally:
         rmod.fused_policy = prev_pol
     assert rel_err(sm['rgb'].cpu().numpy(), g['pts_rgb']) < 1e-3 and rel_err(sm['sigma'].cpu().numpy(), g['pts_sigma']) < 1e-3
+
+
+def test_const_batch_cache_follows_data_writes(hip_lib):
+    """b4's cached batch of learned constants (networks_stylegan2.SynthesisBlock._entry_features): a write through ``.data`` bumps neither the
+    version nor the pointer, so ``pix2pix3d_amd.invalidate_weight_caches()`` — what dp.broadcast_module / misc.copy_params_and_buffers / the checkpoint
+    loader call — has to drop it; every (batch, dtype, layout) keeps its own tensor (a captured hipGraph goes on reading the one it was captured with)."""
+    import pix2pix3d_amd
+    from pix2pix3d_amd.training import networks_stylegan2 as ns
+    G = build_generator('edge2car', 'cuda')
+    b4 = G.backbone.synthesis.b4 if hasattr(G.backbone, 'synthesis') else G.backbone.b4
+    fmt = torch.contiguous_format
+    with torch.no_grad():
+        a2 = b4._entry_features(None, 2, torch.float32, fmt)
+        a3 = b4._entry_features(None, 3, torch.float32, fmt)
+        assert b4._entry_features(None, 2, torch.float32, fmt) is a2, 'a second batch size evicted the first one'
+        assert torch.equal(a2[1], b4.const) and a3.shape[0] == 3
+        b4.const.data.copy_(b4.const.data * 2 + 1)                     # what dist.broadcast(param.data) does: no version bump, same pointer
+        pix2pix3d_amd.invalidate_weight_caches()
+        fresh = b4._entry_features(None, 2, torch.float32, fmt)
+        assert fresh is not a2 and torch.equal(fresh[0], b4.const)
+        b4.const.mul_(0.5)                                             # an in-place update is seen through the version counter
+        assert torch.equal(b4._entry_features(None, 2, torch.float32, fmt)[1], b4.const)
+    assert len(ns._const_batches) >= 1

@@ -284,3 +284,14 @@ def test_last_sr_block_stores_its_activations_when_somebody_looks(hip_lib):
     assert len(seen) == 1 and seen[0] is not None and tuple(seen[0].shape) == (2, 128, 512, 512) and bool(torch.isfinite(seen[0].float()).all())
     assert y0.shape == y1.shape == (2, 3, 512, 512)
     assert float((y0 - y1).abs().max()) <= 1e-5 * float(y1.abs().max())           # two epilogues of the same contraction (another fp32 summation order)
+    # a hook one level down — a feature extractor on the block's last LAYER — must be handed the activations too
+    seen2 = []
+    h = sr.block1.conv1.register_forward_hook(lambda m, a, out: seen2.append(out))
+    try:
+        with torch.no_grad():
+            y2 = sr(x[:, :3].contiguous(), x, ws, noise_mode='none')
+    finally:
+        h.remove()
+    got = seen2[0][0] if isinstance(seen2[0], tuple) else seen2[0]
+    assert len(seen2) == 1 and torch.is_tensor(got) and tuple(got.shape) == (2, 128, 512, 512) and bool(torch.isfinite(got.float()).all())
+    assert torch.equal(y2, y1)
