@@ -79,6 +79,7 @@ struct ConvArgs {
     float* rgb_out;        // [N][rgb_co][H][W] fp32, accumulated into
     int rgb_co;            // <= 8
     float rgb_clamp;       // on (sum + bias) before the accumulation; < 0: off
+    int store_narrow;      // A/B only (P3D_CONV_STORE4=1): the generic kernel's fp32 epilogue with one 4-byte store per value instead of quad-transposed 16-byte ones
     int cb_loop;           // conv3x3_h2_f16_kernel<false> with the fused ToRGB: channel blocks of 128 one work-group walks (grid.y = Co / 128 / cb_loop); 0 / 1 = one
     const float* oscale;   // [N][Co] or null (generic kernel, fp32 tensors): the accumulator is multiplied by oscale[image][channel] before the
                            // rest of the epilogue — the demodulation coefficient of the SHARED-weight form of the modulated convolution
@@ -405,6 +406,62 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
                 const int oy = si * a.osy + kc.ooy, ox = sj * a.osx + kc.oox;
                 opix[i][r] = (mb + d < M && oy < a.OH && ox < a.OW) ? (img * a.OH + oy) * a.OW + ox : -1;    // folded: + the row's image
             }
+        if constexpr (sizeof(T) == 4) {
+            if (((a.Co & 3) == 0) && ((((uintptr_t)a.y) & 15u) == 0) && !a.store_narrow) {
+                // 16-byte stores: a lane holds ONE channel of four consecutive GEMM rows in registers 4 q .. 4 q + 3 and the four lanes of a quad four consecutive
+                // channels; the quad transposes its 4 x 4 values in registers (two DPP stages) and lane 4 m + t then stores channels 4 m .. 4 m + 3 of row t — 16
+                // store instructions per lane and tile instead of 64 four-byte ones (conv3x3_r2_bf16x3_kernel's epilogue: the same change was -9 % of that kernel)
+                const int t = lane & 3, m4 = (lane & 31) >> 2;
+                const bool odd1 = lane & 1, odd2 = lane & 2;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int cq = co0 + wn * 64 + j * 32, co = cq + frow;
+                    const bool cok = co < a.Co;
+                    const float b = (a.bias && cok) ? a.bias[co] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            unsigned w[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int px = opix[i][4 * q + e];
+                                float v = acc[i][j][4 * q + e];
+                                if (px >= 0 && cok) {
+                                    if (a.oscale) v *= a.oscale[(a.fold ? px / (a.OH * a.OW) : n) * a.Co + co];
+                                    if (a.noise) v = fmaf(a.noise[a.fold ? px % (a.OH * a.OW) : px], ns, v);
+                                }
+                                v += b;
+                                if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
+                                v *= a.gain;
+                                if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
+                                w[e] = __float_as_uint(v);
+                            }
+#pragma unroll
+                            for (int pr = 0; pr < 2; ++pr) {                    // lane ^ 1 inside the register pairs (0, 1), (2, 3)
+                                const unsigned send = odd1 ? w[2 * pr] : w[2 * pr + 1];
+                                const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
+                                w[2 * pr]     = odd1 ? recv : w[2 * pr];
+                                w[2 * pr + 1] = odd1 ? w[2 * pr + 1] : recv;
+                            }
+#pragma unroll
+                            for (int pr = 0; pr < 2; ++pr) {                    // lane ^ 2 inside (0, 2), (1, 3)
+                                const unsigned send = odd2 ? w[pr] : w[pr + 2];
+                                const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xF, 0xF, true);      // quad_perm [2, 3, 0, 1]
+                                w[pr]     = odd2 ? recv : w[pr];
+                                w[pr + 2] = odd2 ? w[pr + 2] : recv;
+                            }
+                            const int px0 = opix[i][4 * q], px1 = opix[i][4 * q + 1], px2 = opix[i][4 * q + 2], px3 = opix[i][4 * q + 3];
+                            const int mine = odd2 ? (odd1 ? px3 : px2) : (odd1 ? px1 : px0);
+                            if (mine >= 0 && cq + 4 * m4 < a.Co) {
+                                typedef unsigned u32x4e __attribute__((ext_vector_type(4)));
+                                *(u32x4e*)((float*)a.y + ((int64_t)n * a.OH * a.OW + mine) * a.Co + cq + 4 * m4) = u32x4e{w[0], w[1], w[2], w[3]};
+                            }
+                        }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int co = co0 + wn * 64 + j * 32 + frow;
@@ -1198,6 +1255,69 @@ __global__ void __launch_bounds__(256, 2) conv3x3_r2_bf16x3_kernel(ConvArgs a)
         __syncthreads();
     }
     float* const yimg = (float*)a.y + (int64_t)n * a.H * a.W * a.Co;
+    if (a.y_split == 1) {
+        // Split result in 16-byte stores.  A lane holds ONE channel of four consecutive pixels in registers 4 q .. 4 q + 3; the four lanes of a quad hold four
+        // consecutive channels.  Each finished value becomes one dword (bf16 hi | bf16 lo << 16), the quad transposes its 4 x 4 dwords in registers (two DPP
+        // stages), so lane 4 m + t then holds pixel t's channels 4 m .. 4 m + 3; lanes 4 m + t and 4 (m ^ 1) + t trade halves (ds_swizzle, no memory) and the even
+        // one stores the hi halves of eight channels, the odd one the lo halves: ONE 16-byte store per lane and pixel quad where the lane = channel layout needed
+        // eight 2-byte ones (256 store instructions per lane and tile, 64 bytes each: ~8 % of a work-group's life on the address path its LDS-DMA shares).
+        const int t = lane & 3, m = (lane & 31) >> 2;
+        const bool odd1 = lane & 1, odd2 = lane & 2, oddm = m & 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (co0 + j * 32 >= a.Co) continue;                                  // (whole 32-channel rows: uniform)
+            const float b = a.bias ? a.bias[co0 + j * 32 + frow] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int pbase = wave * 64 + i * 32 + 8 * q + 4 * fk;      // pixels pbase .. pbase + 3 of the 16 x 16 patch: one patch row
+                    unsigned w[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[i][j][4 * q + e];
+                        if (a.noise) v += nz[pbase + e];
+                        v += b;
+                        if (a.act == 1) v = fmaxf(v, 0.2f * v);
+                        v *= a.gain;
+                        if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
+                        const __bf16 hv = (__bf16)v;
+                        const __bf16 lv = (__bf16)(v - (float)hv);
+                        w[e] = (unsigned)__builtin_bit_cast(unsigned short, hv) | ((unsigned)__builtin_bit_cast(unsigned short, lv) << 16);
+                    }
+                    // 4 x 4 transpose across the quad: stage 1 trades with lane ^ 1 inside the register pairs (0, 1), (2, 3); stage 2 with lane ^ 2 inside (0, 2), (1, 3)
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const unsigned send = odd1 ? w[2 * pr] : w[2 * pr + 1];
+                        const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
+                        w[2 * pr]     = odd1 ? recv : w[2 * pr];
+                        w[2 * pr + 1] = odd1 ? w[2 * pr + 1] : recv;
+                    }
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const unsigned send = odd2 ? w[pr] : w[pr + 2];
+                        const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xF, 0xF, true);      // quad_perm [2, 3, 0, 1]
+                        w[pr]     = odd2 ? recv : w[pr];
+                        w[pr + 2] = odd2 ? w[pr + 2] : recv;
+                    }
+                    // w[c] = (hi | lo << 16) of channel 4 m + c at pixel pbase + t
+                    const unsigned h01 = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u), h23 = __builtin_amdgcn_perm(w[3], w[2], 0x05040100u);
+                    const unsigned l01 = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u), l23 = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
+                    const unsigned s0 = oddm ? h01 : l01, s1 = oddm ? h23 : l23;
+                    const unsigned r0 = (unsigned)__builtin_amdgcn_ds_swizzle((int)s0, (4 << 10) | 0x1f);               // lane ^ 4: the neighbouring quad (same pixel)
+                    const unsigned r1 = (unsigned)__builtin_amdgcn_ds_swizzle((int)s1, (4 << 10) | 0x1f);
+                    typedef unsigned u32x4q __attribute__((ext_vector_type(4)));
+                    const u32x4q out = oddm ? u32x4q{r0, r1, l01, l23} : u32x4q{h01, h23, r0, r1};
+                    const int pm = pbase + t;
+                    const int oy = oy0 + (pm >> 4), ox = ox0 + (pm & 15);
+                    if (oy < a.H && ox < a.W) {
+                        __bf16* row = (__bf16*)(yimg + ((int64_t)oy * a.W + ox) * a.Co + co0 + j * 32);
+                        *(u32x4q*)(row + (oddm ? 32 + 4 * (m - 1) : 4 * m)) = out;
+                    }
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int co = co0 + j * 32 + frow;
@@ -1812,6 +1932,7 @@ int p3d::conv2d_nhwc_run_io(const void* x, const void* w, void* y, int dtype, co
     a.N = n_img; a.H = h; a.W = wdt; a.Ci = ci; a.Co = co; a.KT = kernel_size * kernel_size; a.w_img_stride = w_img_stride;
     a.act = act; a.gain = gain; a.clamp = clamp; a.isy = a.isx = 1; a.oscale = out_scale;
     a.iscale = tl_in_scale;                                          // (set by p3d_conv2d_nhwc_scaled_in for the duration of its call)
+    { static const bool narrow = [] { const char* d = getenv("P3D_CONV_STORE4"); return d && atoi(d) != 0; }(); a.store_narrow = narrow; }
     hipStream_t s = (hipStream_t)stream;
     if (down2) {                                                     // valid (unpadded) correlation at stride 2: conv2d_resample.py:108-111 after its FIR
         P3D_REQUIRE(h >= kernel_size && wdt >= kernel_size, "conv2d_nhwc: image smaller than the kernel");
@@ -1848,7 +1969,8 @@ int p3d::conv2d_nhwc_run_io(const void* x, const void* w, void* y, int dtype, co
         const bool r2_ok = !no_r2 && !no_halo && kernel_size == 3 && dtype == P3D_F32_BF16X3 && x_split && h >= 32 && wdt >= 32 && ci % 32 == 0 && co % BN == 0 && !out_scale;
         if (r2_ok && (int64_t)((h + QH - 1) / QH) * ((wdt + QW - 1) / QW) * (co / BN) * n_img >= 192) {      // (smaller grids: the 8 x 16 halo kernel, then split-K)
             if (dry) return P3D_OK;                                       // split activations in: the ring pipeline on 16-channel half rows
-            a.y_split = y_split;
+            static const bool store2 = [] { const char* d = getenv("P3D_R2_STORE2"); return d && atoi(d) != 0; }();      // (A/B only: the 2-byte stores of the lane = channel layout)
+            a.y_split = (y_split && store2) ? 2 : y_split;
             dim3 grid(((h + QH - 1) / QH) * ((wdt + QW - 1) / QW), co / BN, n_img);
             hipLaunchKernelGGL(conv3x3_r2_bf16x3_kernel, grid, dim3(256), 0, s, a);
             count_launch(FAM_CONV);

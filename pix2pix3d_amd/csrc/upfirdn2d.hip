@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(256) fir4_cl_fused_kernel(UpfirArgs a, FirEpil
                     hi[k] = h; lo[k] = (__bf16)(v - (float)h);
                 }
                 __bf16* row = (__bf16*)((T*)a.y + (int64_t)n * a.osn + (int64_t)oy * a.osy + (int64_t)ox * a.osx + cblk * CB);
-                *(bf4*)(row + chunk * 4) = hi;
+                *(bf4*)(row + chunk * 4) = hi;              // (16-byte stores through a lane-pair exchange measured no faster: profiles/round6_d_*)
                 *(bf4*)(row + 32 + chunk * 4) = lo;
                 continue;
             }
