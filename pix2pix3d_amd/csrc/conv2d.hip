@@ -311,6 +311,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
     if (a.ksplit > 1) {                                                         // split K: raw fp32 partial tile, finished by splitk_epilogue_kernel
         const int Mpad = gridDim.x * BM, CoP = gridDim.y * BN;
         float* out = a.partial + ((int64_t)split * (gridDim.z / a.ksplit) + zz) * Mpad * CoP;
+        // (four-byte stores, one 128-byte line per half-wave: the quad-transposed 16-byte form measured 0.4 % SLOWER on the line here, profiles/round6_f_*)
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -437,20 +438,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
                                 if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
                                 w[e] = __float_as_uint(v);
                             }
-#pragma unroll
-                            for (int pr = 0; pr < 2; ++pr) {                    // lane ^ 1 inside the register pairs (0, 1), (2, 3)
-                                const unsigned send = odd1 ? w[2 * pr] : w[2 * pr + 1];
-                                const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
-                                w[2 * pr]     = odd1 ? recv : w[2 * pr];
-                                w[2 * pr + 1] = odd1 ? w[2 * pr + 1] : recv;
-                            }
-#pragma unroll
-                            for (int pr = 0; pr < 2; ++pr) {                    // lane ^ 2 inside (0, 2), (1, 3)
-                                const unsigned send = odd2 ? w[pr] : w[pr + 2];
-                                const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xF, 0xF, true);      // quad_perm [2, 3, 0, 1]
-                                w[pr]     = odd2 ? recv : w[pr];
-                                w[pr + 2] = odd2 ? w[pr + 2] : recv;
-                            }
+                            quad_transpose4(w, odd1, odd2);
                             const int px0 = opix[i][4 * q], px1 = opix[i][4 * q + 1], px2 = opix[i][4 * q + 2], px3 = opix[i][4 * q + 3];
                             const int mine = odd2 ? (odd1 ? px3 : px2) : (odd1 ? px1 : px0);
                             if (mine >= 0 && cq + 4 * m4 < a.Co) {
@@ -1285,21 +1273,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_r2_bf16x3_kernel(ConvArgs a)
                         const __bf16 lv = (__bf16)(v - (float)hv);
                         w[e] = (unsigned)__builtin_bit_cast(unsigned short, hv) | ((unsigned)__builtin_bit_cast(unsigned short, lv) << 16);
                     }
-                    // 4 x 4 transpose across the quad: stage 1 trades with lane ^ 1 inside the register pairs (0, 1), (2, 3); stage 2 with lane ^ 2 inside (0, 2), (1, 3)
-#pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
-                        const unsigned send = odd1 ? w[2 * pr] : w[2 * pr + 1];
-                        const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
-                        w[2 * pr]     = odd1 ? recv : w[2 * pr];
-                        w[2 * pr + 1] = odd1 ? w[2 * pr + 1] : recv;
-                    }
-#pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
-                        const unsigned send = odd2 ? w[pr] : w[pr + 2];
-                        const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xF, 0xF, true);      // quad_perm [2, 3, 0, 1]
-                        w[pr]     = odd2 ? recv : w[pr];
-                        w[pr + 2] = odd2 ? w[pr + 2] : recv;
-                    }
+                    quad_transpose4(w, odd1, odd2);
                     // w[c] = (hi | lo << 16) of channel 4 m + c at pixel pbase + t
                     const unsigned h01 = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u), h23 = __builtin_amdgcn_perm(w[3], w[2], 0x05040100u);
                     const unsigned l01 = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u), l23 = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);

@@ -51,6 +51,27 @@ int conv2d_nhwc_run_io(const void* x, const void* w, void* y, int dtype, const f
                        void* workspace, int64_t workspace_bytes, int64_t* query, const float* out_scale, int32_t x_split, int32_t y_split,
                        p3d_stream_t stream);
 
+// 4 x 4 transpose of one dword per (lane of a quad, register): on return register c of quad lane t holds what register t of quad lane c held.  Two DPP stages:
+// lane ^ 1 inside the register pairs (0, 1), (2, 3), then lane ^ 2 inside (0, 2), (1, 3).  What turns the MFMA accumulator layout (a lane = ONE output channel,
+// four consecutive GEMM rows in registers 4 q .. 4 q + 3) into "a lane = four consecutive channels of one row": 16-byte stores instead of four 4-byte (or 2-byte) ones.
+__device__ __forceinline__ void quad_transpose4(unsigned (&w)[4], const bool odd1, const bool odd2)
+{
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        const unsigned send = odd1 ? w[2 * pr] : w[2 * pr + 1];
+        const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
+        w[2 * pr]     = odd1 ? recv : w[2 * pr];
+        w[2 * pr + 1] = odd1 ? w[2 * pr + 1] : recv;
+    }
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        const unsigned send = odd2 ? w[pr] : w[pr + 2];
+        const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xF, 0xF, true);      // quad_perm [2, 3, 0, 1]
+        w[pr]     = odd2 ? recv : w[pr];
+        w[pr + 2] = odd2 ? w[pr + 2] : recv;
+    }
+}
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 } // namespace p3d
