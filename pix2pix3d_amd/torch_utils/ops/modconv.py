@@ -31,7 +31,7 @@ def side_stream(device):
 _plan_seq = [0]              # position of the newest event on the prefetch stream (monotonic for the life of the process)
 after_prefetch = []          # callables a network's prefetch_styles runs once its own plan is issued (the plans of networks LATER in the step: triplane._render)
 _ahead = {}                  # id(network) -> (the ws it was planned for, the plan's keys): plans issued ahead, picked up by that network's forward
-_plan_first = [0]            # position of the first event of the newest plan issued for the CURRENT network (prefetch_styles, not ahead)
+_plan_own_until = [0]        # waits for positions up to this one are for the entry's OWN event (the current network's first layer, then its ToRGB group); later ones for everything issued
 _plan_latest = [None, -1]    # (event, position): the newest event on the prefetch stream
 _plan_waited = {}            # consuming stream (its handle) -> position on the prefetch stream (the sequence number of an event) it already waits behind
 
@@ -42,9 +42,10 @@ def take_plan(layer):
     last one that did): a layer whose position the stream already waits behind adds no second wait.  In the captured step every such wait is an edge
     between two branches of the graph — idle device in front of the layer's first kernel whether or not the event fired long ago (27 of them per step,
     5.8 us each under the profiler: profiles/round5_u_step_trace.txt; same-box A/B of the elision: +0.4 ... +1.1 %, profiles/round6_a_*).
-    The FIRST wait of a stream on a plan is for the layer's own event (the network's first layer must not stand behind every modulation of the step); a
-    LATER one is for everything issued so far (``_plan_latest``: by then — the first per-image-weight layer, hundreds of microseconds into the network — the
-    prefetch stream has long run dry), so a network costs two edges, and the heads whose plans were issued ahead none."""
+    The waits for a network's first layer and for its ToRGB group (issued right behind it: prefetch_styles) are for those events themselves — the first layers
+    must not stand behind every modulation of the step; any LATER one is for everything issued so far (``_plan_latest``: by then — the first per-image-weight
+    layer, hundreds of microseconds into the network — the prefetch stream has long run dry), so a network costs three edges, and the heads whose plans were
+    issued ahead none."""
     hit = _plan.pop(id(layer), None)
     if hit is None:
         return None
@@ -53,7 +54,7 @@ def take_plan(layer):
     waited = _plan_waited.get(cur.cuda_stream, -1)
     if seq is None or not plan_wait_elision or seq > waited:
         ev = hit[2]
-        if seq is not None and plan_wait_elision and plan_wait_latest and waited >= _plan_first[0] and _plan_latest[0] is not None:
+        if seq is not None and plan_wait_elision and plan_wait_latest and seq > _plan_own_until[0] and _plan_latest[0] is not None:
             ev, seq = _plan_latest
         cur.wait_event(ev)
         if seq is not None:
@@ -68,6 +69,7 @@ def plan_joined(stream):
 
 plan_wait_elision = os.environ.get('P3D_PLAN_WAIT_ELISION', '1') != '0'      # take_plan skips waits its stream already stands behind; 0 = one wait per layer (A/B)
 plan_wait_latest = os.environ.get('P3D_PLAN_WAIT_LATEST', '1') != '0'        # ... and a stream's SECOND wait on a plan is for everything issued so far (0 = the layer's own event)
+premodulate_rgb = os.environ.get('P3D_PREMODULATE_RGB', '1') != '0'          # ToRGB layers' weight modulation on the prefetch stream too (premodulate_torgb)
 sr_prefetch_ahead = os.environ.get('P3D_SR_PREFETCH_AHEAD', '1') != '0'      # the super-resolution heads' plans issued from inside the backbone's forward (superresolution.prefetch_ahead)
 
 
@@ -678,6 +680,16 @@ def _premod_route(weight, styles, up, in_pixels, dtype):
     return 'mfma'
 
 
+def premodulate_torgb(weight, styles, pixels, dtype):
+    """A ToRGB layer's modulated weights (no demodulation: networks_stylegan2.py:355-359) in the form the layer's route will ask for — bf16x3 K rows for the wide
+    fp32 image of a block with ``pixels`` pixels (torgb(), torgb_wide_skip), plain fp32 otherwise (the fused ToRGB of the fp16 heads) — with the tag the consumers
+    compare: a 3-6 us launch per ToRGB layer that otherwise sits in line in front of the layer (eleven per step)."""
+    ci = weight.shape[1]
+    split = split_bf16 and dtype == torch.float32 and pixels >= split_bf16_min_pixels and ci % 32 == 0
+    wtag = BF16X3 if split else torch.float32
+    return modulate_weights(weight, styles, demodulate=False, dtype=wtag), ('rgb', wtag)
+
+
 def premodulate(weight, styles, up, in_pixels, dtype):
     """The modulated weights synthesis_layer will want for a layer whose input has ``in_pixels`` pixels per image, in the layout of
     the route it will take; returns (tensor, route tag).  Used to run every layer's modulation ahead of the convolutions on a
@@ -739,7 +751,8 @@ def synthesis_layer(x, weight, styles, bias, up, resample_filter, noise_const=No
     wmod = wpre if wpre is not None else modulate_weights(weight, styles, demodulate=True, dtype=wtag)
     if rgb is not None:                                    # (rgb_weight, rgb_styles, rgb_bias, rgb_clamp, img[, x_dead]): checked by torgb_fusable
         rgb_w, rgb_s, rgb_b, rgb_c, img = rgb[:5]
-        rgb_wmod = modulate_weights(rgb_w, rgb_s, demodulate=False, dtype=torch.float32)
+        rgb_pre = rgb[6] if len(rgb) > 6 else None
+        rgb_wmod = rgb_pre[0] if rgb_pre is not None and rgb_pre[1] == ('rgb', torch.float32) else modulate_weights(rgb_w, rgb_s, demodulate=False, dtype=torch.float32)
         return conv3x3_torgb(x, wmod, bias, act_idx, act_gain, clampv, rgb_wmod, rgb_b, rgb_c, img, store_y=not (len(rgb) > 5 and rgb[5]))
     if up == 1 and act_idx is not None:
         return conv2d(x, wmod, bias=bias, noise=noise_const, noise_strength=noise_strength, act=act_idx, gain=act_gain, clamp=clampv, split=split, out_split=out_split)
@@ -892,11 +905,11 @@ def torgb_wide_skip_supported(x, weight, prev, f):
             and prev.is_cuda and prev.is_contiguous(memory_format=torch.channels_last) and not prev.requires_grad)
 
 
-def torgb_wide_skip(x, weight, styles, bias, clamp, prev, f):
+def torgb_wide_skip(x, weight, styles, bias, clamp, prev, f, pre=None):
     """ToRGB of a SplitActs (wide image: the backbone's tri-planes) + the block's skip-image sum ``upsample2d(prev, f) + y`` in one launch -> fp32 NHWC."""
     n, ci, h, w = x.shape
     co = weight.shape[0]
-    wmod = modulate_weights(weight, styles, demodulate=False, dtype=BF16X3)
+    wmod = pre[0] if pre is not None and pre[1] == ('rgb', BF16X3) else modulate_weights(weight, styles, demodulate=False, dtype=BF16X3)
     y = torch.empty([n, co, h, w], dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     b32 = None if bias is None else bias.detach().float().contiguous()
     fh = None if prev is None else _filter_host(f)
@@ -917,7 +930,7 @@ def torgb_accumulates(x, weight, out):
             and tuple(out.shape) == (n, weight.shape[0], h, w) and not out.requires_grad)
 
 
-def torgb(x, weight, styles, bias, clamp=None, out=None):
+def torgb(x, weight, styles, bias, clamp=None, out=None, pre=None):
     """ToRGB: 1x1 modulated conv without demodulation + bias (+ clamp).  fp16 activations with a handful of output
     channels take the streaming kernel (-> fp32 NCHW, optionally accumulated into ``out``); wide outputs (the 96-channel
     tri-plane image of the backbone) go through the MFMA kernel as a 1x1 conv and stay channels-last."""
@@ -932,7 +945,8 @@ def torgb(x, weight, styles, bias, clamp=None, out=None):
         return y if out is None else out.add_(y)
     if not (x.dtype == torch.float16 and ci in (64, 128, 256) and co <= 32 and (h * w) % 4 == 0):
         split = use_split_bf16(x, ci)                      # the wide fp32 ToRGB (96 tri-plane channels) as bf16x3 too: as exact-fp32 MFMA it ran at a
-        wmod = modulate_weights(weight, styles, demodulate=False, dtype=BF16X3 if split else x.dtype)      # third of that pipe's peak, 0.29 ms per step
+        wtag = BF16X3 if split else x.dtype                # third of that pipe's peak, 0.29 ms per step
+        wmod = pre[0] if pre is not None and pre[1] == ('rgb', wtag) else modulate_weights(weight, styles, demodulate=False, dtype=wtag)
         y = conv2d(x, wmod, bias=bias, clamp=-1.0 if clamp is None else float(clamp), split=split)
         return y if out is None else out.add_(y)
     w32 = weight.detach().float().reshape(co, ci).contiguous()

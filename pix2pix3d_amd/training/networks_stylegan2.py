@@ -299,7 +299,8 @@ class SynthesisLayer(torch.nn.Module):
                 if modconv.torgb_fusable(x, self.weight, torgb.weight, img, self.up, self.noise_const if const_noise else None, self.activation):
                     planned_rgb = modconv.take_plan(torgb) if modconv._plan else None
                     s_rgb = planned_rgb[0] if planned_rgb is not None else torgb.affine(w_rgb, out_scale=torgb.weight_gain)
-                    fused_rgb = (torgb.weight, s_rgb, torgb.bias, torgb.conv_clamp, img, len(rgb) > 3 and bool(rgb[3]))      # [5]: x has no other reader
+                    fused_rgb = (torgb.weight, s_rgb, torgb.bias, torgb.conv_clamp, img, len(rgb) > 3 and bool(rgb[3]),      # [5]: x has no other reader
+                                 planned_rgb[1] if planned_rgb is not None else None)                                        # [6]: its weights, modulated ahead
             y = modconv.synthesis_layer(x, self.weight, styles, self.bias, self.up, self.resample_filter,
                                         noise_const=self.noise_const if const_noise else None,
                                         noise_strength=self.noise_strength if const_noise else None,
@@ -337,7 +338,7 @@ class ToRGBLayer(torch.nn.Module):
         styles = planned[0] if planned is not None else self.affine(w, out_scale=self.weight_gain)
         if modconv.torgb_supported(x, self.weight, styles, fused_modconv):
             out = accumulate_into if accumulate_into is not None and modconv.torgb_accumulates(x, self.weight, accumulate_into) else None
-            return modconv.torgb(x, self.weight, styles, self.bias, clamp=self.conv_clamp, out=out)      # fp32 NCHW, bias + clamp fused
+            return modconv.torgb(x, self.weight, styles, self.bias, clamp=self.conv_clamp, out=out, pre=planned[1] if planned is not None else None)      # fp32 NCHW, bias + clamp fused
         if isinstance(x, modconv.SplitActs):
             x = x.dense()
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
@@ -470,7 +471,8 @@ class SynthesisBlock(torch.nn.Module):
                 # split activations in: ToRGB and the skip-image sum in ONE pass over the image (csrc/torgb_split.hip)
                 planned = modconv.take_plan(self.torgb) if modconv._plan else None
                 s_rgb = planned[0] if planned is not None else self.torgb.affine(per_layer[self.num_conv], out_scale=self.torgb.weight_gain)
-                img = modconv.torgb_wide_skip(x, self.torgb.weight, s_rgb, self.torgb.bias, self.torgb.conv_clamp, img, self.resample_filter)
+                img = modconv.torgb_wide_skip(x, self.torgb.weight, s_rgb, self.torgb.bias, self.torgb.conv_clamp, img, self.resample_filter,
+                                              pre=planned[1] if planned is not None else None)
                 return x, img
             y = self.torgb(x, per_layer[self.num_conv], fused_modconv=fused_modconv)
             if y.dtype == torch.float32 and y.is_contiguous(memory_format=torch.channels_last):
@@ -581,28 +583,49 @@ def prefetch_styles(blocks, block_ws, block_kwargs, ahead=False):
             for layer, in_res in layers:
                 todo.append((layer, next(ws_iter), 1, in_res * in_res, dtype))
             if block.is_last or block.architecture == 'skip':
-                todo.append((block.torgb, next(ws_iter), block.torgb.weight_gain, None, dtype))
+                # (its modulated weights too — ('rgb', pixels) — where the layer would otherwise launch that modulation in line; premodulate_torgb)
+                todo.append((block.torgb, next(ws_iter), block.torgb.weight_gain, ('rgb', res * res) if modconv.premodulate_rgb else None, dtype))
         # every style affine of the network in one launch (they are ~6 us of launch latency each on their own)
         batched = (0 < len(todo) <= modconv.FC_MAX_JOBS and len({t[1].shape[0] for t in todo}) == 1 and all(t[1].shape[1] % 4 == 0 for t in todo)   # (fc_multi takes whole float4 rows; fc() pads)
                    and all(modconv.fc_supported(w, l.affine.weight, l.affine.bias, l.affine.activation) for l, w, *_ in todo))
         all_styles = (modconv.fc_multi([(w, l.affine, sc) for l, w, sc, _, _ in todo]) if batched
                       else [l.affine(w) if sc == 1 else l.affine(w, out_scale=sc) for l, w, sc, _, _ in todo])
-        items = [(layer.weight, styles, getattr(layer, 'up', 1), in_pixels, dtype) for (layer, _, _, in_pixels, dtype), styles in zip(todo, all_styles)]
+        # (ToRGB entries carry ('rgb', pixels): premodulate_many itself launches nothing for them — their modulations are issued together, below)
+        items = [(layer.weight, styles, getattr(layer, 'up', 1), None if isinstance(in_pixels, tuple) else in_pixels, dtype) for (layer, _, _, in_pixels, dtype), styles in zip(todo, all_styles)]
         pres = modconv.premodulate_many(items)
-        # one event per layer that LAUNCHED something; a layer that did not (ToRGB: styles only; a shared-weight layer after the first) shares the event of the
-        # last one that did, and take_plan skips a position its stream already waits behind — every wait is an edge between two branches of the captured graph.
-        # Positions number the side stream's events for the life of the process (one side stream per device: a later position implies every earlier one).
-        ev = None
-        for (layer, _, _, in_pixels, dtype), styles, pre, fresh in zip(todo, all_styles, pres, modconv.premodulate_launches(items)):
+        # one event per layer that LAUNCHED something; a layer that did not (a shared-weight layer after the first) shares the event of the last one that did, and
+        # take_plan skips a position its stream already waits behind — every wait is an edge between two branches of the captured graph.  Positions number the side
+        # stream's events for the life of the process (one side stream per device: a later position implies every earlier one).
+        # Right behind the FIRST layer's event: every ToRGB layer's weight modulation (3-6 us each, eleven per step, otherwise in line in front of their layers) and
+        # one event for all of them — the network's first layer does not stand behind them, its first ToRGB (tens of microseconds later) waits for that one event,
+        # and from there on a wait is for everything issued (modconv.take_plan).
+        ev, ev_seq = None, -1
+        rgb_entry = {}
+        for k, ((layer, _, _, in_pixels, dtype), styles, pre, fresh) in enumerate(zip(todo, all_styles, pres, modconv.premodulate_launches(items))):
             if fresh or ev is None:
                 first = ev is None
                 ev = torch.cuda.Event()
                 ev.record(side)
                 modconv._plan_seq[0] += 1
-                modconv._plan_latest[:] = [ev, modconv._plan_seq[0]]
+                ev_seq = modconv._plan_seq[0]
+                modconv._plan_latest[:] = [ev, ev_seq]
                 if first and not ahead:
-                    modconv._plan_first[0] = modconv._plan_seq[0]
-            modconv._plan[id(layer)] = (styles, pre, ev, modconv._plan_seq[0])
+                    modconv._plan_own_until[0] = modconv._plan_seq[0]
+                if first:
+                    rgb = [j for j, t in enumerate(todo) if isinstance(t[3], tuple)]
+                    if rgb:
+                        rgb_pre = [modconv.premodulate_torgb(todo[j][0].weight, all_styles[j], todo[j][3][1], todo[j][4]) for j in rgb]
+                        ev_rgb = torch.cuda.Event()
+                        ev_rgb.record(side)
+                        modconv._plan_seq[0] += 1
+                        modconv._plan_latest[:] = [ev_rgb, modconv._plan_seq[0]]
+                        if not ahead:
+                            modconv._plan_own_until[0] = modconv._plan_seq[0]
+                        rgb_entry = {j: (p, ev_rgb, modconv._plan_seq[0]) for j, p in zip(rgb, rgb_pre)}
+            if k in rgb_entry:
+                modconv._plan[id(layer)] = (styles,) + rgb_entry[k]
+            else:
+                modconv._plan[id(layer)] = (styles, pre, ev, ev_seq)
             keys.append(id(layer))
     if not ahead:
         hooks, modconv.after_prefetch[:] = list(modconv.after_prefetch), []
