@@ -240,7 +240,7 @@ struct FirEpilogue { const float* bias; const float* noise; const float* noise_s
                      int y_split; };   // fp32 only: the result leaves as bf16x3 K rows — per 32 channels [32 x bf16 hi | 32 x bf16 lo] — for the next bf16x3 convolution (csrc/conv2d.hip, XS)
 
 template <class T>
-__global__ void __launch_bounds__(256) fir4_cl_fused_kernel(UpfirArgs a, FirEpilogue ep)
+__global__ void __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) fir4_cl_fused_kernel(UpfirArgs a, FirEpilogue ep)
 {
     constexpr int VEC = 16 / sizeof(T);            // elements per 16-byte chunk
     constexpr int CB = 8 * VEC;                    // channels per block (128 bytes)
@@ -293,44 +293,35 @@ __global__ void __launch_bounds__(256) fir4_cl_fused_kernel(UpfirArgs a, FirEpil
             fr[ky][kx] = a.f[fx * a.fsx + fy * a.fsy] * a.gain;
         }
     __syncthreads();
-    float acc[8][VEC];
-#pragma unroll
-    for (int o = 0; o < 8; ++o)
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[o][k] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 11; ++r) {                 // input rows yh*8 .. yh*8+10 feed output rows yh*8 .. yh*8+7
-#pragma unroll
-        for (int kx = 0; kx < 4; ++kx) {
-            const P v = tile[((yh * 8 + r) * TI + x + kx) * 8 + chunk];
-            float vf[VEC];
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) vf[k] = (float)ld(&v.v[k]);
-#pragma unroll
-            for (int ky = 0; ky < 4; ++ky) {
-                const int o = r - ky;              // output row (within the strip) this input row contributes to with tap ky
-                if (o >= 0 && o < 8) {
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc[o][k] = fmaf(vf[k], fr[ky][kx], acc[o][k]);
-                }
-            }
-        }
-    }
     const int ox = ox0 + x;
     if (ox >= a.out_w) return;
     const int c0 = cblk * CB + chunk * VEC;
     float bias[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) bias[k] = ep.bias ? ep.bias[c0 + k] : 0.f;
+    // One output row at a time: its sixteen taps are read from the LDS tile (16-byte reads), summed in the order (ky, kx) ascending, finished and stored before the next
+    // row starts.  (The earlier form walked the eleven INPUT rows once — 44 reads instead of 128 — and the compiler kept all 44 in registers before the first fma:
+    // 235 VGPRs in fp32, 256 in fp16, one to two waves per SIMD for a memory pass.  LDS reads are not what this kernel waits for.)
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
         const int oy = oy0 + yh * 8 + o;
         if (oy >= a.out_h) break;
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) {
+                const P v = tile[((yh * 8 + o + ky) * TI + x + kx) * 8 + chunk];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] = fmaf((float)ld(&v.v[k]), fr[ky][kx], acc[k]);
+            }
         const float nz = nzv[o];
         P outv;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            float v = acc[o][k] + nz + bias[k];
+            float v = acc[k] + nz + bias[k];
             if (ep.act == 3) v = v > 0.f ? v : v * ep.alpha;
             v *= ep.act_gain;
             if (ep.clamp >= 0.f) v = fminf(fmaxf(v, -ep.clamp), ep.clamp);
