@@ -1,4 +1,4 @@
-"""The benchmark line's contract, checked on the line this round's tree printed on an MI355X (profiles/round5_bench_line_default.json) and on
+"""The benchmark line's contract, checked on the line this round's tree printed on an MI355X (profiles/round6_bench_line_default.json) and on
 bench.py's argument surface: the keys the driver parses, the roofline object backed by committed counter passes whose hash matches the
 kernel sources of this tree, the CPU baseline, the exact-fp32 leg and the six-phase training step."""
 import hashlib
@@ -15,7 +15,7 @@ def _line(name):
 
 
 def test_default_line_has_the_contract_keys():
-    d = _line('round5_bench_line_default.json')
+    d = _line('round6_bench_line_default.json')
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
               'roofline', 'cpu_baseline', 'exact_fp32', 'train_step'):
         assert k in d, k
@@ -62,6 +62,8 @@ def test_default_line_has_the_contract_keys():
     assert x6['value'] > e['value'] and x6['mfma_conv']['conv_bf16x6']['tflops'] > e['mfma_conv']['conv_f32']['tflops']
     assert fl['Gmain']['tflop']['bf16x6_convs_fp32_equivalent'] > fl['Gmain']['tflop']['f32_convs']
     assert t['f32_input_mfma']['ms_per_iteration'] > t['ms_per_iteration']
+    # round 6: the iteration's optimizer form is named in the line
+    assert 'fused=True' in t['optimizer']
 
 
 def test_committed_counter_passes_belong_to_this_trees_kernel():

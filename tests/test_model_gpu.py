@@ -80,3 +80,47 @@ def test_const_batch_cache_follows_data_writes(hip_lib):
         b4.const.mul_(0.5)                                             # an in-place update is seen through the version counter
         assert torch.equal(b4._entry_features(None, 2, torch.float32, fmt)[1], b4.const)
     assert len(ns._const_batches) >= 1
+
+
+def test_prefetch_plan_waits_are_few_and_change_nothing(hip_lib):
+    """The captured step's graph edges: with the position rule of modconv.take_plan a synthesis pass makes a handful of cross-stream waits (the backbone's
+    first layer, its ToRGB group, one "everything issued" wait; the heads' plans, issued ahead, none) where one wait per layer is ~30 — and the images are bit-identical
+    either way (the rule only drops waits whose event the stream already stands behind)."""
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    g = load_golden('model_seg2cat')
+    G = build_generator('seg2cat', 'cuda')
+    ws, c, nrr = torch.tensor(g['ws'], device='cuda'), torch.tensor(g['c'], device='cuda'), int(g['nrr'])
+    u_c, u_f = uniforms(g, ws.shape[0], nrr, G.rendering_kwargs)
+
+    def run():
+        counts = {'wait_event': 0, 'wait_stream': 0}
+        we, wst = torch.cuda.Stream.wait_event, torch.cuda.Stream.wait_stream
+
+        def count_we(self, ev):
+            counts['wait_event'] += 1
+            return we(self, ev)
+
+        def count_ws(self, st):
+            counts['wait_stream'] += 1
+            return wst(self, st)
+        torch.cuda.Stream.wait_event, torch.cuda.Stream.wait_stream = count_we, count_ws
+        try:
+            with replay_uniforms(u_c, u_f), torch.no_grad():
+                out = G.synthesis(ws, c, neural_rendering_resolution=nrr, noise_mode='const')
+            torch.cuda.synchronize()
+        finally:
+            torch.cuda.Stream.wait_event, torch.cuda.Stream.wait_stream = we, wst
+        return out, counts
+    saved = (modconv.plan_wait_elision, modconv.sr_prefetch_ahead, modconv.premodulate_rgb)
+    try:
+        run()                                                                    # (weight caches warm: both timed passes launch the same work)
+        out1, n1 = run()
+        modconv.plan_wait_elision, modconv.sr_prefetch_ahead, modconv.premodulate_rgb = False, False, False
+        out0, n0 = run()
+    finally:
+        modconv.plan_wait_elision, modconv.sr_prefetch_ahead, modconv.premodulate_rgb = saved
+    print('waits with the position rule', n1, 'one per layer', n0)
+    assert n1['wait_event'] <= 6 and n0['wait_event'] >= 20, (n1, n0)
+    assert n1['wait_event'] + n1['wait_stream'] < n0['wait_event'] + n0['wait_stream']
+    for k in ('image', 'semantic', 'image_raw', 'semantic_raw', 'image_depth'):
+        assert torch.equal(out1[k], out0[k]), k
