@@ -685,7 +685,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(ConvArgs a)
     if (!a.y_split && !a.store_narrow && (a.Co & 3) == 0 && ((((uintptr_t)a.y) & 15u) == 0)) {
         // Wide stores (quad_transpose4, p3d_common.h): after the 4 x 4 transpose lane 4 m + t holds channels 4 m .. 4 m + 3 of pixel t of the four consecutive pixels in
         // registers 4 q .. 4 q + 3 — one 16-byte store (fp32) or, with the two row tiles i = 0, 1 packed into one dword per value, two 8-byte ones (fp16) where the
-        // lane = channel layout stores one value per instruction (the generic kernel's epilogue: 150 -> 108 ms of a three-iteration training profile with this change).
+        // lane = channel layout stores one value per instruction (with the generic kernel's: 272.9 -> 270.5 ms per training iteration, profiles/round6_j_*).
         const bool odd1 = lane & 1, odd2 = lane & 2;
         const int t = lane & 3, m4 = frow >> 2;
         T* const yimg = (T*)a.y + (int64_t)n * a.H * a.W * a.Co;
