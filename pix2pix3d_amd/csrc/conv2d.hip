@@ -515,6 +515,116 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(ConvArgs a, int Mp
     }
 }
 
+// Epilogue of the 8 x 16-patch kernels (conv3x3_halo_kernel, conv3x3_halo_x6p_kernel): tile i of a wave is patch rows prow0 + 2 i, + 1, column block j is
+// channels co0 + 64 wn + 32 j + (lane & 31); accumulator register r of lane (frow, fk) is tile row (r & 3) + 8 (r >> 2) + 4 fk.
+template <class T, bool BF3>
+__device__ __forceinline__ void halo_epilogue(const ConvArgs& a, f32x16 (&acc)[2][2], int n, int oy0, int ox0, int co0, int prow0, bool co64, int wn, int lane)
+{
+    const int frow = lane & 31, fk = lane >> 5;
+    const float ns = a.noise ? a.noise_strength[0] : 0.f;
+    if (!a.y_split && !a.store_narrow && (a.Co & 3) == 0 && ((((uintptr_t)a.y) & 15u) == 0)) {
+        // Wide stores (quad_transpose4, p3d_common.h): after the 4 x 4 transpose lane 4 m + t holds channels 4 m .. 4 m + 3 of pixel t of the four consecutive pixels in
+        // registers 4 q .. 4 q + 3 — one 16-byte store (fp32) or, with the two row tiles i = 0, 1 packed into one dword per value, two 8-byte ones (fp16) where the
+        // lane = channel layout stores one value per instruction (with the generic kernel's: 272.9 -> 270.5 ms per training iteration, profiles/round6_j_*).
+        const bool odd1 = lane & 1, odd2 = lane & 2;
+        const int t = lane & 3, m4 = frow >> 2;
+        T* const yimg = (T*)a.y + (int64_t)n * a.H * a.W * a.Co;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int cq = co0 + wn * 64 + j * 32, co = cq + frow;
+            const bool cok = co < a.Co;
+            const float b = (a.bias && cok) ? a.bias[co] : 0.f;
+            float fin[2][16];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mrow = (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    const int oy = oy0 + prow0 + i * 2 + (mrow >> 4), ox = ox0 + (mrow & 15);
+                    float v = (co64 && i == 1) ? 0.f : acc[i][j][r];
+                    if (a.noise && oy < a.H && ox < a.W) v = fmaf(a.noise[(int64_t)oy * a.W + ox], ns, v);
+                    v += b;
+                    if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
+                    v *= a.gain;
+                    if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
+                    fin[i][r] = v;
+                }
+            const bool chan_ok = cq + 4 * m4 < a.Co;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int mrow = t + 8 * q + 4 * fk;                           // this lane's pixel after the transpose
+                const int ox = ox0 + (mrow & 15);
+                if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        if (co64 && i == 1) continue;
+                        unsigned w[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(fin[i][4 * q + e]);
+                        quad_transpose4(w, odd1, odd2);
+                        const int oy = oy0 + prow0 + i * 2 + (mrow >> 4);
+                        if (chan_ok && oy < a.H && ox < a.W) {
+                            typedef unsigned u32x4h __attribute__((ext_vector_type(4)));
+                            *(u32x4h*)(yimg + ((int64_t)oy * a.W + ox) * a.Co + cq + 4 * m4) = u32x4h{w[0], w[1], w[2], w[3]};
+                        }
+                    }
+                } else {
+                    unsigned w[4];                                              // (value of row tile 0 | value of row tile 1 << 16) per register
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        typedef _Float16 hp2 __attribute__((ext_vector_type(2)));
+                        hp2 pk; pk[0] = (_Float16)fin[0][4 * q + e]; pk[1] = (_Float16)fin[1][4 * q + e];
+                        w[e] = __builtin_bit_cast(unsigned, pk);
+                    }
+                    quad_transpose4(w, odd1, odd2);
+                    typedef unsigned u32x2h __attribute__((ext_vector_type(2)));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        if (co64 && i == 1) continue;
+                        const unsigned sel = i ? 0x07060302u : 0x05040100u;
+                        const u32x2h out = {__builtin_amdgcn_perm(w[1], w[0], sel), __builtin_amdgcn_perm(w[3], w[2], sel)};
+                        const int oy = oy0 + prow0 + i * 2 + (mrow >> 4);
+                        if (chan_ok && oy < a.H && ox < a.W) *(u32x2h*)(yimg + ((int64_t)oy * a.W + ox) * a.Co + cq + 4 * m4) = out;
+                    }
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = co0 + wn * 64 + j * 32 + frow;
+        if (co >= a.Co) continue;
+        const float b = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (co64 && i == 1) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mrow = (r & 3) + 8 * (r >> 2) + 4 * fk;             // accumulator row within the 32-row tile
+                const int oy = oy0 + prow0 + i * 2 + (mrow >> 4), ox = ox0 + (mrow & 15);
+                if (oy >= a.H || ox >= a.W) continue;
+                float v = acc[i][j][r];
+                if (a.noise) v = fmaf(a.noise[(int64_t)oy * a.W + ox], ns, v);
+                v += b;
+                if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
+                v *= a.gain;
+                if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
+                if constexpr (BF3) {
+                    if (a.y_split) {                                            // this lane's channel inside its 32-channel K row: hi at [frow], lo at [32 + frow]
+                        __bf16* row = (__bf16*)((float*)a.y + (((int64_t)n * a.H + oy) * a.W + ox) * a.Co + (co - frow));
+                        const __bf16 hv = (__bf16)v;
+                        row[frow] = hv;
+                        row[32 + frow] = (__bf16)(v - (float)hv);
+                        continue;
+                    }
+                }
+                st((T*)a.y + (((int64_t)n * a.H + oy) * a.W + ox) * a.Co + co, v);
+            }
+        }
+    }
+}
+
 // ---- 3x3 "same" convolution with halo reuse ---------------------------------------------------------------------------
 // Same GEMM tiling as above, but the A operand of a block — an 8 x 16 pixel patch — is staged ONCE per 128-byte channel
 // chunk as a (8+2) x (16+2) pixel slab; the nine taps then read shifted windows of that slab straight from LDS.  Global /
@@ -681,108 +791,156 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(ConvArgs a)
         __syncthreads();
     }
 
-    const float ns = a.noise ? a.noise_strength[0] : 0.f;
-    if (!a.y_split && !a.store_narrow && (a.Co & 3) == 0 && ((((uintptr_t)a.y) & 15u) == 0)) {
-        // Wide stores (quad_transpose4, p3d_common.h): after the 4 x 4 transpose lane 4 m + t holds channels 4 m .. 4 m + 3 of pixel t of the four consecutive pixels in
-        // registers 4 q .. 4 q + 3 — one 16-byte store (fp32) or, with the two row tiles i = 0, 1 packed into one dword per value, two 8-byte ones (fp16) where the
-        // lane = channel layout stores one value per instruction (with the generic kernel's: 272.9 -> 270.5 ms per training iteration, profiles/round6_j_*).
-        const bool odd1 = lane & 1, odd2 = lane & 2;
-        const int t = lane & 3, m4 = frow >> 2;
-        T* const yimg = (T*)a.y + (int64_t)n * a.H * a.W * a.Co;
+    halo_epilogue<T, BF3>(a, acc, n, oy0, ox0, co0, prow0, co64, wn, lane);
+}
+
+// ---- bf16x6 on operands that are split ONCE per work-group ("x6p") -------------------------------------------------------------
+// conv3x3_halo_kernel<float, false, false, true> keeps fp32 tiles in LDS and splits every fragment it reads: a slab value is split again by each of
+// the nine taps and by both waves that share its rows, a weight by both waves that share its columns — 288 vector instructions per 48 MFMAs, and the
+// counters show the kernel bound by them (vector issue 0.50 against 0.37 of the matrix pipe, profiles/round6_z_kernel_pmc_train6.txt).  Pre-split
+// tiles do not fit the two-blocks-per-CU budget at 32-channel K rows (three 64-byte pieces per row: 114 KB), so this kernel takes 16-channel K rows:
+//   * LDS rows are 96 bytes, [hi | mid | lo] x 16 bf16, 16-byte position 2 piece + (half ^ key), key = (row >> 3) & 1: the 16 rows one ds_read_b128
+//     cycle serves start on 16 different bank quads (6 r mod 16 takes every even value twice, eight rows apart — where the key differs);
+//   * operands travel global -> registers -> split3_bf16x8 -> LDS: a thread owns 8 consecutive channels of one weight row per tap (two 16-byte loads
+//     issued two taps ahead, 36 vector instructions, three ds_write_b128) and of at most two slab pixels per chunk — every value is split exactly once;
+//   * a tap is 12 fragment reads and 24 MFMAs per wave with no vector work between them; two slab buffers, two weight slots, one barrier per tap;
+//     60 KB per block.
+// Same products and the same six terms per product as the in-register form; the summation order over K differs (16-channel chunks outermost).
+constexpr int X6_ROW = 96;
+constexpr int X6_SLAB_BYTES = 184 * X6_ROW;               // 180 slab pixels (+ 4 rows of padding nobody reads)
+constexpr int X6_W_BYTES = BN * X6_ROW;
+constexpr int X6_W_BASE = 2 * X6_SLAB_BYTES;
+constexpr int X6_LDS = X6_W_BASE + 2 * X6_W_BYTES;        // 59 904
+
+__device__ __forceinline__ void x6_put(char* dst, const f32x4& v0, const f32x4& v1)      // dst: the row's hi piece at this thread's (half ^ key) position
+{
+    bf8 hi, mid, lo;
+    split3_bf16x8(v0, v1, hi, mid, lo);
+    *(bf8*)dst = hi; *(bf8*)(dst + 32) = mid; *(bf8*)(dst + 64) = lo;
+}
+
+template <bool CO64>                                                           // Co <= 64: four row tiles against the 64 live columns (see conv3x3_halo_kernel)
+__global__ void __launch_bounds__(256, 2) conv3x3_halo_x6p_kernel(ConvArgs a)
+{
+    __shared__ __attribute__((aligned(16))) char lds_b[X6_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr bool co64 = CO64;
+    const int wn = co64 ? 0 : wave & 1;
+    const int prow0 = co64 ? wave * 2 : (wave >> 1) * 4;
+    const int n = blockIdx.z;
+    const int tiles_x = (a.W + PW - 1) / PW;
+    int mt = blockIdx.x, cb = blockIdx.y;
+    {
+        const int nmt = gridDim.x, ncb = gridDim.y, L = blockIdx.x + blockIdx.y * nmt;
+        if ((nmt & 7) == 0) { const int q = L >> 3, r = L & 7; cb = q % ncb; mt = (q / ncb) * 8 + r; }
+    }
+    const int ty = mt / tiles_x, tx = mt - ty * tiles_x;
+    const int oy0 = ty * PH, ox0 = tx * PW, co0 = cb * BN;
+    const float* const xin = (const float*)a.x + (int64_t)n * a.H * a.W * a.Ci;
+    const float* const wgt = (const float*)a.w + (int64_t)n * a.w_img_stride;
+    const float* const zeros = (const float*)a.zeros;
+
+    // producer roles.  Weights: row tid >> 1 of the 128-row tile, channels 8 (tid & 1) .. + 7 of the 16-channel chunk.
+    const int wrow = tid >> 1, whalf = tid & 1;
+    const bool wok = co0 + wrow < a.Co;
+    const float* const wsrc = wgt + (int64_t)(co0 + wrow) * 9 * a.Ci + whalf * 8;                           // + tap * Ci + chunk * 16
+    char* const wdst = lds_b + X6_W_BASE + wrow * X6_ROW + ((whalf ^ ((wrow >> 3) & 1)) << 4);             // + slot * X6_W_BYTES
+    // slab: items tid and tid + 256 of the 360 (pixel, half) pairs
+    const float* ssrc[2]; char* sdst[2]; bool sval[2], sin[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int cq = co0 + wn * 64 + j * 32, co = cq + frow;
-            const bool cok = co < a.Co;
-            const float b = (a.bias && cok) ? a.bias[co] : 0.f;
-            float fin[2][16];
+    for (int r = 0; r < 2; ++r) {
+        const int item = tid + 256 * r, q = item >> 1, half = item & 1;
+        const int sr = q / SLAB_W, sc = q - sr * SLAB_W;
+        const int iy = oy0 - 1 + sr, ix = ox0 - 1 + sc;
+        sval[r] = item < 2 * SLAB_ROWS;
+        sin[r] = sval[r] & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
+        ssrc[r] = xin + ((int64_t)iy * a.W + ix) * a.Ci + half * 8;                                        // + chunk * 16
+        sdst[r] = lds_b + q * X6_ROW + ((half ^ ((q >> 3) & 1)) << 4);                                      // + buffer * X6_SLAB_BYTES
+    }
+    auto load_w = [&](f32x4 (&v)[2], int cc, int t) {
+        const float* p = wok ? wsrc + (int64_t)t * a.Ci + cc * 16 : zeros;
+        v[0] = *(const f32x4*)p; v[1] = *(const f32x4*)(p + 4);
+    };
+    auto load_s = [&](f32x4 (&v)[2], int r, int cc) {
+        const float* p = sin[r] ? ssrc[r] + cc * 16 : zeros;
+        v[0] = *(const f32x4*)p; v[1] = *(const f32x4*)(p + 4);
+    };
+
+    f32x16 acc[2][2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int mrow = (r & 3) + 8 * (r >> 2) + 4 * fk;
-                    const int oy = oy0 + prow0 + i * 2 + (mrow >> 4), ox = ox0 + (mrow & 15);
-                    float v = (co64 && i == 1) ? 0.f : acc[i][j][r];
-                    if (a.noise && oy < a.H && ox < a.W) v = fmaf(a.noise[(int64_t)oy * a.W + ox], ns, v);
-                    v += b;
-                    if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
-                    v *= a.gain;
-                    if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
-                    fin[i][r] = v;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fk = lane >> 5;
+    int arow[2];                                                               // slab pixel under tap (0, 0) of this lane's row in tile i
+#pragma unroll
+    for (int i = 0; i < 2; ++i) arow[i] = (prow0 + ((co64 && i == 1) ? 0 : i * 2) + (frow >> 4) + 1) * SLAB_W + (frow & 15) + 1;
+    int preB[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int rb = wn * 64 + j * 32 + frow; preB[j] = X6_W_BASE + rb * X6_ROW + ((fk ^ ((rb >> 3) & 1)) << 4); }
+
+    const int nchunks = a.Ci / 16, kpairs = nchunks / 2;                       // (host: Ci % 32 == 0)
+    f32x4 wq[2][2], sq[2];
+    {   // prologue: slab of chunk 0, weights of tap 0; taps 1 and 2 in flight
+        f32x4 s1[2];
+        load_s(sq, 0, 0); load_s(s1, 1, 0); load_w(wq[0], 0, 0);
+        x6_put(sdst[0], sq[0], sq[1]);
+        if (sval[1]) x6_put(sdst[1], s1[0], s1[1]);
+        x6_put(wdst, wq[0][0], wq[0][1]);
+        load_w(wq[1], 0, 1); load_w(wq[0], 0, 2);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int cp = 0; cp < kpairs; ++cp) {
+        const bool more = cp + 1 < kpairs;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int cc = cp * 2 + h;
+            const bool next_chunk = (h == 0) || more;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int st = h * 9 + t;                                       // 0..17, compile-time: weight slot st & 1, register set (st + 1) & 1 holds tap st + 1
+                const int toff = (t / 3 - 1) * SLAB_W + (t % 3 - 1);
+                bf8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int q = arow[i] + toff;
+                    const char* pa = lds_b + h * X6_SLAB_BYTES + q * X6_ROW + ((fk ^ ((q >> 3) & 1)) << 4);
+                    ah[i] = *(const bf8*)pa; am[i] = *(const bf8*)(pa + 32); al[i] = *(const bf8*)(pa + 64);
+                    const char* pb = lds_b + preB[i] + (st & 1) * X6_W_BYTES;
+                    bh[i] = *(const bf8*)pb; bm[i] = *(const bf8*)(pb + 32); bl[i] = *(const bf8*)(pb + 64);
                 }
-            const bool chan_ok = cq + 4 * m4 < a.Co;
+                // tap st + 1's weights: registers -> slot (st + 1) & 1 (its readers left at the last barrier); tap st + 3's loads take the registers over
+                {
+                    const int t1 = t + 1;                                       // tap st + 1 = (cc, t + 1) or (cc + 1, 0)
+                    if (t1 < 9 || next_chunk) x6_put(wdst + ((st + 1) & 1) * X6_W_BYTES, wq[(st + 1) & 1][0], wq[(st + 1) & 1][1]);
+                    const int t3 = t + 3;
+                    if (t3 < 9) load_w(wq[(st + 1) & 1], cc, t3);
+                    else if (next_chunk) load_w(wq[(st + 1) & 1], cc + 1, t3 - 9);
+                }
+                if (next_chunk) {                                               // next chunk's slab into the other buffer, one item at a time
+                    if (t == 0) load_s(sq, 0, cc + 1);
+                    if (t == 2) { x6_put(sdst[0] + (h ^ 1) * X6_SLAB_BYTES, sq[0], sq[1]); load_s(sq, 1, cc + 1); }
+                    if (t == 4 && sval[1]) x6_put(sdst[1] + (h ^ 1) * X6_SLAB_BYTES, sq[0], sq[1]);
+                }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int mrow = t + 8 * q + 4 * fk;                           // this lane's pixel after the transpose
-                const int ox = ox0 + (mrow & 15);
-                if constexpr (sizeof(T) == 4) {
+                for (int term = 0; term < 6; ++term)
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         if (co64 && i == 1) continue;
-                        unsigned w[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(fin[i][4 * q + e]);
-                        quad_transpose4(w, odd1, odd2);
-                        const int oy = oy0 + prow0 + i * 2 + (mrow >> 4);
-                        if (chan_ok && oy < a.H && ox < a.W) {
-                            typedef unsigned u32x4h __attribute__((ext_vector_type(4)));
-                            *(u32x4h*)(yimg + ((int64_t)oy * a.W + ox) * a.Co + cq + 4 * m4) = u32x4h{w[0], w[1], w[2], w[3]};
-                        }
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P3D_X6_A(term, ah[i], am[i], al[i]), P3D_X6_B(term, bh[j], bm[j], bl[j]), acc[i][j], 0, 0, 0);
                     }
-                } else {
-                    unsigned w[4];                                              // (value of row tile 0 | value of row tile 1 << 16) per register
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        typedef _Float16 hp2 __attribute__((ext_vector_type(2)));
-                        hp2 pk; pk[0] = (_Float16)fin[0][4 * q + e]; pk[1] = (_Float16)fin[1][4 * q + e];
-                        w[e] = __builtin_bit_cast(unsigned, pk);
-                    }
-                    quad_transpose4(w, odd1, odd2);
-                    typedef unsigned u32x2h __attribute__((ext_vector_type(2)));
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        if (co64 && i == 1) continue;
-                        const unsigned sel = i ? 0x07060302u : 0x05040100u;
-                        const u32x2h out = {__builtin_amdgcn_perm(w[1], w[0], sel), __builtin_amdgcn_perm(w[3], w[2], sel)};
-                        const int oy = oy0 + prow0 + i * 2 + (mrow >> 4);
-                        if (chan_ok && oy < a.H && ox < a.W) *(u32x2h*)(yimg + ((int64_t)oy * a.W + ox) * a.Co + cq + 4 * m4) = out;
-                    }
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int co = co0 + wn * 64 + j * 32 + frow;
-        if (co >= a.Co) continue;
-        const float b = a.bias ? a.bias[co] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (co64 && i == 1) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int mrow = (r & 3) + 8 * (r >> 2) + 4 * fk;             // accumulator row within the 32-row tile
-                const int oy = oy0 + prow0 + i * 2 + (mrow >> 4), ox = ox0 + (mrow & 15);
-                if (oy >= a.H || ox >= a.W) continue;
-                float v = acc[i][j][r];
-                if (a.noise) v = fmaf(a.noise[(int64_t)oy * a.W + ox], ns, v);
-                v += b;
-                if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
-                v *= a.gain;
-                if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
-                if constexpr (BF3) {
-                    if (a.y_split) {                                            // this lane's channel inside its 32-channel K row: hi at [frow], lo at [32 + frow]
-                        __bf16* row = (__bf16*)((float*)a.y + (((int64_t)n * a.H + oy) * a.W + ox) * a.Co + (co - frow));
-                        const __bf16 hv = (__bf16)v;
-                        row[frow] = hv;
-                        row[32 + frow] = (__bf16)(v - (float)hv);
-                        continue;
-                    }
-                }
-                st((T*)a.y + (((int64_t)n * a.H + oy) * a.W + ox) * a.Co + co, v);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
             }
         }
     }
+    halo_epilogue<float, false>(a, acc, n, oy0, ox0, co0, prow0, co64, wn, lane);
 }
 
 // ---- 3x3 conv, 16 x 16 patch, three-slot weight ring, 64-byte K rows: TWO blocks per CU (fp16) -----------------------------------
@@ -2023,9 +2181,12 @@ int p3d::conv2d_nhwc_run_io(const void* x, const void* w, void* y, int dtype, co
             if (dry) return P3D_OK;
             dim3 grid(((h + PH - 1) / PH) * ((wdt + PW - 1) / PW), (co + BN - 1) / BN, n_img);
             a.y_split = y_split;
+            static const bool x6p = [] { const char* d = getenv("P3D_X6_PRESPLIT"); return !d || atoi(d) != 0; }();      // (0: the in-register splits of round 5, for A/B)
             if (dtype == P3D_F16)             hipLaunchKernelGGL(conv3x3_halo_kernel<__half>, grid, dim3(256), 0, s, a);
             else if (dtype == P3D_F32_BF16X3 && x_split) hipLaunchKernelGGL((conv3x3_halo_kernel<float, true, true>), grid, dim3(256), 0, s, a);
             else if (dtype == P3D_F32_BF16X3) hipLaunchKernelGGL((conv3x3_halo_kernel<float, true>), grid, dim3(256), 0, s, a);
+            else if (dtype == P3D_F32_BF16X6 && x6p && ci % 32 == 0 && co <= 64) hipLaunchKernelGGL(conv3x3_halo_x6p_kernel<true>, grid, dim3(256), 0, s, a);
+            else if (dtype == P3D_F32_BF16X6 && x6p && ci % 32 == 0) hipLaunchKernelGGL(conv3x3_halo_x6p_kernel<false>, grid, dim3(256), 0, s, a);
             else if (dtype == P3D_F32_BF16X6) hipLaunchKernelGGL((conv3x3_halo_kernel<float, false, false, true>), grid, dim3(256), 0, s, a);
             else                              hipLaunchKernelGGL(conv3x3_halo_kernel<float>, grid, dim3(256), 0, s, a);
             count_launch(FAM_CONV);

@@ -511,6 +511,8 @@ def f32_x6():
     (256, 256, 64, 64, 2, 3, 'same'),          # halo-slab kernel
     (64, 96, 70, 52, 2, 3, 'same'),            # ragged tiles, channel count that is no multiple of the tile
     (32, 64, 40, 40, 3, 3, 'same'),            # the 64-channel tile form
+    (96, 160, 26, 34, 2, 3, 'same'),           # three 32-channel K rows (the pre-split kernel walks them as six 16-channel chunks), two column blocks, ragged patches
+    (128, 48, 8, 16, 1, 3, 'same'),            # ONE 8 x 16 patch: every slab pixel outside it is padding
     (512, 512, 16, 16, 4, 3, 'same'),          # the split-K schedule
     (256, 128, 64, 64, 2, 3, 'transposed'),    # four parity classes, class-major order
     (32, 256, 33, 40, 3, 3, 'transposed'),
@@ -518,7 +520,8 @@ def f32_x6():
     (128, 128, 33, 33, 2, 3, 'down'),          # valid, stride 2
 ])
 def test_bf16x6_formulation_of_the_fp32_convolution(hip_lib, f32_x6, ci, co, h, w, n, k, mode):
-    """P3D_F32_BF16X6: plain fp32 activations and weights, every product as six bf16 MFMAs of three-piece splits made in registers.  Bar: the error
+    """P3D_F32_BF16X6: plain fp32 activations and weights, every product as six bf16 MFMAs of three-piece splits (made in registers, or — 3x3 'same' layers on
+    conv3x3_halo_x6p_kernel — once per work-group on the way into LDS).  Bar: the error
     class of the exact fp32 MFMA kernel (3e-6 of the output's maximum against an fp64 convolution of the same fp32 operands) and within 2x of
     what that kernel measures on the same inputs — fp32-accurate, unlike bf16x3 (1e-5)."""
     modconv = f32_x6
