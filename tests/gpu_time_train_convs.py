@@ -25,8 +25,8 @@ def conv(x, w, cfg, k, stride):
     return timed('conv', (str(x.dtype)[6:], n, ci, co, k, stride, int(cfg.transpose), h, wd, int(bool(cfg.split))), orig_conv, x, w, cfg, k, stride)
 
 
-def wgrad(gy, x, cfg, k, stride):
-    return timed('wgrad', (str(x.dtype)[6:], x.shape[0], x.shape[1], gy.shape[1], k, stride, int(cfg.transpose), x.shape[2], x.shape[3], 0), orig_wg, gy, x, cfg, k, stride)
+def wgrad(gy, x, cfg, k, stride, scale=None):
+    return timed('wgrad', (str(x.dtype)[6:], x.shape[0], x.shape[1], gy.shape[1], k, stride, int(cfg.transpose), x.shape[2], x.shape[3], 0), lambda *a: orig_wg(*a, scale=scale), gy, x, cfg, k, stride)
 
 
 class A: pass
@@ -51,7 +51,7 @@ os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 with open(os.path.join(ROOT, 'gpurun_out', 'train_conv_geometries.txt'), 'w') as f:
     f.write(f'# convolution calls of one six-phase iteration: {len(rec)} calls, {tot:.1f} ms (event-bracketed, includes weight re-layout / reduce launches of each call)\n')
     f.write('# kind dtype N Ci Co k stride transposed HxW bf16x3 | calls  total ms  avg us  GFLOP/call  TFLOP/s\n')
-    for key, (n, ms) in rows[:60]:
+    for key, (n, ms) in rows[:90]:
         kind, dt, nb, ci, co, k, stride, tr, h, w, sp = key
         pix = h * w if not (tr and stride == 2) else h * w          # MACs are counted on the input grid for the transposed op and on the output grid of a strided one
         if kind == 'conv' and stride == 2 and not tr:
