@@ -2183,8 +2183,10 @@ int p3d::conv2d_nhwc_run_io(const void* x, const void* w, void* y, int dtype, co
             a.y_split = y_split;
             // bf16x6: operands split once per work-group (conv3x3_halo_x6p_kernel) where the grid gives every CU its two work-groups — one alone has nobody to hide its
             // per-tap rendezvous behind (512 -> 512 at 32^2 x 4, 128 work-groups: 0.149 ms against 0.135 for the in-register kernel, profiles/round6_m_*).  P3D_X6_PRESPLIT=0: never
-            static const bool x6p_on = [] { const char* d = getenv("P3D_X6_PRESPLIT"); return !d || atoi(d) != 0; }();
-            const bool x6p = x6p_on && own_blocks >= 256;
+            // (2: always — read at every call, so that one test process can put small geometries through either kernel)
+            const char* const x6p_env = dtype == P3D_F32_BF16X6 ? getenv("P3D_X6_PRESPLIT") : nullptr;
+            const int x6p_mode = x6p_env ? atoi(x6p_env) : 1;
+            const bool x6p = x6p_mode == 2 || (x6p_mode == 1 && own_blocks >= 256);
             if (dtype == P3D_F16)             hipLaunchKernelGGL(conv3x3_halo_kernel<__half>, grid, dim3(256), 0, s, a);
             else if (dtype == P3D_F32_BF16X3 && x_split) hipLaunchKernelGGL((conv3x3_halo_kernel<float, true, true>), grid, dim3(256), 0, s, a);
             else if (dtype == P3D_F32_BF16X3) hipLaunchKernelGGL((conv3x3_halo_kernel<float, true>), grid, dim3(256), 0, s, a);

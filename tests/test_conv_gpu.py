@@ -2,6 +2,7 @@
 fp16-rounded operands.  fp16 storage, fp32 accumulation: tolerance 2e-3 relative-to-max on the conv output (one fp16
 rounding of the result), 1e-3 on the fp32 ToRGB output."""
 import numpy as np
+import os
 import pytest
 import torch
 import torch.nn.functional as F
@@ -498,13 +499,21 @@ def test_x2_layer_in_one_kernel_fp32_as_bf16x3(hip_lib, ci, co, h, w, n, noise, 
     assert e1 < tol and e0 < tol
 
 
-@pytest.fixture
-def f32_x6():
+@pytest.fixture(params=['auto', 'presplit'])
+def f32_x6(request):
+    """bf16x6 on; 'presplit' forces conv3x3_halo_x6p_kernel on every 3x3 'same' layer the halo-slab route takes (P3D_X6_PRESPLIT=2: the library reads the switch at every
+    call) — by itself it takes the launches of at least 256 work-groups, which few test geometries are."""
     from pix2pix3d_amd.torch_utils.ops import modconv
-    old = modconv.f32_x6
+    old, prev = modconv.f32_x6, os.environ.get('P3D_X6_PRESPLIT')
     modconv.f32_x6 = True
+    if request.param == 'presplit':
+        os.environ['P3D_X6_PRESPLIT'] = '2'
     yield modconv
     modconv.f32_x6 = old
+    if prev is None:
+        os.environ.pop('P3D_X6_PRESPLIT', None)
+    else:
+        os.environ['P3D_X6_PRESPLIT'] = prev
 
 
 @pytest.mark.parametrize('ci,co,h,w,n,k,mode', [

@@ -4,6 +4,8 @@ evaluated on the CPU in float64 on the same values (the fp16 cases on the fp16-r
 
 Tolerances (max |a - b| / max |b|): fp32 2e-5 (f32-input MFMA is an exact fma chain: summation order only), fp16 4e-3 (one
 rounding of the result to fp16; accumulation is fp32)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -170,8 +172,22 @@ X6_GEOM = [g for g in GEOM if g[0] in ('same3x3', 'same3x3_big', 'same1x1', 'dow
 ]
 
 
+@pytest.fixture(params=['auto', 'presplit'])
+def x6_kernel_choice(request):
+    """'presplit': conv3x3_halo_x6p_kernel on every 3x3 'same' forward / data-gradient launch of the halo-slab route, whatever its grid (P3D_X6_PRESPLIT=2, read by the
+    library at every call); 'auto': launches of at least 256 work-groups only."""
+    prev = os.environ.get('P3D_X6_PRESPLIT')
+    if request.param == 'presplit':
+        os.environ['P3D_X6_PRESPLIT'] = '2'
+    yield request.param
+    if prev is None:
+        os.environ.pop('P3D_X6_PRESPLIT', None)
+    else:
+        os.environ['P3D_X6_PRESPLIT'] = prev
+
+
 @pytest.mark.parametrize('geom', X6_GEOM, ids=lambda g: g[0])
-def test_forward_and_data_gradient_as_bf16x6(hip_lib, gradfix, geom):
+def test_forward_and_data_gradient_as_bf16x6(hip_lib, gradfix, x6_kernel_choice, geom):
     """modconv.f32_x6 (P3D_F32_BF16X6, the default): the fp32 forward and data-gradient convolutions — and the weight gradients of whole 128 x 128 tiles (both sides
     > 64 channels; modconv.wgrad_x6) — as six bf16 MFMAs per product of three-piece splits: the error class of the exact fp32 kernels (bar 4e-6 of the range
     against fp64, and within 2x of what the exact kernels measure on the same tensors)."""
