@@ -667,8 +667,9 @@ def main():
                      'roofline': roofline(exact_m, False),
                      'what': 'P3D_BF16X3=0 P3D_MLP_BF16X3=0 P3D_F32_BF16X6=0: every fp32 convolution and the decoder MLPs on the f32-input MFMA (exact fp32 products, the arithmetic class the reference '
                              'insists on, training_loop.py:278-280); super-resolution heads unchanged'}
-            # the same fp32-accurate leg with the backbone's products formed on the bf16 matrix pipe (P3D_F32_BF16X6: three-piece splits in
-            # registers, six MFMAs per product; plain fp32 tensors and weights — DESIGN 2.4c); the decoder stays on the f32-input MFMA
+            # the same fp32-accurate leg with the backbone's products formed on the bf16 matrix pipe (P3D_F32_BF16X6: three-piece splits, six MFMAs
+            # per product; plain fp32 tensors and weights — DESIGN 2.4c) and, since round 6, layer 1 of the decoder MLPs the same way (P3D_MLP_L1X6,
+            # render_forward_kernel<.., L1X6>: DESIGN 2.1); the decoder's layer 2 stays on the f32-input MFMA
             _mc.f32_x6 = True
             try:
                 torch.cuda.empty_cache()
@@ -676,8 +677,9 @@ def main():
                 exact['backbone_as_bf16x6'] = {'value': round(args.batch * world * args.steps / x6_m['elapsed'], 3), 'unit': 'img/s',
                                                'ms_per_step': round(x6_m['elapsed'] / args.steps * 1e3, 3), 'launch': x6_m['launch'],
                                                'stage_ms': {k: round(v, 3) for k, v in x6_m['stage_ms'].items()}, 'mfma_conv': x6_m['mfma_conv'],
-                                               'what': 'P3D_BF16X3=0 P3D_MLP_BF16X3=0 alone (P3D_F32_BF16X6 at its default, 1): the fp32 convolutions as six bf16 MFMAs per product (hi/mid/lo pieces, error class of the exact kernel: '
-                                                       'tests/test_conv_gpu.py::test_bf16x6_formulation_of_the_fp32_convolution)'}
+                                               'what': 'P3D_BF16X3=0 P3D_MLP_BF16X3=0 alone (P3D_F32_BF16X6 and P3D_MLP_L1X6 at their default, 1): the fp32 convolutions and layer 1 of the decoder MLPs as six bf16 MFMAs per '
+                                                       'product (hi/mid/lo pieces, error class of the exact kernels: tests/test_conv_gpu.py::test_bf16x6_formulation_of_the_fp32_convolution, '
+                                                       'tests/test_render_gpu.py::test_layer1_as_bf16x6_is_fp32_accurate); decoder layer 2 on the f32-input MFMA'}
             except Exception as e:                                   # noqa: BLE001
                 exact['backbone_as_bf16x6'] = {'error': f'{type(e).__name__}: {e}'[:300]}
             finally:

@@ -145,7 +145,10 @@ typedef struct p3d_render_desc {
                                              lets the kernel assign 16 x 16 pixel blocks to workgroups for L2 locality  */
     int32_t mlp_bf16x3;                   /* p3d_render_forward only, != 0: the decoder stream comes from p3d_pack_decoder_bf16x3 and the MLPs run
                                              as three bf16 MFMAs per fp32 product (hi/lo splits, fp32 accumulation: ~5e-6 of the hidden range per
-                                             layer) instead of f32-input MFMAs at 1/16 of that rate.  0 = exact fp32 (p3d_pack_decoder).      */
+                                             layer) instead of f32-input MFMAs at 1/16 of that rate.  0 = exact fp32 (p3d_pack_decoder).
+                                             2: the stream comes from p3d_pack_decoder_l1x6 and LAYER 1 of every net runs as six bf16 MFMAs
+                                             per product of three-piece splits (fp32-accurate, csrc/bf16_split.h); layer 2 stays on the
+                                             f32-input MFMA (its third weight image does not fit the LDS).                                   */
 } p3d_render_desc;
 
 int p3d_render_decoder_floats(void);     /* size of the packed decoder stream, in floats        */
@@ -164,6 +167,11 @@ int p3d_pack_decoder(const float* w1_a, const float* b1_a, const float* w2_a, co
 int p3d_pack_decoder_bf16x3(const float* w1_a, const float* b1_a, const float* w2_a, const float* b2_a,
                             const float* w1_b, const float* b1_b, const float* w2_b, const float* b2_b,
                             int32_t n_nets, float lr_mul, float* packed, p3d_stream_t stream);
+
+/* the same parameters with layer 1 in the bf16 operand order and layer 2 in the f32-MFMA order (p3d_render_desc.mlp_bf16x3 == 2); same size, fp32 values */
+int p3d_pack_decoder_l1x6(const float* w1_a, const float* b1_a, const float* w2_a, const float* b2_a,
+                          const float* w1_b, const float* b1_b, const float* w2_b, const float* b2_b,
+                          int32_t n_nets, float lr_mul, float* packed, p3d_stream_t stream);
 
 /* ray_o, ray_d [N*M][3]; u_coarse [N*M][S_c] and u_fine [N*M][S_f] uniforms in [0,1);
  * t_start/t_end optional per-ray limits [N*M] ('auto' ray range), null otherwise.

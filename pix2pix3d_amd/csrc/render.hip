@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) pack_decoder_kernel(PackArgs p, float* ou
             const int q4 = e / 256, lane = (e % 256) / 4, q = q4 * 4 + (e & 3);
             const int row = lane & 31, h = lane >> 5, t = q >> 4, kk = q & 15;
             v = p.w1[0][(32 * t + row) * p.w1_in[0] + 32 + 16 * h + kk] * p.wg1[0];
-        } else if (i < 2 * kNetStride && p.bf16_order) {
+        } else if (i < 2 * kNetStride && (p.bf16_order == 1 || (p.bf16_order == 2 && (i % kNetStride) < kNetStride / 2))) {   // (2: layer 1 only — p3d_pack_decoder_l1x6)
             const int n = i / kNetStride, f = i % kNetStride;
             const int block = f / 512, lane = (f % 512) / 8, e = f & 7;
             const int row = lane & 31, kb = lane >> 5;
@@ -258,6 +258,13 @@ extern "C" int p3d_pack_decoder(const float* w1_a, const float* b1_a, const floa
     return pack_decoder_impl(w1_a, b1_a, w2_a, b2_a, w1_b, b1_b, w2_b, b2_b, n_nets, lr_mul, packed, 0, stream);
 }
 
+extern "C" int p3d_pack_decoder_l1x6(const float* w1_a, const float* b1_a, const float* w2_a, const float* b2_a,
+                                     const float* w1_b, const float* b1_b, const float* w2_b, const float* b2_b,
+                                     int32_t n_nets, float lr_mul, float* packed, p3d_stream_t stream)
+{
+    return pack_decoder_impl(w1_a, b1_a, w2_a, b2_a, w1_b, b1_b, w2_b, b2_b, n_nets, lr_mul, packed, 2, stream);
+}
+
 extern "C" int p3d_pack_decoder_bf16x3(const float* w1_a, const float* b1_a, const float* w2_a, const float* b2_a,
                                        const float* w1_b, const float* b1_b, const float* w2_b, const float* b2_b,
                                        int32_t n_nets, float lr_mul, float* packed, p3d_stream_t stream)
@@ -333,6 +340,17 @@ static int render_forward_impl(const float* planes_cl, const float* planes_sem_c
         static std::atomic<uint64_t> onced_devs{0}; const hipError_t onced = reserve_lds_once((const void*)render_forward_kernel<2, false, true>, (int)lds_bytes, onced_devs);
         if (onced != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_forward_dual: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(onced));
         hipLaunchKernelGGL((render_forward_kernel<2, false, true>), dim3(blocks), dim3(wpb * 64), lds_bytes, s, a);
+    } else if (d->mlp_bf16x3 == 2) {                        // layer 1 as bf16x6 (stream: p3d_pack_decoder_l1x6)
+        const size_t lds6 = lds_bytes + (size_t)(kDecoderFloatsL1X6 - kDecoderFloats) * sizeof(float);
+        if (d->n_nets == 1) {
+            static std::atomic<uint64_t> oncex1_devs{0}; const hipError_t e1 = reserve_lds_once((const void*)render_forward_kernel<1, false, false, false, true>, (int)lds6, oncex1_devs);
+            if (e1 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_forward: cannot reserve %zu B of LDS: %s", lds6, hipGetErrorString(e1));
+            hipLaunchKernelGGL((render_forward_kernel<1, false, false, false, true>), dim3(blocks), dim3(wpb * 64), lds6, s, a);
+        } else {
+            static std::atomic<uint64_t> oncex2_devs{0}; const hipError_t e2 = reserve_lds_once((const void*)render_forward_kernel<2, false, false, false, true>, (int)lds6, oncex2_devs);
+            if (e2 != hipSuccess) return fail(P3D_ERR_LAUNCH, "render_forward: cannot reserve %zu B of LDS: %s", lds6, hipGetErrorString(e2));
+            hipLaunchKernelGGL((render_forward_kernel<2, false, false, false, true>), dim3(blocks), dim3(wpb * 64), lds6, s, a);
+        }
     } else if (d->mlp_bf16x3) {
         if (d->n_nets == 1) {
             static std::atomic<uint64_t> onceb1_devs{0}; const hipError_t e1 = reserve_lds_once((const void*)render_forward_kernel<1, false, false, true>, (int)lds_bytes, onceb1_devs);

@@ -8,6 +8,7 @@ namespace p3d {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4  __attribute__((ext_vector_type(4)));
+#include "bf16_split.h"
 
 // ---- decoder stream layout (floats); identical in the packed global buffer and in LDS ------------
 constexpr int kNetStride = 4096;                 // per net: 64 MFMA steps x 64 lanes
@@ -20,6 +21,10 @@ constexpr int kDecoderFloats = 8464;             // padded to 16 floats
 // semantic features); the weights of inputs 32..63 follow the common stream as one more 32-step block in the same per-lane order.
 constexpr int OFF_W1X  = kDecoderFloats;
 constexpr int kDecoderFloatsDual = kDecoderFloats + 2048;
+// L1X6 (render_forward_kernel<.., L1X6>, p3d_pack_decoder_l1x6): layer 1 of every net as bf16x6 (csrc/bf16_split.h) — its weights sit in LDS as three bf16 images
+// [block 4][lane 64][8] of 4 KB each: hi and mid in the 8 KB the net's fp32 layer-1 stream occupied, lo (both nets) in 8 KB behind the common stream.
+constexpr int OFF_L1LO = kDecoderFloats;
+constexpr int kDecoderFloatsL1X6 = kDecoderFloats + 2048;
 constexpr int kPitch = 33;                       // LDS pitch of the per-wave [sample][ray] tile
 constexpr int kMaxS = 64;                        // max coarse / fine samples per ray
 constexpr int kWaveTile = kMaxS * kPitch + 128;  // + two 64-float scratch rows (unused since the importance sampler went to registers; kept: the tile bases are 16-byte aligned with it)
@@ -484,6 +489,49 @@ __device__ __forceinline__ void mlp_layer2_bf3(const float* lds, int n, int lane
     }
 }
 
+// ---- layer 1 as bf16x6 (fp32-accurate; training forward and the exact legs) ---------------------------------------------------------------
+// The exact decoder's 128 f32-input MFMAs per sample are half of the exact launch (they do not hide vector work).  Layer 1 reads the gathered features:
+// split ONCE per sample into three bf16 pieces (72 vector instructions, shared by both nets), against weights split once per work-group by the block prologue, it is
+// 24 bf16 MFMAs of half the duration where the f32 form issues 32 — six terms per product (hh, hm, mh, hl, lh, mm), the error of one fp32 multiply-add.  Layer 2
+// stays on the f32-input MFMA: its third weight image does not fit the 160 KB of LDS next to eight waves' tiles (layer 1's fits with 960 bytes to spare).
+// Fragment order as in mlp_layer1_bf3: tile t, k-step s: k (h, e) <-> input channel 16 h + 8 s + e.
+template <bool LOG2>
+__device__ __forceinline__ void mlp_layer1_x6(const float* lds, int n, int lane, int h, const bf8 (&fh)[2], const bf8 (&fm)[2], const bf8 (&fl)[2], f32x16& h0, f32x16& h1)
+{
+    const f32x4* b1 = (const f32x4*)(lds + OFF_B1 + (n * 2 + h) * 32);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v0 = b1[q], v1 = b1[4 + q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h0[q * 4 + e] = v0[e]; h1[q * 4 + e] = v1[e]; }
+    }
+    const char* wb = (const char*)lds + lane * 16 + n * (kNetStride * 4);              // hi at + block * 1024, mid 4 KB further
+    const char* wl = (const char*)(lds + OFF_L1LO) + lane * 16 + n * 4096;             // lo
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const bf8 a0h = *(const bf8*)(wb + (0 * 2 + s) * 1024), a0m = *(const bf8*)(wb + 4096 + (0 * 2 + s) * 1024), a0l = *(const bf8*)(wl + (0 * 2 + s) * 1024);
+        const bf8 a1h = *(const bf8*)(wb + (1 * 2 + s) * 1024), a1m = *(const bf8*)(wb + 4096 + (1 * 2 + s) * 1024), a1l = *(const bf8*)(wl + (1 * 2 + s) * 1024);
+#pragma unroll
+        for (int term = 0; term < 6; ++term) {                                          // the two tiles alternate: consecutive MFMAs on different accumulators
+            h0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P3D_X6_A(term, a0h, a0m, a0l), P3D_X6_B(term, fh[s], fm[s], fl[s]), h0, 0, 0, 0);
+            h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P3D_X6_A(term, a1h, a1m, a1l), P3D_X6_B(term, fh[s], fm[s], fl[s]), h1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        h0[r] = LOG2 ? softplus20_log2(h0[r]) : softplus20(h0[r]);
+        h1[r] = LOG2 ? softplus20_log2(h1[r]) : softplus20(h1[r]);
+    }
+}
+__device__ __forceinline__ void split3_feat(const float (&feat)[16], bf8 (&fh)[2], bf8 (&fm)[2], bf8 (&fl)[2])
+{
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const f32x4 a0 = {feat[8 * s], feat[8 * s + 1], feat[8 * s + 2], feat[8 * s + 3]}, a1 = {feat[8 * s + 4], feat[8 * s + 5], feat[8 * s + 6], feat[8 * s + 7]};
+        split3_bf16x8(a0, a1, fh[s], fm[s], fl[s]);
+    }
+}
+
 // ---- importance sampling, wave-cooperative (renderer.py:194-253), NR rays at a time ------------------------------
 // Per ray: lane i holds coarse weight w_i (i < Sc-1) and coarse depth z_i (i < Sc); lane j returns fine depth j (unsorted), +inf for j >= Sf.
 // Everything stays in registers: lane k keeps pdf entry k, bin midpoint k and (after the scan) cdf entry k; the two sequential fp32 sums
@@ -572,13 +620,14 @@ __device__ __forceinline__ void bitonic_sort64(float (&v)[NR], int lane)
 // net reads cat(texture features, semantic features) through a 64-input first layer (renderer.py:324-333); everything else —
 // sampling, merge, compositing over cat(colour, label) — is the same sweep.
 constexpr int kWavesPerBlockDual = 4;            // the DUAL kernel keeps two feature vectors live: one wave per SIMD (512 registers) instead of spilling
-template <int NNETS, bool TAPE, bool DUAL = false, bool BF3 = false>
+template <int NNETS, bool TAPE, bool DUAL = false, bool BF3 = false, bool L1X6 = false>
 __global__ void __launch_bounds__((DUAL ? kWavesPerBlockDual : kWavesPerBlock) * 64, DUAL ? 1 : 2)
 render_forward_kernel(RenderArgs a)
 {
     static_assert(!DUAL || (NNETS == 2 && !TAPE), "the two-plane-set variant is the two-net inference kernel");
     static_assert(!BF3 || (!TAPE && !DUAL), "the bf16x3 decoder is the one-plane-set inference kernel");
-    constexpr int kDecFloats = DUAL ? kDecoderFloatsDual : kDecoderFloats;
+    static_assert(!L1X6 || (!BF3 && !DUAL && !TAPE), "layer 1 as bf16x6 is a form of the exact one-plane-set forward kernel");
+    constexpr int kDecFloats = DUAL ? kDecoderFloatsDual : (L1X6 ? kDecoderFloatsL1X6 : kDecoderFloats);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -590,7 +639,8 @@ render_forward_kernel(RenderArgs a)
     {   // decoder stream -> LDS (16 B per lane)
         const f32x4* src = (const f32x4*)a.decoder;
         f32x4* dst = (f32x4*)lds;
-        for (int i = tid; i < kDecFloats / 4; i += blockDim.x) {
+        constexpr int kSrcFloats = L1X6 ? kDecoderFloats : kDecFloats;         // (the lo images of L1X6 are made here, not streamed)
+        for (int i = tid; i < kSrcFloats / 4; i += blockDim.x) {
             f32x4 v = src[i];
             if (LOG2) {
                 const int f = i * 4;
@@ -605,6 +655,18 @@ render_forward_kernel(RenderArgs a)
                 __bf16* lo = hi + kNetStride;                                           // lo image: 8 KB further
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { const __bf16 hx = (__bf16)v[c]; hi[c] = hx; lo[c] = (__bf16)(v[c] - (float)hx); }
+            } else if (L1X6 && i * 4 < 2 * kNetStride && ((i * 4) & (kNetStride - 1)) < kNetStride / 2) {      // layer-1 weights ([net][block 4][lane][8] floats): three bf16 images
+                const int f = i * 4, n = f / kNetStride, e = f - n * kNetStride;
+                __bf16* hi = (__bf16*)(lds + n * kNetStride) + e;                       // [block][lane][8], 2-byte elements: 4 KB
+                __bf16* mid = hi + kNetStride / 2;                                      // 4 KB further (still inside the net's layer-1 half)
+                __bf16* lo = (__bf16*)(lds + OFF_L1LO + n * 1024) + e;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const __bf16 hx = (__bf16)v[c];
+                    const float r1 = v[c] - (float)hx;
+                    const __bf16 mx = (__bf16)r1;
+                    hi[c] = hx; mid[c] = mx; lo[c] = (__bf16)(r1 - (float)mx);
+                }
             } else
             dst[i] = v;
         }
@@ -671,6 +733,10 @@ render_forward_kernel(RenderArgs a)
                 bf8 fh[2], fl[2];
                 split8(feat, fh[0], fl[0]); split8(feat + 8, fh[1], fl[1]);
                 mlp_layer1_bf3(lds, SN, lane, h, fh, fl, h0, h1);
+            } else if constexpr (L1X6) {
+                bf8 fh[2], fm[2], fl[2];
+                split3_feat(feat, fh, fm, fl);
+                mlp_layer1_x6<LOG2>(lds, SN, lane, h, fh, fm, fl, h0, h1);
             } else
             mlp_layer1<LOG2>(lds, SN, lane, h, feat, h0, h1);
             const float sigma = mlp_sigma(lds, h, h0, h1);
@@ -748,12 +814,15 @@ render_forward_kernel(RenderArgs a)
         float sigma = 0.f, hw = 0.f;
         float t_alpha = 0.f, t_T = 0.f, t_sm = 0.f, t_A = 0.f;               // TAPE: record of interval k-1
         bf8 fh[2], fl[2];                                                    // BF3: the sample's features, split once for both nets
+        [[maybe_unused]] bf8 fm[2];                                          // L1X6: three pieces
         if constexpr (BF3) { split8(feat, fh[0], fl[0]); split8(feat + 8, fh[1], fl[1]); }
+        if constexpr (L1X6) split3_feat(feat, fh, fm, fl);
 #pragma unroll
         for (int idx = 0; idx < NNETS; ++idx) {
             const int n = (idx == 0) ? SN : idx - 1;
             f32x16 h0, h1, o;
             if constexpr (BF3)  mlp_layer1_bf3(lds, n, lane, h, fh, fl, h0, h1);
+            else if constexpr (L1X6) mlp_layer1_x6<LOG2>(lds, n, lane, h, fh, fm, fl, h0, h1);
             else if (DUAL && n == 0) mlp_layer1<LOG2, true>(lds, n, lane, h, feat_tex, h0, h1, feat);     // colour net: cat(texture, semantic)
             else                mlp_layer1<LOG2>(lds, n, lane, h, feat, h0, h1);
             if (idx == 0) {

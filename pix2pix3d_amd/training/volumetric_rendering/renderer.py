@@ -35,6 +35,7 @@ def _warn_tensor_op_route(who, reason):
 fused_training = True          # graphs that need gradients: fused forward + recompute-in-backward (see _FusedRenderFn)
 fused_backward = True          # ... with the backward on the device kernels of csrc/render_bwd.hip (False: replay the tensor-op renderer)
 mlp_bf16x3 = os.environ.get('P3D_MLP_BF16X3', '1') != '0'      # inference: the decoder MLPs as three bf16 MFMAs per fp32 product (csrc/render_device.h)
+mlp_l1x6 = os.environ.get('P3D_MLP_L1X6', '1') != '0'          # exact forward passes (training, bf16x3 off), with modconv.f32_x6: layer 1 of the decoder MLPs as bf16x6 (fp32-accurate)
 
 
 class _RenderDesc(ctypes.Structure):          # p3d_render_desc (include/p3d_hip.h)
@@ -51,6 +52,7 @@ _lib.register('p3d_render_decoder_floats', ctypes.c_int, [])
 _lib.register('p3d_planes_to_channels_last', ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp])
 _lib.register('p3d_pack_decoder', ctypes.c_int, [_vp] * 8 + [_i32, _f32, _vp, _vp])
 _lib.register('p3d_pack_decoder_bf16x3', ctypes.c_int, [_vp] * 8 + [_i32, _f32, _vp, _vp])
+_lib.register('p3d_pack_decoder_l1x6', ctypes.c_int, [_vp] * 8 + [_i32, _f32, _vp, _vp])
 _lib.register('p3d_render_bwd_decoder_floats', ctypes.c_int, [])
 _lib.register('p3d_render_grad_decoder_floats', ctypes.c_int, [])
 _lib.register('p3d_pack_decoder_bwd', ctypes.c_int, [_vp] * 4 + [ctypes.c_int32, ctypes.c_float, _vp, _vp])
@@ -139,7 +141,7 @@ def _f32c(t):
 
 
 def pack_decoder(decoder_info, device, bf16x3):
-    """The decoder's FullyConnectedLayer parameters in the kernels' LDS image (p3d_pack_decoder / _bf16x3), on the current stream."""
+    """The decoder's FullyConnectedLayer parameters in the kernels' LDS image (p3d_pack_decoder / _bf16x3 / _l1x6 for ``bf16x3`` = 0 / 1 / 2), on the current stream."""
     nets, lr_mul, _ = decoder_info
     lib = _lib.lib()
     packed = torch.empty([lib.p3d_render_decoder_floats()], dtype=torch.float32, device=device)
@@ -147,7 +149,7 @@ def pack_decoder(decoder_info, device, bf16x3):
     for fc1, fc2 in nets:
         ws += [_f32c(fc1.weight), _f32c(fc1.bias), _f32c(fc2.weight), _f32c(fc2.bias)]
     ptrs = [_lib.ptr(t) for t in ws] + [None] * (8 - len(ws))
-    pack = lib.p3d_pack_decoder_bf16x3 if bf16x3 else lib.p3d_pack_decoder
+    pack = (lib.p3d_pack_decoder, lib.p3d_pack_decoder_bf16x3, lib.p3d_pack_decoder_l1x6)[int(bf16x3)]
     _lib.check(pack(*ptrs, len(nets), lr_mul, _lib.ptr(packed), _lib.stream_of(packed)), 'pack_decoder')
     return packed, ws
 
@@ -157,7 +159,7 @@ class _FusedContext:
 
     def __init__(self, planes, decoder_info, bf16x3=False, packed=None):
         nets, lr_mul, sem_sigmoid = decoder_info
-        self.bf16x3 = bool(bf16x3)
+        self.bf16x3 = int(bf16x3)                               # p3d_render_desc.mlp_bf16x3: 0 exact, 1 bf16x3, 2 layer 1 as bf16x6
         lib = _lib.lib()
         n, k, c, h, w = planes.shape
         assert k == 3 and c == 32
@@ -757,7 +759,9 @@ def fused_render(planes, decoder, ray_origins, ray_directions, opt, u_coarse, u_
     n, m, _ = ray_origins.shape
     sc, sf = int(opt['depth_resolution']), int(opt['depth_resolution_importance'])
     dev = planes.device
-    ctx = _FusedContext(planes, info, bf16x3=mlp_bf16x3 and not exact_fp32, packed=packed)      # (the training forward stays exact fp32: its backward recomputes in fp32)
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    mode = 1 if (mlp_bf16x3 and not exact_fp32) else (2 if (mlp_l1x6 and modconv.f32_x6) else 0)      # (the training forward stays fp32-accurate: its backward recomputes in fp32)
+    ctx = _FusedContext(planes, info, bf16x3=mode, packed=packed)
     auto = t_start is not None
     t0 = _f32c(t_start).reshape(-1) if auto else None
     t1 = _f32c(t_end).reshape(-1) if auto else None

@@ -51,6 +51,40 @@ def test_fused_render_matches_reference_and_oracle(hip_lib, name):
 
 
 @pytest.mark.parametrize('name', CASES)
+def test_layer1_as_bf16x6_is_fp32_accurate(hip_lib, name):
+    """The exact forward (training; bf16x3 off) with layer 1 of the decoder MLPs as bf16x6 (render_forward_kernel<.., L1X6>, p3d_pack_decoder_l1x6: six bf16 MFMAs per
+    product of three-piece splits, weights split once per work-group) against the same launch with every product on the f32-input MFMA: both hold the oracle's bound, they
+    differ from each other by rounding only, and they are not the same bits (the other arithmetic did run)."""
+    rmod = _renderer()
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    g, opts, dec_arrays = load_case(name)
+    dec = make_decoder(g, 'cuda')
+    dev = 'cuda'
+    planes = torch.tensor(g['planes'], device=dev)
+    o, d = torch.tensor(g['ray_o'], device=dev), torch.tensor(g['ray_d'], device=dev)
+    t0 = t1 = None
+    if opts['ray_start'] == 'auto':
+        t0, t1 = rmod.ImportanceRenderer()._ray_limits(o, d, opts)
+    kw = dict(t_start=t0.cpu().numpy(), t_end=t1.cpu().numpy()) if t0 is not None else {}
+    fo, do, wo = R.render(g['planes'], dec_arrays, g['ray_o'], g['ray_d'], opts, g['u_coarse'], g['u_fine'], **kw)
+    outs = {}
+    prev = (rmod.mlp_l1x6, modconv.f32_x6)
+    try:
+        modconv.f32_x6 = True
+        for l1x6 in (True, False):
+            rmod.mlp_l1x6 = l1x6
+            out = rmod.fused_render(planes, dec, o, d, opts, torch.tensor(g['u_coarse'], device=dev), torch.tensor(g['u_fine'], device=dev), t0, t1, exact_fp32=True)
+            feat, depth, wsum = [t.cpu().numpy() for t in out[:3]]
+            assert rel_err(feat, fo) < 2e-4 and np.abs(depth[..., 0] - do).max() < 5e-5 and rel_err(wsum[..., 0], wo) < 2e-4, l1x6
+            outs[l1x6] = (feat, depth, wsum)
+    finally:
+        rmod.mlp_l1x6, modconv.f32_x6 = prev
+    e = rel_err(outs[True][0], outs[False][0])
+    print(name, 'layer 1 as bf16x6 vs f32-input MFMA', e, 'vs oracle', rel_err(outs[True][0], fo), rel_err(outs[False][0], fo))
+    assert e < 2e-4 and not np.array_equal(outs[True][0], outs[False][0])
+
+
+@pytest.mark.parametrize('name', CASES)
 def test_module_level_dispatch_uses_the_fused_kernel(hip_lib, name):
     """ImportanceRenderer.forward / run_model on device tensors: fused path, reference RNG order."""
     from pix2pix3d_amd import _lib
