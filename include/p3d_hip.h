@@ -346,6 +346,19 @@ int p3d_conv3x3_torgb_f16(const void* x, const void* w, void* y, const float* bi
                           float* rgb_out, int32_t rgb_co, float rgb_clamp, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co,
                           int64_t w_img_stride, int32_t act, float gain, float clamp, p3d_stream_t stream);
 
+/* The LAST 3x3 layer of the tri-plane backbone and its wide ToRGB + skip-image sum in one launch (bf16x3 on split activations, Co = 128: SynthesisBlock.conv1 +
+ * .torgb + the upsampled predecessor image, training/networks_stylegan2.py:449-459, for a block whose x the network drops — SynthesisNetwork.forward returns img only,
+ * :511-528).  x_split / w_split as p3d_conv2d_nhwc_bf16x3_io takes them (x_split = 1); the layer's activations y = clamp(act(conv3x3 + noise + bias) * gain) are formed in
+ * registers, split into (hi, lo) as their stored form would have been, and contracted with rgb_wmod_split ([N][rgb_co][1][Co] split K rows: p3d_modulate_weights,
+ * P3D_F32_BF16X3, no demodulation) as p3d_torgb_wide_split does:
+ *   img[n][pixel][o] = clamp(sum_c y[n][pixel][c] * rgb_w[n][o][c] + rgb_bias[o], rgb_clamp) + upsample2d(prev, f)[n][pixel][o]       (img, prev fp32 NHWC)
+ * y itself is never written.  prev (and f4x4_host: sixteen HOST floats, the 4 x 4 filter) may be NULL: no skip term.  rgb_co in {32, 64, 96}; Co != 128, Ci % 32 != 0,
+ * images under 32 x 32 or odd-sized, or fewer than 192 patches of 16 x 16 pixels: P3D_ERR_UNSUPPORTED (the caller keeps the two-launch form).                          */
+int p3d_conv3x3_torgb_split(const void* x_split, const void* w_split, const float* bias, const float* noise, const float* noise_strength, const void* zeros128,
+                            const void* rgb_wmod_split, const float* rgb_bias, float* img_nhwc, const float* prev_nhwc, const float* f4x4_host,
+                            int32_t rgb_co, float rgb_clamp, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
+                            int32_t act, float gain, float clamp, p3d_stream_t stream);
+
 /* p3d_conv2d_nhwc_ws with a per-(image, output channel) factor on the accumulator, ahead of noise / bias / activation: out_scale fp32
  * [N][Co].  With p3d_demod_coefs and p3d_bcast_fma this is the SHARED-weight form of the modulated convolution
  * (training/networks_stylegan2.py:70-79: x * styles -> convolution with the unmodulated weights -> * demodulation coefficients), which for

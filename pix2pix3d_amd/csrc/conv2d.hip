@@ -1309,7 +1309,21 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
 // are then exactly the hi and the lo fragments: same slab (18 x 20 rows), same three-slot weight ring (8 KB tiles), same swizzle, same
 // fragment addresses, 70 KB, two blocks per CU.  What differs: the DMA source of a row is two 32-byte runs of the 128-byte source row, a tap is
 // 24 MFMAs (hi x hi, hi x lo, lo x hi) on 12 fragment reads, and the epilogue stores from registers.  Weights: p3d_modulate_weights(P3D_F32_BF16X3).
-__global__ void __launch_bounds__(256, 2) conv3x3_r2_bf16x3_kernel(ConvArgs a)
+//
+// TR (p3d_conv3x3_torgb_split: the LAST block of the tri-plane backbone, Co = 128, whose activations only its wide ToRGB reads): conv3x3_h2_f16_kernel<TR>'s idea on
+// the bf16x3 pipeline.  The MFMA operands are swapped (weights as A, pixels as B), so an accumulator tile is y^T and a lane ends up with 16 channels of ONE pixel per
+// 32-channel group; after noise / bias / activation / clamp those registers, split into (hi, lo) exactly as the stored form would have been, ARE the B fragments of the
+// ToRGB contraction over channels (the k <-> channel permutation goes into the ToRGB weights' A fragments, gathered once per work-group into LDS in fragment order).
+// The ToRGB result has the pixel in the lane again: bias, clamp, the x2-upsampled predecessor image (torgb_wide_split_kernel's taps in its order) and 16-byte stores of
+// the [N][H][W][rgb_co] image follow from registers.  The layer's 134 MB of split activations (256^2 x 128 channels x batch 4) are neither written nor read back, and
+// the ToRGB launch (92 us) is gone; the price is 144 more MFMAs per wave behind the K loop's 1 728.
+struct WideRgbTail {
+    const float* prev;     // [N][H/2][W/2][rgb_co] fp32 or null: the skip image of the block below, upsampled x2 here
+    float fr[4][4];        // the upsampling filter as torgb_wide_split_kernel takes it (fr[ky][kx] = f[3 - ky][3 - kx] * 4)
+};
+
+template <bool TR>
+__global__ void __launch_bounds__(256, 2) conv3x3_r2_bf16x3_kernel(ConvArgs a, WideRgbTail tail)
 {
     // ONE __shared__ object on purpose: with two, hipcc drains vmcnt to 0 before the first ds_read of every step and the counted
     // waits below are moot (cdna_hip_programming.md, 'three .s-level traps' (a))
@@ -1426,7 +1440,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_r2_bf16x3_kernel(ConvArgs a)
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, hiA[cur][i]), __builtin_bit_cast(bf8, hiB[cur][j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, hiB[cur][j]), __builtin_bit_cast(bf8, hiA[cur][i]), acc[i][j], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, hiA[cur][i]), __builtin_bit_cast(bf8, hiB[cur][j]), acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- sub-step b
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1447,17 +1462,169 @@ __global__ void __launch_bounds__(256, 2) conv3x3_r2_bf16x3_kernel(ConvArgs a)
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, hiA[cur][i]), __builtin_bit_cast(bf8, loB[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, loB[j]), __builtin_bit_cast(bf8, hiA[cur][i]), acc[i][j], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, hiA[cur][i]), __builtin_bit_cast(bf8, loB[j]), acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, loA[i]), __builtin_bit_cast(bf8, hiB[cur][j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, hiB[cur][j]), __builtin_bit_cast(bf8, loA[i]), acc[i][j], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, loA[i]), __builtin_bit_cast(bf8, hiB[cur][j]), acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
     __syncthreads();                                                            // every wave is done with the slabs and tiles
+
+    if constexpr (TR) {
+        // acc[i][j][r] = y^T: channel 32 j + (r & 3) + 8 (r >> 2) + 4 fk of patch pixel p = wave * 64 + i * 32 + frow.  (host: Co == 128, one channel block, rgb_co in {32, 64, 96})
+        // Nothing in the loops below waits on global memory: noise, both biases and the ToRGB weights are staged into LDS once, the predecessor image's 10 x 10 pixel patch
+        // arrives by LDS-DMA one 32-channel block ahead of its use (out-of-image taps read the zeros page: fma(0, w, up) as torgb_wide_split_kernel has it).  The first form
+        // of this epilogue loaded biases and taps where it used them, each under its null / bounds branch and therefore waited for inside it: 29 dependent memory round trips
+        // per work-group, +43 us per launch.
+        typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+        constexpr int TR_BS = 1024, TR_RBS = 1536, TR_WL = 2048, TR_PV = TR_WL + 3 * 8 * 2 * 64 * 16, TR_PVBUF = 13 * 1024;       // 51 200; two predecessor buffers of 13 DMA pieces
+        static_assert(TR_PV + 2 * TR_PVBUF <= H2_LDS, "the TR epilogue's LDS image");
+        float* const nz = (float*)lds_b;                                        // [256] the tile's noise * strength
+        float* const bs = (float*)(lds_b + TR_BS);                              // [128] the layer's bias
+        float* const rbs = (float*)(lds_b + TR_RBS);                            // [96]  the ToRGB's bias
+        f32x4* const wl = (f32x4*)(lds_b + TR_WL);                              // ToRGB weights in fragment order: [((ot * 8 + sidx) * 2 + hl) * 64 + lane], 48 KB at rgb_co = 96
+        const int not_ = a.rgb_co >> 5;
+        const int PH2 = a.H >> 1, PW2 = a.W >> 1;
+        const bool have_prev = tail.prev != nullptr;
+        const float* const pn = have_prev ? tail.prev + (int64_t)n * PH2 * PW2 * a.rgb_co : nullptr;
+        const int py0 = (oy0 >> 1) - 1, px0 = (ox0 >> 1) - 1;                   // the patch's taps: predecessor rows py0 .. py0 + 9, columns px0 .. px0 + 9
+        auto stage_prev = [&](int ot, int buf) {                                // 100 pixels x 128 bytes: slot (pixel, 16-byte chunk) = 8 pixel + chunk
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int piece = wave + 4 * g;
+                if (piece < 13) {
+                    const int slot = piece * 64 + lane, pp = slot >> 3, py = pp / 10, pxx = pp - py * 10;
+                    const int iy = py0 + py, ix = px0 + pxx;
+                    const bool ok = (pp < 100) & (iy >= 0) & (iy < PH2) & (ix >= 0) & (ix < PW2);
+                    const float* src = ok ? pn + ((int64_t)iy * PW2 + ix) * a.rgb_co + ot * 32 + (slot & 7) * 4 : (const float*)a.zeros;
+                    __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(lds_b + TR_PV + buf * TR_PVBUF + piece * 1024), 16, 0, 0);
+                }
+            }
+        };
+        if (have_prev) stage_prev(0, 0);
+        {
+            const float ns = a.noise ? a.noise_strength[0] : 0.f;
+            const int oy = oy0 + (tid >> 4), ox = ox0 + (tid & 15);
+            nz[tid] = (a.noise && oy < a.H && ox < a.W) ? a.noise[(int64_t)oy * a.W + ox] * ns : 0.f;
+            if (tid < 128) bs[tid] = a.bias ? a.bias[tid] : 0.f;
+            else if (tid < 128 + 96) rbs[tid - 128] = (a.rgb_bias && tid - 128 < a.rgb_co) ? a.rgb_bias[tid - 128] : 0.f;
+            // A fragment of k-step sidx = (j, half), piece hl, lane (row o = 32 ot + frow, k group fk): element e = w[o][32 j + 16 half + (e & 3) + 8 (e >> 2) + 4 fk] — the
+            // channels the pixel lanes' registers 8 half + e carry; in the weights' split rows ([32 hi | 32 lo] bf16 per 32 channels) that is two 8-byte runs 16 bytes apart
+            const char* const wn = (const char*)(a.rgb_w + (int64_t)n * a.rgb_co * 128);
+            const int nfr = not_ * 8 * 2 * 64;                                   // 1 024 fragment slots per 32 image channels: 4 per thread
+            u32x2w p0[12], p1[12];
+#pragma unroll
+            for (int it = 0; it < 12; ++it) {                                   // (all 24 loads in flight; slots past the image's channel count re-read the last one and are not written)
+                const int e = min(tid + 256 * it, nfr - 1);
+                const int ln = e & 63, frag = e >> 6, hl = frag & 1, sidx = (frag >> 1) & 7, ot = frag >> 4;
+                const char* src = wn + (int64_t)(ot * 32 + (ln & 31)) * 512 + (sidx >> 1) * 128 + hl * 64 + (sidx & 1) * 32 + (ln >> 5) * 8;
+                p0[it] = *(const u32x2w*)src; p1[it] = *(const u32x2w*)(src + 16);
+            }
+#pragma unroll
+            for (int it = 0; it < 12; ++it)
+                if (it < not_ * 4) wl[tid + 256 * it] = __builtin_bit_cast(f32x4, (u32x4_t){p0[it][0], p0[it][1], p1[it][0], p1[it][1]});
+        }
+        wait_vmcnt<0>();                                                        // (the DMA pieces of predecessor block 0)
+        __syncthreads();
+        bf8 yh[2][4][2], yl[2][4][2];                                           // the finished activations as the stored split form would hold them: B fragments of k-steps (j, half)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 b4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b4[q] = *(const f32x4*)(bs + j * 32 + 8 * q + 4 * fk);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float nzv = nz[wave * 64 + i * 32 + frow];
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float t = acc[i][j][r];
+                    if (a.noise) t += nzv;
+                    t += b4[r >> 2][r & 3];
+                    if (a.act == 1) t = fmaxf(t, 0.2f * t);
+                    t *= a.gain;
+                    if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
+                    v[r] = t;
+                }
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+                    split_bf16x8(f32x4{v[8 * hf], v[8 * hf + 1], v[8 * hf + 2], v[8 * hf + 3]}, f32x4{v[8 * hf + 4], v[8 * hf + 5], v[8 * hf + 6], v[8 * hf + 7]}, yh[i][j][hf], yl[i][j][hf]);
+            }
+        }
+        float* const yimg = a.rgb_out + (int64_t)n * a.H * a.W * a.rgb_co;
+        // per tile i: this lane's pixel and its four predecessor taps (torgb_wide_split_kernel::store_tile: taps (jy, jx) in {0, 1}^2 of prev rows iyb + jy, columns ixb + jx with
+        // weights fr[2 jy + ky0][2 jx + kx0], ky0 = (oy - 2) & 1, iyb = (oy - 2 + ky0) >> 1, x likewise; summed in that order)
+        int toff[2]; float fw[2][2][2]; int64_t yoff[2]; bool inside[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = wave * 64 + i * 32 + frow, oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
+            inside[i] = oy < a.H && ox < a.W;
+            yoff[i] = ((int64_t)oy * a.W + ox) * a.rgb_co + 4 * fk;
+            const int by = oy - 2, bx = ox - 2, ky0 = by & 1, kx0 = bx & 1, iyb = (by + ky0) >> 1, ixb = (bx + kx0) >> 1;
+            toff[i] = ((iyb - py0) * 10 + (ixb - px0)) * 128 + fk * 16;         // LDS byte offset of tap (0, 0), channel 4 fk, inside a predecessor buffer; tap (jy, jx) adds (10 jy + jx) * 128
+#pragma unroll
+            for (int jy = 0; jy < 2; ++jy)
+#pragma unroll
+                for (int jx = 0; jx < 2; ++jx)
+                    fw[i][jy][jx] = ky0 ? (kx0 ? tail.fr[2 * jy + 1][2 * jx + 1] : tail.fr[2 * jy + 1][2 * jx]) : (kx0 ? tail.fr[2 * jy][2 * jx + 1] : tail.fr[2 * jy][2 * jx]);
+        }
+#pragma unroll 1
+        for (int ot = 0; ot < not_; ++ot) {
+            if (have_prev && ot + 1 < not_) stage_prev(ot + 1, (ot + 1) & 1);   // lands under this block's 48 MFMAs per wave (its buffer's readers left at the last rendezvous)
+            const char* const pvb = lds_b + TR_PV + (ot & 1) * TR_PVBUF;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x16 rr;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) rr[e] = 0.f;
+#pragma unroll
+                for (int sidx = 0; sidx < 8; ++sidx) {                          // torgb_wide_split_kernel's term order: x_hi w_hi, x_hi w_lo, x_lo w_hi
+                    const bf8 wh = __builtin_bit_cast(bf8, wl[((ot * 8 + sidx) * 2 + 0) * 64 + lane]);
+                    const bf8 wlo = __builtin_bit_cast(bf8, wl[((ot * 8 + sidx) * 2 + 1) * 64 + lane]);
+                    rr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, yh[i][sidx >> 1][sidx & 1], rr, 0, 0, 0);
+                    rr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, yh[i][sidx >> 1][sidx & 1], rr, 0, 0, 0);
+                    rr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, yl[i][sidx >> 1][sidx & 1], rr, 0, 0, 0);
+                }
+                // rr[r]: image channel 32 ot + (r & 3) + 8 (r >> 2) + 4 fk of this lane's pixel
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 rb = *(const f32x4*)(rbs + ot * 32 + 8 * q + 4 * fk);
+                    f32x4 out;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = rr[4 * q + e] + rb[e];
+                        if (a.rgb_clamp >= 0.f) t = fminf(fmaxf(t, -a.rgb_clamp), a.rgb_clamp);
+                        out[e] = t;
+                    }
+                    if (have_prev) {
+                        f32x4 up = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int jy = 0; jy < 2; ++jy)
+#pragma unroll
+                            for (int jx = 0; jx < 2; ++jx) {
+                                const f32x4 pv = *(const f32x4*)(pvb + toff[i] + (10 * jy + jx) * 128 + q * 32);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) up[e] = fmaf(pv[e], fw[i][jy][jx], up[e]);
+                            }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) out[e] = up[e] + out[e];
+                    }
+                    if (inside[i]) *(f32x4*)(yimg + yoff[i] + ot * 32 + 8 * q) = out;
+                }
+            }
+            if (have_prev && ot + 1 < not_) {                                   // the next predecessor block has landed; every wave is done reading this one
+                wait_vmcnt<0>();
+                __syncthreads();
+            }
+        }
+        return;
+    }
 
     // Epilogue straight from the accumulators (an fp32 tile would not fit the LDS next to a second block): a lane holds ONE channel of 64 pixels;
     // the 32 lanes of a half-wave are the 32 consecutive channels of one pixel — 128 bytes per store instruction, or, for a split result
@@ -2031,6 +2198,41 @@ extern "C" int p3d_conv3x3_torgb_f16(const void* x, const void* w, void* y, cons
     return check_launch("conv3x3_torgb_f16");
 }
 
+extern "C" int p3d_conv3x3_torgb_split(const void* x_split, const void* w_split, const float* bias, const float* noise, const float* noise_strength, const void* zeros128,
+                                       const void* rgb_wmod_split, const float* rgb_bias, float* img_nhwc, const float* prev_nhwc, const float* f4x4_host,
+                                       int32_t rgb_co, float rgb_clamp, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
+                                       int32_t act, float gain, float clamp, p3d_stream_t stream)
+{
+    using namespace p3d;
+    P3D_REQUIRE(x_split && w_split && zeros128 && rgb_wmod_split && img_nhwc, "conv3x3_torgb_split: null pointer");
+    P3D_REQUIRE(!prev_nhwc || f4x4_host, "conv3x3_torgb_split: the skip image needs its upsampling filter");
+    P3D_REQUIRE(!noise || noise_strength, "conv3x3_torgb_split: noise without its strength");
+    P3D_REQUIRE(act == 0 || act == 1, "conv3x3_torgb_split: act must be 0 (linear) or 1 (lrelu)");
+    P3D_REQUIRE(n_img >= 1 && n_img < 65536 && h >= 1 && wdt >= 1, "conv3x3_torgb_split: bad sizes");
+    const int64_t blocks = (int64_t)((h + QH - 1) / QH) * ((wdt + QW - 1) / QW) * n_img;
+    if (co != BN || ci % 32 != 0 || h < 32 || wdt < 32 || rgb_co % 32 != 0 || rgb_co < 32 || rgb_co > 96 || (prev_nhwc && ((h | wdt) & 1)) || blocks < 192)
+        return fail(P3D_ERR_UNSUPPORTED, "conv3x3_torgb_split: needs Co = 128, Ci %% 32 = 0, rgb_co in {32, 64, 96}, an even image of 32 x 32 or more and >= 192 patches (got %d, %d, %d, %d x %d x %d)",
+                    co, ci, rgb_co, n_img, h, wdt);
+    P3D_REQUIRE(((((uintptr_t)x_split) | ((uintptr_t)w_split) | ((uintptr_t)zeros128) | ((uintptr_t)rgb_wmod_split) | ((uintptr_t)img_nhwc) | ((uintptr_t)prev_nhwc) | ((uintptr_t)bias)
+                  | ((uintptr_t)rgb_bias)) & 15u) == 0, "conv3x3_torgb_split: pointers must be 16-byte aligned");
+    ConvArgs a{};
+    a.x = x_split; a.w = w_split; a.bias = bias; a.noise = noise; a.noise_strength = noise_strength; a.zeros = zeros128;
+    a.N = n_img; a.H = h; a.W = wdt; a.Ci = ci; a.Co = co; a.KT = 9; a.w_img_stride = w_img_stride;
+    a.act = act; a.gain = gain; a.clamp = clamp; a.isy = a.isx = 1; a.OH = h; a.OW = wdt; a.osy = a.osx = 1; a.ncls = 1; a.ksplit = 1;
+    a.cls[0].SH = h; a.cls[0].SW = wdt; a.cls[0].ntaps = 9;
+    for (int t = 0; t < 9; ++t) a.cls[0].taps[t] = ConvTap{t / 3 - 1, t % 3 - 1, t};
+    a.rgb_w = (const float*)rgb_wmod_split; a.rgb_bias = rgb_bias; a.rgb_out = img_nhwc; a.rgb_co = rgb_co; a.rgb_clamp = rgb_clamp;
+    WideRgbTail tail{};
+    tail.prev = prev_nhwc;
+    if (prev_nhwc)
+        for (int ky = 0; ky < 4; ++ky)                                            // (f4x4_host: sixteen floats in HOST memory, row-major; as p3d_torgb_wide_split builds them)
+            for (int kx = 0; kx < 4; ++kx) tail.fr[ky][kx] = f4x4_host[(3 - kx) + (3 - ky) * 4] * 4.f;
+    dim3 grid(((h + QH - 1) / QH) * ((wdt + QW - 1) / QW), 1, n_img);
+    hipLaunchKernelGGL(conv3x3_r2_bf16x3_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a, tail);
+    count_launch(FAM_CONV);
+    return check_launch("conv3x3_torgb_split");
+}
+
 extern "C" int p3d_conv2d_nhwc_bf16x3_io(const void* x, const void* w, void* y, const float* bias, const float* noise, const float* noise_strength,
                                          const void* zeros128, int32_t n_img, int32_t h, int32_t wdt, int32_t ci, int32_t co, int64_t w_img_stride,
                                          int32_t kernel_size, int32_t resample, int32_t act, float gain, float clamp, int32_t x_split, int32_t y_split,
@@ -2173,7 +2375,7 @@ int p3d::conv2d_nhwc_run_io(const void* x, const void* w, void* y, int dtype, co
             static const bool store2 = [] { const char* d = getenv("P3D_R2_STORE2"); return d && atoi(d) != 0; }();      // (A/B only: the 2-byte stores of the lane = channel layout)
             a.y_split = (y_split && store2) ? 2 : y_split;
             dim3 grid(((h + QH - 1) / QH) * ((wdt + QW - 1) / QW), co / BN, n_img);
-            hipLaunchKernelGGL(conv3x3_r2_bf16x3_kernel, grid, dim3(256), 0, s, a);
+            hipLaunchKernelGGL(conv3x3_r2_bf16x3_kernel<false>, grid, dim3(256), 0, s, a, WideRgbTail{});
             count_launch(FAM_CONV);
             return check_launch("conv3x3_r2_bf16x3");
         }

@@ -80,6 +80,7 @@ _lib.register('p3d_conv2d_nhwc_ws', ctypes.c_int, [_vp] * 3 + [ctypes.c_int] + [
 _lib.register('p3d_conv2d_nhwc_workspace', _i64, [ctypes.c_int] + [_i32] * 5 + [_i64, _i32, _i32])
 
 _lib.register('p3d_conv3x3_torgb_f16', ctypes.c_int, [_vp] * 8 + [_i32, _f32] + [_i32] * 5 + [ctypes.c_int64, _i32, _f32, _f32, _vp])
+_lib.register('p3d_conv3x3_torgb_split', ctypes.c_int, [_vp] * 11 + [_i32, _f32] + [_i32] * 5 + [ctypes.c_int64, _i32, _f32, _f32, _vp])
 _lib.register('p3d_conv2d_nhwc_scaled', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp] + [_i32] * 5 + [ctypes.c_int64] + [_i32] * 3 + [_f32, _f32, _vp, ctypes.c_int64, _vp])
 _lib.register('p3d_demod_coefs', ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp])
 _lib.register('p3d_conv2d_nhwc_scaled_in', ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int] + [_vp] * 6 + [_i32] * 5 + [ctypes.c_int64, _i32, _i32, _i32, _f32, _f32, _vp, ctypes.c_int64, _vp])
@@ -921,6 +922,55 @@ def torgb_wide_skip(x, weight, styles, bias, clamp, prev, f, pre=None):
     if log is not None:
         log.append(('bf16x3', 2.0 * n * ci * co * h * w))
     return y
+
+
+fuse_conv_wide_torgb = os.environ.get('P3D_FUSE_CONV_WIDE_TORGB', '1') != '0'      # the LAST backbone block: conv1 + wide ToRGB + skip-image sum in one launch, x never stored
+                             # (csrc/conv2d.hip: conv3x3_r2_bf16x3_kernel<TR>); 0 = conv1, then torgb_wide_skip
+conv_wide_torgb_calls = 0
+
+
+def conv3x3_torgb_wide_supported(x, conv_weight, rgb_weight, prev, f, up, act):
+    """p3d_conv3x3_torgb_split takes it: a SplitActs into a 3x3 'same' layer of 128 output channels whose result nobody but the block's wide ToRGB reads (the caller
+    vouches for that), 32 / 64 / 96 image channels, enough 16 x 16 patches to fill the chip, and (if given) a channels-last fp32 predecessor image at half the resolution."""
+    if not (fuse_conv_wide_torgb and fuse_wide_torgb and enabled and split_bf16 and split_activations and isinstance(x, SplitActs) and up == 1 and act in ('linear', 'lrelu')
+            and not torch.is_grad_enabled()):
+        return False
+    n, ci, h, w = x.shape
+    co, rco = conv_weight.shape[0], rgb_weight.shape[0]
+    if (co != 128 or tuple(conv_weight.shape[1:]) != (ci, 3, 3) or tuple(rgb_weight.shape[1:]) != (co, 1, 1) or rco not in (32, 64, 96) or ci % 32 != 0 or h < 32 or w < 32
+            or (h | w) & 1 or n * ((h + 15) // 16) * ((w + 15) // 16) < 192 or use_shared_weights(x.t, conv_weight, None) or not use_split_bf16(x.t, ci)):
+        return False
+    if prev is None:
+        return True
+    return (f is not None and tuple(f.shape) == (4, 4) and prev.dtype == torch.float32 and tuple(prev.shape) == (n, rco, h // 2, w // 2)
+            and prev.is_cuda and prev.is_contiguous(memory_format=torch.channels_last) and not prev.requires_grad)
+
+
+def conv3x3_torgb_wide(x, wmod, bias, noise, noise_strength, act, gain, clamp, rgb_wmod, rgb_bias, rgb_clamp, prev, f):
+    """SplitActs x -> the block's fp32 NHWC image: clamp(ToRGB(act(conv3x3(x) + noise + bias) * gain) + rgb_bias) + upsample2d(prev, f), one launch; the layer's own
+    activations are never written.  wmod / rgb_wmod: modulate_weights(dtype=BF16X3) of the 3x3 layer (demodulated) and of the ToRGB (not)."""
+    n, ci, h, w = x.shape
+    co, rco = wmod.shape[1], rgb_wmod.shape[1]
+    assert wmod.dtype == torch.float32 and wmod.is_contiguous() and tuple(wmod.shape[1:]) == (co, 9, ci) and wmod.shape[0] in (1, n)
+    assert rgb_wmod.dtype == torch.float32 and rgb_wmod.is_contiguous() and tuple(rgb_wmod.shape) == (n, rco, 1, co)
+    img = torch.empty([n, rco, h, w], dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    stride = 0 if wmod.shape[0] == 1 else co * 9 * ci
+    b32 = None if bias is None else bias.detach().float().contiguous()
+    rb32 = None if rgb_bias is None else rgb_bias.detach().float().contiguous()
+    nz = None if noise is None else noise.detach().float().contiguous()
+    ns = None if noise is None else noise_strength.detach().float().reshape(1).contiguous()
+    fh = None if prev is None else _filter_host(f)
+    with _lib.kernel_timer('conv_bf16x3', x.t):
+        code = _lib.lib().p3d_conv3x3_torgb_split(_lib.ptr(x.t), _lib.ptr(wmod), _lib.ptr(b32), _lib.ptr(nz), _lib.ptr(ns), _lib.ptr(_zeros_page(x.device)), _lib.ptr(rgb_wmod),
+                                                  _lib.ptr(rb32), _lib.ptr(img), _lib.ptr(prev), None if fh is None else ctypes.cast(fh, ctypes.c_void_p), rco,
+                                                  -1.0 if rgb_clamp is None else float(rgb_clamp), n, h, w, ci, co, stride, int(act), float(gain), float(clamp), _lib.stream_of(x.t))
+    _lib.check(code, 'conv3x3_torgb_split')
+    global conv_wide_torgb_calls
+    conv_wide_torgb_calls += 1
+    log = _lib.kernel_events.get('conv_flops')
+    if log is not None:
+        log.append(('bf16x3', 2.0 * n * ci * co * 9 * h * w + 2.0 * n * co * rco * h * w))
+    return img
 
 
 def torgb_accumulates(x, weight, out):

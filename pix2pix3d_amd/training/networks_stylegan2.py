@@ -263,14 +263,35 @@ class SynthesisLayer(torch.nn.Module):
             self.noise_strength = torch.nn.Parameter(torch.zeros([]))                       # state_dict / optimizer indices line up with its runs
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
 
-    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, rgb=None, out_split=False):
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, rgb=None, out_split=False, rgb_wide=None):
         """``rgb`` (device inference, from SynthesisBlock): (torgb layer, its latent, skip image) — when the native kernel can, this layer
         also adds the block's ToRGB output into the skip image from its own launch and returns (x, True); otherwise (x, False).
-        ``out_split`` (device inference, bf16x3): the caller's consumers read modconv.SplitActs; x may be one."""
+        ``out_split`` (device inference, bf16x3): the caller's consumers read modconv.SplitActs; x may be one.
+        ``rgb_wide`` (device inference, bf16x3, from the LAST block of a network whose x nobody reads): (torgb layer, its latent, the skip image of the
+        block below or None, the resampling filter) — returns (None, img) when this layer's launch also produced the block's wide image
+        (modconv.conv3x3_torgb_wide: the activations are never stored), else (x, None) with x as ``out_split`` asks."""
         if noise_mode not in ('random', 'const', 'none'):
             raise AssertionError(f'unknown noise_mode {noise_mode!r}')
         in_res = self.resolution // self.up
         misc.assert_shape(x, [None, self.in_channels, in_res, in_res])
+        if rgb_wide is not None:
+            assert rgb is None
+            torgb, w_rgb, prev, f = rgb_wide
+            if fused_modconv is True and noise_mode != 'random' and x.is_cuda and \
+                    modconv.conv3x3_torgb_wide_supported(x, self.weight, torgb.weight, prev, f, self.up, self.activation):
+                planned = modconv.take_plan(self) if modconv._plan else None
+                styles, pre = planned if planned is not None else (self.affine(w), None)
+                wmod = pre[0] if pre is not None and pre[1] == ('mfma', 1, modconv.BF16X3) else modconv.modulate_weights(self.weight, styles, demodulate=True, dtype=modconv.BF16X3)
+                planned_rgb = modconv.take_plan(torgb) if modconv._plan else None
+                s_rgb, pre_rgb = planned_rgb if planned_rgb is not None else (torgb.affine(w_rgb, out_scale=torgb.weight_gain), None)
+                rgb_wmod = pre_rgb[0] if pre_rgb is not None and pre_rgb[1] == ('rgb', modconv.BF16X3) else \
+                    modconv.modulate_weights(torgb.weight, s_rgb, demodulate=False, dtype=modconv.BF16X3)
+                const_noise = self.use_noise and noise_mode == 'const'
+                img = modconv.conv3x3_torgb_wide(x, wmod, self.bias, self.noise_const if const_noise else None, self.noise_strength if const_noise else None,
+                                                 {'linear': 0, 'lrelu': 1}[self.activation], self.act_gain * gain,
+                                                 -1.0 if self.conv_clamp is None else float(self.conv_clamp * gain), rgb_wmod, torgb.bias, torgb.conv_clamp, prev, f)
+                return None, img
+            return self.forward(x, w, noise_mode=noise_mode, fused_modconv=fused_modconv, gain=gain, out_split=out_split), None
         if isinstance(x, modconv.SplitActs) and (rgb is not None or not modconv.layer_supported(x, self.weight, None, noise_mode, fused_modconv, self.up)):
             x = x.dense()
         planned = modconv.take_plan(self) if modconv._plan else None
@@ -447,7 +468,16 @@ class SynthesisBlock(torch.nn.Module):
                           and self.conv1.out_channels % 32 == 0 and layer_kwargs.get('noise_mode', 'random') != 'random' and self.img_channels > 8
                           and modconv.accepts_split_input(ws.shape[0], self.conv1.out_channels, self.resolution ** 2, 1))
             x = self.conv0(x, per_layer[0], out_split=keep_split, **conv_kwargs)
-            if keep_split:
+            if keep_split and _x_dead and wants_rgb and self._in_div == 2 and (img is None or img.is_contiguous(memory_format=torch.channels_last)):
+                # the network's LAST block (SynthesisNetwork.forward: nobody reads its x): conv1, the wide ToRGB and the skip-image sum in one launch where
+                # the kernel takes the sizes — the layer's activations are then never written (csrc/conv2d.hip: conv3x3_r2_bf16x3_kernel<TR>)
+                if img is not None:
+                    misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
+                x, fused_img = self.conv1(x, per_layer[1], out_split=True, rgb_wide=(self.torgb, per_layer[self.num_conv], img, self.resample_filter), **conv_kwargs)
+                if fused_img is not None:
+                    return None, fused_img
+                img_carried = False
+            elif keep_split:
                 x = self.conv1(x, per_layer[1], out_split=True, **conv_kwargs)
                 img_carried = False
             elif wants_rgb and img is not None and self.img_channels <= 8 and x.is_cuda and not torch.is_grad_enabled():
@@ -685,7 +715,11 @@ class SynthesisNetwork(torch.nn.Module):
                 # the consuming block (its input), or a global hook of either kind — then it stays a tensor.  Sampled per block, not per pass.
                 nxt = blocks[i + 1] if i + 1 < len(blocks) else None
                 hooked = bool(_m._global_forward_hooks or _m._global_forward_pre_hooks or block._forward_hooks or (nxt is not None and nxt._forward_pre_hooks))
-                x, img = block(x, img, cur, _split_ok=not hooked, **block_kwargs)
+                # the last block's x is dropped here (only img is returned): unless a hook on the block, on its conv1 or on its ToRGB could see the activations,
+                # the block may leave them unwritten (SynthesisBlock.forward: _x_dead)
+                dead = (nxt is None and not hooked and getattr(block, 'conv1', None) is not None and getattr(block, 'torgb', None) is not None
+                        and not (block.conv1._forward_hooks or block.conv1._forward_pre_hooks or block.torgb._forward_hooks or block.torgb._forward_pre_hooks))
+                x, img = block(x, img, cur, _split_ok=not hooked, _x_dead=dead, **block_kwargs)
         finally:
             if planned is not None:
                 finish_prefetch(ws.device, planned)

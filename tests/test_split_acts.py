@@ -124,6 +124,61 @@ def test_wide_torgb_with_the_skip_image_in_one_launch(hip_lib, ci, co, h, w, n, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('ci,rco,h,w,n,skip,noise,act,clamp', [
+    (128, 96, 256, 256, 1, True, True, 1, 256.0),        # the backbone's last block at its own size (one image)
+    (128, 96, 128, 128, 4, True, True, 1, 256.0),
+    (64, 96, 100, 90, 5, True, True, 1, 0.7),            # ragged patches on both axes, one chunk pair, the layer's clamp active
+    (256, 64, 72, 96, 8, False, False, 0, -1.0),         # no skip image, no noise, linear
+    (96, 32, 64, 64, 12, True, False, 1, -1.0),
+])
+def test_last_conv_wide_torgb_and_skip_image_in_one_launch(hip_lib, ci, rco, h, w, n, skip, noise, act, clamp):
+    """conv3x3_r2_bf16x3_kernel<TR> (p3d_conv3x3_torgb_split): the 128-channel 3x3 layer on split activations, its wide ToRGB and the skip-image sum in one launch, the
+    layer's activations never stored — against the two launches it replaces (the same layer writing a split result, then torgb_wide_skip: the same (hi, lo) pieces
+    into the same three products per term, another summation order: <= 2e-6 of the range) and against fp64 of the same dense input (the bf16x3 bar per layer: 1e-5)."""
+    import torch.nn.functional as F
+    from pix2pix3d_amd import _lib
+    from pix2pix3d_amd.torch_utils.ops import modconv, upfirdn2d
+    torch.manual_seed(ci + rco + h)
+    co = 128
+    x = _nhwc(torch.randn(n, ci, h, w, device='cuda'))
+    xs = modconv.SplitActs(_nhwc(_split_storage(x.cpu())).cuda())
+    weight = torch.randn(co, ci, 3, 3, device='cuda'); styles = torch.randn(n, ci, device='cuda') + 1
+    rgb_weight = torch.randn(rco, co, 1, 1, device='cuda'); rgb_styles = (torch.randn(n, co, device='cuda') + 1) / co ** 0.5
+    bias, rgb_bias = torch.randn(co, device='cuda'), torch.randn(rco, device='cuda')
+    nz = torch.randn(h, w, device='cuda') if noise else None
+    ns = torch.tensor(0.3, device='cuda') if noise else None
+    f = upfirdn2d.setup_filter([1, 3, 3, 1], device=torch.device('cuda'))
+    prev = _nhwc(torch.randn(n, rco, h // 2, w // 2, device='cuda')) if skip else None
+    gain = 2 ** 0.5 if act else 1.0
+    with torch.no_grad():
+        assert modconv.conv3x3_torgb_wide_supported(xs, weight, rgb_weight, prev, f, 1, 'lrelu' if act else 'linear')
+        w3 = modconv.modulate_weights(weight, styles, dtype=modconv.BF16X3)
+        w1 = modconv.modulate_weights(rgb_weight, rgb_styles, demodulate=False, dtype=modconv.BF16X3)
+        n0 = _lib.launch_count('conv')
+        got = modconv.conv3x3_torgb_wide(xs, w3, bias, nz, ns, act, gain, clamp, w1, rgb_bias, 256.0, prev, f)
+        assert _lib.launch_count('conv') == n0 + 1
+        assert got.shape == (n, rco, h, w) and got.dtype == torch.float32 and got.is_contiguous(memory_format=torch.channels_last)
+        y = modconv.conv2d(xs, w3, bias=bias, noise=nz, noise_strength=ns, act=act, gain=gain, clamp=clamp, split=True, out_split=True)
+        assert isinstance(y, modconv.SplitActs)
+        two = modconv.torgb_wide_skip(y, rgb_weight, rgb_styles, rgb_bias, 256.0, prev, f) if w % 32 == 0 else None
+    wq = modconv.modulate_weights(weight, styles, dtype=torch.float32).double().reshape(n, co, 3, 3, ci).permute(0, 1, 4, 2, 3).cpu()
+    ref = torch.stack([F.conv2d(x[i:i + 1].double().cpu(), wq[i], padding=1)[0] for i in range(n)])
+    if noise:
+        ref = ref + (nz * ns).double().cpu()
+    ref = ref + bias.double().cpu().view(1, -1, 1, 1)
+    ref = (F.leaky_relu(ref, 0.2) if act else ref) * gain
+    if clamp >= 0:
+        ref = ref.clamp(-clamp, clamp)
+    ref = (torch.einsum('oc,nc,nchw->nohw', rgb_weight.reshape(rco, co).double().cpu(), rgb_styles.double().cpu(), ref) + rgb_bias.double().cpu().view(1, rco, 1, 1)).clamp(-256, 256)
+    if skip:
+        ref = ref + upfirdn2d.upsample2d(prev.double().cpu().contiguous(), f.cpu())
+    e64 = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+    e2 = float((got - two).abs().max() / two.abs().max()) if two is not None else None
+    print((ci, rco, h, w, n, skip), 'vs two launches', e2, 'vs fp64', e64)
+    assert (e2 is None or e2 < 2e-6) and e64 < 2e-5                    # (two bf16x3 layers in sequence: twice the one-layer bar; the two-launch form carries the same error)
+
+
+@pytest.mark.gpu
 def test_wide_torgb_narrow_output_first_then_wide_in_a_fresh_process(hip_lib):
     """The kernel's dynamic-LDS limit is reserved once per device: a process whose FIRST call is the narrow form (Ci 256, Co 32: 32 KB) must still
     be able to launch the widest one (Co 96: 96 KB) afterwards.  Needs its own process — in this one the order of the tests above decides."""
@@ -181,10 +236,54 @@ def test_generator_outputs_do_not_change_with_split_activations(hip_lib, batch):
                 o = G.synthesis(ws, c, noise_mode='const', neural_rendering_resolution=nrr)
             outs.append((o, made))
         (a, made_on), (b, made_off) = outs
-        assert len(made_on) >= (6 if batch > 1 else 8) and not made_off, (made_on, made_off)    # batch 4: conv0 and conv1 of b64, b128, b256 hand their results over split
+        assert len(made_on) >= (5 if batch > 1 else 7) and not made_off, (made_on, made_off)    # batch 4: conv0 and conv1 of b64, b128 and conv0 of b256 hand their results over split
+                                                                                                # (b256.conv1's never leave the registers: test_last_backbone_layer_never_stores_its_activations)
         for k in ('image', 'image_raw', 'semantic', 'semantic_raw', 'image_depth'):      # (the 3x3 layers on split input take the ring kernel: same products, another summation order)
             e = float((a[k].float() - b[k].float()).abs().max() / b[k].float().abs().max())
             assert e < (2e-3 if k in ('image', 'semantic') else 2e-5), (k, e)       # fp16 SR heads amplify a last-bit difference of their input to fp16 rounding
     finally:
         modconv.split_activations = prev
         modconv.SplitActs.__init__ = orig
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('batch', [4, 1])
+def test_last_backbone_layer_never_stores_its_activations(hip_lib, batch):
+    """G.synthesis at the benchmark's size: the backbone's last block runs conv1 + wide ToRGB + skip-image sum as ONE launch (modconv.conv3x3_torgb_wide, x never written)
+    — the outputs against the same pass with that fusion off (conv1 writing split activations, then torgb_wide_skip): the same products in another summation order.  A
+    forward hook on the block's conv1 (somebody wants the activations) keeps the two-launch form."""
+    from pix2pix3d_amd.torch_utils.ops import modconv
+    from conftest import load_golden
+    from model_cases import build_generator, uniforms, replay_uniforms
+    g = load_golden('model_full_seg2cat_128')
+    G = build_generator('seg2cat', 'cuda', depth=tuple(int(v) for v in g['depth']))
+    ws, c, nrr = torch.tensor(g['ws'], device='cuda'), torch.tensor(g['c'], device='cuda'), int(g['nrr'])
+    u_c, u_f = uniforms(g, ws.shape[0], nrr, G.rendering_kwargs)
+    ws, c, u_c, u_f = ws[:batch], c[:batch], u_c[:batch], u_f[:batch * nrr * nrr]
+    prev = modconv.fuse_conv_wide_torgb
+    try:
+        outs = []
+        for on in (True, False):
+            modconv.fuse_conv_wide_torgb = on
+            n0 = modconv.conv_wide_torgb_calls
+            with replay_uniforms(u_c, u_f), torch.no_grad():
+                o = G.synthesis(ws, c, noise_mode='const', neural_rendering_resolution=nrr)
+            outs.append(o)
+            assert modconv.conv_wide_torgb_calls - n0 == (1 if on else 0)
+        a, b = outs
+        for k in ('image', 'image_raw', 'semantic', 'semantic_raw', 'image_depth'):
+            e = float((a[k].float() - b[k].float()).abs().max() / b[k].float().abs().max())
+            assert e < (2e-3 if k in ('image', 'semantic') else 2e-5), (k, e)       # fp16 SR heads amplify a last-bit difference of their input to fp16 rounding
+        modconv.fuse_conv_wide_torgb = True
+        last = getattr(G.backbone.synthesis, f'b{G.backbone.synthesis.img_resolution}')
+        seen = []
+        handle = last.conv1.register_forward_hook(lambda m, a_, o_: seen.append(type(o_)))
+        try:
+            n0 = modconv.conv_wide_torgb_calls
+            with replay_uniforms(u_c, u_f), torch.no_grad():
+                G.synthesis(ws, c, noise_mode='const', neural_rendering_resolution=nrr)
+            assert modconv.conv_wide_torgb_calls == n0 and len(seen) == 1
+        finally:
+            handle.remove()
+    finally:
+        modconv.fuse_conv_wide_torgb = prev
