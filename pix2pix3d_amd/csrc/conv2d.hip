@@ -1074,6 +1074,21 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
     // TWO steps earlier, while the group issued one step earlier (tile ks+2, plus a slab after tap 0) stays in flight under a counted
     // vmcnt.  Two full steps of flight out of three slots (PMC on a one-step version: 46 % of the wave cycles waiting at vmcnt(0) +
     // barrier).  Nine taps and three slots: the slot index is t % 3, a compile-time constant of the unrolled body.
+    // TR: everything the epilogue reads from global memory apart from the skip image — the ToRGB weights (as fp16 A fragments, rows < 8), the layer's bias, the ToRGB's — is
+    // requested HERE, ahead of the pipeline's first DMA, and parked in the 8 KB of LDS behind the weight ring that only the channel-block loop uses; the epilogue then starts
+    // from LDS.  (Loaded where they were used, each under its null / row-bound branch and therefore waited for inside it, they were 12 dependent memory round trips of every
+    // work-group's epilogue, and the read-modify-writes of the skip image 8 more: tools/sessions/gpu_round6_zi.sh.)
+    constexpr int TRP_BW = H2_RGB_BASE, TRP_BIAS = TRP_BW + 16 * 9 * 16, TRP_RB = TRP_BIAS + 512;       // [k-step 8][k group 2][row 8 + a zero row] x 16 B; [128] floats; [8] floats
+    f32x4 prm_w = {0.f, 0.f, 0.f, 0.f}; float prm_b = 0.f, prm_rb = 0.f;
+    if constexpr (TR) {
+        const int row = tid >> 5;
+        prm_w = *(const f32x4*)(a.rgb_w + ((int64_t)n * a.rgb_co + min(row, a.rgb_co - 1)) * 128 + (tid & 31) * 4);
+        if (row >= a.rgb_co) prm_w = f32x4{0.f, 0.f, 0.f, 0.f};
+        prm_b = (a.bias ? a.bias : (const float*)a.zeros)[a.bias ? (tid & 127) : 0];
+        const bool rbok = a.rgb_bias && (tid & 7) < a.rgb_co;
+        prm_rb = (a.rgb_bias ? a.rgb_bias : (const float*)a.zeros)[rbok ? (tid & 7) : 0];
+        if (!rbok) prm_rb = 0.f;
+    }
 #pragma nounroll
     for (int cbi = 0; cbi < ncbi; ++cbi, co0 += BN, wgt_cb += (int64_t)BN * 9 * a.Ci * 2) {
 #pragma unroll
@@ -1087,6 +1102,16 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
     stage_w(0, 1, 1);
     stage_w(0, 2, 2);
     wait_vmcnt<2>();                                                            // slab 0, tiles 0 and 1 (tile 2 stays in flight)
+    if constexpr (TR) {                                                         // (the parameter loads are older than the DMA pieces: they have landed)
+        typedef _Float16 hp4 __attribute__((ext_vector_type(4)));
+        const int row = tid >> 5, c0 = (tid & 31) * 4, off = c0 & 15;
+        // element e of lane (row, k group) of k-step s is channel 16 s + (e & 3) + 8 (e >> 2) + 4 (k group): a run of four channels from 16 s + off is k group (off >> 2) & 1, e = 4 (off >> 3) ..
+        *(hp4*)(lds_b + TRP_BW + (((c0 >> 4) * 2 + ((off >> 2) & 1)) * 9 + row) * 16 + (off >> 3) * 8) = hp4{(_Float16)prm_w[0], (_Float16)prm_w[1], (_Float16)prm_w[2], (_Float16)prm_w[3]};
+        if (tid < 16) *(f32x4*)(lds_b + TRP_BW + (tid * 9 + 8) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tid < 128) *(float*)(lds_b + TRP_BIAS + tid * 4) = prm_b;
+        else if (tid < 136) *(float*)(lds_b + TRP_RB + (tid & 7) * 4) = prm_rb;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     load_frags(0, 0, 0, fa[0], fb[0]);
     for (int cp = 0; cp < kpairs; ++cp) {
@@ -1131,29 +1156,33 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
         // acc[i][j][r] = y^T: channel 32 j + (r & 3) + 8 (r >> 2) + 4 fk of pixel wave * 64 + i * 32 + frow.  (host: Co == 128, one channel block, no noise)
         // ToRGB weights as A fragments: lane (row o = frow, k group fk) of k-step (j, half) holds w[o][32 j + 16 half + (e & 3) + 8 (e >> 2) + 4 fk], e = 0 .. 7 —
         // the channels the pixel lanes' registers 8 half + e carry — rounded to fp16 like the reference's fp16 layer does
-        h8 bw[8];
+        h8 bw[8];                                                               // (parked in LDS by the kernel's first instructions; rows >= 8 read the zero row)
 #pragma unroll
-        for (int sidx = 0; sidx < 8; ++sidx) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bw[sidx][e] = (_Float16)0.f;
-            if (frow < a.rgb_co) {
-                const float* wp = a.rgb_w + ((int64_t)n * a.rgb_co + frow) * 128 + sidx * 16 + fk * 4;
-                const f32x4 w0 = *(const f32x4*)wp, w1 = *(const f32x4*)(wp + 8);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { bw[sidx][e] = (_Float16)w0[e]; bw[sidx][4 + e] = (_Float16)w1[e]; }
-            }
-        }
+        for (int sidx = 0; sidx < 8; ++sidx) bw[sidx] = *(const h8*)(lds_b + TRP_BW + ((sidx * 2 + fk) * 9 + (frow < 8 ? frow : 8)) * 16);
         f32x16 rr[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) rr[i][e] = 0.f;
+        // the skip image's old values: requested before the activation arithmetic and the ToRGB MFMAs, added behind them (lanes without a pixel / channel read the image's first element)
+        float* dstp[2][4]; bool dok[2][4]; float old[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int oy = oy0 + wave * 4 + 2 * i + (frow >> 4), ox = ox0 + (frow & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = r + 4 * fk;
+                dok[i][r] = oy < a.H && ox < a.W && o < a.rgb_co;
+                dstp[i][r] = dok[i][r] ? a.rgb_out + (((int64_t)n * a.rgb_co + o) * a.H + oy) * a.W + ox : a.rgb_out;
+                old[i][r] = *dstp[i][r];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float b[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 b4 = a.bias ? *(const f32x4*)(a.bias + co0 + j * 32 + 8 * q + 4 * fk) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 b4 = *(const f32x4*)(lds_b + TRP_BIAS + (j * 32 + 8 * q + 4 * fk) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) b[q * 4 + e] = b4[e];
             }
@@ -1174,21 +1203,13 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
         }
         // rr[i][r]: image channel (r & 3) + 8 (r >> 2) + 4 fk of pixel (wave * 4 + 2 i + (frow >> 4), frow & 15) of the patch: channels 0 .. 7 are r = 0 .. 3 of the two halves
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int oy = oy0 + wave * 4 + 2 * i + (frow >> 4), ox = ox0 + (frow & 15);
-            if (oy < a.H && ox < a.W) {
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = r + 4 * fk;
-                    if (o < a.rgb_co) {
-                        float v = rr[i][r] + (a.rgb_bias ? a.rgb_bias[o] : 0.f);
-                        if (a.rgb_clamp >= 0.f) v = fminf(fmaxf(v, -a.rgb_clamp), a.rgb_clamp);
-                        float* dst = a.rgb_out + (((int64_t)n * a.rgb_co + o) * a.H + oy) * a.W + ox;
-                        *dst += v;
-                    }
-                }
+            for (int r = 0; r < 4; ++r) {
+                float v = rr[i][r] + *(const float*)(lds_b + TRP_RB + (r + 4 * fk) * 4);
+                if (a.rgb_clamp >= 0.f) v = fminf(fmaxf(v, -a.rgb_clamp), a.rgb_clamp);
+                if (dok[i][r]) *dstp[i][r] = old[i][r] + v;
             }
-        }
         return;
     }
     __syncthreads();                                                            // every wave is done with the slabs and tiles
@@ -1207,6 +1228,15 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
     __half* const ot = (__half*)lds_b;
     float* const nz = (float*)(ot + 256 * OP);                                   // the tile's noise: bytes 69632 .. 70656 < H2_LDS
     const float ns = a.noise ? a.noise_strength[0] : 0.f;
+    // the four column blocks' biases in ONE batch of unconditional loads (an absent / out-of-range one reads the zeros page): as `cond ? load : 0` inside the loop each
+    // was a branch with its own wait — four dependent memory round trips per pass (and eight more for the ToRGB weights below)
+    float bj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int co = co0 + j * 32 + frow;
+        const bool bok = a.bias && co < a.Co;
+        bj[j] = (bok ? a.bias : (const float*)a.zeros)[bok ? co : 0];
+    }
     if (a.noise) {
         const int oy = oy0e + (tid >> 4), ox = ox0e + (tid & 15);
         nz[tid] = (oy < a.H && ox < a.W) ? a.noise[(int64_t)oy * a.W + ox] * ns : 0.f;
@@ -1214,8 +1244,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int cl = j * 32 + frow, co = co0 + cl;
-        const float b = (a.bias && co < a.Co) ? a.bias[co] : 0.f;
+        const int cl = j * 32 + frow;
+        const float b = bj[j];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1246,16 +1276,16 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
         // modulated 1x1 weights rounded to fp16 (what the reference's fp16 layer multiplies by), 32 padded output columns.
         const int col = lane & 31, kg = lane >> 5;
         h8 bw[8];
+        {
+            const bool wok = col < a.rgb_co;                                    // (columns past the image's channels: the last row is read and discarded — no branch, sixteen loads in flight)
+            const float* const wrow = a.rgb_w + ((int64_t)n * a.rgb_co + (wok ? col : a.rgb_co - 1)) * a.Co + co0 + kg * 8;
+            f32x4 w0[8], w1[8];
 #pragma unroll
-        for (int sidx = 0; sidx < 8; ++sidx) {
+            for (int sidx = 0; sidx < 8; ++sidx) { w0[sidx] = *(const f32x4*)(wrow + sidx * 16); w1[sidx] = *(const f32x4*)(wrow + sidx * 16 + 4); }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bw[sidx][e] = (_Float16)0.f;
-            if (col < a.rgb_co) {
-                const float* wp = a.rgb_w + ((int64_t)n * a.rgb_co + col) * a.Co + co0 + sidx * 16 + kg * 8;
-                const f32x4 w0 = *(const f32x4*)wp, w1 = *(const f32x4*)(wp + 4);
+            for (int sidx = 0; sidx < 8; ++sidx)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { bw[sidx][e] = (_Float16)w0[e]; bw[sidx][4 + e] = (_Float16)w1[e]; }
-            }
+                for (int e = 0; e < 4; ++e) { bw[sidx][e] = wok ? (_Float16)w0[sidx][e] : (_Float16)0.f; bw[sidx][4 + e] = wok ? (_Float16)w1[sidx][e] : (_Float16)0.f; }
         }
         f32x16 rr[2];
 #pragma unroll
@@ -1287,11 +1317,16 @@ __global__ void __launch_bounds__(256, 2) conv3x3_h2_f16_kernel(ConvArgs a)
         if (last) {
             __syncthreads();
             const int p = tid, oy = oy0e + (p >> 4), ox = ox0e + (p & 15);
-            if (oy < a.H && ox < a.W)
-                for (int o = 0; o < a.rgb_co; ++o) {
-                    float* dst = a.rgb_out + (((int64_t)n * a.rgb_co + o) * a.H + oy) * a.W + ox;
-                    *dst += ro[o * 256 + p];
-                }
+            if (oy < a.H && ox < a.W) {                                          // (rgb_co <= 8: every channel's old value requested at once, then added and stored)
+                float* const d0 = a.rgb_out + ((int64_t)n * a.rgb_co * a.H + oy) * a.W + ox;
+                const int64_t cs = (int64_t)a.H * a.W;
+                float old[8];
+#pragma unroll
+                for (int o = 0; o < 8; ++o) old[o] = d0[o < a.rgb_co ? o * cs : 0];
+#pragma unroll
+                for (int o = 0; o < 8; ++o)
+                    if (o < a.rgb_co) d0[o * cs] = old[o] + ro[o * 256 + p];
+            }
         }
     }
     }   // ---- epilogue scope
@@ -1637,6 +1672,13 @@ __global__ void __launch_bounds__(256, 2) conv3x3_r2_bf16x3_kernel(ConvArgs a, W
         __syncthreads();
     }
     float* const yimg = (float*)a.y + (int64_t)n * a.H * a.W * a.Co;
+    float bj[4];                                                                // the four column blocks' biases in one batch (see conv3x3_h2_f16_kernel's epilogue)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int co = co0 + j * 32 + frow;
+        const bool bok = a.bias && co < a.Co;
+        bj[j] = (bok ? a.bias : (const float*)a.zeros)[bok ? co : 0];
+    }
     if (a.y_split == 1) {
         // Split result in 16-byte stores.  A lane holds ONE channel of four consecutive pixels in registers 4 q .. 4 q + 3; the four lanes of a quad hold four
         // consecutive channels.  Each finished value becomes one dword (bf16 hi | bf16 lo << 16), the quad transposes its 4 x 4 dwords in registers (two DPP
@@ -1648,7 +1690,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_r2_bf16x3_kernel(ConvArgs a, W
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (co0 + j * 32 >= a.Co) continue;                                  // (whole 32-channel rows: uniform)
-            const float b = a.bias ? a.bias[co0 + j * 32 + frow] : 0.f;
+            const float b = bj[j];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1689,7 +1731,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_r2_bf16x3_kernel(ConvArgs a, W
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int co = co0 + j * 32 + frow;
-        const float b = (a.bias && co < a.Co) ? a.bias[co] : 0.f;
+        const float b = bj[j];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll

@@ -183,9 +183,10 @@ __global__ void __launch_bounds__(256, 2) up2_fir_f16_kernel(Up2Args a)
 
     // the epilogue's noise tile and bias: loaded NOW, into five registers, so that their global-memory latency passes under the K loop (as part
     // of the epilogue it was ~2 us of every block's life with nothing to hide it)
-    float nz_pre[4], bias_pre = 0.f;
+    float nz_pre[4], bias_pre = 0.f, ns_pre = 0.f;                                // (+ the noise strength: read behind the K loop it was one exposed memory round trip of every block's ~25 us)
     if constexpr (MFMA_FIR) {
         const int OH = 2 * a.H, OW = 2 * a.W;
+        if (a.noise) ns_pre = a.noise_strength[0];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int e = tid + 256 * q;
@@ -266,7 +267,7 @@ __global__ void __launch_bounds__(256, 2) up2_fir_f16_kernel(Up2Args a)
         const float slope = (a.act == 1) ? 0.2f : 1.f, lim = (a.clamp >= 0.f) ? a.clamp : INFINITY;
         float* const bs = nz + UF_NZ_FLOATS;                                    // [32] bias * act_gain
         {
-            const float ns = a.noise ? a.noise_strength[0] * a.act_gain : 0.f;
+            const float ns = a.noise ? ns_pre * a.act_gain : 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (tid + 256 * q < UF_NZ_FLOATS) nz[tid + 256 * q] = nz_pre[q] * ns;
