@@ -492,21 +492,54 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(ConvArgs a, int Mp
         if (m >= (a.fold ? MI * a.N : MI)) continue;
         const float* src = a.partial + ((int64_t)zz * Mpad + m) * CoP + co;
         const int64_t split_stride = (int64_t)zcount * Mpad * CoP;
-        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < a.ksplit; ++k) sum += *(const f32x4*)(src + k * split_stride);
         if (a.fold) { n = m / MI; m -= n * MI; }
         const int si = m / kc.SW, sj = m - si * kc.SW;
         const int oy = si * a.osy + kc.ooy, ox = sj * a.osx + kc.oox;
         if (oy >= a.OH || ox >= a.OW) continue;
+        // the row's noise, scales and biases: requested ahead of the partial tiles (one batch, no load between two stores); the partial tiles eight / four / two at a time,
+        // ADDED in k order as before.  As written first — `for k: sum += load`, then `if (oscale) v *= load; if (bias) v += load; store` per channel — a thread ran
+        // ksplit + 8 dependent memory round trips, which is what these 5 - 15 us launches on the low-resolution layers' critical path consisted of.
         const float nz = a.noise ? a.noise[(int64_t)oy * a.OW + ox] * ns : 0.f;
+        float osv[4] = {1.f, 1.f, 1.f, 1.f}, bsv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.oscale) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) osv[c] = a.oscale[n * a.Co + min(co + c, a.Co - 1)];
+        }
+        if (a.bias) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bsv[c] = a.bias[min(co + c, a.Co - 1)];
+        }
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 8 <= a.ksplit; k += 8) {
+            f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(src + (k + u) * split_stride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += t[u];
+        }
+        if (k + 4 <= a.ksplit) {
+            f32x4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = *(const f32x4*)(src + (k + u) * split_stride);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sum += t[u];
+            k += 4;
+        }
+        if (k + 2 <= a.ksplit) {
+            const f32x4 t0 = *(const f32x4*)(src + k * split_stride), t1 = *(const f32x4*)(src + (k + 1) * split_stride);
+            sum += t0; sum += t1;
+            k += 2;
+        }
+        if (k < a.ksplit) sum += *(const f32x4*)(src + k * split_stride);
         T* dst = (T*)a.y + (((int64_t)n * a.OH + oy) * a.OW + ox) * a.Co + co;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (co + c >= a.Co) break;
             float v = sum[c];
-            if (a.oscale) v *= a.oscale[n * a.Co + co + c];
+            if (a.oscale) v *= osv[c];
             v += nz;
-            if (a.bias) v += a.bias[co + c];
+            if (a.bias) v += bsv[c];
             if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
             v *= a.gain;
             if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
