@@ -555,6 +555,29 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, f32x16 (&acc)[2
 {
     const int frow = lane & 31, fk = lane >> 5;
     const float ns = a.noise ? a.noise_strength[0] : 0.f;
+    // this lane's 32 noise values (one per accumulator row of its two tiles; the same for every column block) in ONE batch of unconditional loads — read where they were
+    // used, under `if (noise && inside)`, each was a branch with its own wait: 32 dependent memory round trips in the epilogue of every work-group of a layer with noise
+    // (the exact-fp32 and bf16x6 inference legs' 3x3 layers)
+    float nzr[2][16];
+    {
+        const float* const np = a.noise ? a.noise : (const float*)a.zeros;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mrow = (r & 3) + 8 * (r >> 2) + 4 * fk;
+                const int oy = oy0 + prow0 + i * 2 + (mrow >> 4), ox = ox0 + (mrow & 15);
+                const bool ok = a.noise && oy < a.H && ox < a.W;
+                nzr[i][r] = np[ok ? (int64_t)oy * a.W + ox : 0];
+            }
+    }
+    float bjh[2];                                                               // (and the two column blocks' biases)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = co0 + wn * 64 + j * 32 + frow;
+        const bool bok = a.bias && co < a.Co;
+        bjh[j] = (bok ? a.bias : (const float*)a.zeros)[bok ? co : 0];
+    }
     if (!a.y_split && !a.store_narrow && (a.Co & 3) == 0 && ((((uintptr_t)a.y) & 15u) == 0)) {
         // Wide stores (quad_transpose4, p3d_common.h): after the 4 x 4 transpose lane 4 m + t holds channels 4 m .. 4 m + 3 of pixel t of the four consecutive pixels in
         // registers 4 q .. 4 q + 3 — one 16-byte store (fp32) or, with the two row tiles i = 0, 1 packed into one dword per value, two 8-byte ones (fp16) where the
@@ -566,7 +589,7 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, f32x16 (&acc)[2
         for (int j = 0; j < 2; ++j) {
             const int cq = co0 + wn * 64 + j * 32, co = cq + frow;
             const bool cok = co < a.Co;
-            const float b = (a.bias && cok) ? a.bias[co] : 0.f;
+            const float b = bjh[j];
             float fin[2][16];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -575,7 +598,7 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, f32x16 (&acc)[2
                     const int mrow = (r & 3) + 8 * (r >> 2) + 4 * fk;
                     const int oy = oy0 + prow0 + i * 2 + (mrow >> 4), ox = ox0 + (mrow & 15);
                     float v = (co64 && i == 1) ? 0.f : acc[i][j][r];
-                    if (a.noise && oy < a.H && ox < a.W) v = fmaf(a.noise[(int64_t)oy * a.W + ox], ns, v);
+                    if (a.noise && oy < a.H && ox < a.W) v = fmaf(nzr[i][r], ns, v);
                     v += b;
                     if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
                     v *= a.gain;
@@ -628,7 +651,7 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, f32x16 (&acc)[2
     for (int j = 0; j < 2; ++j) {
         const int co = co0 + wn * 64 + j * 32 + frow;
         if (co >= a.Co) continue;
-        const float b = a.bias ? a.bias[co] : 0.f;
+        const float b = bjh[j];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (co64 && i == 1) continue;
@@ -638,7 +661,7 @@ __device__ __forceinline__ void halo_epilogue(const ConvArgs& a, f32x16 (&acc)[2
                 const int oy = oy0 + prow0 + i * 2 + (mrow >> 4), ox = ox0 + (mrow & 15);
                 if (oy >= a.H || ox >= a.W) continue;
                 float v = acc[i][j][r];
-                if (a.noise) v = fmaf(a.noise[(int64_t)oy * a.W + ox], ns, v);
+                if (a.noise) v = fmaf(nzr[i][r], ns, v);
                 v += b;
                 if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
                 v *= a.gain;
@@ -1988,13 +2011,16 @@ __global__ void __launch_bounds__(256) modulate_weights_kernel(const float* __re
     const float* s = styles + (int64_t)n * Ci;
     const bool staged = total <= MW_MAX_ROW;
     float sq = 0.f;
+    // (unrolled by six: rolled, every iteration was its own memory round trip — eighteen in a row for a 512-channel 3x3 layer)
     if (staged) {                                                    // row[e] = w * pre_scale * s: the value both passes need
+#pragma unroll 6
         for (int e = threadIdx.x; e < total; e += 256) {
             const float v = wr[e] * pre_scale * s[e / KT];
             row[e] = v;
             sq = fmaf(v, v, sq);
         }
     } else {
+#pragma unroll 6
         for (int e = threadIdx.x; e < total; e += 256) {
             const float v = wr[e] * pre_scale * s[e / KT];
             sq = fmaf(v, v, sq);

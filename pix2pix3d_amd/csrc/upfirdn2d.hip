@@ -194,6 +194,16 @@ __global__ void __launch_bounds__(256) upfirdn2d_cl_kernel(UpfirArgs a)
         float acc[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+        // every tap of the output requested at once, unconditionally (an out-of-image tap reads a clamped address and is skipped below): as `if (inside) { load; fma }`
+        // each tap was a branch with its own wait — sixteen dependent memory round trips per output at up = 1 (0.18 of the HBM peak, waves 69 % at s_waitcnt)
+        P tap[NJ][NJ];
+#pragma unroll
+        for (int jy = 0; jy < NJ; ++jy)
+#pragma unroll
+            for (int jx = 0; jx < NJ; ++jx) {
+                const int iy = min(max(iyb + jy, 0), a.in_h - 1), ix = min(max(ixb + jx, 0), a.in_w - 1);
+                tap[jy][jx] = *(const P*)(img + (int64_t)iy * a.isy + (int64_t)ix * a.isx);
+            }
 #pragma unroll
         for (int jy = 0; jy < NJ; ++jy) {
             const int iy = iyb + jy;
@@ -210,7 +220,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_cl_kernel(UpfirArgs a)
                     w = ky0 ? wb : wa;
                 }
                 if ((iy >= 0) & (iy < a.in_h) & (ix >= 0) & (ix < a.in_w)) {
-                    const P v = *(const P*)(img + (int64_t)iy * a.isy + (int64_t)ix * a.isx);
+                    const P v = tap[jy][jx];
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) acc[e] = fmaf((float)ld(&v.v[e]), w, acc[e]);
                 }
@@ -257,6 +267,38 @@ __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) fir4_cl_fused_ker
     const int ix0 = ox0 - a.pad_x0, iy0 = oy0 - a.pad_y0;
     const T* img = (const T*)a.x + (int64_t)n * a.isn + cblk * CB;
     const int chunk = threadIdx.x & 7;
+    // Everything the block reads besides its tile — the sixteen filter taps, the thread's biases, the noise strength and its eight noise values — is requested FIRST and
+    // unconditionally (an absent operand reads the filter's first tap and is discarded), so that it shares the tile's round trip.  Read where they were used — the noise under
+    // its bounds branch, the taps behind the staging stores, the biases behind the rendezvous — they were three more dependent round trips of a block that lives for little
+    // more than one (waves of this kernel spent 53 % of their life at s_waitcnt: profiles/round6_zk_kernel_pmc_infer.txt).
+    float fr[4][4];
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            const int fx = a.flip ? kx : 3 - kx, fy = a.flip ? ky : 3 - ky;
+            fr[ky][kx] = a.f[fx * a.fsx + fy * a.fsy] * a.gain;
+        }
+    const int c0 = cblk * CB + chunk * VEC;
+    float bias[VEC];
+    {
+        const float* const bp = ep.bias ? ep.bias + c0 : a.f;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) { const float v = bp[ep.bias ? k : 0]; bias[k] = ep.bias ? v : 0.f; }
+    }
+    const int x = (threadIdx.x >> 3) & 15, yh = threadIdx.x >> 7;
+    float nzv[8];
+    {
+        const float ns = (ep.noise ? ep.noise_strength : a.f)[0];
+        const float* const np = ep.noise ? ep.noise : a.f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const int oy = oy0 + yh * 8 + o, ox = ox0 + x;
+            const bool ok = ep.noise && oy < a.out_h && ox < a.out_w;
+            const float v = np[ok ? (int64_t)oy * a.out_w + ox : 0];
+            nzv[o] = ok ? v * ns : 0.f;
+        }
+    }
     // all twelve footprint loads of a thread are issued before the first one is consumed: the block pays ONE HBM round
     // trip for its tile, not one per load (the rolled loop did, and ran at a quarter of the memory rate)
     constexpr int NLD = (TI * TI + 31) / 32;       // 12
@@ -271,34 +313,14 @@ __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) fir4_cl_fused_ker
         if ((e < TI * TI) & (iy >= 0) & (iy < a.in_h) & (ix >= 0) & (ix < a.in_w))
             stage[k] = *(const P*)(img + (int64_t)iy * a.isy + (int64_t)ix * a.isx + chunk * VEC);
     }
-    const int x = (threadIdx.x >> 3) & 15, yh = threadIdx.x >> 7;
-    const float ns = ep.noise ? ep.noise_strength[0] : 0.f;
-    float nzv[8];
-#pragma unroll
-    for (int o = 0; o < 8; ++o) {
-        const int oy = oy0 + yh * 8 + o, ox = ox0 + x;
-        nzv[o] = (ep.noise && oy < a.out_h && ox < a.out_w) ? ep.noise[(int64_t)oy * a.out_w + ox] * ns : 0.f;
-    }
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
         const int e = (threadIdx.x >> 3) + 32 * k;
         if (e < TI * TI) tile[e * 8 + chunk] = stage[k];
     }
-    float fr[4][4];
-#pragma unroll
-    for (int ky = 0; ky < 4; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 4; ++kx) {
-            const int fx = a.flip ? kx : 3 - kx, fy = a.flip ? ky : 3 - ky;
-            fr[ky][kx] = a.f[fx * a.fsx + fy * a.fsy] * a.gain;
-        }
     __syncthreads();
     const int ox = ox0 + x;
     if (ox >= a.out_w) return;
-    const int c0 = cblk * CB + chunk * VEC;
-    float bias[VEC];
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) bias[k] = ep.bias ? ep.bias[c0 + k] : 0.f;
     // One output row at a time: its sixteen taps are read from the LDS tile (16-byte reads), summed in the order (ky, kx) ascending, finished and stored before the next
     // row starts.  (The earlier form walked the eleven INPUT rows once — 44 reads instead of 128 — and the compiler kept all 44 in registers before the first fma:
     // 235 VGPRs in fp32, 256 in fp16, one to two waves per SIMD for a memory pass.  LDS reads are not what this kernel waits for.)
