@@ -20,6 +20,7 @@ __device__ __forceinline__ void fc_block(float* xs, int block, const float* __re
                                          float* __restrict__ y, int n_rows, int in_f, int out_f, int64_t x_stride, float wg, float bg,
                                          int act, float alpha, float act_gain, float out_scale)
 {
+#pragma unroll 4
     for (int e = threadIdx.x * 4; e < n_rows * in_f; e += 256 * 4) {
         const int n = e / in_f, k = e - n * in_f;
         *(float4*)(xs + e) = *(const float4*)(x + n * x_stride + k);
@@ -32,6 +33,8 @@ __device__ __forceinline__ void fc_block(float* xs, int block, const float* __re
 #pragma unroll
     for (int n = 0; n < FC_MAXN; ++n) acc[n] = 0.f;
     const float* wr = w + (int64_t)o * in_f;
+    const float bias_raw = b ? b[o] : 0.f;                          // (requested with the weights, not behind the reduction)
+#pragma unroll 4
     for (int k = lane * 4; k < in_f; k += 256) {
         const float4 wv = *(const float4*)(wr + k);
 #pragma unroll
@@ -52,7 +55,7 @@ __device__ __forceinline__ void fc_block(float* xs, int block, const float* __re
         }
     }
     if (lane == 0) {
-        const float bias = b ? b[o] * bg : 0.f;
+        const float bias = b ? bias_raw * bg : 0.f;
 #pragma unroll
         for (int n = 0; n < FC_MAXN; ++n) {
             if (n < n_rows) {
@@ -111,7 +114,8 @@ __global__ void __launch_bounds__(256) demod_coefs_multi_kernel(DemodJobs a)
     while (j + 1 < a.njobs && (int)blockIdx.x >= a.first_block[j + 1]) ++j;
     const p3d_demod_job& q = a.job[j];
     const int ci = q.ci, co = q.co, n_rows = a.n_rows;
-    for (int e = threadIdx.x; e < n_rows * ci; e += 256) { const float v = q.styles[e]; xs[e] = v * v; }
+#pragma unroll 8
+    for (int e = threadIdx.x; e < n_rows * ci; e += 256) { const float v = q.styles[e]; xs[e] = v * v; }      // (unrolled: rolled, every iteration was a memory round trip of its own)
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int o = ((int)blockIdx.x - a.first_block[j]) * 4 + wave;
@@ -119,6 +123,7 @@ __global__ void __launch_bounds__(256) demod_coefs_multi_kernel(DemodJobs a)
     float acc[FC_MAXN];
 #pragma unroll
     for (int n = 0; n < FC_MAXN; ++n) acc[n] = 0.f;
+#pragma unroll 8
     for (int k = lane; k < ci; k += 64) {                           // (demod_coefs_kernel's arithmetic, operation for operation: the results are bit-identical)
         const float wv = q.w2[(int64_t)o * ci + k];
 #pragma unroll
