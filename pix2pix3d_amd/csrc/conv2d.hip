@@ -414,11 +414,18 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
                 // store instructions per lane and tile instead of 64 four-byte ones (conv3x3_r2_bf16x3_kernel's epilogue: the same change was -9 % of that kernel)
                 const int t = lane & 3, m4 = (lane & 31) >> 2;
                 const bool odd1 = lane & 1, odd2 = lane & 2;
+                float bj2[2];                                                       // (both column blocks' biases in one batch)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int co = co0 + wn * 64 + j * 32 + frow;
+                    const bool bok = a.bias && co < a.Co;
+                    bj2[j] = (bok ? a.bias : (const float*)a.zeros)[bok ? co : 0];
+                }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int cq = co0 + wn * 64 + j * 32, co = cq + frow;
                     const bool cok = co < a.Co;
-                    const float b = (a.bias && cok) ? a.bias[co] : 0.f;
+                    const float b = bj2[j];
 #pragma unroll
                     for (int i = 0; i < NI; ++i)
 #pragma unroll

@@ -572,11 +572,14 @@ __global__ void __launch_bounds__(256) skinny_wgrad_kernel(const T* __restrict__
                 T mv[2][EPC];
                 *(f32x4*)mv[0] = *(const f32x4*)(many + m * W + col * EPC);
                 *(f32x4*)mv[1] = two ? *(const f32x4*)(many + (m + rl) * W + col * EPC) : f32x4{0.f, 0.f, 0.f, 0.f};
-                float fv[2][8];
+                float fv[2][8];                                                 // (unconditional loads of clamped addresses, discarded by a select: as `cond ? load : 0` each of the sixteen
+                const int64_t m1 = two ? m + rl : m;                            // was a branch with its own wait)
 #pragma unroll
                 for (int f = 0; f < 8; ++f) {
-                    fv[0][f] = (f0 + f < F) ? (float)ld(few + m * F + f0 + f) : 0.f;
-                    fv[1][f] = (two && f0 + f < F) ? (float)ld(few + (m + rl) * F + f0 + f) : 0.f;
+                    const int fc = f0 + f < F ? f0 + f : F - 1;
+                    const float v0 = (float)ld(few + m * F + fc), v1 = (float)ld(few + m1 * F + fc);
+                    fv[0][f] = (f0 + f < F) ? v0 : 0.f;
+                    fv[1][f] = (two && f0 + f < F) ? v1 : 0.f;
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u)

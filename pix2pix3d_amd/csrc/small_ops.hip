@@ -149,6 +149,7 @@ __global__ void __launch_bounds__(256) demod_bwd_styles_kernel(const float* __re
                                                                const float* __restrict__ w2, float* __restrict__ gs, int n_rows, int ci, int co)
 {
     extern __shared__ float ts[];                                   // [n_rows][co] of t, then [4][64][n_rows] partial sums
+#pragma unroll 4
     for (int e = threadIdx.x; e < n_rows * co; e += 256) { const float dv = d[e]; ts[e] = gd[e] * dv * dv * dv; }
     __syncthreads();
     const int il = threadIdx.x & 63, slice = threadIdx.x >> 6;
@@ -157,6 +158,9 @@ __global__ void __launch_bounds__(256) demod_bwd_styles_kernel(const float* __re
 #pragma unroll
     for (int n = 0; n < FC_MAXN; ++n) acc[n] = 0.f;
     if (i < ci)
+        // (unrolled by sixteen: the launch is ci / 64 blocks whose threads each walk co / 4 weight rows — rolled, 128 dependent memory round trips, 67 us per launch and 117
+        // launches per three training iterations: profiles/round6_zk_kernel_pmc_train6.txt; the sums are formed in the same order)
+#pragma unroll 16
         for (int o = slice; o < co; o += 4) {
             const float wv = w2[(int64_t)o * ci + i];
 #pragma unroll
@@ -184,6 +188,7 @@ __global__ void __launch_bounds__(256) demod_bwd_weight_kernel(const float* __re
         const int64_t oi = e / taps;
         const int o = (int)(oi / ci), i = (int)(oi - (int64_t)o * ci);
         float coef = 0.f;
+#pragma unroll 4
         for (int n = 0; n < n_rows; ++n) {
             const float dv = d[n * co + o], sv = styles[n * ci + i];
             coef = fmaf(gd[n * co + o] * dv * dv * dv, sv * sv, coef);

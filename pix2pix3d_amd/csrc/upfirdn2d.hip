@@ -204,6 +204,9 @@ __global__ void __launch_bounds__(256) upfirdn2d_cl_kernel(UpfirArgs a)
                 const int iy = min(max(iyb + jy, 0), a.in_h - 1), ix = min(max(ixb + jx, 0), a.in_w - 1);
                 tap[jy][jx] = *(const P*)(img + (int64_t)iy * a.isy + (int64_t)ix * a.isx);
             }
+        P* const dst = (P*)((T*)a.y + (int64_t)n * a.osn + (int64_t)oy * a.osy + (int64_t)ox * a.osx + cv * VEC);
+        P old = tap[0][0];
+        if (a.accumulate) old = *dst;                                // (with the taps, not behind them)
 #pragma unroll
         for (int jy = 0; jy < NJ; ++jy) {
             const int iy = iyb + jy;
@@ -227,9 +230,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_cl_kernel(UpfirArgs a)
             }
         }
         P o;
-        P* const dst = (P*)((T*)a.y + (int64_t)n * a.osn + (int64_t)oy * a.osy + (int64_t)ox * a.osx + cv * VEC);
         if (a.accumulate) {
-            const P old = *dst;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[e] += (float)ld(&old.v[e]);
         }
