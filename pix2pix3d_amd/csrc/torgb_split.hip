@@ -49,6 +49,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 1) torgb_wide_split_kernel
     const int nj = a.Co / 32;
     {
         const char* wn = (const char*)(a.wm + (int64_t)n * a.Co * Ci);
+#pragma unroll 6                                                                // (rolled, each of the twelve iterations was a memory round trip of its own: a fifth of the 128^2 launch)
         for (int e = tid; e < nj * KS * 2 * 64; e += NT) {
             const int ln = e & 63, frag = e >> 6, hl = frag & 1, ks = (frag >> 1) % KS, j = frag / (2 * KS);
             const int co = j * 32 + (ln & 31);
@@ -63,7 +64,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 1) torgb_wide_split_kernel
     const float* __restrict__ const pn = a.prev ? a.prev + (int64_t)n * PH * PW * a.Co : nullptr;
     float bias[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) bias[j] = (a.bias && j < nj) ? a.bias[j * 32 + col] : 0.f;
+    for (int j = 0; j < 3; ++j) { const bool bok = a.bias && j < nj; const float v = (bok ? a.bias : a.x)[bok ? j * 32 + col : 0]; bias[j] = bok ? v : 0.f; }      // (one batch, no branch)
 
     auto load_chunk = [&](tf4 (&ah)[8], tf4 (&al)[8], int tile, int kc) {
         const char* px = xn + ((int64_t)tile * 32 + col) * Ci * 4 + kg * 16 + kc * 512;       // 8 k-steps = four 128-byte rows

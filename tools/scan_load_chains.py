@@ -5,7 +5,8 @@ previous store (it may alias), and does not unroll a runtime-trip loop whose bod
 flight beside it.  Counters only show the symptom ("waves at s_waitcnt"); this lists where the chains are.  Round 6 found and removed them in the epilogues of the patch
 kernels, the split-K finish, fir4_cl_fused_kernel, upfirdn2d_cl_kernel, modulate_weights_kernel, the FC / demodulation kernels (profiles/round6_z{i,j,n,o,p,q}_*).
 
-    python tools/scan_load_chains.py [min_chain]        (no GPU needed: hipcc -S for gfx950; prints kernel, longest chain)
+    python tools/scan_load_chains.py [min_chain]        (no GPU needed: hipcc -S for gfx950; prints kernel, longest chain, and the number of ROLLED loops — a backward branch
+                                                         over a short body — that hold a load and a full vmcnt drain: one round trip per iteration)
 
 A reported chain is the STATIC worst case — it may sit on a path a launch never takes (a null noise pointer skips its branch); read the kernel before acting on it."""
 import glob, os, re, subprocess, sys, tempfile
@@ -23,14 +24,25 @@ def scan(path, min_chain):
         if r.returncode != 0:
             raise RuntimeError(r.stdout[-2000:])
         name, seq = None, []
+        labels, body, loops = {}, [], 0                     # rolled loops: a backward branch over a short body that holds a load and a full vmcnt drain
         for line in open(asm):
             m = re.match(r'^(_Z\w+):', line)
             if m:
                 name, seq = m.group(1), []
+                labels, body, loops = {}, [], 0
                 continue
             if name is None:
                 continue
             t = line.strip()
+            ml = re.match(r'^(\.LBB\w+):', t)
+            if ml:
+                labels[ml.group(1)] = len(body)
+            body.append(t)
+            mb = re.match(r'^s_cbranch_\w+\s+(\.LBB\w+)', t)
+            if mb and mb.group(1) in labels and len(body) - labels[mb.group(1)] <= 120:
+                inner = body[labels[mb.group(1)]:]
+                if any(x.startswith(('global_load', 'buffer_load', 'flat_load')) and 'lds' not in x.split()[0] for x in inner) and any(x.startswith('s_waitcnt') and 'vmcnt(0)' in x for x in inner):
+                    loops += 1
             if t.startswith(('global_load', 'buffer_load', 'flat_load')) and 'lds' not in t.split()[0]:
                 seq.append('L')
             elif t.startswith('s_waitcnt') and 'vmcnt(0)' in t:
@@ -38,8 +50,8 @@ def scan(path, min_chain):
             elif t.startswith('s_endpgm'):
                 runs = re.findall(r'(?:L{1,2}W){%d,}' % min_chain, ''.join(seq))
                 worst = max((r.count('W') for r in runs), default=0)
-                if worst:
-                    out.append((worst, subprocess.run(['c++filt', name], stdout=subprocess.PIPE, text=True).stdout.strip()))
+                if worst or loops:
+                    out.append((worst, loops, subprocess.run(['c++filt', name], stdout=subprocess.PIPE, text=True).stdout.strip()))
                 name = None
     return sorted(out, reverse=True)
 
@@ -47,5 +59,5 @@ def scan(path, min_chain):
 if __name__ == '__main__':
     min_chain = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     for src in sorted(glob.glob(os.path.join(CSRC, '*.hip'))):
-        for worst, kernel in scan(src, min_chain):
-            print(f'{os.path.basename(src):22s} {worst:4d}  {kernel[:160]}')
+        for worst, loops, kernel in scan(src, min_chain):
+            print(f'{os.path.basename(src):22s} chain {worst:4d}  rolled load loops {loops:2d}  {kernel[:150]}')
