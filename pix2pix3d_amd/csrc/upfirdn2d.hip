@@ -99,16 +99,28 @@ __global__ void __launch_bounds__(256) upfirdn2d_tiled_kernel(UpfirArgs a)
     const int bx0 = tx0 * DN - a.pad_x0, by0 = ty0 * DN - a.pad_y0;
     const int ix0 = (bx0 >= 0 ? bx0 : bx0 - (UP - 1)) / UP, iy0 = (by0 >= 0 ? by0 : by0 - (UP - 1)) / UP;
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-    for (int r = ly; r < IH; r += 4) {
-        const int iy = iy0 + r;
-        const bool rowok = (iy >= 0) & (iy < a.in_h);
-        for (int c = lx; c < IW; c += 64) {
-            const int ix = ix0 + c;
-            float v = 0.f;
-            if (rowok & (ix >= 0) & (ix < a.in_w)) v = (float)ld(img + (int64_t)iy * a.in_w + ix);
-            tile[r * PITCH + c] = v;
+    // (every load of the tile first — unconditional, clamped addresses, discarded by a select — then the LDS stores: rolled and under its bounds branch, every tile row was a
+    // memory round trip of its own)
+    constexpr int NR = (IH + 3) / 4, NCC = (IW + 63) / 64;
+    float stg[NR][NCC];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int iy = iy0 + k * 4 + ly;
+#pragma unroll
+        for (int q = 0; q < NCC; ++q) {
+            const int ix = ix0 + q * 64 + lx;
+            const bool ok = (iy >= 0) & (iy < a.in_h) & (ix >= 0) & (ix < a.in_w);
+            const float v = (float)ld(img + (int64_t)min(max(iy, 0), a.in_h - 1) * a.in_w + min(max(ix, 0), a.in_w - 1));
+            stg[k][q] = ok ? v : 0.f;
         }
     }
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+#pragma unroll
+        for (int q = 0; q < NCC; ++q) {
+            const int r = k * 4 + ly, c = q * 64 + lx;
+            if ((r < IH) & (c < IW)) tile[r * PITCH + c] = stg[k][q];
+        }
     // filter taps in registers, already mirrored for convolution unless flip
     float fr[F][F];
 #pragma unroll
