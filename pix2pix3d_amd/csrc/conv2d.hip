@@ -206,11 +206,10 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
     if (s_end > nsteps) s_end = nsteps;
     int cc = s_begin / ntaps, t = s_begin - cc * ntaps;
     if (s_begin < s_end) stage(cc, t, 0);
-    __syncthreads();
     const int frow = lane & 31, fk = lane >> 5;                                 // fragment row / k-group of this lane
     __shared__ __attribute__((aligned(16))) float isc_tab[ISC ? kIscaleFloats : 4];
     int isc_off[2] = {0, 0};                                                    // table offset of the image of this lane's fragment rows (i = 0, 1)
-    if constexpr (ISC) {
+    if constexpr (ISC) {                                                        // (the table's loads share the first tile's round trip: one rendezvous for both — they came one after the other)
         const int img0 = a.fold ? m0 / MI : n;
         const int img1 = a.fold ? min((min(m0 + BM, M) - 1) / MI, a.N - 1) : n;
         for (int e = tid; e < (img1 - img0 + 1) * a.Ci; e += 256) isc_tab[e] = a.iscale[(int64_t)img0 * a.Ci + e];
@@ -219,8 +218,8 @@ __global__ void __launch_bounds__(256, 2) conv2d_nhwc_kernel(ConvArgs a)
             const int m = min(m0 + rbase + i * 32 + frow, M - 1);
             isc_off[i] = (a.fold ? m / MI - img0 : 0) * a.Ci + 8 * fk;
         }
-        __syncthreads();
     }
+    __syncthreads();
     int pa[NI][4], pb[2][4];                                                    // fragment slots of this lane (buffer 0)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
